@@ -1,0 +1,91 @@
+"""ctypes binding of libmpn_hip.so (the C ABI declared in include/mpn.h).
+
+There is NO fallback: if the shared library is missing or a call fails, the product
+path raises. (The CPU restatement under oracle/ is test infrastructure only.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpn_hip.so")
+
+MPN_F32, MPN_BF16, MPN_F16 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_F = _c.c_float
+_D = _c.c_double
+_Z = _c.c_size_t
+_L = _c.c_longlong
+
+# name -> (restype, argtypes); filled in below, checked against include/mpn.h by the tests
+SIGNATURES = {
+    "mpn_version": (_I, []),
+    "mpn_last_error": (_I, [_c.c_char_p, _Z]),
+    "mpn_heatmap_decode_workspace_bytes": (_Z, [_I]),
+    "mpn_heatmap_decode": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+class MpnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Returns the loaded CDLL; raises if libmpn_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MpnError(
+                f"{LIB_PATH} not found: build it with `python -m multiposenet_amd.build` "
+                "(there is no CPU fallback)")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def last_error():
+    buf = ctypes.create_string_buffer(512)
+    lib().mpn_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+_ERR_NAMES = {-1: "BAD_SHAPE", -2: "BAD_DTYPE", -3: "BAD_ALIGN", -4: "HIP", -5: "BAD_ARG", -6: "WORKSPACE"}
+
+
+def check(rc):
+    if rc != 0:
+        msg = f"MPN_ERR_{_ERR_NAMES.get(rc, rc)}: {last_error()}"
+        if rc in (-1, -2, -3, -5):
+            raise ValueError(msg)
+        raise MpnError(msg)
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else _P(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(torch_dtype):
+    import torch
+    try:
+        return {torch.float32: MPN_F32, torch.bfloat16: MPN_BF16, torch.float16: MPN_F16}[torch_dtype]
+    except KeyError:
+        raise ValueError(f"unsupported dtype {torch_dtype}")

@@ -1,0 +1,113 @@
+// Common device/host helpers for libmpn_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/mpn.h"
+
+// ---------------------------------------------------------------- errors
+void mpn_set_error(const char* fmt, ...);
+
+#define MPN_FAIL(code, ...)            \
+    do {                               \
+        mpn_set_error(__VA_ARGS__);    \
+        return (code);                 \
+    } while (0)
+
+#define MPN_REQUIRE(cond, code, ...)   \
+    do {                               \
+        if (!(cond)) MPN_FAIL(code, __VA_ARGS__); \
+    } while (0)
+
+#define MPN_LAUNCH_CHECK()                                                        \
+    do {                                                                          \
+        hipError_t e_ = hipGetLastError();                                        \
+        if (e_ != hipSuccess)                                                     \
+            MPN_FAIL(MPN_ERR_HIP, "%s:%d launch failed: %s", __FILE__, __LINE__, \
+                     hipGetErrorString(e_));                                      \
+    } while (0)
+
+#define MPN_HIP(call)                                                             \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            MPN_FAIL(MPN_ERR_HIP, "%s:%d %s: %s", __FILE__, __LINE__, #call,      \
+                     hipGetErrorString(e_));                                      \
+    } while (0)
+
+static inline bool mpn_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// ---------------------------------------------------------------- storage types
+// Activations are stored either as f32 (parity build) or bf16 (throughput build);
+// all arithmetic accumulates in f32.
+typedef __bf16 bf16_t;
+
+template <typename T> struct StoreTraits;
+template <> struct StoreTraits<float> {
+    static constexpr int kDtype = MPN_F32;
+    static constexpr int kVec = 4;  // elements per 16-byte vector
+};
+template <> struct StoreTraits<bf16_t> {
+    static constexpr int kDtype = MPN_BF16;
+    static constexpr int kVec = 8;
+};
+
+__device__ __forceinline__ float to_f32(float x) { return x; }
+__device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// 16-byte vector of T, unpacked to / packed from f32 registers.
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    float4 raw;
+    __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
+    __device__ __forceinline__ void zero() { raw = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void unpack(float (&f)[4]) const { f[0] = raw.x; f[1] = raw.y; f[2] = raw.z; f[3] = raw.w; }
+    __device__ __forceinline__ void pack(const float (&f)[4]) { raw = make_float4(f[0], f[1], f[2], f[3]); }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    uint4 raw;
+    __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+    __device__ __forceinline__ void zero() { raw = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const {
+        const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f[2 * i] = __uint_as_float(u[i] << 16);
+            f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void pack(const float (&f)[8]) {
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+            const bf16_t lo = (bf16_t)f[2 * i], hi = (bf16_t)f[2 * i + 1];
+            u[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) |
+                   ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+        }
+        raw = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+// ---------------------------------------------------------------- wave helpers (wave = 64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+static inline int mpn_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+#define MPN_DISPATCH_DTYPE(dtype, ...)                                  \
+    do {                                                                \
+        if ((dtype) == MPN_F32) { using T = float; __VA_ARGS__; }       \
+        else if ((dtype) == MPN_BF16) { using T = bf16_t; __VA_ARGS__; }\
+        else MPN_FAIL(MPN_ERR_BAD_DTYPE, "unsupported dtype %d", (int)(dtype)); \
+    } while (0)

@@ -1,0 +1,1 @@
+from .utils import get_keypoints, get_keypoints_batch, KeypointDecoder  # noqa: F401

@@ -1,0 +1,39 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/mpn.h declares."""
+import os
+import re
+
+from multiposenet_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mpn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_bound():
+    names = _declared()
+    assert "mpn_heatmap_decode" in names and "mpn_version" in names
+    l = _lib.lib()
+    for n in names:
+        assert hasattr(l, n), f"{n} declared in include/mpn.h but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.SIGNATURES"
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} bound in _lib.py but not declared in include/mpn.h"
+
+
+def test_version_and_error_string():
+    l = _lib.lib()
+    assert l.mpn_version() == 100
+    assert isinstance(_lib.last_error(), str)
+
+
+def test_host_side_validation_needs_no_gpu():
+    # argument checks run before any HIP call
+    import ctypes
+    import pytest
+    with pytest.raises(ValueError, match="C must be 17"):
+        _lib.call("mpn_heatmap_decode", None, 0, 1, 4, 4, 16, None, 0.0, None, None, None, None, 0, None)
+    assert _lib.lib().mpn_heatmap_decode_workspace_bytes(32) >= 32 * 17 * 8
