@@ -43,6 +43,13 @@ def lib():
             raise MpnError(
                 f"{LIB_PATH} not found: build it with `python -m multiposenet_amd.build` "
                 "(there is no CPU fallback)")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same soname as
+        # /opt/rocm's). Load torch's copy first so that libmpn_hip.so binds to it and shares
+        # torch's device context, streams and allocations.
+        import torch
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
