@@ -70,6 +70,153 @@ int mpn_heatmap_decode(const void* heatmaps, int dtype, int B, int h, int w, int
                        int32_t* out_xyv, float* out_score, int32_t* out_index,
                        void* workspace, size_t workspace_bytes, mpn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * K5/K6/K8  dense convolution on the MFMA matrix cores (NHWC, stride 1; 3x3 uses pad 1).
+ * Replaces slim.conv2d 1x1 (detector/backbones/mobilenet_v1.py:73) and conv2d_same
+ * (detector/utils/layer_utils.py:19-39; call sites detector/fpn.py:38,39,50,52 and
+ * detector/keypoint_subnet.py:38,75,77). The same kernel computes data-gradients when it is
+ * given weights packed with transpose=1 (flipped taps, Cin/Cout swapped).
+ *
+ *   x        [N,H,W,Cin]  raw output of the producing conv (or any tensor)
+ *   in_scale, in_shift [Cin] f32 or NULL: the producer's batch-norm affine, applied on load
+ *            together with in_act (MPN_ACT_*), so normalised activations never touch HBM
+ *   w_packed weights from mpn_conv_pack_weights (same dtype as x)
+ *   y        [N,H,W,Cout]
+ *   stats_part NULL or [mpn_conv_num_parts()][2][Cout] f32: per-tile sum and sum of squares
+ *            of y for the following batch-norm (mpn_bn_finalize reduces them)
+ *   up_res   NULL or [N,H/2,W/2,Cout]: y += nearest-2x-upsample(up_res)  (detector/fpn.py:51,58-76)
+ */
+size_t mpn_conv_packed_bytes(int Cin, int Cout, int ksize, int transpose, int dtype);
+/* w_hwio: f32 [ksize,ksize,Cin,Cout] in the reference's variable layout (HWIO) */
+int mpn_conv_pack_weights(const float* w_hwio, int Cin, int Cout, int ksize, int transpose,
+                          int dtype, void* out, mpn_stream_t stream);
+int mpn_conv_num_parts(int N, int H, int W, int ksize);
+int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin,
+                 int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,
+                 int in_act, float* stats_part, const void* up_res, mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  batch normalisation (tf.layers.batch_normalization(fused=True, momentum=.95, eps=1e-3):
+ * detector/backbones/mobilenet_v1.py:29-38, detector/utils/layer_utils.py:9-16).
+ * Producers emit partial sums [nparts][2][C] (sum, sum of squares); mpn_bn_finalize turns them
+ * into the per-channel affine (scale = gamma*invstd, shift = beta - mean*scale) that CONSUMERS
+ * apply on load, and updates the moving statistics (unbiased variance, TF-1.15 semantic) when
+ * moving_mean/moving_var are non-NULL. x is viewed as [M rows][C channels] (NHWC).
+ */
+int mpn_bn_stats_num_parts(long long M);
+int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream);
+int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
+                    const float* beta, float* moving_mean, float* moving_var, float momentum,
+                    float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                    mpn_stream_t stream);
+/* is_training=False path: affine from the moving statistics */
+int mpn_bn_inference_affine(int C, const float* gamma, const float* beta, const float* moving_mean,
+                            const float* moving_var, float eps, float* scale, float* shift,
+                            mpn_stream_t stream);
+/* y = act(x*scale + shift), materialised (only needed at the API edge) */
+int mpn_bn_act_apply(const void* x, void* y, long long M, int C, int dtype, const float* scale,
+                     const float* shift, int act, mpn_stream_t stream);
+/* backward: g = dA*act'(.), partials of sum(g), sum(g*xhat) -> [mpn_bn_stats_num_parts(M)][2][C] */
+int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dtype,
+                      const float* scale, const float* shift, const float* mean,
+                      const float* invstd, int act, float* part, mpn_stream_t stream);
+int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
+                        float* dbeta, float* k1, float* k2, mpn_stream_t stream);
+/* dA <- scale*(g - k1 - xhat*k2) in place; add_ch0 (NULL or [M] f32) is added to channel 0 */
+int mpn_bn_bwd_apply(void* dA, const void* x, long long M, int C, int dtype, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, const float* k1,
+                     const float* k2, int act, const float* add_ch0, mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  depthwise 3x3, TF 'SAME' padding, stride 1|2 (tf.nn.depthwise_conv2d,
+ * detector/backbones/mobilenet_v1.py:82-104). w = `depthwise_weights` [3,3,C,1] f32 as is.
+ * x [N,H,W,C] -> y [N,OH,OW,C], OH = ceil(H/stride). in_scale/in_shift/in_act as for mpn_conv_fwd.
+ * stats_part: NULL or [mpn_dwconv_num_parts()][2][C].
+ */
+int mpn_dwconv_out_size(int size, int stride);
+int mpn_dwconv_num_parts(int N, int H, int W, int stride);
+int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
+                   int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
+                   float* stats_part, mpn_stream_t stream);
+/* dy [N,OH,OW,C] -> dx [N,H,W,C]  (H, W: forward input size) */
+int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C,
+                        int stride, int dtype, mpn_stream_t stream);
+int mpn_dwconv_wgrad_num_parts(int N, int H, int W, int C, int stride, int dtype);
+/* part [mpn_dwconv_wgrad_num_parts()][9][C]; finish with mpn_reduce_partials */
+int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int C,
+                          int stride, int dtype, const float* in_scale, const float* in_shift,
+                          int in_act, mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K1+K2  `2*x-1` + Conv2d_0 (3x3 stride 2 'SAME', 3 -> C0) fused
+ * (detector/backbones/mobilenet_v1.py:41,53,56). images NHWC f32 in [0,1], or uint8
+ * (images_u8=1: scaled by 1/255 first, create_pb.py:167). w = `Conv2d_0/weights` [3,3,3,C0] f32.
+ */
+int mpn_stem_conv_fwd(const void* images, int images_u8, const float* w, void* y, int N, int H,
+                      int W, int C0, int dtype, mpn_stream_t stream);
+int mpn_stem_conv_wgrad_num_parts(int N, int H, int W);
+/* part [num_parts][27*C0] */
+int mpn_stem_conv_bwd_weight(const void* images, int images_u8, const void* dy, float* part, int N,
+                             int H, int W, int C0, int dtype, mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K9/K10  legacy bilinear up-sampling by an integer factor into a channel slice of the concat
+ * tensor (tf.image.resize_bilinear + tf.concat, detector/keypoint_subnet.py:37,86), its transpose,
+ * and the gradient of the FPN's nearest-2x upsample (detector/fpn.py:58-76).
+ */
+int mpn_bilinear_up_fwd(const void* x, void* y, int N, int h, int w, int C, int upsample,
+                        int y_channel_offset, int y_channels_total, int dtype,
+                        const float* in_scale, const float* in_shift, int in_act,
+                        mpn_stream_t stream);
+int mpn_bilinear_up_bwd(const void* dy, void* dx, int N, int h, int w, int C, int upsample,
+                        int y_channel_offset, int y_channels_total, int dtype, mpn_stream_t stream);
+/* src [N,2h,2w,C] -> dst [N,h,w,C] (2x2 sums); accumulate != 0 adds into dst */
+int mpn_sumpool2x2(const void* src, void* dst, int N, int h, int w, int C, int accumulate,
+                   int dtype, mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K11  `heatmaps` head: 1x1 conv Cin -> 18 + bias, f32 NHWC logits
+ * (detector/keypoint_subnet.py:49-58); mode 1 = inference post-ops of create_pb.py:73-76.
+ * w = `heatmaps/kernel` [1,1,Cin,18] f32, bias [18].
+ */
+int mpn_heatmap_head_fwd(const void* x, const float* w, const float* bias, long long M, int Cin,
+                         int dtype, const float* in_scale, const float* in_shift, int in_act,
+                         int mode, float* out, float* out_seg, mpn_stream_t stream);
+int mpn_heatmap_head_bwd_num_parts(long long M);
+/* dA [M][Cin]; part [num_parts][Cin*18 + 18] (dW then db) */
+int mpn_heatmap_head_bwd(const void* x, const float* dlogits, const float* w, long long M, int Cin,
+                         int dtype, const float* in_scale, const float* in_shift, int in_act,
+                         void* dA, float* part, mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K12  fused losses + gradients (keypoints_model.py:43-90,141-178).
+ * losses_out[8] = focal, regression, seg@2, seg@3, seg@4, seg@5, total, per_pixel_reg_loss.
+ * dlogits / daux* may be NULL (evaluation). part: [mpn_keypoint_loss_num_parts()][8].
+ */
+int mpn_keypoint_loss_num_parts(int B, int h, int w);
+int mpn_keypoint_loss(const float* logits, const float* heatmaps, const float* loss_masks,
+                      const float* segmentation_masks, const int* num_boxes, const void* p2,
+                      const void* p3, const void* p4, const void* p5, int p_channels, int p_dtype,
+                      float* dlogits, float* daux2, float* daux3, float* daux4, float* daux5,
+                      float* part, float* losses_out, int B, int h, int w, mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * K13  optimizer step (keypoints_model.py:107-120): cosine-decayed learning rate,
+ * tf.clip_by_value(g,-200,200), TF-1.15 Adam over a flat f32 arena. `step` (device int64 global
+ * step, incremented by mpn_adam_prepare) and `hyper` (device f32[4]: lr_t, lr) stay on the
+ * device so the whole step replays from a hipGraph.
+ */
+int mpn_adam_prepare(long long* step, float* hyper, double initial_learning_rate,
+                     double decay_steps, double alpha, double beta1, double beta2,
+                     mpn_stream_t stream);
+int mpn_adam_step(float* params, const float* grads, float* m, float* v, long long n,
+                  const float* hyper, float beta1, float beta2, float eps, float clip,
+                  float grad_scale, mpn_stream_t stream);
+/* out[j] (+)= scale * sum_p part[p][j] in a fixed order (deterministic) */
+int mpn_reduce_partials(const float* part, int nparts, long long n, float* out, int accumulate,
+                        float scale, mpn_stream_t stream);
+int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

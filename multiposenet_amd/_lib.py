@@ -26,6 +26,39 @@ SIGNATURES = {
     "mpn_last_error": (_I, [_c.c_char_p, _Z]),
     "mpn_heatmap_decode_workspace_bytes": (_Z, [_I]),
     "mpn_heatmap_decode": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _Z, _P]),
+    "mpn_conv_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
+    "mpn_conv_pack_weights": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "mpn_conv_num_parts": (_I, [_I, _I, _I, _I]),
+    "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "mpn_bn_stats_num_parts": (_I, [_L]),
+    "mpn_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
+    "mpn_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
+    "mpn_bn_inference_affine": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
+    "mpn_bn_act_apply": (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P]),
+    "mpn_bn_bwd_reduce": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mpn_bn_bwd_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P]),
+    "mpn_bn_bwd_apply": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "mpn_dwconv_out_size": (_I, [_I, _I]),
+    "mpn_dwconv_num_parts": (_I, [_I, _I, _I, _I]),
+    "mpn_dwconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    "mpn_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mpn_dwconv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I]),
+    "mpn_dwconv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "mpn_stem_conv_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mpn_stem_conv_wgrad_num_parts": (_I, [_I, _I, _I]),
+    "mpn_stem_conv_bwd_weight": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "mpn_bilinear_up_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "mpn_bilinear_up_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mpn_sumpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mpn_heatmap_head_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
+    "mpn_heatmap_head_bwd_num_parts": (_I, [_L]),
+    "mpn_heatmap_head_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "mpn_keypoint_loss_num_parts": (_I, [_I, _I, _I]),
+    "mpn_keypoint_loss": (_I, [_P] * 9 + [_I, _I] + [_P] * 7 + [_I, _I, _I, _P]),
+    "mpn_adam_prepare": (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),
+    "mpn_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
+    "mpn_reduce_partials": (_I, [_P, _I, _L, _P, _I, _F, _P]),
+    "mpn_axpy": (_I, [_L, _F, _P, _P, _P]),
 }
 
 _lib = None

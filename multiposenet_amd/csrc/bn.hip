@@ -1,0 +1,386 @@
+// K4: fused batch normalisation pieces (training and inference), NHWC.
+// Replaces tf.layers.batch_normalization(fused=True) at detector/backbones/mobilenet_v1.py:29-38
+// and detector/utils/layer_utils.py:9-16 (momentum 0.95, eps 1e-3).
+//
+// Design: a conv kernel writes its RAW output once plus per-tile partial sums; bn_finalize
+// turns the partials into a per-channel affine (scale, shift) and updates the moving
+// statistics; every CONSUMER applies `act(x*scale+shift)` while loading (conv_mfma, dwconv,
+// bilinear, head), so normalised activations never make a round trip through HBM.
+// Backward: bn_bwd_reduce (sum g, sum g*xhat with the activation mask folded in),
+// bn_bwd_finalize (dgamma, dbeta, per-channel coefficients), bn_bwd_apply (dx, in place).
+// All reductions are deterministic: partial slabs + fixed-order f64 finalisation, no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// thread -> (row lane, channel vector) mapping shared by the streaming kernels below
+struct RowMap {
+    int cvec;   // 16-byte vectors per row
+    int ppb;    // rows processed per pass by one block
+    int vg;     // this thread's channel vector
+    int prow;   // this thread's row lane
+    bool active;
+};
+__device__ __forceinline__ RowMap make_rowmap(int C, int VE) {
+    RowMap m;
+    m.cvec = C / VE;
+    m.ppb = kThreads / m.cvec;
+    if (m.ppb < 1) m.ppb = 1;
+    m.vg = threadIdx.x % m.cvec;
+    m.prow = threadIdx.x / m.cvec;
+    m.active = m.prow < m.ppb;
+    return m;
+}
+
+// Block-level reduction of NV per-thread values over threads that share a channel vector.
+// out (per block) is written by the first `cvec` threads: part[which][c].
+template <int NV, int VE>
+__device__ __forceinline__ void block_reduce_store(const RowMap& m, float (&v)[NV][VE], float* smem,
+                                                   float* __restrict__ dst, long long which_stride) {
+    // smem: [kThreads][NV*VE]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < VE; ++j) smem[threadIdx.x * (NV * VE) + k * VE + j] = m.active ? v[k][j] : 0.f;
+    __syncthreads();
+    if ((int)threadIdx.x < m.cvec) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                float t = 0.f;
+                for (int r = 0; r < m.ppb; ++r) t += smem[(r * m.cvec + m.vg) * (NV * VE) + k * VE + j];
+                dst[k * which_stride + m.vg * VE + j] = t;
+            }
+    }
+}
+
+// ---------------------------------------------------------------- forward statistics (standalone)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict__ x, long long M, int C,
+                                                            float* __restrict__ part, int rows_per_block) {
+    constexpr int VE = Vec16<T>::N;
+    __shared__ float smem[kThreads * 2 * VE];
+    const RowMap m = make_rowmap(C, VE);
+    float acc[2][VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { acc[0][j] = 0.f; acc[1][j] = 0.f; }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    if (m.active) {
+        for (long long r = r0 + m.prow; r < r1; r += m.ppb) {
+            Vec16<T> v;
+            v.load(x + r * C + m.vg * VE);
+            float f[VE];
+            v.unpack(f);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) { acc[0][j] += f[j]; acc[1][j] += f[j] * f[j]; }
+        }
+    }
+    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C);
+}
+
+// ---------------------------------------------------------------- finalize
+// part [nparts][2][C] -> mean, biased var -> scale/shift (+ moving-average update with the
+// unbiased variance, TF-1.15 fused batch-norm semantic). 16 channels x 16 part-lanes per block.
+__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(
+    const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
+    float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int p = pl; p < nparts; p += 16) {
+            s += (double)part[((long long)p * 2 + 0) * C + c];
+            q += (double)part[((long long)p * 2 + 1) * C + c];
+        }
+    }
+    red[0][pl][cl] = s;
+    red[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        s = 0.0; q = 0.0;
+        for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        if (save_mean) save_mean[c] = (float)mean;
+        if (save_invstd) save_invstd[c] = invstd;
+        if (mov_mean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            mov_mean[c] = mov_mean[c] * momentum + (float)mean * (1.f - momentum);
+            mov_var[c] = mov_var[c] * momentum + (float)unbiased * (1.f - momentum);
+        }
+    }
+}
+
+__global__ void bn_inference_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ mov_mean, const float* __restrict__ mov_var,
+                                    float eps, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * (1.0f / sqrtf(mov_var[c] + eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - mov_mean[c] * sc;
+}
+
+// ---------------------------------------------------------------- materialise act(x*scale+shift)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_act_apply_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                                long long nvec, int C,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int act) {
+    constexpr int VE = Vec16<T>::N;
+    const int cvec = C / VE;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long long)gridDim.x * kThreads) {
+        const int c0 = (int)(i % cvec) * VE;
+        Vec16<T> v;
+        v.load(x + i * VE);
+        float f[VE];
+        v.unpack(f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            float t = f[j] * scale[c0 + j] + shift[c0 + j];
+            if (act != MPN_ACT_NONE) t = fmaxf(t, 0.f);
+            if (act == MPN_ACT_RELU6) t = fminf(t, 6.f);
+            f[j] = t;
+        }
+        v.pack(f);
+        v.store(y + i * VE);
+    }
+}
+
+// ---------------------------------------------------------------- backward
+// g = dA * act'(x*scale+shift);  partials of sum(g) and sum(g*xhat), xhat = (x-mean)*invstd
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
+    const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+    float* __restrict__ part, int rows_per_block) {
+    constexpr int VE = Vec16<T>::N;
+    __shared__ float smem[kThreads * 2 * VE];
+    const RowMap m = make_rowmap(C, VE);
+    float acc[2][VE];
+    float sc[VE], sh[VE], mu[VE], is[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+        acc[0][j] = 0.f; acc[1][j] = 0.f;
+        const int c = m.vg * VE + j;
+        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+    }
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    if (m.active) {
+        for (long long r = r0 + m.prow; r < r1; r += m.ppb) {
+            Vec16<T> vd, vx;
+            vd.load(dA + r * C + m.vg * VE);
+            vx.load(x + r * C + m.vg * VE);
+            float d[VE], f[VE];
+            vd.unpack(d);
+            vx.unpack(f);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                const float pre = f[j] * sc[j] + sh[j];
+                bool pass = true;
+                if (act != MPN_ACT_NONE) pass = pre > 0.f;
+                if (act == MPN_ACT_RELU6) pass = pass && (pre < 6.f);
+                const float g = pass ? d[j] : 0.f;
+                acc[0][j] += g;
+                acc[1][j] += g * ((f[j] - mu[j]) * is[j]);
+            }
+        }
+    }
+    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C);
+}
+
+// part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
+__global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                                   double count, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta,
+                                                                   float* __restrict__ k1, float* __restrict__ k2) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C) {
+        for (int p = pl; p < nparts; p += 16) {
+            s += (double)part[((long long)p * 2 + 0) * C + c];
+            q += (double)part[((long long)p * 2 + 1) * C + c];
+        }
+    }
+    red[0][pl][cl] = s;
+    red[1][pl][cl] = q;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        s = 0.0; q = 0.0;
+        for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+        k1[c] = (float)(s / count);
+        k2[c] = (float)(q / count);
+    }
+}
+
+// dx = scale * (g - k1 - xhat*k2), written over dA (same storage type); optional extra gradient
+// added to channel 0 (the auxiliary segmentation loss on p_l[...,0], keypoints_model.py:59-66).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+    T* __restrict__ dA, const T* __restrict__ x, long long nvec, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ k1, const float* __restrict__ k2, int act, const float* __restrict__ add_ch0) {
+    constexpr int VE = Vec16<T>::N;
+    const int cvec = C / VE;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long long)gridDim.x * kThreads) {
+        const int vg = (int)(i % cvec);
+        const int c0 = vg * VE;
+        Vec16<T> vd, vx;
+        vd.load(dA + i * VE);
+        vx.load(x + i * VE);
+        float d[VE], f[VE];
+        vd.unpack(d);
+        vx.unpack(f);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            const int c = c0 + j;
+            const float sc = scale[c];
+            const float pre = f[j] * sc + shift[c];
+            bool pass = true;
+            if (act != MPN_ACT_NONE) pass = pre > 0.f;
+            if (act == MPN_ACT_RELU6) pass = pass && (pre < 6.f);
+            const float g = pass ? d[j] : 0.f;
+            const float xhat = (f[j] - mean[c]) * invstd[c];
+            d[j] = sc * (g - k1[c] - xhat * k2[c]);
+        }
+        if (add_ch0 != nullptr && vg == 0) d[0] += add_ch0[i / cvec];
+        vd.pack(d);
+        vd.store(dA + i * VE);
+    }
+}
+
+int stream_blocks(long long nvec) {
+    long long b = (nvec + kThreads - 1) / kThreads;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+int check_rows(long long M, int C, int dtype, int* ve_out) {
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "bn: dtype %d", dtype);
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    MPN_REQUIRE(M > 0 && C > 0 && C % ve == 0, MPN_ERR_BAD_SHAPE, "bn: C (%d) must be a multiple of %d", C, ve);
+    MPN_REQUIRE(C / ve <= kThreads, MPN_ERR_BAD_SHAPE, "bn: C too large (%d)", C);
+    *ve_out = ve;
+    return MPN_OK;
+}
+
+}  // namespace
+
+extern "C" int mpn_bn_stats_num_parts(long long M) {
+    // ~1024 rows per block, at most 2048 blocks
+    long long rows = 1024;
+    long long parts = (M + rows - 1) / rows;
+    if (parts > 2048) parts = 2048;
+    if (parts < 1) parts = 1;
+    return (int)parts;
+}
+
+static long long rows_per_block_for(long long M, int nparts) { return (M + nparts - 1) / nparts; }
+
+extern "C" int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream) {
+    int ve;
+    if (int rc = check_rows(M, C, dtype, &ve)) return rc;
+    MPN_REQUIRE(x && part, MPN_ERR_BAD_ARG, "bn_stats: null pointer");
+    const int nparts = mpn_bn_stats_num_parts(M);
+    const int rpb = (int)rows_per_block_for(M, nparts);
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (bn_stats_kernel<T><<<nparts, kThreads, 0, st>>>((const T*)x, M, C, part, rpb)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
+                               const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                               float* scale, float* shift, float* save_mean, float* save_invstd,
+                               mpn_stream_t stream) {
+    MPN_REQUIRE(part && gamma && beta && scale && shift, MPN_ERR_BAD_ARG, "bn_finalize: null pointer");
+    MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_finalize: bad sizes");
+    MPN_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), MPN_ERR_BAD_ARG, "bn_finalize: moving stats");
+    bn_finalize_kernel<<<(C + 15) / 16, kThreads, 0, (hipStream_t)stream>>>(
+        part, nparts, C, (double)count, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift, save_mean,
+        save_invstd);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_bn_inference_affine(int C, const float* gamma, const float* beta, const float* moving_mean,
+                                       const float* moving_var, float eps, float* scale, float* shift,
+                                       mpn_stream_t stream) {
+    MPN_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift, MPN_ERR_BAD_ARG, "bn_inference: null");
+    MPN_REQUIRE(C > 0, MPN_ERR_BAD_SHAPE, "bn_inference: C");
+    bn_inference_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(C, gamma, beta, moving_mean, moving_var, eps,
+                                                                        scale, shift);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_bn_act_apply(const void* x, void* y, long long M, int C, int dtype, const float* scale,
+                                const float* shift, int act, mpn_stream_t stream) {
+    int ve;
+    if (int rc = check_rows(M, C, dtype, &ve)) return rc;
+    MPN_REQUIRE(x && y && scale && shift, MPN_ERR_BAD_ARG, "bn_act_apply: null pointer");
+    const long long nvec = M * (C / ve);
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (bn_act_apply_kernel<T><<<stream_blocks(nvec), kThreads, 0, st>>>(
+                                  (const T*)x, (T*)y, nvec, C, scale, shift, act)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dtype, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd, int act, float* part,
+                                 mpn_stream_t stream) {
+    int ve;
+    if (int rc = check_rows(M, C, dtype, &ve)) return rc;
+    MPN_REQUIRE(dA && x && scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "bn_bwd_reduce: null pointer");
+    const int nparts = mpn_bn_stats_num_parts(M);
+    const int rpb = (int)rows_per_block_for(M, nparts);
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (bn_bwd_reduce_kernel<T><<<nparts, kThreads, 0, st>>>(
+                                  (const T*)dA, (const T*)x, M, C, scale, shift, mean, invstd, act, part, rpb)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
+                                   float* dbeta, float* k1, float* k2, mpn_stream_t stream) {
+    MPN_REQUIRE(part && dgamma && dbeta && k1 && k2, MPN_ERR_BAD_ARG, "bn_bwd_finalize: null pointer");
+    MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_bwd_finalize: bad sizes");
+    bn_bwd_finalize_kernel<<<(C + 15) / 16, kThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
+                                                                               dgamma, dbeta, k1, k2);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_bn_bwd_apply(void* dA, const void* x, long long M, int C, int dtype, const float* scale,
+                                const float* shift, const float* mean, const float* invstd, const float* k1,
+                                const float* k2, int act, const float* add_ch0, mpn_stream_t stream) {
+    int ve;
+    if (int rc = check_rows(M, C, dtype, &ve)) return rc;
+    MPN_REQUIRE(dA && x && scale && shift && mean && invstd && k1 && k2, MPN_ERR_BAD_ARG, "bn_bwd_apply: null pointer");
+    const long long nvec = M * (C / ve);
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<stream_blocks(nvec), kThreads, 0, st>>>(
+                                  (T*)dA, (const T*)x, nvec, C, scale, shift, mean, invstd, k1, k2, act, add_ch0)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}

@@ -1,0 +1,411 @@
+// K3: depthwise 3x3 convolution (TF 'SAME' padding, stride 1 or 2), NHWC, fwd / dgrad / wgrad.
+// Replaces tf.nn.depthwise_conv2d at detector/backbones/mobilenet_v1.py:101 (weights
+// `depthwise_weights` [3,3,C,1] == [9][C] in memory) and its gradients.
+//
+// HBM-bound (9 MAC per 2-4 bytes): every input element is fetched from HBM once per tile with
+// 16-byte channel-vector loads that are coalesced across the lanes of a pixel (NHWC), the
+// producer's batch-norm affine + ReLU6 is applied on the way into an LDS halo tile (f32), and
+// each thread then produces 16 bytes of output channels for a few pixels out of LDS.
+// The following batch-norm's partial statistics come out of the same pass (wave shuffles over
+// the lanes that share a channel vector, then one LDS hop across the 4 waves).
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+template <int STRIDE> struct DwTile;
+template <> struct DwTile<1> { static constexpr int TH = 8, TW = 8, HH = 10, HW = 10; };
+template <> struct DwTile<2> { static constexpr int TH = 4, TW = 8, HH = 9, HW = 17; };
+
+struct DwParams {
+    const void* x;      // input  [N,H,W,C]
+    const float* w;     // [9][C]
+    void* y;            // output [N,OH,OW,C]
+    const void* dy;     // wgrad: output gradient [N,OH,OW,C]
+    float* part;        // fwd: stats partials [nparts][2][C]; wgrad: [nblk][9][C]
+    const float* in_scale;
+    const float* in_shift;
+    int in_act;
+    int flip;           // use w[8-t] (stride-1 dgrad)
+    int N, H, W, C, OH, OW;
+    int pad_t, pad_l;
+    int tiles_x, tiles_y;
+    int nvg;            // channel vectors handled per block (<= 8)
+    int cblocks;        // channel blocks
+};
+
+// reduce over the lanes/waves that share this thread's channel vector; result valid in threads
+// with pt == 0 (pixel lane 0). nvg is a power of two <= 8.
+template <int NV>
+__device__ __forceinline__ void reduce_same_vg(float (&v)[NV], int nvg, float* smem /*[4][8][NV]*/) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+        for (int o = nvg; o < 64; o <<= 1) v[k] += __shfl_xor(v[k], o, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane < nvg)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) smem[(wave * 8 + lane) * NV + k] = v[k];
+    __syncthreads();
+    if ((int)threadIdx.x < nvg)
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+            v[k] = smem[(0 * 8 + lane) * NV + k] + smem[(1 * 8 + lane) * NV + k] + smem[(2 * 8 + lane) * NV + k] +
+                   smem[(3 * 8 + lane) * NV + k];
+}
+
+// stage the (affine+activated) input halo tile of one (image, tile, channel block) into LDS as f32
+template <typename T, int STRIDE>
+__device__ __forceinline__ void stage_halo(const DwParams& p, float* tile, int img, int oy0, int ox0, int c0,
+                                           int cb_vecs) {
+    using TL = DwTile<STRIDE>;
+    constexpr int VE = Vec16<T>::N;
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const int total = TL::HH * TL::HW * p.nvg;
+    const int iy0 = oy0 * STRIDE - p.pad_t, ix0 = ox0 * STRIDE - p.pad_l;
+    for (int i = threadIdx.x; i < total; i += kThreads) {
+        const int vg = i % p.nvg;
+        const int hp = i / p.nvg;
+        const int hy = hp / TL::HW, hx = hp - hy * TL::HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        float f[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) f[j] = 0.f;
+        if (vg < cb_vecs && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+            Vec16<T> v;
+            v.load(x + (((long long)img * p.H + iy) * p.W + ix) * p.C + c0 + vg * VE);
+            v.unpack(f);
+            if (p.in_scale != nullptr) {
+#pragma unroll
+                for (int j = 0; j < VE; ++j) {
+                    float t = f[j] * p.in_scale[c0 + vg * VE + j] + p.in_shift[c0 + vg * VE + j];
+                    if (p.in_act != MPN_ACT_NONE) t = fmaxf(t, 0.f);
+                    if (p.in_act == MPN_ACT_RELU6) t = fminf(t, 6.f);
+                    f[j] = t;
+                }
+            }
+        }
+        float* dst = tile + (hp * p.nvg + vg) * VE;
+#pragma unroll
+        for (int j = 0; j < VE; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+    }
+}
+
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(kThreads) void dwconv_fwd_kernel(const DwParams p) {
+    using TL = DwTile<STRIDE>;
+    constexpr int VE = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* tile = smem_f;                                   // [HH*HW][nvg*VE]
+    float* red = smem_f + TL::HH * TL::HW * 8 * VE;         // [4][8][2*VE]
+
+    int b = blockIdx.x;
+    const int cb = b % p.cblocks; b /= p.cblocks;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int img = b / p.tiles_y;
+    const int part_idx = (img * p.tiles_y + ty) * p.tiles_x + tx;
+    const int oy0 = ty * TL::TH, ox0 = tx * TL::TW;
+    const int c0 = cb * p.nvg * VE;
+    const int cb_vecs = min(p.nvg, (p.C - c0) / VE);
+
+    stage_halo<T, STRIDE>(p, tile, img, oy0, ox0, c0, cb_vecs);
+    __syncthreads();
+
+    const int vg = threadIdx.x % p.nvg;
+    const int pt = threadIdx.x / p.nvg;
+    const int npt = kThreads / p.nvg;
+    const bool vg_ok = vg < cb_vecs;
+    float wr[9][VE];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < VE; ++j)
+            wr[t][j] = vg_ok ? p.w[(p.flip ? 8 - t : t) * p.C + c0 + vg * VE + j] : 0.f;
+
+    float st[2 * VE];
+#pragma unroll
+    for (int j = 0; j < 2 * VE; ++j) st[j] = 0.f;
+    T* __restrict__ y = reinterpret_cast<T*>(p.y);
+
+    for (int op = pt; op < TL::TH * TL::TW; op += npt) {
+        const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        float acc[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float* src = tile + (((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * p.nvg + vg) * VE;
+#pragma unroll
+                for (int j = 0; j < VE; j += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(src + j);
+                    acc[j] += q.x * wr[ky * 3 + kx][j];
+                    acc[j + 1] += q.y * wr[ky * 3 + kx][j + 1];
+                    acc[j + 2] += q.z * wr[ky * 3 + kx][j + 2];
+                    acc[j + 3] += q.w * wr[ky * 3 + kx][j + 3];
+                }
+            }
+        if (vg_ok && oy < p.OH && ox < p.OW) {
+#pragma unroll
+            for (int j = 0; j < VE; ++j) { st[j] += acc[j]; st[VE + j] += acc[j] * acc[j]; }
+            Vec16<T> ov;
+            ov.pack(acc);
+            ov.store(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + vg * VE);
+        }
+    }
+    if (p.part != nullptr) {
+        reduce_same_vg<2 * VE>(st, p.nvg, red);
+        if ((int)threadIdx.x < cb_vecs) {
+            float* dst = p.part + (long long)part_idx * 2 * p.C + c0 + vg * VE;
+#pragma unroll
+            for (int j = 0; j < VE; ++j) { dst[j] = st[j]; dst[p.C + j] = st[VE + j]; }
+        }
+    }
+}
+
+// stride-2 data gradient (gather form): dx[iy,ix,c] = sum_{ky,kx} dy[(iy+pt-ky)/2,(ix+pl-kx)/2,c]*w[ky,kx,c]
+// over the taps for which the division is exact. One thread = one input pixel x 16 bytes of channels.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                                   T* __restrict__ dx, int N, int H, int W, int C, int OH,
+                                                                   int OW, int pad_t, int pad_l, long long total_vec) {
+    constexpr int VE = Vec16<T>::N;
+    const int cvec = C / VE;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total_vec;
+         i += (long long)gridDim.x * kThreads) {
+        const int vg = (int)(i % cvec);
+        long long r = i / cvec;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int n = (int)(r / H);
+        float acc[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + pad_t - ky;
+            if (ty < 0 || (ty & 1) || (ty >> 1) >= OH) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + pad_l - kx;
+                if (tx < 0 || (tx & 1) || (tx >> 1) >= OW) continue;
+                Vec16<T> v;
+                v.load(dy + (((long long)n * OH + (ty >> 1)) * OW + (tx >> 1)) * C + vg * VE);
+                float f[VE];
+                v.unpack(f);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) acc[j] += f[j] * w[(ky * 3 + kx) * C + vg * VE + j];
+            }
+        }
+        Vec16<T> ov;
+        ov.pack(acc);
+        ov.store(dx + i * VE);
+    }
+}
+
+// weight gradient: dw[t][c] = sum a[n, oy*S+ky-pt, ox*S+kx-pl, c] * dy[n,oy,ox,c].
+// Blocks walk many tiles of one channel block with the 9 x VE accumulators in registers and reduce once.
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(kThreads) void dwconv_wgrad_kernel(const DwParams p, int nsplit) {
+    using TL = DwTile<STRIDE>;
+    constexpr int VE = Vec16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    float* tile = smem_f;
+    float* red = smem_f + TL::HH * TL::HW * 8 * VE;  // [4][8][9*VE]
+
+    const int cb = blockIdx.x % p.cblocks;
+    const int split = blockIdx.x / p.cblocks;
+    const int c0 = cb * p.nvg * VE;
+    const int cb_vecs = min(p.nvg, (p.C - c0) / VE);
+    const int vg = threadIdx.x % p.nvg;
+    const int pt = threadIdx.x / p.nvg;
+    const int npt = kThreads / p.nvg;
+    const bool vg_ok = vg < cb_vecs;
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+
+    float acc[9 * VE];
+#pragma unroll
+    for (int j = 0; j < 9 * VE; ++j) acc[j] = 0.f;
+
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    for (int t = split; t < ntiles; t += nsplit) {
+        const int tx = t % p.tiles_x;
+        const int t2 = t / p.tiles_x;
+        const int ty = t2 % p.tiles_y;
+        const int img = t2 / p.tiles_y;
+        const int oy0 = ty * TL::TH, ox0 = tx * TL::TW;
+        __syncthreads();
+        stage_halo<T, STRIDE>(p, tile, img, oy0, ox0, c0, cb_vecs);
+        __syncthreads();
+        for (int op = pt; op < TL::TH * TL::TW; op += npt) {
+            const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
+            const int oy = oy0 + oyl, ox = ox0 + oxl;
+            if (!(vg_ok && oy < p.OH && ox < p.OW)) continue;
+            Vec16<T> gv;
+            gv.load(dy + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + vg * VE);
+            float g[VE];
+            gv.unpack(g);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float* src = tile + (((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * p.nvg + vg) * VE;
+#pragma unroll
+                    for (int j = 0; j < VE; j += 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(src + j);
+                        acc[(ky * 3 + kx) * VE + j] += q.x * g[j];
+                        acc[(ky * 3 + kx) * VE + j + 1] += q.y * g[j + 1];
+                        acc[(ky * 3 + kx) * VE + j + 2] += q.z * g[j + 2];
+                        acc[(ky * 3 + kx) * VE + j + 3] += q.w * g[j + 3];
+                    }
+                }
+        }
+    }
+    reduce_same_vg<9 * VE>(acc, p.nvg, red);
+    if ((int)threadIdx.x < cb_vecs) {
+        float* dst = p.part + (long long)split * 9 * p.C + c0 + vg * VE;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < VE; ++j) dst[t * p.C + j] = acc[t * VE + j];
+    }
+}
+
+void tf_same_pad(int size, int stride, int* out, int* pad_before) {
+    *out = (size + stride - 1) / stride;
+    int total = (*out - 1) * stride + 3 - size;
+    if (total < 0) total = 0;
+    *pad_before = total / 2;
+}
+
+int fill_params(DwParams& p, int N, int H, int W, int C, int stride, int dtype) {
+    MPN_REQUIRE(stride == 1 || stride == 2, MPN_ERR_BAD_SHAPE, "dwconv: stride must be 1 or 2");
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "dwconv: dtype %d", dtype);
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    MPN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0, MPN_ERR_BAD_SHAPE,
+                "dwconv: C (%d) must be a multiple of %d", C, ve);
+    p.N = N; p.H = H; p.W = W; p.C = C;
+    tf_same_pad(H, stride, &p.OH, &p.pad_t);
+    tf_same_pad(W, stride, &p.OW, &p.pad_l);
+    const int th = stride == 1 ? 8 : 4, tw = 8;
+    p.tiles_y = (p.OH + th - 1) / th;
+    p.tiles_x = (p.OW + tw - 1) / tw;
+    int nvg = 8;
+    while (nvg > C / ve) nvg >>= 1;
+    p.nvg = nvg;
+    p.cblocks = (C / ve + nvg - 1) / nvg;
+    return MPN_OK;
+}
+
+template <int STRIDE> size_t dw_smem(int ve, int nred) {
+    using TL = DwTile<STRIDE>;
+    return (size_t)(TL::HH * TL::HW * 8 * ve + 4 * 8 * nred) * sizeof(float);
+}
+
+template <typename K> int set_smem(K kernel, size_t bytes) {
+    if (bytes > 48 * 1024)
+        MPN_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MPN_OK;
+}
+
+}  // namespace
+
+extern "C" int mpn_dwconv_out_size(int size, int stride) { return (size + stride - 1) / stride; }
+
+extern "C" int mpn_dwconv_num_parts(int N, int H, int W, int stride) {
+    const int oh = (H + stride - 1) / stride, ow = (W + stride - 1) / stride;
+    const int th = stride == 1 ? 8 : 4;
+    return N * ((oh + th - 1) / th) * ((ow + 7) / 8);
+}
+
+extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
+                              int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
+                              float* stats_part, mpn_stream_t stream) {
+    DwParams p = {};
+    if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
+    MPN_REQUIRE(x && w && y, MPN_ERR_BAD_ARG, "dwconv_fwd: null pointer");
+    MPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), MPN_ERR_BAD_ARG, "dwconv_fwd: scale/shift mismatch");
+    p.x = x; p.w = w; p.y = y; p.part = stats_part;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.flip = flip;
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    const int grid = N * p.tiles_y * p.tiles_x * p.cblocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1) {
+        const size_t sm = dw_smem<1>(ve, 2 * ve);
+        MPN_DISPATCH_DTYPE(dtype, {
+            if (int rc = set_smem(dwconv_fwd_kernel<T, 1>, sm)) return rc;
+            dwconv_fwd_kernel<T, 1><<<grid, kThreads, sm, st>>>(p);
+        });
+    } else {
+        const size_t sm = dw_smem<2>(ve, 2 * ve);
+        MPN_DISPATCH_DTYPE(dtype, {
+            if (int rc = set_smem(dwconv_fwd_kernel<T, 2>, sm)) return rc;
+            dwconv_fwd_kernel<T, 2><<<grid, kThreads, sm, st>>>(p);
+        });
+    }
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* data gradient: dy [N,OH,OW,C] -> dx [N,H,W,C] (H, W = the forward INPUT size) */
+extern "C" int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
+                                   int dtype, mpn_stream_t stream) {
+    if (stride == 1)  // correlation with the flipped kernel, pad 1
+        return mpn_dwconv_fwd(dy, w, dx, N, H, W, C, 1, dtype, nullptr, nullptr, MPN_ACT_NONE, 1, nullptr, stream);
+    DwParams p = {};
+    if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
+    MPN_REQUIRE(dy && w && dx, MPN_ERR_BAD_ARG, "dwconv_bwd_data: null pointer");
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    const long long total_vec = (long long)N * H * W * (C / ve);
+    long long blocks = (total_vec + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_kernel<T><<<(int)blocks, kThreads, 0, st>>>(
+                                  (const T*)dy, w, (T*)dx, N, H, W, C, p.OH, p.OW, p.pad_t, p.pad_l, total_vec)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_dwconv_wgrad_num_parts(int N, int H, int W, int C, int stride, int dtype) {
+    DwParams p = {};
+    if (fill_params(p, N, H, W, C, stride, dtype)) return 0;
+    const int ntiles = N * p.tiles_y * p.tiles_x;
+    int nsplit = 2048 / p.cblocks;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    return nsplit;
+}
+
+/* weight gradient partials: part [mpn_dwconv_wgrad_num_parts][9][C]; reduce with mpn_reduce_partials */
+extern "C" int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int C,
+                                     int stride, int dtype, const float* in_scale, const float* in_shift, int in_act,
+                                     mpn_stream_t stream) {
+    DwParams p = {};
+    if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
+    MPN_REQUIRE(x && dy && part, MPN_ERR_BAD_ARG, "dwconv_bwd_weight: null pointer");
+    p.x = x; p.dy = dy; p.part = part;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    const int nsplit = mpn_dwconv_wgrad_num_parts(N, H, W, C, stride, dtype);
+    const int grid = nsplit * p.cblocks;
+    hipStream_t st = (hipStream_t)stream;
+    if (stride == 1) {
+        const size_t sm = dw_smem<1>(ve, 9 * ve);
+        MPN_DISPATCH_DTYPE(dtype, {
+            if (int rc = set_smem(dwconv_wgrad_kernel<T, 1>, sm)) return rc;
+            dwconv_wgrad_kernel<T, 1><<<grid, kThreads, sm, st>>>(p, nsplit);
+        });
+    } else {
+        const size_t sm = dw_smem<2>(ve, 9 * ve);
+        MPN_DISPATCH_DTYPE(dtype, {
+            if (int rc = set_smem(dwconv_wgrad_kernel<T, 2>, sm)) return rc;
+            dwconv_wgrad_kernel<T, 2><<<grid, kThreads, sm, st>>>(p, nsplit);
+        });
+    }
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}

@@ -1,0 +1,168 @@
+// K12: fused keypoint losses, forward + gradient in one pass over the logits.
+// Replaces keypoints_model.py:43-79 and focal_loss :141-178:
+//   focal (CornerNet, alpha 2 / beta 4, on logits, / (num_boxes+1), * loss_mask, / batch),
+//   1e-3 * l2_loss(loss_mask*(seg_pred - seg)) / batch,
+//   for level l = 2..5: 1e-5 * l2_loss(mask_l*(p_l[...,0] - seg_l)) / batch with both masks
+//   subsampled [::2] per level (the legacy resize_bilinear to [h//2, w//2] is exactly that),
+//   and the eval metric per_pixel_reg_loss (:81-90).  tf.nn.l2_loss(t) = sum(t^2)/2.
+// Outputs d(total)/d(logits) and d(total)/d(p_l[...,0]). Deterministic block partials.
+#include "common.h"
+
+namespace {
+constexpr int kThreads = 256;
+constexpr int kNL = 8;  // focal, regression, seg2..seg5, total(unused here), per_pixel_reg
+
+struct LossParams {
+    const float* logits;   // [B,h,w,18]
+    const float* heat;     // [B,h,w,17]
+    const float* lmask;    // [B,h,w]
+    const float* smask;    // [B,h,w]
+    const int* num_boxes;  // [B]
+    const void* p[4];      // p2..p5 raw FPN outputs [B,h>>k,w>>k,Cp]
+    int Cp;
+    float* dlogits;        // [B,h,w,18] or null
+    float* daux[4];        // [B,h>>k,w>>k] or null
+    float* part;           // [nblocks][8]
+    int B, h, w;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void loss_kernel(const LossParams q) {
+    __shared__ float red[kThreads / 64][kNL];
+    float acc[kNL];
+#pragma unroll
+    for (int k = 0; k < kNL; ++k) acc[k] = 0.f;
+    const long long npix = (long long)q.B * q.h * q.w;
+    const float invb = 1.0f / (float)q.B;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < npix; i += (long long)gridDim.x * kThreads) {
+        const int x = (int)(i % q.w);
+        const long long r = i / q.w;
+        const int y = (int)(r % q.h);
+        const int b = (int)(r / q.h);
+        const float lm = q.lmask[i], sg = q.smask[i];
+        const float norm = 1.0f / ((float)q.num_boxes[b] + 1.0f);
+        const float* lg = q.logits + i * 18;
+        const float* hm = q.heat + i * 17;
+        float fsum = 0.f, ppr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 17; ++c) {
+            const float xl = lg[c], yv = hm[c];
+            const float e = expf(-fabsf(xl));
+            const float sp = log1pf(e);                          // log(1+exp(-|x|))
+            const float p = xl >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);   // sigmoid(x)
+            const bool pos = (yv == 1.0f);
+            float wgt, ce, dwdx, dcedx;
+            if (pos) {
+                ce = fmaxf(xl, 0.f) - xl + sp;                   // -log p
+                const float omp = 1.0f - p;
+                wgt = omp * omp;
+                dwdx = -2.0f * omp * p * omp;                    // d (1-p)^2 / dx
+                dcedx = p - 1.0f;
+            } else {
+                ce = fmaxf(xl, 0.f) + sp;                        // -log(1-p)
+                const float omy = 1.0f - yv;
+                const float b4 = (omy * omy) * (omy * omy);
+                wgt = b4 * p * p;
+                dwdx = b4 * 2.0f * p * p * (1.0f - p);
+                dcedx = p;
+            }
+            fsum += wgt * ce;
+            if (q.dlogits) q.dlogits[i * 18 + c] = (dwdx * ce + wgt * dcedx) * norm * lm * invb;
+            const float d = lm * (p - yv);
+            ppr += d * d;
+        }
+        acc[0] += lm * fsum * norm;
+        acc[7] += ppr;
+        {
+            const float d = lm * (lg[17] - sg);
+            acc[1] += d * d;
+            if (q.dlogits) q.dlogits[i * 18 + 17] = 1e-3f * lm * d * invb;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int mk = (1 << k) - 1;
+            if ((y & mk) == 0 && (x & mk) == 0 && q.p[k] != nullptr) {
+                const int hk = q.h >> k, wk = q.w >> k;
+                const int yk = y >> k, xk = x >> k;
+                if (yk < hk && xk < wk) {
+                    const long long pi = ((long long)b * hk + yk) * wk + xk;
+                    const float v = to_f32(reinterpret_cast<const T*>(q.p[k])[pi * q.Cp]);
+                    const float d = lm * (v - sg);
+                    acc[2 + k] += d * d;
+                    if (q.daux[k]) q.daux[k][pi] = 1e-5f * lm * d * invb;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kNL; ++k) acc[k] = wave_sum(acc[k]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < kNL; ++k) red[wave][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < kNL) {
+        float s = 0.f;
+        for (int wv = 0; wv < kThreads / 64; ++wv) s += red[wv][threadIdx.x];
+        q.part[blockIdx.x * kNL + threadIdx.x] = s;
+    }
+}
+
+__global__ void loss_finalize_kernel(const float* __restrict__ part, int nparts, int B, int h, int w,
+                                     float* __restrict__ losses) {
+    __shared__ double s[kNL];
+    if (threadIdx.x < kNL) {
+        double t = 0.0;
+        for (int p = 0; p < nparts; ++p) t += (double)part[p * kNL + threadIdx.x];
+        s[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double b = (double)B;
+        const double focal = s[0] / b;
+        const double reg = 1e-3 * 0.5 * s[1] / b;
+        double total = focal + reg;
+        losses[0] = (float)focal;
+        losses[1] = (float)reg;
+        for (int k = 0; k < 4; ++k) {
+            const double v = 1e-5 * 0.5 * s[2 + k] / b;
+            losses[2 + k] = (float)v;
+            total += v;
+        }
+        losses[6] = (float)total;
+        losses[7] = (float)(0.5 * s[7] / (b * (double)h * (double)w));
+    }
+}
+}  // namespace
+
+extern "C" int mpn_keypoint_loss_num_parts(int B, int h, int w) {
+    const long long npix = (long long)B * h * w;
+    const long long b = (npix + kThreads - 1) / kThreads;
+    return (int)(b < 1024 ? b : 1024);
+}
+
+/* losses_out[8] = focal, regression, seg@2, seg@3, seg@4, seg@5, total (sum of the six), per_pixel_reg_loss */
+extern "C" int mpn_keypoint_loss(const float* logits, const float* heatmaps, const float* loss_masks,
+                                 const float* segmentation_masks, const int* num_boxes, const void* p2, const void* p3,
+                                 const void* p4, const void* p5, int p_channels, int p_dtype, float* dlogits, float* daux2,
+                                 float* daux3, float* daux4, float* daux5, float* part, float* losses_out, int B, int h,
+                                 int w, mpn_stream_t stream) {
+    MPN_REQUIRE(logits && heatmaps && loss_masks && segmentation_masks && num_boxes && part && losses_out, MPN_ERR_BAD_ARG,
+                "loss: null pointer");
+    MPN_REQUIRE(B > 0 && h > 0 && w > 0, MPN_ERR_BAD_SHAPE, "loss: bad shape");
+    MPN_REQUIRE(h % 8 == 0 && w % 8 == 0, MPN_ERR_BAD_SHAPE, "loss: h, w must be multiples of 8 (images are multiples of 128)");
+    MPN_REQUIRE(p_dtype == MPN_F32 || p_dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "loss: dtype %d", p_dtype);
+    LossParams q;
+    q.logits = logits; q.heat = heatmaps; q.lmask = loss_masks; q.smask = segmentation_masks; q.num_boxes = num_boxes;
+    q.p[0] = p2; q.p[1] = p3; q.p[2] = p4; q.p[3] = p5; q.Cp = p_channels;
+    q.dlogits = dlogits; q.daux[0] = daux2; q.daux[1] = daux3; q.daux[2] = daux4; q.daux[3] = daux5;
+    q.part = part; q.B = B; q.h = h; q.w = w;
+    const int grid = mpn_keypoint_loss_num_parts(B, h, w);
+    hipStream_t st = (hipStream_t)stream;
+    if (p_dtype == MPN_F32) loss_kernel<float><<<grid, kThreads, 0, st>>>(q);
+    else loss_kernel<bf16_t><<<grid, kThreads, 0, st>>>(q);
+    MPN_LAUNCH_CHECK();
+    loss_finalize_kernel<<<1, 64, 0, st>>>(part, grid, B, h, w, losses_out);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}

@@ -1,0 +1,121 @@
+// K13: optimizer step of train_keypoints.py / keypoints_model.py:107-120 as ONE fused pass over a flat
+// parameter arena: tf.clip_by_value(g, -200, 200), TF-1.15 AdamOptimizer
+//   lr_t = lr*sqrt(1-b2^t)/(1-b1^t);  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;
+//   theta -= lr_t * m / (sqrt(v) + eps)      (eps OUTSIDE the bias correction, unlike torch.optim.Adam)
+// with lr from tf.train.cosine_decay(alpha=1e-4). Step count and learning rate live in device memory so the
+// whole training step can be replayed from a hipGraph. Also: deterministic reduction of partial slabs, axpy.
+#include "common.h"
+
+namespace {
+constexpr int kThreads = 256;
+
+__global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restrict__ hyper, double lr0,
+                                    double decay_steps, double alpha, double beta1, double beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long gs = *step;
+    const double s = (double)gs < decay_steps ? (double)gs : decay_steps;
+    const double cosine = 0.5 * (1.0 + cos(3.14159265358979323846 * s / decay_steps));
+    const double lr = lr0 * ((1.0 - alpha) * cosine + alpha);
+    const double t = (double)(gs + 1);
+    const double lr_t = lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t));
+    hyper[0] = (float)lr_t;
+    hyper[1] = (float)lr;
+    *step = gs + 1;
+}
+
+__global__ __launch_bounds__(kThreads) void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ m, float* __restrict__ v, long long n4,
+                                                              const float* __restrict__ hyper, float beta1, float beta2,
+                                                              float eps, float clip, float grad_scale) {
+    const float lr_t = hyper[0];
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n4; i += (long long)gridDim.x * kThreads) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        float* pa = reinterpret_cast<float*>(&pp);
+        const float* ga = reinterpret_cast<const float*>(&gg);
+        float* ma = reinterpret_cast<float*>(&mm);
+        float* va = reinterpret_cast<float*>(&vv);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gj = ga[j] * grad_scale;
+            gj = fminf(fmaxf(gj, -clip), clip);
+            ma[j] = beta1 * ma[j] + (1.0f - beta1) * gj;
+            va[j] = beta2 * va[j] + (1.0f - beta2) * gj * gj;
+            pa[j] -= lr_t * ma[j] / (sqrtf(va[j]) + eps);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp;
+        reinterpret_cast<float4*>(m)[i] = mm;
+        reinterpret_cast<float4*>(v)[i] = vv;
+    }
+}
+
+// out[j] (+)= scale * sum_p part[p][j], fixed order
+__global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* __restrict__ part, int nparts, long long n,
+                                                                   float* __restrict__ out, int accumulate, float scale) {
+    const long long j = (long long)blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= nparts; p += 4) {
+        s0 += part[(long long)p * n + j];
+        s1 += part[(long long)(p + 1) * n + j];
+        s2 += part[(long long)(p + 2) * n + j];
+        s3 += part[(long long)(p + 3) * n + j];
+    }
+    for (; p < nparts; ++p) s0 += part[(long long)p * n + j];
+    const float s = ((s0 + s1) + (s2 + s3)) * scale;
+    out[j] = accumulate ? out[j] + s : s;
+}
+
+__global__ __launch_bounds__(kThreads) void axpy_kernel(long long n, float a, const float* __restrict__ x, float* __restrict__ y) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+        y[i] += a * x[i];
+}
+}  // namespace
+
+/* step: device int64 global_step (incremented); hyper: device f32[4] -> {lr_t, lr, -, -} */
+extern "C" int mpn_adam_prepare(long long* step, float* hyper, double initial_learning_rate, double decay_steps, double alpha,
+                                double beta1, double beta2, mpn_stream_t stream) {
+    MPN_REQUIRE(step && hyper, MPN_ERR_BAD_ARG, "adam_prepare: null pointer");
+    MPN_REQUIRE(decay_steps > 0, MPN_ERR_BAD_ARG, "adam_prepare: decay_steps must be positive");
+    adam_prepare_kernel<<<1, 1, 0, (hipStream_t)stream>>>(step, hyper, initial_learning_rate, decay_steps, alpha, beta1, beta2);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* n must be a multiple of 4 (the arena pads each tensor); all pointers 16-byte aligned */
+extern "C" int mpn_adam_step(float* params, const float* grads, float* m, float* v, long long n, const float* hyper,
+                             float beta1, float beta2, float eps, float clip, float grad_scale, mpn_stream_t stream) {
+    MPN_REQUIRE(params && grads && m && v && hyper, MPN_ERR_BAD_ARG, "adam_step: null pointer");
+    MPN_REQUIRE(n > 0 && n % 4 == 0, MPN_ERR_BAD_SHAPE, "adam_step: n must be a positive multiple of 4");
+    MPN_REQUIRE(mpn_aligned16(params) && mpn_aligned16(grads) && mpn_aligned16(m) && mpn_aligned16(v), MPN_ERR_BAD_ALIGN,
+                "adam_step: arenas must be 16-byte aligned");
+    const long long n4 = n / 4;
+    long long blocks = (n4 + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    adam_apply_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(params, grads, m, v, n4, hyper, beta1, beta2, eps,
+                                                                        clip, grad_scale);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_reduce_partials(const float* part, int nparts, long long n, float* out, int accumulate, float scale,
+                                   mpn_stream_t stream) {
+    MPN_REQUIRE(part && out, MPN_ERR_BAD_ARG, "reduce_partials: null pointer");
+    MPN_REQUIRE(nparts > 0 && n > 0, MPN_ERR_BAD_SHAPE, "reduce_partials: bad sizes");
+    reduce_partials_kernel<<<(int)((n + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(part, nparts, n, out,
+                                                                                                     accumulate, scale);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream) {
+    MPN_REQUIRE(x && y && n > 0, MPN_ERR_BAD_ARG, "axpy: bad arguments");
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 2048) blocks = 2048;
+    axpy_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(n, a, x, y);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}

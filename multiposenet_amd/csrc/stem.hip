@@ -1,0 +1,197 @@
+// K1+K2: input standardisation fused into the first convolution.
+// Replaces `x = 2*images - 1` (detector/backbones/mobilenet_v1.py:41), the NHWC->NCHW transpose
+// (:53, not needed: we stay NHWC) and `Conv2d_0` = slim.conv2d 3x3 stride 2 'SAME', 3 -> C0
+// channels (:56; TF SAME on an even input pads 0 before / 1 after), plus its weight gradient.
+// K = 27 is too thin for the matrix cores: VALU direct convolution out of an LDS input patch.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kTile = 16;              // 16x16 output pixels per block
+constexpr int kIn = 2 * kTile + 1;     // 33x33 input patch
+constexpr int kMaxC0 = 64;
+
+template <typename T, bool U8>
+__device__ __forceinline__ void stage_patch(const void* images, float* patch, int img, int oy0, int ox0, int H, int W,
+                                            int pad_t, int pad_l) {
+    const int iy0 = oy0 * 2 - pad_t, ix0 = ox0 * 2 - pad_l;
+    for (int i = threadIdx.x; i < kIn * kIn * 3; i += kThreads) {
+        const int ch = i % 3;
+        const int px = (i / 3) % kIn;
+        const int py = i / (3 * kIn);
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;  // SAME padding: zeros of the STANDARDISED tensor
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+            const long long off = (((long long)img * H + iy) * W + ix) * 3 + ch;
+            const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] * (1.0f / 255.0f)
+                                 : reinterpret_cast<const float*>(images)[off];
+            v = 2.0f * raw - 1.0f;
+        }
+        patch[i] = v;
+    }
+}
+
+template <typename T, bool U8>
+__global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restrict__ images, const float* __restrict__ w,
+                                                            T* __restrict__ y, int N, int H, int W, int C0, int OH, int OW,
+                                                            int pad_t, int pad_l, int tiles_x, int tiles_y) {
+    constexpr int VE = Vec16<T>::N;
+    __shared__ float patch[kIn * kIn * 3];
+    __shared__ __attribute__((aligned(16))) float wl[27 * kMaxC0];
+    int b = blockIdx.x;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int img = b / tiles_y;
+    const int oy0 = ty * kTile, ox0 = tx * kTile;
+    for (int i = threadIdx.x; i < 27 * C0; i += kThreads) wl[i] = w[i];
+    stage_patch<T, U8>(images, patch, img, oy0, ox0, H, W, pad_t, pad_l);
+    __syncthreads();
+    const int lx = threadIdx.x % kTile, ly = threadIdx.x / kTile;
+    const int oy = oy0 + ly, ox = ox0 + lx;
+    float in[27];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                in[(ky * 3 + kx) * 3 + ch] = patch[((2 * ly + ky) * kIn + 2 * lx + kx) * 3 + ch];
+    if (oy >= OH || ox >= OW) return;
+    T* dst = y + (((long long)img * OH + oy) * OW + ox) * C0;
+    for (int c0 = 0; c0 < C0; c0 += VE) {
+        float acc[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+#pragma unroll
+            for (int j = 0; j < VE; j += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(&wl[t * C0 + c0 + j]);  // LDS broadcast
+                acc[j] += in[t] * q.x; acc[j + 1] += in[t] * q.y; acc[j + 2] += in[t] * q.z; acc[j + 3] += in[t] * q.w;
+            }
+        }
+        Vec16<T> ov;
+        ov.pack(acc);
+        ov.store(dst + c0);
+    }
+}
+
+// weight gradient: dW[27][C0] = sum_pixels patch[27] (x) dy[C0]; blocks walk tiles, each thread owns
+// up to ceil(27*C0/256) outputs in registers; partials [nblocks][27*C0] reduced by mpn_reduce_partials.
+template <typename T, bool U8>
+__global__ __launch_bounds__(kThreads) void stem_wgrad_kernel(const void* __restrict__ images, const T* __restrict__ dy,
+                                                              float* __restrict__ part, int N, int H, int W, int C0, int OH,
+                                                              int OW, int pad_t, int pad_l, int tiles_x, int tiles_y) {
+    extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
+    float* patch = dyn_smem;                  // [33*33*3]
+    float* g = dyn_smem + kIn * kIn * 3 + 1;  // [256][C0+1]
+    constexpr int kOutPerThread = (27 * kMaxC0 + kThreads - 1) / kThreads;  // 7
+    float acc[kOutPerThread];
+#pragma unroll
+    for (int k = 0; k < kOutPerThread; ++k) acc[k] = 0.f;
+    const int nout = 27 * C0;
+    const int gs = C0 + 1;
+    const int ntiles = N * tiles_y * tiles_x;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = t % tiles_x;
+        const int t2 = t / tiles_x;
+        const int ty = t2 % tiles_y;
+        const int img = t2 / tiles_y;
+        const int oy0 = ty * kTile, ox0 = tx * kTile;
+        __syncthreads();
+        stage_patch<T, U8>(images, patch, img, oy0, ox0, H, W, pad_t, pad_l);
+        for (int i = threadIdx.x; i < kTile * kTile * C0; i += kThreads) {
+            const int c = i % C0, px = i / C0;
+            const int oy = oy0 + px / kTile, ox = ox0 + px % kTile;
+            float v = 0.f;
+            if (oy < OH && ox < OW) v = to_f32(dy[(((long long)img * OH + oy) * OW + ox) * C0 + c]);
+            g[px * gs + c] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kOutPerThread; ++k) {
+            const int o = threadIdx.x + k * kThreads;
+            if (o < nout) {
+                const int tap = o / C0, c = o % C0;  // tap = (ky*3+kx)*3+ch
+                const int ch = tap % 3, kx = (tap / 3) % 3, ky = tap / 9;
+                float s = 0.f;
+                for (int px = 0; px < kTile * kTile; ++px) {
+                    const int ly = px / kTile, lx = px % kTile;
+                    s += patch[((2 * ly + ky) * kIn + 2 * lx + kx) * 3 + ch] * g[px * gs + c];
+                }
+                acc[k] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kOutPerThread; ++k) {
+        const int o = threadIdx.x + k * kThreads;
+        if (o < nout) part[(long long)blockIdx.x * nout + o] = acc[k];
+    }
+}
+
+void same_pad(int size, int* out, int* pad_before) {
+    *out = (size + 1) / 2;
+    int total = (*out - 1) * 2 + 3 - size;
+    if (total < 0) total = 0;
+    *pad_before = total / 2;
+}
+
+int check(int N, int H, int W, int C0, int dtype) {
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "stem: dtype %d", dtype);
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    MPN_REQUIRE(N > 0 && H > 0 && W > 0, MPN_ERR_BAD_SHAPE, "stem: bad shape");
+    MPN_REQUIRE(C0 > 0 && C0 <= kMaxC0 && C0 % ve == 0, MPN_ERR_BAD_SHAPE, "stem: C0 (%d) must be <= %d and a multiple of %d",
+                C0, kMaxC0, ve);
+    return MPN_OK;
+}
+
+}  // namespace
+
+extern "C" int mpn_stem_conv_fwd(const void* images, int images_u8, const float* w, void* y, int N, int H, int W, int C0,
+                                 int dtype, mpn_stream_t stream) {
+    if (int rc = check(N, H, W, C0, dtype)) return rc;
+    MPN_REQUIRE(images && w && y, MPN_ERR_BAD_ARG, "stem_fwd: null pointer");
+    int OH, OW, pt, pl;
+    same_pad(H, &OH, &pt);
+    same_pad(W, &OW, &pl);
+    const int tiles_y = (OH + kTile - 1) / kTile, tiles_x = (OW + kTile - 1) / kTile;
+    const int grid = N * tiles_y * tiles_x;
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, {
+        if (images_u8)
+            stem_fwd_kernel<T, true><<<grid, kThreads, 0, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+        else
+            stem_fwd_kernel<T, false><<<grid, kThreads, 0, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+    });
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" int mpn_stem_conv_wgrad_num_parts(int N, int H, int W) {
+    const int ntiles = N * (((H + 1) / 2 + kTile - 1) / kTile) * (((W + 1) / 2 + kTile - 1) / kTile);
+    return ntiles < 1024 ? ntiles : 1024;
+}
+
+extern "C" int mpn_stem_conv_bwd_weight(const void* images, int images_u8, const void* dy, float* part, int N, int H, int W,
+                                        int C0, int dtype, mpn_stream_t stream) {
+    if (int rc = check(N, H, W, C0, dtype)) return rc;
+    MPN_REQUIRE(images && dy && part, MPN_ERR_BAD_ARG, "stem_wgrad: null pointer");
+    int OH, OW, pt, pl;
+    same_pad(H, &OH, &pt);
+    same_pad(W, &OW, &pl);
+    const int tiles_y = (OH + kTile - 1) / kTile, tiles_x = (OW + kTile - 1) / kTile;
+    const int grid = mpn_stem_conv_wgrad_num_parts(N, H, W);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t sm = (size_t)(kIn * kIn * 3 + 1 + kTile * kTile * (C0 + 1)) * sizeof(float);
+    MPN_REQUIRE(sm <= 64 * 1024, MPN_ERR_BAD_SHAPE, "stem_wgrad: C0 too large");
+    MPN_DISPATCH_DTYPE(dtype, {
+        if (images_u8)
+            stem_wgrad_kernel<T, true><<<grid, kThreads, sm, st>>>(images, (const T*)dy, part, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+        else
+            stem_wgrad_kernel<T, false><<<grid, kThreads, sm, st>>>(images, (const T*)dy, part, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+    });
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}

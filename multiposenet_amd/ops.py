@@ -1,0 +1,302 @@
+"""Thin host wrappers over the C ABI (include/mpn.h): shape checks, buffer allocation, launch.
+
+Tensors are torch CUDA tensors used purely as device-memory owners; activations are NHWC
+(`[N, H, W, C]`, contiguous) in float32 or bfloat16. Nothing here computes on the host and
+nothing falls back to PyTorch ops: every function ends in a `_lib.call` into libmpn_hip.so.
+"""
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, call, ptr, stream_ptr
+
+BN_MOMENTUM = 0.95   # detector/utils/layer_utils.py:5, detector/backbones/mobilenet_v1.py:7
+BN_EPSILON = 1e-3    # layer_utils.py:6, mobilenet_v1.py:8
+
+# Producer-side batch-norm record that consumers apply on load.
+Affine = namedtuple("Affine", ["scale", "shift", "act"])
+
+
+def _f32(n, dev):
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
+def _check_nhwc(x, name="x"):
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous NHWC tensor, got shape {tuple(x.shape)}")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"{name}: unsupported dtype {x.dtype}")
+
+
+def _aff(a):
+    if a is None:
+        return None, None, ACT_NONE
+    return ptr(a.scale), ptr(a.shift), int(a.act)
+
+
+# ----------------------------------------------------------------------------- dense conv (MFMA)
+class PackedConv:
+    """Weights of one dense conv packed for the MFMA kernel (forward and, lazily, data-gradient)."""
+
+    def __init__(self, w_hwio, dtype):
+        k, k2, cin, cout = w_hwio.shape
+        assert k == k2 and k in (1, 3)
+        self.ksize, self.cin, self.cout, self.dtype = k, cin, cout, dtype
+        self.w = w_hwio  # f32 master view [k,k,Cin,Cout] (HWIO, the reference's variable layout)
+        dc = _lib.dtype_code(dtype)
+        self.fwd = torch.empty(_lib.lib().mpn_conv_packed_bytes(cin, cout, k, 0, dc), dtype=torch.uint8, device=w_hwio.device)
+        self.bwd = torch.empty(_lib.lib().mpn_conv_packed_bytes(cin, cout, k, 1, dc), dtype=torch.uint8, device=w_hwio.device)
+        self.repack()
+
+    def repack(self, with_bwd=True):
+        dc = _lib.dtype_code(self.dtype)
+        call("mpn_conv_pack_weights", ptr(self.w), self.cin, self.cout, self.ksize, 0, dc, ptr(self.fwd), stream_ptr())
+        if with_bwd:
+            call("mpn_conv_pack_weights", ptr(self.w), self.cin, self.cout, self.ksize, 1, dc, ptr(self.bwd), stream_ptr())
+
+
+def conv_num_parts(N, H, W, ksize):
+    return _lib.lib().mpn_conv_num_parts(N, H, W, ksize)
+
+
+def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_res=None):
+    """y = conv(act(bn(x))) [+ nearest2x(up_res)]; optional per-tile BN partial sums."""
+    _check_nhwc(x)
+    N, H, W, cin = x.shape
+    if out is None:
+        out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device)
+    sc, sh, act = _aff(affine)
+    call("mpn_conv_fwd", ptr(x), ptr(packed), ptr(out), N, H, W, cin, cout, ksize, _lib.dtype_code(x.dtype),
+         sc, sh, act, ptr(stats_part), ptr(up_res), stream_ptr())
+    return out
+
+
+# ----------------------------------------------------------------------------- batch norm
+class BNState:
+    """Device state of one batch-norm layer: views into the parameter arenas + per-step buffers."""
+
+    def __init__(self, gamma, beta, moving_mean, moving_var, act):
+        C = gamma.numel()
+        dev = gamma.device
+        self.C, self.act = C, act
+        self.gamma, self.beta, self.moving_mean, self.moving_var = gamma, beta, moving_mean, moving_var
+        self.scale, self.shift = _f32(C, dev), _f32(C, dev)
+        self.mean, self.invstd = _f32(C, dev), _f32(C, dev)
+        self.k1, self.k2 = _f32(C, dev), _f32(C, dev)
+        self.dgamma = self.dbeta = None  # views into the gradient arena, set by the owner
+
+    @property
+    def affine(self):
+        return Affine(self.scale, self.shift, self.act)
+
+
+def bn_stats(x, part=None):
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    nparts = _lib.lib().mpn_bn_stats_num_parts(M)
+    if part is None:
+        part = _f32(nparts * 2 * C, x.device)
+    call("mpn_bn_stats", ptr(x), M, C, _lib.dtype_code(x.dtype), ptr(part), stream_ptr())
+    return part, nparts
+
+
+def bn_finalize(bn, part, nparts, count, training=True):
+    call("mpn_bn_finalize", ptr(part), nparts, bn.C, count, ptr(bn.gamma), ptr(bn.beta),
+         ptr(bn.moving_mean) if training else None, ptr(bn.moving_var) if training else None,
+         BN_MOMENTUM, BN_EPSILON, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd), stream_ptr())
+
+
+def bn_inference_affine(bn):
+    call("mpn_bn_inference_affine", bn.C, ptr(bn.gamma), ptr(bn.beta), ptr(bn.moving_mean), ptr(bn.moving_var),
+         BN_EPSILON, ptr(bn.scale), ptr(bn.shift), stream_ptr())
+
+
+def bn_act_apply(x, affine, out=None):
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    if out is None:
+        out = torch.empty_like(x)
+    call("mpn_bn_act_apply", ptr(x), ptr(out), M, C, _lib.dtype_code(x.dtype), ptr(affine.scale), ptr(affine.shift),
+         int(affine.act), stream_ptr())
+    return out
+
+
+def bn_backward(bn, dA, x, part, add_ch0=None):
+    """In place: dA (gradient w.r.t. act(bn(x))) -> gradient w.r.t. the raw conv output x.
+    Writes bn.dgamma / bn.dbeta. `part` must hold mpn_bn_stats_num_parts(M)*2*C floats."""
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    dc = _lib.dtype_code(x.dtype)
+    nparts = _lib.lib().mpn_bn_stats_num_parts(M)
+    call("mpn_bn_bwd_reduce", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
+         int(bn.act), ptr(part), stream_ptr())
+    call("mpn_bn_bwd_finalize", ptr(part), nparts, C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), stream_ptr())
+    call("mpn_bn_bwd_apply", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
+         ptr(bn.k1), ptr(bn.k2), int(bn.act), ptr(add_ch0), stream_ptr())
+    return dA
+
+
+# ----------------------------------------------------------------------------- depthwise
+def dwconv_out_hw(H, W, stride):
+    l = _lib.lib()
+    return l.mpn_dwconv_out_size(H, stride), l.mpn_dwconv_out_size(W, stride)
+
+
+def dwconv_num_parts(N, H, W, stride):
+    return _lib.lib().mpn_dwconv_num_parts(N, H, W, stride)
+
+
+def dwconv_fwd(x, w, stride, affine=None, out=None, stats_part=None):
+    _check_nhwc(x)
+    N, H, W, C = x.shape
+    OH, OW = dwconv_out_hw(H, W, stride)
+    if out is None:
+        out = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+    sc, sh, act = _aff(affine)
+    call("mpn_dwconv_fwd", ptr(x), ptr(w), ptr(out), N, H, W, C, stride, _lib.dtype_code(x.dtype), sc, sh, act, 0,
+         ptr(stats_part), stream_ptr())
+    return out
+
+
+def dwconv_bwd_data(dy, w, in_hw, stride, out=None):
+    N, OH, OW, C = dy.shape
+    H, W = in_hw
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
+    call("mpn_dwconv_bwd_data", ptr(dy), ptr(w), ptr(out), N, H, W, C, stride, _lib.dtype_code(dy.dtype), stream_ptr())
+    return out
+
+
+def dwconv_bwd_weight(x, dy, stride, affine, dw_out, part=None):
+    N, H, W, C = x.shape
+    dc = _lib.dtype_code(x.dtype)
+    nparts = _lib.lib().mpn_dwconv_wgrad_num_parts(N, H, W, C, stride, dc)
+    if part is None:
+        part = _f32(nparts * 9 * C, x.device)
+    sc, sh, act = _aff(affine)
+    call("mpn_dwconv_bwd_weight", ptr(x), ptr(dy), ptr(part), N, H, W, C, stride, dc, sc, sh, act, stream_ptr())
+    call("mpn_reduce_partials", ptr(part), nparts, 9 * C, ptr(dw_out), 0, 1.0, stream_ptr())
+    return dw_out
+
+
+# ----------------------------------------------------------------------------- stem
+def stem_conv_fwd(images, w, c0, dtype, out=None):
+    if images.dim() != 4 or images.shape[3] != 3 or not images.is_contiguous():
+        raise ValueError("images must be contiguous [N,H,W,3]")
+    u8 = images.dtype == torch.uint8
+    if not u8 and images.dtype != torch.float32:
+        raise ValueError("images must be float32 in [0,1] or uint8")
+    N, H, W, _ = images.shape
+    if out is None:
+        out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, c0), dtype=dtype, device=images.device)
+    call("mpn_stem_conv_fwd", ptr(images), int(u8), ptr(w), ptr(out), N, H, W, c0, _lib.dtype_code(dtype), stream_ptr())
+    return out
+
+
+def stem_conv_bwd_weight(images, dy, dw_out, part=None):
+    N, H, W, _ = images.shape
+    c0 = dy.shape[3]
+    nparts = _lib.lib().mpn_stem_conv_wgrad_num_parts(N, H, W)
+    if part is None:
+        part = _f32(nparts * 27 * c0, dy.device)
+    call("mpn_stem_conv_bwd_weight", ptr(images), int(images.dtype == torch.uint8), ptr(dy), ptr(part), N, H, W, c0,
+         _lib.dtype_code(dy.dtype), stream_ptr())
+    call("mpn_reduce_partials", ptr(part), nparts, 27 * c0, ptr(dw_out), 0, 1.0, stream_ptr())
+    return dw_out
+
+
+# ----------------------------------------------------------------------------- resizes
+def bilinear_up_fwd(x, upsample, out, channel_offset, affine=None):
+    N, h, w, C = x.shape
+    sc, sh, act = _aff(affine)
+    call("mpn_bilinear_up_fwd", ptr(x), ptr(out), N, h, w, C, upsample, channel_offset, out.shape[3],
+         _lib.dtype_code(x.dtype), sc, sh, act, stream_ptr())
+    return out
+
+
+def bilinear_up_bwd(dy, upsample, channel_offset, C, out=None):
+    N, OH, OW, ctot = dy.shape
+    h, w = OH // upsample, OW // upsample
+    if out is None:
+        out = torch.empty((N, h, w, C), dtype=dy.dtype, device=dy.device)
+    call("mpn_bilinear_up_bwd", ptr(dy), ptr(out), N, h, w, C, upsample, channel_offset, ctot, _lib.dtype_code(dy.dtype),
+         stream_ptr())
+    return out
+
+
+def sumpool2x2(src, dst=None, accumulate=False):
+    N, H2, W2, C = src.shape
+    if dst is None:
+        dst = torch.empty((N, H2 // 2, W2 // 2, C), dtype=src.dtype, device=src.device)
+    call("mpn_sumpool2x2", ptr(src), ptr(dst), N, H2 // 2, W2 // 2, C, int(accumulate), _lib.dtype_code(src.dtype), stream_ptr())
+    return dst
+
+
+# ----------------------------------------------------------------------------- head, loss, optimizer
+def heatmap_head_fwd(x, w, bias, affine, inference=False, out=None, out_seg=None):
+    N, H, W, cin = x.shape
+    M = N * H * W
+    sc, sh, act = _aff(affine)
+    if inference:
+        if out is None:
+            out = torch.empty((N, H, W, 17), dtype=torch.float32, device=x.device)
+        if out_seg is None:
+            out_seg = torch.empty((N, H, W), dtype=torch.float32, device=x.device)
+    elif out is None:
+        out = torch.empty((N, H, W, 18), dtype=torch.float32, device=x.device)
+    call("mpn_heatmap_head_fwd", ptr(x), ptr(w), ptr(bias), M, cin, _lib.dtype_code(x.dtype), sc, sh, act,
+         int(inference), ptr(out), ptr(out_seg), stream_ptr())
+    return (out, out_seg) if inference else out
+
+
+def heatmap_head_bwd(x, dlogits, w, affine, dA, dw_db_out, part=None):
+    """dA <- gradient w.r.t. the activated input; dw_db_out: flat f32 view [Cin*18 + 18]."""
+    N, H, W, cin = x.shape
+    M = N * H * W
+    nparts = _lib.lib().mpn_heatmap_head_bwd_num_parts(M)
+    nout = cin * 18 + 18
+    if part is None:
+        part = _f32(nparts * nout, x.device)
+    sc, sh, act = _aff(affine)
+    call("mpn_heatmap_head_bwd", ptr(x), ptr(dlogits), ptr(w), M, cin, _lib.dtype_code(x.dtype), sc, sh, act, ptr(dA),
+         ptr(part), stream_ptr())
+    call("mpn_reduce_partials", ptr(part), nparts, nout, ptr(dw_db_out), 0, 1.0, stream_ptr())
+    return dA
+
+
+LOSS_NAMES = ["focal_loss", "regression_loss", "segmentation_loss_at_level_2", "segmentation_loss_at_level_3",
+              "segmentation_loss_at_level_4", "segmentation_loss_at_level_5", "total_loss", "per_pixel_reg_loss"]
+
+
+def keypoint_loss(logits, labels, ps, dlogits=None, daux=None, part=None, losses_out=None):
+    """labels: dict of device tensors (heatmaps f32 [B,h,w,17], loss_masks, segmentation_masks f32 [B,h,w],
+    num_boxes int32 [B]); ps: [p2,p3,p4,p5] raw FPN outputs (NHWC). Returns f32[8] device tensor (LOSS_NAMES)."""
+    B, h, w, _ = logits.shape
+    dev = logits.device
+    nparts = _lib.lib().mpn_keypoint_loss_num_parts(B, h, w)
+    if part is None:
+        part = _f32(nparts * 8, dev)
+    if losses_out is None:
+        losses_out = _f32(8, dev)
+    da = daux if daux is not None else [None] * 4
+    call("mpn_keypoint_loss", ptr(logits), ptr(labels["heatmaps"]), ptr(labels["loss_masks"]),
+         ptr(labels["segmentation_masks"]), ptr(labels["num_boxes"]), ptr(ps[0]), ptr(ps[1]), ptr(ps[2]), ptr(ps[3]),
+         ps[0].shape[3], _lib.dtype_code(ps[0].dtype), ptr(dlogits), ptr(da[0]), ptr(da[1]), ptr(da[2]), ptr(da[3]),
+         ptr(part), ptr(losses_out), B, h, w, stream_ptr())
+    return losses_out
+
+
+def adam_prepare(step, hyper, initial_learning_rate, num_steps, alpha=1e-4, beta1=0.9, beta2=0.999):
+    call("mpn_adam_prepare", ptr(step), ptr(hyper), float(initial_learning_rate), float(num_steps), float(alpha),
+         float(beta1), float(beta2), stream_ptr())
+
+
+def adam_step(params, grads, m, v, hyper, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, clip=200.0):
+    call("mpn_adam_step", ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), ptr(hyper), beta1, beta2, eps, clip,
+         float(grad_scale), stream_ptr())
+
+
+def reduce_partials(part, nparts, n, out, accumulate=False, scale=1.0):
+    call("mpn_reduce_partials", ptr(part), nparts, n, ptr(out), int(accumulate), float(scale), stream_ptr())
+
+
+def axpy(a, x, y):
+    call("mpn_axpy", x.numel(), float(a), ptr(x), ptr(y), stream_ptr())
