@@ -42,6 +42,8 @@ class PackedConv:
     def __init__(self, w_hwio, dtype):
         k, k2, cin, cout = w_hwio.shape
         assert k == k2 and k in (1, 3)
+        if w_hwio.dtype != torch.float32 or not w_hwio.is_contiguous():
+            raise ValueError("conv weights must be a contiguous float32 HWIO tensor")
         self.ksize, self.cin, self.cout, self.dtype = k, cin, cout, dtype
         self.w = w_hwio  # f32 master view [k,k,Cin,Cout] (HWIO, the reference's variable layout)
         dc = _lib.dtype_code(dtype)

@@ -255,4 +255,4 @@ def test_adam_matches_tf_semantics(cuda):
         assert int(step.item()) == it + 1
         np.testing.assert_allclose(float(hyper[1]), lr, rtol=1e-6)
         np.testing.assert_allclose(dp.cpu().numpy(), p64, rtol=1e-5, atol=1e-7)
-        np.testing.assert_allclose(dv.cpu().numpy(), v64, rtol=1e-5)
+        np.testing.assert_allclose(dv.cpu().numpy(), v64, rtol=1e-4)  # (1-beta2) is rounded in f32, as in TF

@@ -15,6 +15,8 @@ def dev(x, dtype=None):
     t = torch.as_tensor(np.asarray(x)) if not torch.is_tensor(x) else x
     if dtype is not None:
         t = t.to(dtype)
+    elif t.dtype == torch.float64:
+        t = t.float()
     return t.contiguous().cuda()
 
 
