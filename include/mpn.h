@@ -95,6 +95,14 @@ int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int
                  int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,
                  int in_act, float* stats_part, const void* up_res, mpn_stream_t stream);
 
+/* Weight gradient of mpn_conv_fwd: dW[tap][ci][co] = sum_pixels act(bn(x))[pixel+tap][ci]*dy[pixel][co].
+ * Split-K over pixel tiles: part [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (one HWIO slab
+ * per split), summed in a fixed order by mpn_reduce_partials. */
+int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, int ksize, int dtype);
+int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int Cin,
+                        int Cout, int ksize, int dtype, const float* in_scale,
+                        const float* in_shift, int in_act, mpn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K4  batch normalisation (tf.layers.batch_normalization(fused=True, momentum=.95, eps=1e-3):
  * detector/backbones/mobilenet_v1.py:29-38, detector/utils/layer_utils.py:9-16).

@@ -1,0 +1,350 @@
+// Weight gradients of the dense 1x1 / 3x3 convolutions on the MFMA matrix cores, NHWC.
+//   dW[tap][ci][co] = sum over pixels  act(bn(x))[pixel+tap][ci] * dY[pixel][co]
+// i.e. a GEMM whose reduction dimension is the PIXEL axis (hundreds of thousands long) and whose
+// output is tiny, so: split-K over pixel tiles, register accumulation across a long tile loop, one
+// partial slab per split, deterministic reduction afterwards (mpn_reduce_partials).
+//
+// Both operands are pixel-major in memory (channels contiguous) while the MFMA wants 8
+// consecutive k (= pixels) per lane. bf16: the LDS images stay row-major [pixel][channel] exactly
+// as loaded (16-byte coalesced) and the fragments are fetched with ds_read_b64_tr_b16, the gfx950
+// transposing LDS read (4 pixels x 16 channels per 16-lane group). f32 parity build: one
+// ds_read_b32 per element and v_mfma_f32_16x16x4_f32.
+//   3x3: a block owns 32 input channels (64-byte rows) x all 9 taps x 128 output channels; the
+//        10x18 halo image of the input patch serves all 9 taps (tap = address offset);
+//   1x1: a block owns a 128 x 128 (ci x co) tile, classic 2x2 wave layout.
+// LDS rows are XOR-swizzled in 32-byte segments so the 8 pixel rows one half-wave touches per
+// transposed read land in 8 different bank groups.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kHaloW = 18, kHaloH = 10;
+
+struct WgradParams {
+    const void* x;    // [N,H,W,Cin]
+    const void* dy;   // [N,H,W,Cout]
+    float* part;      // [nsplit][TAPS][Cin][Cout]
+    const float* in_scale;
+    const float* in_shift;
+    int in_act;
+    int N, H, W, Cin, Cout;
+    int tiles_x, tiles_y;
+    long long M;
+    int ntiles;   // pixel tiles
+    int nsplit;
+    int n_cg, n_cb;
+};
+
+__device__ __forceinline__ int fsw256(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+// 64-byte rows stay linear: their transposed reads are at worst 2-way conflicted (rows r and r+8 of a
+// half-wave), which is noise next to the MFMAs, and linear rows make every tap a constant address offset.
+__device__ __forceinline__ int fsw64(int) { return 0; }
+
+template <int RB> __device__ __forceinline__ int lds_off(int row, int seg, int within) {
+    const int f = (RB == 64) ? fsw64(row) : fsw256(row);
+    return row * RB + ((seg ^ f) << 5) + within;
+}
+
+__device__ __forceinline__ bf16x4_t tr_read(const unsigned char* base, int off) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+        (bf16x4_t __attribute__((address_space(3)))*)(base + off));
+}
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradParams p) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int VE = 16 / ES;
+    constexpr int RBA = TAPS == 9 ? 64 : 256;      // A image row bytes
+    constexpr int CG = RBA / ES;                   // input channels per block
+    constexpr int BNW = 256 / ES;                  // output channels per block
+    constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int MT_TOTAL = CG / 16, NT_TOTAL = BNW / 16;
+    // wave layout: 2x2 over (m-tiles, n-tiles) when there are >= 2 m-tiles, else 1x4
+    constexpr int WM = MT_TOTAL >= 2 ? 2 : 1;
+    constexpr int WN = 4 / WM;
+    constexpr int MTW = MT_TOTAL / WM;
+    constexpr int NTW = NT_TOTAL / WN;
+    constexpr int KPIX = ES == 2 ? 32 : 4;         // pixels per MFMA k-step
+    constexpr int KSTEPS = 128 / KPIX;
+    constexpr int ASLOTS = RBA / 16;
+    constexpr int AVEC = (NPIXA * ASLOTS + kThreads - 1) / kThreads;
+    constexpr int DVEC = 128 * 16 / kThreads;      // 8
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                      // [NPIXA][RBA]
+    unsigned char* Ds = smem + NPIXA * RBA;        // [128][256]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int b = blockIdx.x;
+    const int cg = b % p.n_cg; b /= p.n_cg;
+    const int cb = b % p.n_cb;
+    const int split = b / p.n_cb;
+    const int ci0 = cg * CG, co0 = cb * BNW;
+
+    const int mt0 = (wave / WN) * MTW;
+    const int nt0 = (wave % WN) * NTW;
+
+    f32x4_t acc[TAPS][MTW][NTW];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+
+    // per-thread constants of the A staging: 16-byte slot -> channels, affine
+    const int aslot = tid % ASLOTS;
+    const int ace = ci0 + aslot * VE;
+    const bool acvalid = ace < p.Cin;
+    const bool affine = p.in_scale != nullptr;
+    const int dslot = tid & 15;
+    const int dce = co0 + dslot * VE;
+    const bool dcvalid = dce < p.Cout;
+
+    for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+        int img = 0, oy0 = 0, ox0 = 0;
+        long long m0 = 0;
+        if (TAPS == 9) {
+            const int tx = tile % p.tiles_x;
+            const int t2 = tile / p.tiles_x;
+            const int ty = t2 % p.tiles_y;
+            img = t2 / p.tiles_y;
+            oy0 = ty * 8;
+            ox0 = tx * 16;
+        } else {
+            m0 = (long long)tile * 128;
+        }
+        __syncthreads();  // previous tile's fragment reads are done
+        // ---------------- stage A (activated input, halo for 3x3)
+        {
+            Vec16<T> v[AVEC];
+            bool inb[AVEC];
+#pragma unroll
+            for (int i = 0; i < AVEC; ++i) {
+                const int vi = tid + i * kThreads;
+                const int pix = vi / ASLOTS;
+                bool ok = acvalid && vi < NPIXA * ASLOTS;
+                long long off = 0;
+                if (TAPS == 9) {
+                    const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
+                    const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+                    ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    off = (((long long)img * p.H + iy) * p.W + ix) * p.Cin + ace;
+                } else {
+                    const long long m = m0 + pix;
+                    ok = ok && m < p.M;
+                    off = m * p.Cin + ace;
+                }
+                inb[i] = ok;
+                if (ok) v[i].load(x + off); else v[i].zero();
+            }
+#pragma unroll
+            for (int i = 0; i < AVEC; ++i) {
+                const int vi = tid + i * kThreads;
+                if (vi < NPIXA * ASLOTS) {
+                    const int pix = vi / ASLOTS;
+                    if (affine && inb[i]) {
+                        float f[VE];
+                        v[i].unpack(f);
+#pragma unroll
+                        for (int j = 0; j < VE; ++j) {
+                            float t = f[j] * p.in_scale[ace + j] + p.in_shift[ace + j];
+                            if (p.in_act != MPN_ACT_NONE) t = fmaxf(t, 0.f);
+                            if (p.in_act == MPN_ACT_RELU6) t = fminf(t, 6.f);
+                            f[j] = t;
+                        }
+                        v[i].pack(f);
+                    }
+                    *reinterpret_cast<uint4*>(As + lds_off<RBA>(pix, aslot >> 1, (aslot & 1) * 16)) =
+                        *reinterpret_cast<const uint4*>(&v[i].raw);
+                }
+            }
+        }
+        // ---------------- stage dY tile [128 px][256 B]
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            Vec16<T> v[DVEC / 2];
+#pragma unroll
+            for (int i = 0; i < DVEC / 2; ++i) {
+                const int r = (tid >> 4) + (half * (DVEC / 2) + i) * (kThreads / 16);
+                bool ok = dcvalid;
+                long long off = 0;
+                if (TAPS == 9) {
+                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                    ok = ok && oy < p.H && ox < p.W;
+                    off = (((long long)img * p.H + oy) * p.W + ox) * p.Cout + dce;
+                } else {
+                    const long long m = m0 + r;
+                    ok = ok && m < p.M;
+                    off = m * p.Cout + dce;
+                }
+                if (ok) v[i].load(dy + off); else v[i].zero();
+            }
+#pragma unroll
+            for (int i = 0; i < DVEC / 2; ++i) {
+                const int r = (tid >> 4) + (half * (DVEC / 2) + i) * (kThreads / 16);
+                *reinterpret_cast<uint4*>(Ds + lds_off<256>(r, dslot >> 1, (dslot & 1) * 16)) =
+                    *reinterpret_cast<const uint4*>(&v[i].raw);
+            }
+        }
+        __syncthreads();
+
+        // ---------------- MFMA over the 128 pixels of the tile
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+            if constexpr (ES == 2) {
+                const int qq = l15 >> 2, pp = l15 & 3;
+                const int r0 = ks * 32 + 8 * lq + qq;  // this lane's pixel row for the first 4-row block
+                bf16x8_t bfr[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const bf16x4_t lo = tr_read(Ds, lds_off<256>(r0, nt0 + j, pp * 8));
+                    const bf16x4_t hi = tr_read(Ds, lds_off<256>(r0 + 4, nt0 + j, pp * 8));
+                    bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+                // software-pipelined over (tap, m-tile): the fragment of step n+1 is fetched while the
+                // MFMAs of step n issue; sched_group_barrier pins that interleave so hipcc does not hoist all
+                // 18 fragment reads (72 VGPRs) above the MFMAs and spill the accumulators.
+                auto a_row = [&](int t) -> int {
+                    if (TAPS == 9) {
+                        const int ty = 2 * ks + (lq >> 1), tx0 = 8 * (lq & 1);
+                        return (ty + t / 3) * kHaloW + tx0 + (t % 3) + qq;
+                    }
+                    return r0;
+                };
+                auto a_load = [&](int step) -> bf16x8_t {
+                    const int t = step / MTW, i = step % MTW;
+                    const int arow = a_row(t);
+                    const bf16x4_t lo = tr_read(As, lds_off<RBA>(arow, mt0 + i, pp * 8));
+                    const bf16x4_t hi = tr_read(As, lds_off<RBA>(arow + 4, mt0 + i, pp * 8));
+                    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                };
+                bf16x8_t a_next = a_load(0);
+#pragma unroll
+                for (int step = 0; step < TAPS * MTW; ++step) {
+                    const bf16x8_t afr = a_next;
+                    if (step + 1 < TAPS * MTW) a_next = a_load(step + 1);
+                    const int t = step / MTW, i = step % MTW;
+#pragma unroll
+                    for (int j = 0; j < NTW; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[t][i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // 2 DS reads (next fragment)
+                    __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);  // NTW MFMAs (this fragment)
+                }
+            } else {
+                const int r = ks * 4 + lq;  // pixel of this lane's k index
+                float bfr[NTW];
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) {
+                    const int c = (nt0 + j) * 16 + l15;  // channel (float index) in the 64-float row
+                    bfr[j] = *reinterpret_cast<const float*>(Ds + lds_off<256>(r, c >> 3, (c & 7) * 4));
+                }
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int arow = (TAPS == 9) ? (((r >> 4) + t / 3) * kHaloW + (r & 15) + (t % 3)) : r;
+#pragma unroll
+                    for (int i = 0; i < MTW; ++i) {
+                        const int c = (mt0 + i) * 16 + l15;
+                        const float afr = *reinterpret_cast<const float*>(As + lds_off<RBA>(arow, c >> 3, (c & 7) * 4));
+#pragma unroll
+                        for (int j = 0; j < NTW; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr, bfr[j], acc[t][i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- write this split's partial [TAPS][Cin][Cout]
+    float* __restrict__ dst = p.part + (long long)split * TAPS * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + (mt0 + i) * 16 + lq * 4 + r;
+                    const int co = co0 + (nt0 + j) * 16 + l15;
+                    if (ci < p.Cin && co < p.Cout)
+                        dst[((long long)t * p.Cin + ci) * p.Cout + co] = acc[t][i][j][r];
+                }
+}
+
+struct WgradGeom {
+    int n_cg, n_cb, ntiles, nsplit;
+};
+
+WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout, int ksize, int es) {
+    WgradGeom g;
+    const int cgsz = (ksize == 3 ? 64 : 256) / es;
+    const int bnw = 256 / es;
+    g.n_cg = (Cin + cgsz - 1) / cgsz;
+    g.n_cb = (Cout + bnw - 1) / bnw;
+    g.ntiles = ksize == 3 ? N * ((H + 7) / 8) * ((W + 15) / 16) : (int)(((long long)N * H * W + 127) / 128);
+    int ns = 512 / (g.n_cg * g.n_cb);
+    if (ns < 1) ns = 1;
+    if (ns > g.ntiles) ns = g.ntiles;
+    g.nsplit = ns;
+    return g;
+}
+
+template <typename T, int TAPS>
+int launch_wgrad(const WgradParams& p, hipStream_t st) {
+    constexpr int ES = (int)sizeof(T);
+    constexpr int RBA = TAPS == 9 ? 64 : 256;
+    constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int smem = NPIXA * RBA + 128 * 256;
+    (void)ES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    conv_wgrad_kernel<T, TAPS><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(kThreads), smem, st>>>(p);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+}  // namespace
+
+extern "C" int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    return wgrad_geom(N, H, W, Cin, Cout, ksize, dtype == MPN_F32 ? 4 : 2).nsplit;
+}
+
+/* part: [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (HWIO per split); finish with mpn_reduce_partials */
+extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int Cin, int Cout,
+                                   int ksize, int dtype, const float* in_scale, const float* in_shift, int in_act,
+                                   mpn_stream_t stream) {
+    MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv wgrad: ksize must be 1 or 3");
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "conv wgrad: dtype %d", dtype);
+    const int es = dtype == MPN_F32 ? 4 : 2;
+    const int ve = 16 / es;
+    MPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % ve == 0 && Cout % ve == 0, MPN_ERR_BAD_SHAPE,
+                "conv wgrad: bad shape (channels must be multiples of %d)", ve);
+    MPN_REQUIRE(x && dy && part, MPN_ERR_BAD_ARG, "conv wgrad: null pointer");
+    MPN_REQUIRE(mpn_aligned16(x) && mpn_aligned16(dy), MPN_ERR_BAD_ALIGN, "conv wgrad: pointers must be 16-byte aligned");
+    MPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), MPN_ERR_BAD_ARG, "conv wgrad: scale/shift mismatch");
+    const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout, ksize, es);
+    WgradParams p;
+    p.x = x; p.dy = dy; p.part = part;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
+    p.M = (long long)N * H * W;
+    p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = g.n_cg; p.n_cb = g.n_cb;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPN_F32) return ksize == 3 ? launch_wgrad<float, 9>(p, st) : launch_wgrad<float, 1>(p, st);
+    return ksize == 3 ? launch_wgrad<bf16_t, 9>(p, st) : launch_wgrad<bf16_t, 1>(p, st);
+}

@@ -74,6 +74,25 @@ def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_
     return out
 
 
+def conv_wgrad_num_parts(N, H, W, cin, cout, ksize, dtype):
+    return _lib.lib().mpn_conv_wgrad_num_parts(N, H, W, cin, cout, ksize, _lib.dtype_code(dtype))
+
+
+def conv_bwd_weight(x, dy, ksize, affine, dw_out, part=None):
+    """dw_out (f32 HWIO view, [k,k,Cin,Cout]) <- sum over pixels of act(bn(x)) (x) dy."""
+    N, H, W, cin = x.shape
+    cout = dy.shape[3]
+    nparts = conv_wgrad_num_parts(N, H, W, cin, cout, ksize, x.dtype)
+    n = ksize * ksize * cin * cout
+    if part is None:
+        part = _f32(nparts * n, x.device)
+    sc, sh, act = _aff(affine)
+    call("mpn_conv_bwd_weight", ptr(x), ptr(dy), ptr(part), N, H, W, cin, cout, ksize, _lib.dtype_code(x.dtype),
+         sc, sh, act, stream_ptr())
+    call("mpn_reduce_partials", ptr(part), nparts, n, ptr(dw_out), 0, 1.0, stream_ptr())
+    return dw_out
+
+
 # ----------------------------------------------------------------------------- batch norm
 class BNState:
     """Device state of one batch-norm layer: views into the parameter arenas + per-step buffers."""

@@ -1,0 +1,163 @@
+"""GPU: backward kernels (through the C ABI) vs torch autograd over the oracle's forward restatement."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network as onet
+from util import DTYPES, act_ref, assert_close, dev, nchw, nhwc, rnd
+
+pytestmark = pytest.mark.gpu
+IDS = ["f32", "bf16"]
+
+
+def _ops():
+    from multiposenet_amd import ops
+    return ops
+
+
+WGRAD_CASES = [
+    # N, H, W, Cin, Cout, k, act
+    (2, 16, 16, 128, 128, 3, 1),
+    (1, 12, 20, 128, 128, 3, 0),     # partial tiles
+    (2, 16, 16, 512, 64, 3, 0),      # final_conv3x3
+    (1, 4, 4, 128, 128, 3, 1),
+    (2, 16, 16, 32, 64, 1, 2),       # pointwise 1
+    (2, 16, 16, 256, 128, 1, 2),     # lateral
+    (3, 16, 16, 1024, 1024, 1, 2),   # pointwise 13
+    (1, 10, 6, 64, 128, 1, 2),       # ragged M
+    (40, 16, 16, 128, 128, 3, 1),    # many tiles per split
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[f"{c[3]}to{c[4]}k{c[5]}_{c[0]}x{c[1]}x{c[2]}" for c in WGRAD_CASES])
+def test_conv_wgrad(cuda, dtype, case):
+    ops = _ops()
+    N, H, W, Cin, Cout, k, act = case
+    rs = np.random.RandomState(Cin + k + N)
+    x = rnd(rs.randn(N, H, W, Cin), dtype)
+    dy = rnd(rs.randn(N, H, W, Cout), dtype)
+    aff = None
+    a = x
+    if act:
+        sc = torch.tensor(0.5 + rs.rand(Cin), dtype=torch.float32)
+        sh = torch.tensor(rs.randn(Cin) * 0.5, dtype=torch.float32)
+        aff = ops.Affine(dev(sc), dev(sh), act)
+        a = rnd(act_ref(x * sc + sh, act), dtype)
+    w = torch.zeros(k, k, Cin, Cout, requires_grad=True)
+    out = onet.conv2d_same(nchw(a), w)
+    out.backward(nchw(dy))
+    dw = torch.full((k, k, Cin, Cout), float("nan"), device="cuda")
+    ops.conv_bwd_weight(dev(x, dtype), dev(dy, dtype), k, aff, dw)
+    # sum over N*H*W products of O(1) values
+    assert_close(dw, w.grad, torch.float32 if dtype == torch.float32 else dtype, N * H * W,
+                 scale=float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 64, 2), (1, 12, 20, 128, 1), (1, 14, 10, 256, 2),
+                                            (1, 9, 7, 64, 2), (2, 8, 8, 1024, 1), (1, 32, 32, 512, 2)])
+def test_dwconv_backward(cuda, dtype, N, H, W, C, stride):
+    ops = _ops()
+    rs = np.random.RandomState(C + stride)
+    x = rnd(rs.randn(N, H, W, C), dtype)
+    wnp = (rs.randn(3, 3, C, 1) / 3).astype(np.float32)
+    sc = torch.tensor(0.5 + rs.rand(C), dtype=torch.float32)
+    sh = torch.tensor(rs.randn(C) * 0.5, dtype=torch.float32)
+    a = torch.clamp(x * sc + sh, 0, 6).requires_grad_(True)
+    w = torch.tensor(wnp, requires_grad=True)
+    out = onet.depthwise_conv2d_tf_same(nchw(a), w, stride)
+    dy = rnd(rs.randn(*nhwc(out).shape), dtype)
+    out.backward(nchw(dy))
+    da = ops.dwconv_bwd_data(dev(dy, dtype), dev(wnp), (H, W), stride)
+    assert_close(da, a.grad, dtype, 9)
+    dw = torch.full((3, 3, C, 1), float("nan"), device="cuda")
+    ops.dwconv_bwd_weight(dev(x, dtype), dev(dy, dtype), stride, ops.Affine(dev(sc), dev(sh), 2), dw)
+    assert_close(dw, w.grad, torch.float32, N * H * W, scale=float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (1, 64, 48), (1, 30, 34), (3, 128, 128)])
+def test_stem_wgrad(cuda, dtype, N, H, W):
+    ops = _ops()
+    rs = np.random.RandomState(H)
+    img = torch.tensor(rs.rand(N, H, W, 3).astype(np.float32))
+    w = torch.zeros(3, 3, 3, 32, requires_grad=True)
+    out = onet.conv2d_tf_same(nchw(2.0 * img - 1.0), w, 2)
+    dy = rnd(rs.randn(*nhwc(out).shape), dtype)
+    out.backward(nchw(dy))
+    dw = torch.full((3, 3, 3, 32), float("nan"), device="cuda")
+    ops.stem_conv_bwd_weight(dev(img), dev(dy, dtype), dw)
+    assert_close(dw, w.grad, torch.float32, N * H * W // 4, scale=float(w.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("M,C,act,ch0", [(4096, 128, 1, True), (777, 32, 2, False), (50000, 64, 2, False), (300, 1024, 0, False)])
+def test_bn_backward(cuda, dtype, M, C, act, ch0):
+    ops = _ops()
+    rs = np.random.RandomState(C + 1)
+    x = rnd(rs.randn(1, 1, M, C) * 1.5 + 0.4, dtype)
+    dA = rnd(rs.randn(1, 1, M, C), dtype)
+    g, b = rs.rand(C).astype(np.float32) + 0.5, rs.randn(C).astype(np.float32)
+    bn = ops.BNState(dev(g), dev(b), dev(np.zeros(C, np.float32)), dev(np.ones(C, np.float32)), act)
+    bn.dgamma, bn.dbeta = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx = dev(x, dtype)
+    part, nparts = ops.bn_stats(dx)
+    ops.bn_finalize(bn, part, nparts, M)
+    # oracle: autograd through act(batch_norm(x)) with gamma/beta as leaves
+    xt = x.clone().double().reshape(1, M, 1, C).permute(0, 3, 1, 2).requires_grad_(True)   # NCHW [1,C,M,1]
+    p = {"bn/gamma": torch.tensor(g).double().requires_grad_(True), "bn/beta": torch.tensor(b).double().requires_grad_(True),
+         "bn/moving_mean": torch.zeros(C).double(), "bn/moving_variance": torch.ones(C).double()}
+    y = act_ref(onet.batch_norm(xt, p, "bn", True), act)
+    y.backward(dA.double().reshape(1, M, 1, C).permute(0, 3, 1, 2))
+    want_dx = xt.grad.permute(0, 2, 3, 1).reshape(M, C)
+    add = None
+    if ch0:
+        a0 = rs.randn(M).astype(np.float32)
+        add = dev(a0)
+        want_dx = want_dx.clone()
+        want_dx[:, 0] += torch.tensor(a0).double()
+    dAd = dev(dA, dtype)
+    nb = ops._lib.lib().mpn_bn_stats_num_parts(M)
+    part2 = torch.empty(nb * 2 * C, device="cuda")
+    ops.bn_backward(bn, dAd, dx, part2, add_ch0=add)
+    assert_close(dAd.reshape(M, C), want_dx, dtype, scale=float(want_dx.abs().max()))
+    np.testing.assert_allclose(bn.dgamma.cpu().numpy(), p["bn/gamma"].grad.numpy(), rtol=2e-3, atol=2e-3 * float(p["bn/gamma"].grad.abs().max()))
+    np.testing.assert_allclose(bn.dbeta.cpu().numpy(), p["bn/beta"].grad.numpy(), rtol=2e-3, atol=2e-3 * float(p["bn/beta"].grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("u", [1, 2, 4, 8])
+def test_bilinear_backward(cuda, dtype, u):
+    ops = _ops()
+    rs = np.random.RandomState(u)
+    N, h, w, C = 2, 6, 10, 128
+    a = torch.zeros(N, C, h, w, requires_grad=True)
+    out = onet.resize_bilinear_legacy(a, h * u, w * u)
+    dyfull = rnd(rs.randn(N, h * u, w * u, 512), dtype)
+    out.backward(nchw(dyfull[..., 128:256]))
+    got = ops.bilinear_up_bwd(dev(dyfull, dtype), u, 128, 128)
+    assert_close(got, nhwc(a.grad), dtype, 4 * u * u)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("M", [128 * 5, 1000, 128 * 700])
+def test_heatmap_head_backward(cuda, dtype, M):
+    ops = _ops()
+    rs = np.random.RandomState(M % 1000)
+    x = rnd(rs.randn(1, 1, M, 64), dtype)
+    wnp = (rs.randn(1, 1, 64, 18) * 0.1).astype(np.float32)
+    sc = torch.tensor(0.5 + rs.rand(64), dtype=torch.float32)
+    sh = torch.tensor(rs.randn(64) * 0.5, dtype=torch.float32)
+    a = torch.relu(x * sc + sh).reshape(M, 64).requires_grad_(True)
+    w = torch.tensor(wnp).reshape(64, 18).requires_grad_(True)
+    b = torch.zeros(18, requires_grad=True)
+    out = a @ w + b
+    dl = torch.tensor(rs.randn(M, 18).astype(np.float32))
+    out.backward(dl)
+    dA = torch.empty((1, 1, M, 64), dtype=dtype, device="cuda")
+    dwdb = torch.full((64 * 18 + 18,), float("nan"), device="cuda")
+    ops.heatmap_head_bwd(dev(x, dtype), dev(dl).reshape(1, 1, M, 18), dev(wnp), ops.Affine(dev(sc), dev(sh), 1), dA, dwdb)
+    assert_close(dA.reshape(M, 64), a.grad, dtype, 18)
+    assert_close(dwdb[:64 * 18].reshape(64, 18), w.grad, torch.float32, M, scale=float(w.grad.abs().max()))
+    assert_close(dwdb[64 * 18:], b.grad, torch.float32, M, scale=float(b.grad.abs().max()))
