@@ -181,6 +181,8 @@ int mpn_bilinear_up_bwd(const void* dy, void* dx, int N, int h, int w, int C, in
 /* src [N,2h,2w,C] -> dst [N,h,w,C] (2x2 sums); accumulate != 0 adds into dst */
 int mpn_sumpool2x2(const void* src, void* dst, int N, int h, int w, int C, int accumulate,
                    int dtype, mpn_stream_t stream);
+/* dst += src over n elements: joins the two gradient paths that meet at c2..c4 */
+int mpn_add_inplace(void* dst, const void* src, long long n, int dtype, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K11  `heatmaps` head: 1x1 conv Cin -> 18 + bias, f32 NHWC logits

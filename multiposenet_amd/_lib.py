@@ -52,6 +52,7 @@ SIGNATURES = {
     "mpn_bilinear_up_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_bilinear_up_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mpn_sumpool2x2": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mpn_add_inplace": (_I, [_P, _P, _L, _I, _P]),
     "mpn_heatmap_head_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "mpn_heatmap_head_bwd_num_parts": (_I, [_L]),
     "mpn_heatmap_head_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),

@@ -148,6 +148,24 @@ __global__ __launch_bounds__(kThreads) void sumpool2x2_kernel(const T* __restric
     }
 }
 
+// dst += src (same shape)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void add_inplace_kernel(T* __restrict__ dst, const T* __restrict__ src, long long nvec) {
+    constexpr int VE = Vec16<T>::N;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long long)gridDim.x * kThreads) {
+        Vec16<T> a, b;
+        a.load(dst + i * VE);
+        b.load(src + i * VE);
+        float fa[VE], fb[VE];
+        a.unpack(fa);
+        b.unpack(fb);
+#pragma unroll
+        for (int j = 0; j < VE; ++j) fa[j] += fb[j];
+        a.pack(fa);
+        a.store(dst + i * VE);
+    }
+}
+
 int blocks_for(long long total) {
     long long b = (total + kThreads - 1) / kThreads;
     if (b > 8192) b = 8192;
@@ -207,6 +225,19 @@ extern "C" int mpn_sumpool2x2(const void* src, void* dst, int N, int h, int w, i
     hipStream_t st = (hipStream_t)stream;
     MPN_DISPATCH_DTYPE(dtype, (sumpool2x2_kernel<T><<<blocks_for(total), kThreads, 0, st>>>((const T*)src, (T*)dst, N, h, w,
                                                                                           C, accumulate, total)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* dst += src, n elements (multiple of 16 bytes) */
+extern "C" int mpn_add_inplace(void* dst, const void* src, long long n, int dtype, mpn_stream_t stream) {
+    MPN_REQUIRE(dst && src && n > 0, MPN_ERR_BAD_ARG, "add_inplace: bad arguments");
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "add_inplace: dtype %d", dtype);
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    MPN_REQUIRE(n % ve == 0, MPN_ERR_BAD_SHAPE, "add_inplace: n must be a multiple of %d", ve);
+    const long long nvec = n / ve;
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (add_inplace_kernel<T><<<blocks_for(nvec), kThreads, 0, st>>>((T*)dst, (const T*)src, nvec)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

@@ -1,0 +1,492 @@
+"""KeypointNet: the device-resident keypoint model (MobileNet-v1 -> FPN -> keypoint subnet),
+its losses, backward pass and optimizer step, orchestrating the HIP kernels of libmpn_hip.so.
+
+Mirrors, layer for layer, the reference graph built by keypoints_model.py:14-21,
+detector/backbones/mobilenet_v1.py, detector/fpn.py and detector/keypoint_subnet.py; variable
+names and HWIO shapes are the reference's (so a TF checkpoint exported to .npz loads as is).
+
+Layout decisions (MI355X-first):
+  * activations NHWC in bf16 (throughput) or f32 (parity), accumulation always f32;
+  * every conv writes its RAW output once; batch-norm is a per-channel affine that the NEXT
+    kernel applies while loading, so normalised activations never round-trip through HBM;
+  * all trainable parameters live in ONE flat f32 arena (+ grad / m / v arenas of the same
+    layout): Adam is a single fused pass and the data-parallel all-reduce sees one buffer;
+  * all buffers are allocated once per input shape, so a whole train step is hipGraph-capturable.
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6
+
+NUM_KEYPOINTS = 17   # detector/constants.py:10
+DOWNSAMPLE = 4       # detector/constants.py:13
+DIVISOR = 128        # detector/constants.py:4
+DEPTH = 128          # detector/keypoint_subnet.py:7
+STRIDES_AND_FILTERS = [(1, 64), (2, 128), (1, 128), (2, 256), (1, 256), (2, 512), (1, 512), (1, 512),
+                       (1, 512), (1, 512), (1, 512), (2, 1024), (1, 1024)]   # mobilenet_v1.py:59-65
+FEATURE_BLOCKS = {3: "c2", 5: "c3", 11: "c4", 13: "c5"}                     # mobilenet_v1.py:76-79
+
+
+def depth(x, depth_multiplier):
+    return max(int(x * depth_multiplier), 8)   # mobilenet_v1.py:25-27
+
+
+def variable_shapes(depth_multiplier=1.0):
+    """Ordered {reference variable name: shape} (trainables + batch-norm moving statistics)."""
+    s = OrderedDict()
+
+    def bn(prefix, c):
+        for n in ("gamma", "beta", "moving_mean", "moving_variance"):
+            s[f"{prefix}/{n}"] = (c,)
+
+    c = depth(32, depth_multiplier)
+    s["MobilenetV1/Conv2d_0/weights"] = (3, 3, 3, c)
+    bn("MobilenetV1/Conv2d_0/BatchNorm", c)
+    for i, (_, f) in enumerate(STRIDES_AND_FILTERS, 1):
+        s[f"MobilenetV1/Conv2d_{i}_depthwise/depthwise_weights"] = (3, 3, c, 1)
+        bn(f"MobilenetV1/Conv2d_{i}_depthwise/BatchNorm", c)
+        f = depth(f, depth_multiplier)
+        s[f"MobilenetV1/Conv2d_{i}_pointwise/weights"] = (1, 1, c, f)
+        bn(f"MobilenetV1/Conv2d_{i}_pointwise/BatchNorm", f)
+        c = f
+    feat = {2: depth(128, depth_multiplier), 3: depth(256, depth_multiplier),
+            4: depth(512, depth_multiplier), 5: depth(1024, depth_multiplier)}
+    s["keypoint_fpn/lateral5/kernel"] = (1, 1, feat[5], DEPTH)
+    s["keypoint_fpn/p5/kernel"] = (3, 3, DEPTH, DEPTH)
+    for i in (4, 3, 2):
+        s[f"keypoint_fpn/lateral{i}/kernel"] = (1, 1, feat[i], DEPTH)
+        s[f"keypoint_fpn/p{i}/kernel"] = (3, 3, DEPTH, DEPTH)
+    for l in (2, 3, 4, 5):
+        bn(f"p{l}_batch_norm", DEPTH)
+    for l in (2, 3, 4, 5):
+        s[f"phi_subnet_{l}/conv1/kernel"] = (3, 3, DEPTH, DEPTH)
+        bn(f"phi_subnet_{l}/bn1", DEPTH)
+        s[f"phi_subnet_{l}/conv2/kernel"] = (3, 3, DEPTH, DEPTH)
+        bn(f"phi_subnet_{l}/bn2", DEPTH)
+    s["final_conv3x3/kernel"] = (3, 3, 4 * DEPTH, 64)
+    bn("final_bn", 64)
+    s["heatmaps/kernel"] = (1, 1, 64, NUM_KEYPOINTS + 1)
+    s["heatmaps/bias"] = (NUM_KEYPOINTS + 1,)
+    return s
+
+
+def is_trainable(name):
+    return not (name.endswith("moving_mean") or name.endswith("moving_variance"))
+
+
+def initial_values(seed=0, depth_multiplier=1.0):
+    """Seeded initial values following the reference's initialiser families: variance scaling for conv
+    kernels (layer_utils.py:37), N(0,1e-4) `heatmaps/kernel` and bias -log(99)x17 + 0
+    (keypoint_subnet.py:41-53), gamma 1 / beta 0 / moving (0,1)."""
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for name, shape in variable_shapes(depth_multiplier).items():
+        if name.endswith("/gamma") or name.endswith("moving_variance"):
+            v = np.ones(shape)
+        elif name.endswith("/beta") or name.endswith("moving_mean"):
+            v = np.zeros(shape)
+        elif name == "heatmaps/bias":
+            v = np.array([-math.log(99.0)] * NUM_KEYPOINTS + [0.0])
+        elif name == "heatmaps/kernel":
+            v = rs.randn(*shape) * 1e-4
+        else:
+            fan_in = shape[0] * shape[1] * (shape[2] if not name.endswith("depthwise_weights") else 1)
+            v = rs.randn(*shape) * math.sqrt(1.0 / fan_in) * 1.2
+        out[name] = v.astype(np.float32)
+    return out
+
+
+class _Arena:
+    """Flat f32 device arena with named, 16-byte aligned views."""
+
+    def __init__(self, shapes, device):
+        self.offsets = OrderedDict()
+        off = 0
+        for name, shape in shapes.items():
+            n = int(np.prod(shape))
+            self.offsets[name] = (off, n, tuple(shape))
+            off += (n + 3) // 4 * 4
+        self.size = off
+        self.device = device
+
+    def new(self):
+        return torch.zeros(self.size, dtype=torch.float32, device=self.device)
+
+    def views(self, flat):
+        return OrderedDict((k, flat[o:o + n].view(shape)) for k, (o, n, shape) in self.offsets.items())
+
+
+class _Conv:
+    """One dense conv: reference variable + packed MFMA operands."""
+
+    def __init__(self, name, w, dw, dtype):
+        self.name, self.w, self.dw = name, w, dw
+        self.ksize, _, self.cin, self.cout = w.shape
+        self.packed = ops.PackedConv(w, dtype)
+
+
+class KeypointNet:
+    def __init__(self, values=None, depth_multiplier=1.0, dtype=torch.bfloat16, device="cuda:0", seed=0):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("dtype must be torch.float32 or torch.bfloat16")
+        self.dtype, self.device, self.dm = dtype, torch.device(device), depth_multiplier
+        shapes = variable_shapes(depth_multiplier)
+        ve = 8 if dtype == torch.bfloat16 else 4
+        for n, s in shapes.items():
+            if n.endswith("gamma") and (s[0] % 16 != 0):
+                raise ValueError(f"depth_multiplier={depth_multiplier}: {n} has {s[0]} channels; the MFMA kernels need "
+                                 f"multiples of 16 (and of {ve} for {dtype})")
+        self._train_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if is_trainable(k)), self.device)
+        self._stat_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if not is_trainable(k)), self.device)
+        self.theta = self._train_arena.new()
+        self.grad = self._train_arena.new()
+        self.adam_m = self._train_arena.new()
+        self.adam_v = self._train_arena.new()
+        self.moving = self._stat_arena.new()
+        self.vars = self._train_arena.views(self.theta)
+        self.grads = self._train_arena.views(self.grad)
+        self.stats = self._stat_arena.views(self.moving)
+        self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.load_state_dict(values if values is not None else initial_values(seed, depth_multiplier))
+        self._build_layers()
+        self._bufs = {}
+
+    # ------------------------------------------------------------------ variables
+    def state_dict(self):
+        """{reference variable name: numpy array} (HWIO kernels, as in a TF checkpoint)."""
+        out = OrderedDict()
+        for k, v in list(self.vars.items()) + list(self.stats.items()):
+            out[k] = v.detach().cpu().numpy().copy()
+        return out
+
+    def load_state_dict(self, values, strict=True):
+        for k, v in values.items():
+            dst = self.vars.get(k, self.stats.get(k))
+            if dst is None:
+                if strict:
+                    raise KeyError(f"unknown variable {k}")
+                continue
+            v = np.asarray(v, dtype=np.float32)
+            if tuple(v.shape) != tuple(dst.shape):
+                raise ValueError(f"{k}: shape {v.shape} != {tuple(dst.shape)}")
+            dst.copy_(torch.from_numpy(v))
+        if strict:
+            missing = [k for k in list(self.vars) + list(self.stats) if k not in values]
+            if missing:
+                raise KeyError(f"missing variables: {missing[:5]}...")
+        if hasattr(self, "convs"):
+            self.repack_weights()
+
+    def _bn(self, prefix, act):
+        bn = ops.BNState(self.vars[prefix + "/gamma"], self.vars[prefix + "/beta"], self.stats[prefix + "/moving_mean"],
+                         self.stats[prefix + "/moving_variance"], act)
+        bn.dgamma, bn.dbeta = self.grads[prefix + "/gamma"], self.grads[prefix + "/beta"]
+        bn.name = prefix
+        return bn
+
+    def _conv(self, name):
+        c = _Conv(name, self.vars[name], self.grads[name], self.dtype)
+        self.convs.append(c)
+        return c
+
+    def _build_layers(self):
+        self.convs = []
+        self.stem_w = self.vars["MobilenetV1/Conv2d_0/weights"]
+        self.stem_dw = self.grads["MobilenetV1/Conv2d_0/weights"]
+        self.stem_bn = self._bn("MobilenetV1/Conv2d_0/BatchNorm", ACT_RELU6)
+        self.blocks = []
+        for i, (stride, _) in enumerate(STRIDES_AND_FILTERS, 1):
+            d, p = f"MobilenetV1/Conv2d_{i}_depthwise", f"MobilenetV1/Conv2d_{i}_pointwise"
+            self.blocks.append(dict(
+                i=i, stride=stride,
+                dw_w=self.vars[d + "/depthwise_weights"], dw_dw=self.grads[d + "/depthwise_weights"],
+                dw_bn=self._bn(d + "/BatchNorm", ACT_RELU6),
+                pw=self._conv(p + "/weights"), pw_bn=self._bn(p + "/BatchNorm", ACT_RELU6)))
+        self.lateral = {l: self._conv(f"keypoint_fpn/lateral{l}/kernel") for l in (5, 4, 3, 2)}
+        self.pconv = {l: self._conv(f"keypoint_fpn/p{l}/kernel") for l in (5, 4, 3, 2)}
+        self.p_bn = {l: self._bn(f"p{l}_batch_norm", ACT_RELU) for l in (2, 3, 4, 5)}
+        self.phi = {}
+        for l in (2, 3, 4, 5):
+            s = f"phi_subnet_{l}"
+            self.phi[l] = dict(conv1=self._conv(s + "/conv1/kernel"), bn1=self._bn(s + "/bn1", ACT_RELU),
+                               conv2=self._conv(s + "/conv2/kernel"), bn2=self._bn(s + "/bn2", ACT_RELU))
+        self.final_conv = self._conv("final_conv3x3/kernel")
+        self.final_bn = self._bn("final_bn", ACT_RELU)
+        self.heat_w, self.heat_b = self.vars["heatmaps/kernel"], self.vars["heatmaps/bias"]
+        # `heatmaps/kernel` and `heatmaps/bias` are adjacent in the arena, so the head backward (dW then db,
+        # contiguous) writes straight into the gradient arena.
+        ok, nk, _ = self._train_arena.offsets["heatmaps/kernel"]
+        ob, nb, _ = self._train_arena.offsets["heatmaps/bias"]
+        assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
+        self._head_grad = self.grad[ok:ob + nb]
+        self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
+            [self.p_bn[l] for l in (2, 3, 4, 5)] + [self.phi[l][k] for l in (2, 3, 4, 5) for k in ("bn1", "bn2")] + [self.final_bn]
+
+    def repack_weights(self):
+        """Refresh the packed (bf16/f32, MFMA tile order) copies after the f32 masters changed."""
+        for c in self.convs:
+            c.packed.repack()
+
+    # ------------------------------------------------------------------ buffers (allocated once per input shape)
+    def _buffers(self, N, H, W):
+        key = (N, H, W)
+        b = self._bufs.get(key)
+        if b is not None:
+            return b
+        if H % DIVISOR or W % DIVISOR:
+            raise ValueError(f"image height and width must be multiples of {DIVISOR} (got {H}x{W})")   # detector.py:45
+        dt, dev = self.dtype, self.device
+
+        def act(h, w, c):
+            return torch.empty((N, h, w, c), dtype=dt, device=dev)
+
+        b = {"shape": key}
+        h, w = H // 2, W // 2
+        c = self.stem_w.shape[3]
+        b["stem"] = act(h, w, c)
+        b["dw"], b["pw"], b["hw"] = [], [], [(h, w)]
+        for blk in self.blocks:
+            if blk["stride"] == 2:
+                h, w = h // 2, w // 2
+            b["dw"].append(act(h, w, c))
+            c = blk["pw"].cout
+            b["pw"].append(act(h, w, c))
+            b["hw"].append((h, w))
+        lv = {l: (H >> l, W >> l) for l in (2, 3, 4, 5)}
+        b["lv"] = lv
+        b["x"] = {l: act(*lv[l], DEPTH) for l in lv}
+        b["p"] = {l: act(*lv[l], DEPTH) for l in lv}
+        b["y1"] = {l: act(*lv[l], DEPTH) for l in lv}
+        b["y2"] = {l: act(*lv[l], DEPTH) for l in lv}
+        b["concat"] = act(*lv[2], 4 * DEPTH)
+        b["final"] = act(*lv[2], 64)
+        b["logits"] = torch.empty((N, lv[2][0], lv[2][1], NUM_KEYPOINTS + 1), dtype=torch.float32, device=dev)
+        # scratch for batch-norm partial sums (forward statistics and backward reductions share it):
+        # the largest producer decides
+        nbn = ops._lib.lib().mpn_bn_stats_num_parts
+
+        def rows(t):
+            return t.numel() // t.shape[3]
+
+        stat_floats = nbn(rows(b["stem"])) * 2 * b["stem"].shape[3]
+        for i, blk in enumerate(self.blocks):
+            hh, ww = b["hw"][i]
+            cdw, cpw = b["dw"][i].shape[3], blk["pw"].cout
+            stat_floats = max(stat_floats, ops.dwconv_num_parts(N, hh, ww, blk["stride"]) * 2 * cdw,
+                              nbn(rows(b["dw"][i])) * 2 * cdw,
+                              ops.conv_num_parts(N, *b["hw"][i + 1], 1) * 2 * cpw, nbn(rows(b["pw"][i])) * 2 * cpw)
+        for l in lv:
+            stat_floats = max(stat_floats, ops.conv_num_parts(N, *lv[l], 3) * 2 * DEPTH, nbn(N * lv[l][0] * lv[l][1]) * 2 * DEPTH)
+        b["stat_part"] = torch.empty(stat_floats, dtype=torch.float32, device=dev)
+        b["loss_part"] = torch.empty(ops._lib.lib().mpn_keypoint_loss_num_parts(N, *lv[2]) * 8, dtype=torch.float32, device=dev)
+        b["losses"] = torch.zeros(8, dtype=torch.float32, device=dev)
+        self._bufs[key] = b
+        return b
+
+    def _grad_buffers(self, b):
+        if "g" in b:
+            return b["g"]
+        N, H, W = b["shape"]
+        dt, dev = self.dtype, self.device
+        g = {}
+        g["dlogits"] = torch.empty_like(b["logits"])
+        g["daux"] = {l: torch.empty((N, *b["lv"][l]), dtype=torch.float32, device=dev) for l in b["lv"]}
+        g["final"] = torch.empty_like(b["final"])
+        g["concat"] = torch.empty_like(b["concat"])
+        for k in ("y2", "y1", "p", "x"):
+            g[k] = {l: torch.empty_like(b[k][l]) for l in b["lv"]}
+        g["c"] = {}   # gradient w.r.t. the activated c_l (from the lateral convs)
+        for i, name in FEATURE_BLOCKS.items():
+            g["c"][name] = torch.empty_like(b["pw"][i - 1])
+        g["pw"] = [torch.empty_like(t) for t in b["pw"]]
+        g["dw"] = [torch.empty_like(t) for t in b["dw"]]
+        g["stem"] = torch.empty_like(b["stem"])
+        # weight-gradient partial slabs: the largest layer decides
+        wfloats = 0
+        for c in self.convs:
+            hw = self._conv_hw(b, c)
+            wfloats = max(wfloats, ops.conv_wgrad_num_parts(N, hw[0], hw[1], c.cin, c.cout, c.ksize, dt) * c.w.numel())
+        for i, blk in enumerate(self.blocks):
+            hh, ww = b["hw"][i]
+            cc = b["dw"][i].shape[3]
+            wfloats = max(wfloats, ops._lib.lib().mpn_dwconv_wgrad_num_parts(N, hh, ww, cc, blk["stride"],
+                                                                           ops._lib.dtype_code(dt)) * 9 * cc)
+        wfloats = max(wfloats, ops._lib.lib().mpn_stem_conv_wgrad_num_parts(N, H, W) * self.stem_w.numel())
+        wfloats = max(wfloats, ops._lib.lib().mpn_heatmap_head_bwd_num_parts(N * b["lv"][2][0] * b["lv"][2][1]) *
+                      self._head_grad.numel())
+        g["wpart"] = torch.empty(wfloats, dtype=torch.float32, device=dev)
+        b["g"] = g
+        return g
+
+    def _conv_hw(self, b, c):
+        n = c.name
+        if n.startswith("MobilenetV1"):
+            i = int(n.split("Conv2d_")[1].split("_")[0])
+            return b["hw"][i]
+        if n.startswith("keypoint_fpn") or n.startswith("phi_subnet"):
+            l = int(n.split("/")[0][-1]) if n.startswith("phi") else int(n.split("/")[1].replace("lateral", "").replace("p", ""))
+            return b["lv"][l]
+        return b["lv"][2]
+
+    # ------------------------------------------------------------------ forward
+    def _finish_bn(self, bn, b, nparts, count, training):
+        if training:
+            ops.bn_finalize(bn, b["stat_part"], nparts, count, training=True)
+
+    def prepare_inference(self):
+        """is_training=False: every batch-norm becomes the affine of its moving statistics."""
+        for bn in self.all_bn:
+            ops.bn_inference_affine(bn)
+
+    def backbone_forward(self, images, is_training, b=None):
+        """mobilenet_v1 (detector/backbones/mobilenet_v1.py:11-79). Returns {'c2'..'c5': (raw NHWC tensor, Affine)}."""
+        N, H, W, _ = images.shape
+        b = b or self._buffers(N, H, W)
+        if not is_training:
+            self.prepare_inference()
+        sp = b["stat_part"]
+        stem = ops.stem_conv_fwd(images, self.stem_w, self.stem_w.shape[3], self.dtype, out=b["stem"])
+        if is_training:
+            _, nparts = ops.bn_stats(stem, sp)
+            ops.bn_finalize(self.stem_bn, sp, nparts, stem.numel() // stem.shape[3])
+        x, aff = stem, self.stem_bn.affine
+        feats = {}
+        for i, blk in enumerate(self.blocks):
+            hin, win = b["hw"][i]
+            ydw = ops.dwconv_fwd(x, blk["dw_w"], blk["stride"], aff, out=b["dw"][i], stats_part=sp if is_training else None)
+            if is_training:
+                ops.bn_finalize(blk["dw_bn"], sp, ops.dwconv_num_parts(N, hin, win, blk["stride"]), ydw.numel() // ydw.shape[3])
+            h, w = b["hw"][i + 1]
+            ypw = ops.conv_fwd(ydw, blk["pw"].packed.fwd, blk["pw"].cout, 1, blk["dw_bn"].affine, out=b["pw"][i],
+                               stats_part=sp if is_training else None)
+            if is_training:
+                ops.bn_finalize(blk["pw_bn"], sp, ops.conv_num_parts(N, h, w, 1), N * h * w)
+            x, aff = ypw, blk["pw_bn"].affine
+            if blk["i"] in FEATURE_BLOCKS:
+                feats[FEATURE_BLOCKS[blk["i"]]] = (x, aff)
+        return feats
+
+    def subnet_forward(self, feats, is_training, b, inference_outputs=False):
+        """KeypointSubnet (detector/keypoint_subnet.py:11-62) on top of feature_pyramid_network (detector/fpn.py:36-55)."""
+        N = b["shape"][0]
+        sp = b["stat_part"] if is_training else None
+        prev = None
+        for l in (5, 4, 3, 2):
+            raw, aff = feats[f"c{l}"]
+            h, w = b["lv"][l]
+            ops.conv_fwd(raw, self.lateral[l].packed.fwd, DEPTH, 1, aff, out=b["x"][l], up_res=prev)    # fpn.py:38,50-51
+            prev = b["x"][l]
+            ops.conv_fwd(prev, self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=sp)    # fpn.py:39,52
+            if is_training:
+                ops.bn_finalize(self.p_bn[l], sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
+        for l in (2, 3, 4, 5):
+            ph = self.phi[l]
+            h, w = b["lv"][l]
+            nparts, cnt = ops.conv_num_parts(N, h, w, 3), N * h * w
+            ops.conv_fwd(b["p"][l], ph["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=sp)
+            if is_training:
+                ops.bn_finalize(ph["bn1"], sp, nparts, cnt)
+            ops.conv_fwd(b["y1"][l], ph["conv2"].packed.fwd, DEPTH, 3, ph["bn1"].affine, out=b["y2"][l], stats_part=sp)
+            if is_training:
+                ops.bn_finalize(ph["bn2"], sp, nparts, cnt)
+            ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, ph["bn2"].affine)   # :86 + :37
+        h, w = b["lv"][2]
+        ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, None, out=b["final"], stats_part=sp)   # :38
+        if is_training:
+            ops.bn_finalize(self.final_bn, sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
+        if inference_outputs:
+            return ops.heatmap_head_fwd(b["final"], self.heat_w, self.heat_b, self.final_bn.affine, inference=True)
+        return ops.heatmap_head_fwd(b["final"], self.heat_w, self.heat_b, self.final_bn.affine, out=b["logits"])
+
+    def forward(self, images, is_training):
+        """images: [N,H,W,3] f32 in [0,1] (or uint8). Returns (logits [N,H/4,W/4,18] f32 NHWC,
+        enriched_features {'p2'..'p5': raw FPN outputs NHWC})."""
+        N, H, W, _ = images.shape
+        b = self._buffers(N, H, W)
+        feats = self.backbone_forward(images, is_training, b)
+        logits = self.subnet_forward(feats, is_training, b)
+        self._last = (b, feats, images)
+        return logits, {f"p{l}": b["p"][l] for l in (2, 3, 4, 5)}
+
+    def predict(self, images):
+        """Inference outputs of create_pb.py:73-76: (sigmoid keypoint heatmaps [N,h,w,17], segmentation masks [N,h,w])."""
+        N, H, W, _ = images.shape
+        b = self._buffers(N, H, W)
+        feats = self.backbone_forward(images, False, b)
+        return self.subnet_forward(feats, False, b, inference_outputs=True)
+
+    # ------------------------------------------------------------------ loss + backward
+    def compute_losses(self, labels, with_grad=True):
+        b = self._last[0]
+        g = self._grad_buffers(b) if with_grad else None
+        ps = [b["p"][l] for l in (2, 3, 4, 5)]
+        return ops.keypoint_loss(b["logits"], labels, ps, g["dlogits"] if g else None,
+                                 [g["daux"][l] for l in (2, 3, 4, 5)] if g else None, b["loss_part"], b["losses"])
+
+    def backward(self):
+        """Gradients of the total loss w.r.t. every trainable variable -> self.grad (call after compute_losses)."""
+        b, feats, images = self._last
+        g = self._grad_buffers(b)
+        N = b["shape"][0]
+        sp, wp = b["stat_part"], g["wpart"]
+        # ---- head + final conv
+        ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad, wp)
+        ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
+        ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, wp)
+        ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
+        # ---- phi subnets + p{l}_batch_norm
+        for l in (2, 3, 4, 5):
+            ph = self.phi[l]
+            ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
+            ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp)
+            ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, wp)
+            ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
+            ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp)
+            ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, wp)
+            ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
+            ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l])
+        # ---- FPN (top-down path reversed)
+        for l in (2, 3, 4, 5):
+            ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, wp)
+            ops.conv_fwd(g["p"][l], self.pconv[l].packed.bwd, DEPTH, 3, None, out=g["x"][l])
+            if l > 2:
+                ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample
+            raw, aff = feats[f"c{l}"]
+            ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, wp)
+            ops.conv_fwd(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, None, out=g["c"][f"c{l}"])
+        # ---- backbone
+        dA = g["c"]["c5"]
+        for i in range(len(self.blocks) - 1, -1, -1):
+            blk = self.blocks[i]
+            if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13:
+                ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
+            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp)
+            ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, wp)
+            ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
+            ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
+            xin = b["pw"][i - 1] if i > 0 else b["stem"]
+            ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
+            ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], wp)
+            dst = g["pw"][i - 1] if i > 0 else g["stem"]
+            ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst)
+            dA = dst
+        ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp)
+        ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, wp)
+
+    def add_weight_decay_gradients(self, weight_decay):
+        """keypoints_model.py:129-138: + wd * l2_loss(k) for every 'weights'/'kernel' variable except depthwise."""
+        for k, w in self.vars.items():
+            if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k:
+                ops.axpy(weight_decay, w.view(-1), self.grads[k].view(-1))
+
+    # ------------------------------------------------------------------ optimizer
+    def optimizer_step(self, initial_learning_rate, num_steps, grad_scale=1.0):
+        """Cosine LR + clip(+-200) + TF-Adam over the flat arena, then refresh the packed weights."""
+        ops.adam_prepare(self.global_step, self.hyper, initial_learning_rate, num_steps)
+        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, grad_scale=grad_scale)
+        self.repack_weights()

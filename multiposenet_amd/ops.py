@@ -251,6 +251,13 @@ def sumpool2x2(src, dst=None, accumulate=False):
     return dst
 
 
+def add_inplace(dst, src):
+    if dst.shape != src.shape or dst.dtype != src.dtype:
+        raise ValueError("add_inplace: shape/dtype mismatch")
+    call("mpn_add_inplace", ptr(dst), ptr(src), dst.numel(), _lib.dtype_code(dst.dtype), stream_ptr())
+    return dst
+
+
 # ----------------------------------------------------------------------------- head, loss, optimizer
 def heatmap_head_fwd(x, w, bias, affine, inference=False, out=None, out_seg=None):
     N, H, W, cin = x.shape

@@ -1,0 +1,94 @@
+"""Training-step driver: forward + losses + backward + (all-reduce) + Adam, replayed from a hipGraph.
+
+Equivalent of the `train_op` that keypoints_model.py:115-120 hands to tf.estimator: one call =
+one optimizer step (batch-norm moving statistics included, as under UPDATE_OPS).
+"""
+import torch
+
+from . import ops
+from .parallel import GradientAllReducer
+
+
+class Trainer:
+    def __init__(self, net, params, use_graph=True, distributed=False, bucket_bytes=8 << 20):
+        self.net = net
+        self.lr0 = float(params["initial_learning_rate"])
+        self.num_steps = int(params["num_steps"])
+        self.weight_decay = float(params.get("weight_decay", 0.0))
+        self.use_graph = use_graph
+        self.reducer = GradientAllReducer(net.grad, bucket_bytes=bucket_bytes) if distributed else None
+        self._static = None
+        self._graph_fb = None
+        self._graph_opt = None
+
+    # ---- pieces
+    def _fwd_bwd(self):
+        s = self._static
+        self.net.forward(s["images"], True)
+        self.net.compute_losses(s["labels"])
+        self.net.backward()
+        if self.weight_decay > 0.0:
+            self.net.add_weight_decay_gradients(self.weight_decay)
+
+    def _opt(self):
+        scale = self.reducer.grad_scale if self.reducer else 1.0
+        self.net.optimizer_step(self.lr0, self.num_steps, grad_scale=scale)
+
+    def _bind(self, features, labels):
+        imgs = features["images"]
+        s = self._static
+        if s is None or s["images"].shape != imgs.shape or s["images"].dtype != imgs.dtype:
+            self._static = {"images": imgs.clone(), "labels": {k: v.clone() for k, v in labels.items()}}
+            self._graph_fb = self._graph_opt = None
+            return
+        if s["images"].data_ptr() != imgs.data_ptr():
+            s["images"].copy_(imgs)
+        for k, v in labels.items():
+            if s["labels"][k].data_ptr() != v.data_ptr():
+                s["labels"][k].copy_(v)
+
+    def _capture(self):
+        # eager warm-up on a side stream (sets kernel attributes, fills caches), then capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._fwd_bwd()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._graph_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph_fb):
+            self._fwd_bwd()
+            if self.reducer is None:
+                self._opt()
+        if self.reducer is not None:
+            self._graph_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_opt):
+                self._opt()
+
+    def step(self, features, labels):
+        """One optimizer step on this rank's shard. Returns the device tensor f32[8] of losses (ops.LOSS_NAMES)."""
+        self._bind(features, labels)
+        if not self.use_graph:
+            self._fwd_bwd()
+            if self.reducer:
+                self.reducer.all_reduce()
+            self._opt()
+        else:
+            if self._graph_fb is None:
+                # the warm-up pass inside _capture must not count as a step: snapshot & restore state
+                snap = [t.clone() for t in (self.net.theta, self.net.adam_m, self.net.adam_v, self.net.moving,
+                                            self.net.global_step)]
+                self._capture()
+                for dst, src in zip((self.net.theta, self.net.adam_m, self.net.adam_v, self.net.moving,
+                                     self.net.global_step), snap):
+                    dst.copy_(src)
+                self.net.repack_weights()
+            self._graph_fb.replay()
+            if self.reducer is not None:
+                self.reducer.all_reduce()
+                self._graph_opt.replay()
+        return self.net._last[0]["losses"]
+
+    def eval_step(self, features, labels):
+        self.net.forward(features["images"], False)
+        return self.net.compute_losses(labels, with_grad=False)
