@@ -241,46 +241,59 @@ def mobilenet_v1(images, p, is_training, depth_multiplier=1.0, updates=None, tap
             "c4": feats["MobilenetV1/Conv2d_11_pointwise"], "c5": feats["MobilenetV1/Conv2d_13_pointwise"]}
 
 
-def feature_pyramid_network(features, p, scope="keypoint_fpn", min_level=2):
+def feature_pyramid_network(features, p, scope="keypoint_fpn", min_level=2, taps=None):
     """fpn.py:36-55 with add_coarse_features=False (the keypoint configuration)."""
     x = conv2d_same(features["c5"], p[f"{scope}/lateral5/kernel"])          # :38
+    if taps is not None:
+        taps["x5"] = x
     enriched = {"p5": conv2d_same(x, p[f"{scope}/p5/kernel"])}              # :39
     for i in reversed(range(min_level, 5)):                                 # :49-53
         lateral = conv2d_same(features[f"c{i}"], p[f"{scope}/lateral{i}/kernel"])
         x = nearest_neighbor_upsample(x) + lateral
+        if taps is not None:
+            taps[f"x{i}"] = x
         enriched[f"p{i}"] = conv2d_same(x, p[f"{scope}/p{i}/kernel"])
     return enriched
 
 
-def phi_subnet(x, p, scope, is_training, upsample, updates=None):
+def phi_subnet(x, p, scope, is_training, upsample, updates=None, taps=None):
     """keypoint_subnet.py:65-91."""
     x = conv2d_same(x, p[scope + "/conv1/kernel"])
+    if taps is not None:
+        taps[scope + "/y1"] = x
     x = F.relu(batch_norm(x, p, scope + "/bn1", is_training, updates))
     x = conv2d_same(x, p[scope + "/conv2/kernel"])
+    if taps is not None:
+        taps[scope + "/y2"] = x
     x = F.relu(batch_norm(x, p, scope + "/bn2", is_training, updates))
     return resize_bilinear_legacy(x, upsample * x.shape[2], upsample * x.shape[3])   # :86
 
 
-def keypoint_subnet(backbone_features, p, is_training, updates=None):
+def keypoint_subnet(backbone_features, p, is_training, updates=None, taps=None):
     """keypoint_subnet.py:11-62. Returns (heatmaps NHWC [b,h/4,w/4,18] logits,
     enriched_features NHWC dict p2..p5 - the PRE-batch-norm FPN outputs)."""
-    enriched = feature_pyramid_network(backbone_features, p)                # :20-23
+    enriched = feature_pyramid_network(backbone_features, p, taps=taps)     # :20-23
     normalized = {n: F.relu(batch_norm(x, p, f"{n}_batch_norm", is_training, updates))
                   for n, x in enriched.items()}                             # :24-27
     ups = []
     for level in range(2, 6):                                               # :30-35
         ups.append(phi_subnet(normalized[f"p{level}"], p, f"phi_subnet_{level}", is_training,
-                              2 ** (level - 2), updates))
+                              2 ** (level - 2), updates, taps))
     x = torch.cat(ups, dim=1)                                               # :37
+    if taps is not None:
+        taps["concat"] = x
     x = conv2d_same(x, p["final_conv3x3/kernel"])                           # :38
+    if taps is not None:
+        taps["final"] = x
     x = F.relu(batch_norm(x, p, "final_bn", is_training, updates))          # :39
     heat = conv2d_same(x, p["heatmaps/kernel"], bias=p["heatmaps/bias"])    # :49-54
     return heat.permute(0, 2, 3, 1), {n: v.permute(0, 2, 3, 1) for n, v in enriched.items()}   # :56-62
 
 
-def forward(images, p, is_training, depth_multiplier=1.0, updates=None):
-    feats = mobilenet_v1(images, p, is_training, depth_multiplier, updates)
-    return keypoint_subnet(feats, p, is_training, updates)
+def forward(images, p, is_training, depth_multiplier=1.0, updates=None, taps=None):
+    """taps: optional dict that receives the RAW (pre-batch-norm) output of every conv, NCHW."""
+    feats = mobilenet_v1(images, p, is_training, depth_multiplier, updates, taps)
+    return keypoint_subnet(feats, p, is_training, updates, taps)
 
 
 # ----------------------------------------------------------------------------- losses (keypoints_model.py)
