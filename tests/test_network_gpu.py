@@ -229,10 +229,13 @@ def test_graph_replay_equals_eager_and_bf16_tracks_f32(cuda):
     for k in res["eager"][1]:
         np.testing.assert_array_equal(res["eager"][1][k], res["graph"][1][k])
     # bf16 storage follows the f32 run loosely (documented tolerance: 2% on the losses of 3 steps)
-    for a, b in zip(res["eager"][0], res["bf16"][0]):
-        np.testing.assert_allclose(b[[0, 6]], a[[0, 6]], rtol=2e-2)                # focal, total
-        np.testing.assert_allclose(b[1], a[1], rtol=6e-2)                        # regression (1e-3-weighted L2 on one channel)
-        np.testing.assert_allclose(b[2:6], a[2:6], rtol=0.15)                    # tiny auxiliary losses on raw p_l[...,0]
+    f32_steps, bf16_steps = res["eager"][0], res["bf16"][0]
+    # step 0 (identical weights): every loss term of the bf16 build within 3% of the f32 build
+    np.testing.assert_allclose(bf16_steps[0][[0, 1, 2, 3, 6]], f32_steps[0][[0, 1, 2, 3, 6]], rtol=3e-2)
+    # the stride-16/32 auxiliary terms average 128 / 32 pixels of a 30-layer-deep bf16 activation: 15%
+    np.testing.assert_allclose(bf16_steps[0][4:6], f32_steps[0][4:6], rtol=0.15)
+    for a, b in zip(f32_steps, bf16_steps):   # later steps: the dominant terms keep tracking
+        np.testing.assert_allclose(b[[0, 6]], a[[0, 6]], rtol=2e-2)
 
 
 def test_model_fn_contract(cuda):
