@@ -1,0 +1,97 @@
+"""Benchmark of the keypoint-training hot path (BASELINE.json metric: images/sec, keypoint fwd+bwd(+Adam) @512x512,
+per-GPU batch 32, bf16 storage / f32 accumulate), one process per GPU.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = forward + losses + backward + gradient all-reduce (N>1) + Adam + weight repack on one synthetic batch
+that is resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+GMAC_PER_IMAGE = 17.946     # forward MACs per 512x512 image
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from multiposenet_amd import _lib
+    from multiposenet_amd.parallel import init_distributed
+    rank, local_rank, world = init_distributed("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    _lib.lib()   # fail loudly if the HIP library is missing
+
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.synthetic import synthetic_batch
+    from multiposenet_amd.train import Trainer
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dev = f"cuda:{local_rank}"
+    net = KeypointNet(dtype=dt, device=dev, seed=0)          # identical replicas on every rank
+    params = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
+    trainer = Trainer(net, params, use_graph=not args.no_graph, distributed=world > 1)
+    feats, labels = synthetic_batch(args.batch, args.size, args.size, rank=rank, device=dev)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(feats, labels)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step(feats, labels)
+    barrier()
+    dt_s = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt_s = float(t.item())
+    loss = float(trainer.net._last[0]["losses"][6])
+    images_per_s = args.batch * world * args.steps / dt_s
+    out = {
+        "metric": "images/sec keypoint fwd+bwd+Adam @512x512 bs32/GPU", "value": round(images_per_s, 2), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"MobileNet-v1+FPN+keypoint_subnet fwd+bwd+Adam, {args.size}x{args.size}, per-GPU batch {args.batch}",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                   "final_total_loss": loss},
+    }
+    if rank == 0 and not args.no_roofline:
+        from multiposenet_amd.benchmarks import dominant_kernel_roofline, whole_step_mfma_fraction
+        out["roofline"] = dominant_kernel_roofline(net, args.batch, args.size, dt)
+        out["config"]["step_mfma_frac_of_peak"] = whole_step_mfma_fraction(args.batch, args.size, dt_s / args.steps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from multiposenet_amd.benchmarks import cpu_baseline
+        out["cpu_baseline"] = cpu_baseline(args.size)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,7 +142,7 @@ int mpn_bn_bwd_apply(void* dA, const void* x, long long M, int C, int dtype, con
  * stats_part: NULL or [mpn_dwconv_num_parts()][2][C].
  */
 int mpn_dwconv_out_size(int size, int stride);
-int mpn_dwconv_num_parts(int N, int H, int W, int stride);
+int mpn_dwconv_num_parts(int N, int H, int W, int C, int stride, int dtype);
 int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
                    int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
                    float* stats_part, mpn_stream_t stream);

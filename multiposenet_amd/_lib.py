@@ -41,7 +41,7 @@ SIGNATURES = {
     "mpn_bn_bwd_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P]),
     "mpn_bn_bwd_apply": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "mpn_dwconv_out_size": (_I, [_I, _I]),
-    "mpn_dwconv_num_parts": (_I, [_I, _I, _I, _I]),
+    "mpn_dwconv_num_parts": (_I, [_I, _I, _I, _I, _I, _I]),
     "mpn_dwconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
     "mpn_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mpn_dwconv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I]),

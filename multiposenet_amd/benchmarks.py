@@ -1,0 +1,75 @@
+"""Measurement helpers used by bench.py (roofline of the dominant kernel, CPU baseline leg)."""
+import os
+import time
+
+import torch
+
+from . import ops
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+GMAC_PER_IMAGE_512 = 17.946
+
+
+def whole_step_mfma_fraction(batch, size, step_seconds):
+    flops = 6.0 * GMAC_PER_IMAGE_512 * 1e9 * (size / 512.0) ** 2 * batch
+    return round(flops / step_seconds / (PEAK_BF16_TFLOPS * 1e12), 4)
+
+
+def dominant_kernel_roofline(net, batch, size, dtype, iters=20):
+    """The dominant kernel of the step is the dense 3x3 implicit-GEMM conv (conv_mfma_kernel, 128->128 channels
+    at stride 4: p2, phi_subnet_2/conv1, conv2 forward and their three data-gradients = 6 launches per step).
+    Times that launch with HIP events on the launch stream, on the tensors of the live network."""
+    h = w = size // 4
+    x = net._bufs[(batch, size, size)]["p"][2]
+    conv = net.phi[2]["conv1"]
+    y = torch.empty_like(x)
+    stream = torch.cuda.current_stream()
+    for _ in range(3):
+        ops.conv_fwd(x, conv.packed.fwd, 128, 3, net.p_bn[2].affine, out=y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        ops.conv_fwd(x, conv.packed.fwd, 128, 3, net.p_bn[2].affine, out=y)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 2.0 * batch * h * w * 128 * 128 * 9          # algorithmic FLOPs of one launch
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    achieved = flops / sec / 1e12
+    return {"kernel": "conv_mfma_kernel<3x3,128->128> @ [%d,%d,%d,128]" % (batch, h, w), "bound": "mfma",
+            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": None, "launch_us": round(sec * 1e6, 2)}
+
+
+def cpu_baseline(size, budget_s=20.0):
+    """CPU restatement of the reference (oracle/network.py: torch-CPU ops in TF-1.15 semantics, f32), forward + backward
+    + Adam on a bounded sample of the same workload, all host cores. Reported next to the GPU number; not the target.
+    (TensorFlow 1.15 itself is not installable here - see BASELINE.md.)"""
+    import numpy as np
+    from oracle import network as onet   # checker used as the measured CPU baseline leg only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    bs = 2
+    rs = np.random.RandomState(1234)
+    img = rs.rand(bs, size, size, 3).astype(np.float32)
+    h = size // 4
+    lab = {"heatmaps": (rs.rand(bs, h, h, 17) * 0.9).astype(np.float32),
+           "loss_masks": (rs.rand(bs, h, h) < 0.95).astype(np.float32),
+           "segmentation_masks": (rs.rand(bs, h, h) < 0.3).astype(np.float32),
+           "num_boxes": rs.randint(1, 8, bs).astype(np.int32)}
+    params = onet.init_params(0)
+    m = {k: np.zeros_like(v) for k, v in params.items()}
+    v = {k: np.zeros_like(v) for k, v in params.items()}
+    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
+    onet.train_step(params, m, v, img, lab, 0, hp)   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        onet.train_step(params, m, v, img, lab, n + 1, hp)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    return {"value": round(bs * n / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} train steps of batch {bs} at {size}x{size}, f32, torch-CPU restatement of the reference "
+                      f"(TF-1.15 semantics), {cores} threads"}

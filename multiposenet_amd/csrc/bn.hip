@@ -71,13 +71,21 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     if (m.active) {
-        for (long long r = r0 + m.prow; r < r1; r += m.ppb) {
-            Vec16<T> v;
-            v.load(x + r * C + m.vg * VE);
-            float f[VE];
-            v.unpack(f);
+        constexpr int U = 4;  // rows in flight per thread
+        for (long long r = r0 + m.prow; r < r1; r += (long long)U * m.ppb) {
+            Vec16<T> v[U];
 #pragma unroll
-            for (int j = 0; j < VE; ++j) { acc[0][j] += f[j]; acc[1][j] += f[j] * f[j]; }
+            for (int u = 0; u < U; ++u) {
+                const long long rr = r + (long long)u * m.ppb;
+                if (rr < r1) v[u].load(x + rr * C + m.vg * VE); else v[u].zero();
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float f[VE];
+                v[u].unpack(f);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) { acc[0][j] += f[j]; acc[1][j] += f[j] * f[j]; }
+            }
         }
     }
     block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C);
@@ -86,17 +94,23 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
 // ---------------------------------------------------------------- finalize
 // part [nparts][2][C] -> mean, biased var -> scale/shift (+ moving-average update with the
 // unbiased variance, TF-1.15 fused batch-norm semantic). 16 channels x 16 part-lanes per block.
-__global__ __launch_bounds__(kThreads) void bn_finalize_kernel(
-    const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
-    float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
-    float* __restrict__ save_invstd) {
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
-    double s = 0.0, q = 0.0;
+constexpr int kFinThreads = 1024, kFinLanes = 64;   // 64 part-lanes x 16 channels per block
+
+// fixed-order f64 reduction of part[nparts][2][C] for the block's 16 channels; result in (s, q) of lanes pl == 0
+__device__ __forceinline__ void reduce_parts16(const float* __restrict__ part, int nparts, int C, int c, int cl, int pl,
+                                               double (*red)[kFinLanes][16], double& s, double& q) {
+    s = 0.0; q = 0.0;
     if (c < C) {
-        for (int p = pl; p < nparts; p += 16) {
+        int p = pl;
+        for (; p + 3 * kFinLanes < nparts; p += 4 * kFinLanes) {   // 8 independent loads in flight
+            const float a0 = part[((long long)p * 2 + 0) * C + c], b0 = part[((long long)p * 2 + 1) * C + c];
+            const float a1 = part[((long long)(p + kFinLanes) * 2 + 0) * C + c], b1 = part[((long long)(p + kFinLanes) * 2 + 1) * C + c];
+            const float a2 = part[((long long)(p + 2 * kFinLanes) * 2 + 0) * C + c], b2 = part[((long long)(p + 2 * kFinLanes) * 2 + 1) * C + c];
+            const float a3 = part[((long long)(p + 3 * kFinLanes) * 2 + 0) * C + c], b3 = part[((long long)(p + 3 * kFinLanes) * 2 + 1) * C + c];
+            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+            q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+        }
+        for (; p < nparts; p += kFinLanes) {
             s += (double)part[((long long)p * 2 + 0) * C + c];
             q += (double)part[((long long)p * 2 + 1) * C + c];
         }
@@ -104,9 +118,25 @@ __global__ __launch_bounds__(kThreads) void bn_finalize_kernel(
     red[0][pl][cl] = s;
     red[1][pl][cl] = q;
     __syncthreads();
-    if (pl == 0 && c < C) {
+    if (pl == 0) {
         s = 0.0; q = 0.0;
-        for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
+        for (int r = 0; r < kFinLanes; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
+    }
+}
+
+// part [nparts][2][C] -> mean, biased var -> scale/shift (+ moving-average update with the
+// unbiased variance, TF-1.15 fused batch-norm semantic).
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(
+    const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
+    float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd) {
+    __shared__ double red[2][kFinLanes][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s, q;
+    reduce_parts16(part, nparts, C, c, cl, pl, red, s, q);
+    if (pl == 0 && c < C) {
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -171,32 +201,45 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     __shared__ float smem[kThreads * 2 * VE];
     const RowMap m = make_rowmap(C, VE);
     float acc[2][VE];
-    float sc[VE], sh[VE], mu[VE], is[VE];
+    float sc[VE], sh[VE], is[VE], nmi[VE];
 #pragma unroll
     for (int j = 0; j < VE; ++j) {
         acc[0][j] = 0.f; acc[1][j] = 0.f;
         const int c = m.vg * VE + j;
-        sc[j] = scale[c]; sh[j] = shift[c]; mu[j] = mean[c]; is[j] = invstd[c];
+        sc[j] = scale[c]; sh[j] = shift[c]; is[j] = invstd[c]; nmi[j] = -mean[c] * invstd[c];
     }
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     if (m.active) {
-        for (long long r = r0 + m.prow; r < r1; r += m.ppb) {
-            Vec16<T> vd, vx;
-            vd.load(dA + r * C + m.vg * VE);
-            vx.load(x + r * C + m.vg * VE);
-            float d[VE], f[VE];
-            vd.unpack(d);
-            vx.unpack(f);
+        constexpr int U = 4;  // rows in flight per thread (8 x 16-byte loads)
+        for (long long r = r0 + m.prow; r < r1; r += (long long)U * m.ppb) {
+            Vec16<T> vd[U], vx[U];
 #pragma unroll
-            for (int j = 0; j < VE; ++j) {
-                const float pre = f[j] * sc[j] + sh[j];
-                bool pass = true;
-                if (act != MPN_ACT_NONE) pass = pre > 0.f;
-                if (act == MPN_ACT_RELU6) pass = pass && (pre < 6.f);
-                const float g = pass ? d[j] : 0.f;
-                acc[0][j] += g;
-                acc[1][j] += g * ((f[j] - mu[j]) * is[j]);
+            for (int u = 0; u < U; ++u) {
+                const long long rr = r + (long long)u * m.ppb;
+                if (rr < r1) {
+                    vd[u].load(dA + rr * C + m.vg * VE);
+                    vx[u].load(x + rr * C + m.vg * VE);
+                } else {
+                    vd[u].zero();
+                    vx[u].zero();
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float d[VE], f[VE];
+                vd[u].unpack(d);
+                vx[u].unpack(f);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) {
+                    const float pre = f[j] * sc[j] + sh[j];
+                    bool pass = true;
+                    if (act != MPN_ACT_NONE) pass = pre > 0.f;
+                    if (act == MPN_ACT_RELU6) pass = pass && (pre < 6.f);
+                    const float g = pass ? d[j] : 0.f;   // (zero-filled tail rows contribute g = 0)
+                    acc[0][j] += g;
+                    acc[1][j] += g * (f[j] * is[j] + nmi[j]);
+                }
             }
         }
     }
@@ -204,26 +247,16 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
 }
 
 // part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
-__global__ __launch_bounds__(kThreads) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
-                                                                   double count, float* __restrict__ dgamma,
-                                                                   float* __restrict__ dbeta,
-                                                                   float* __restrict__ k1, float* __restrict__ k2) {
-    __shared__ double red[2][16][16];
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                                      double count, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta,
+                                                                      float* __restrict__ k1, float* __restrict__ k2) {
+    __shared__ double red[2][kFinLanes][16];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    double s = 0.0, q = 0.0;
-    if (c < C) {
-        for (int p = pl; p < nparts; p += 16) {
-            s += (double)part[((long long)p * 2 + 0) * C + c];
-            q += (double)part[((long long)p * 2 + 1) * C + c];
-        }
-    }
-    red[0][pl][cl] = s;
-    red[1][pl][cl] = q;
-    __syncthreads();
+    double s, q;
+    reduce_parts16(part, nparts, C, c, cl, pl, red, s, q);
     if (pl == 0 && c < C) {
-        s = 0.0; q = 0.0;
-        for (int r = 0; r < 16; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         k1[c] = (float)(s / count);
@@ -286,8 +319,8 @@ int check_rows(long long M, int C, int dtype, int* ve_out) {
 }  // namespace
 
 extern "C" int mpn_bn_stats_num_parts(long long M) {
-    // ~1024 rows per block, at most 2048 blocks
-    long long rows = 1024;
+    // >= 128 rows per block, at most 2048 blocks (8 waves per SIMD on 256 CUs)
+    long long rows = 128;
     long long parts = (M + rows - 1) / rows;
     if (parts > 2048) parts = 2048;
     if (parts < 1) parts = 1;
@@ -315,7 +348,7 @@ extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long c
     MPN_REQUIRE(part && gamma && beta && scale && shift, MPN_ERR_BAD_ARG, "bn_finalize: null pointer");
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_finalize: bad sizes");
     MPN_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), MPN_ERR_BAD_ARG, "bn_finalize: moving stats");
-    bn_finalize_kernel<<<(C + 15) / 16, kThreads, 0, (hipStream_t)stream>>>(
+    bn_finalize_kernel<<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(
         part, nparts, C, (double)count, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift, save_mean,
         save_invstd);
     MPN_LAUNCH_CHECK();
@@ -365,7 +398,7 @@ extern "C" int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long lo
                                    float* dbeta, float* k1, float* k2, mpn_stream_t stream) {
     MPN_REQUIRE(part && dgamma && dbeta && k1 && k2, MPN_ERR_BAD_ARG, "bn_bwd_finalize: null pointer");
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_bwd_finalize: bad sizes");
-    bn_bwd_finalize_kernel<<<(C + 15) / 16, kThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
+    bn_bwd_finalize_kernel<<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
                                                                                dgamma, dbeta, k1, k2);
     MPN_LAUNCH_CHECK();
     return MPN_OK;

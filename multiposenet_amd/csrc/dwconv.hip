@@ -15,7 +15,7 @@ namespace {
 constexpr int kThreads = 256;
 
 template <int STRIDE> struct DwTile;
-template <> struct DwTile<1> { static constexpr int TH = 8, TW = 8, HH = 10, HW = 10; };
+template <> struct DwTile<1> { static constexpr int TH = 8, TW = 16, HH = 10, HW = 18; };
 template <> struct DwTile<2> { static constexpr int TH = 4, TW = 8, HH = 9, HW = 17; };
 
 struct DwParams {
@@ -35,10 +35,33 @@ struct DwParams {
     int cblocks;        // channel blocks
 };
 
+// 4-channel (one LDS float4) accessors of the storage type: the COMPUTE granule. 72 weight registers per thread
+// (9 taps x 8 channels) pushed the 8-channel version to 2 waves/SIMD; 4 channels per lane need 36 and keep every
+// global access a contiguous 8/16-byte piece of a fully used line.
+__device__ __forceinline__ void load4(const float* p, float (&f)[4]) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+}
+__device__ __forceinline__ void load4(const bf16_t* p, float (&f)[4]) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    f[0] = __uint_as_float(q.x << 16); f[1] = __uint_as_float(q.x & 0xffff0000u);
+    f[2] = __uint_as_float(q.y << 16); f[3] = __uint_as_float(q.y & 0xffff0000u);
+}
+__device__ __forceinline__ void store4(float* p, const float (&f)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&f)[4]) {
+    const bf16_t a = (bf16_t)f[0], b = (bf16_t)f[1], c = (bf16_t)f[2], d = (bf16_t)f[3];
+    uint2 q;
+    q.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    q.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    *reinterpret_cast<uint2*>(p) = q;
+}
+
 // reduce over the lanes/waves that share this thread's channel vector; result valid in threads
 // with pt == 0 (pixel lane 0). nvg is a power of two <= 8.
 template <int NV>
-__device__ __forceinline__ void reduce_same_vg(float (&v)[NV], int nvg, float* smem /*[4][8][NV]*/) {
+__device__ __forceinline__ void reduce_same_vg(float (&v)[NV], int nvg, float* smem /*[4][16][NV]*/) {
 #pragma unroll
     for (int k = 0; k < NV; ++k)
         for (int o = nvg; o < 64; o <<= 1) v[k] += __shfl_xor(v[k], o, 64);
@@ -46,123 +69,157 @@ __device__ __forceinline__ void reduce_same_vg(float (&v)[NV], int nvg, float* s
     __syncthreads();
     if (lane < nvg)
 #pragma unroll
-        for (int k = 0; k < NV; ++k) smem[(wave * 8 + lane) * NV + k] = v[k];
+        for (int k = 0; k < NV; ++k) smem[(wave * 16 + lane) * NV + k] = v[k];
     __syncthreads();
     if ((int)threadIdx.x < nvg)
 #pragma unroll
         for (int k = 0; k < NV; ++k)
-            v[k] = smem[(0 * 8 + lane) * NV + k] + smem[(1 * 8 + lane) * NV + k] + smem[(2 * 8 + lane) * NV + k] +
-                   smem[(3 * 8 + lane) * NV + k];
+            v[k] = smem[(0 * 16 + lane) * NV + k] + smem[(1 * 16 + lane) * NV + k] + smem[(2 * 16 + lane) * NV + k] +
+                   smem[(3 * 16 + lane) * NV + k];
 }
 
 // stage the (affine+activated) input halo tile of one (image, tile, channel block) into LDS as f32
+template <typename T> struct HaloAffine {
+    float sc[Vec16<T>::N], sh[Vec16<T>::N];
+    bool on;
+};
+
+// per-thread affine of the staging lane (the lane's channel vector is the same for every vector it stages,
+// because kThreads % nvg == 0) - loaded once per kernel
+template <typename T>
+__device__ __forceinline__ HaloAffine<T> load_halo_affine(const DwParams& p, int c0, int cb_vecs) {
+    constexpr int VE = Vec16<T>::N;
+    HaloAffine<T> a;
+    const int vg = threadIdx.x % p.nvg;
+    a.on = p.in_scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < VE; ++j) {
+        const bool ok = a.on && vg < cb_vecs;
+        a.sc[j] = ok ? p.in_scale[c0 + vg * VE + j] : 1.f;
+        a.sh[j] = ok ? p.in_shift[c0 + vg * VE + j] : 0.f;
+    }
+    return a;
+}
+
 template <typename T, int STRIDE>
-__device__ __forceinline__ void stage_halo(const DwParams& p, float* tile, int img, int oy0, int ox0, int c0,
-                                           int cb_vecs) {
+__device__ __forceinline__ void stage_halo(const DwParams& p, const HaloAffine<T>& aff, float* tile, int img, int oy0,
+                                           int ox0, int c0, int cb_vecs) {
     using TL = DwTile<STRIDE>;
     constexpr int VE = Vec16<T>::N;
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
-    const int total = TL::HH * TL::HW * p.nvg;
     const int iy0 = oy0 * STRIDE - p.pad_t, ix0 = ox0 * STRIDE - p.pad_l;
-    for (int i = threadIdx.x; i < total; i += kThreads) {
-        const int vg = i % p.nvg;
-        const int hp = i / p.nvg;
+    constexpr int MAXV = (TL::HH * TL::HW * 8 + kThreads - 1) / kThreads;
+    const int vg = threadIdx.x % p.nvg;
+    const int hp0 = threadIdx.x / p.nvg, hstep = kThreads / p.nvg;
+    // phase 1: issue every global load of this thread (up to MAXV 16-byte vectors in flight)
+    Vec16<T> v[MAXV];
+    bool ok[MAXV];
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        const int hp = hp0 + k * hstep;
         const int hy = hp / TL::HW, hx = hp - hy * TL::HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
-        float f[VE];
+        ok[k] = hp < TL::HH * TL::HW && vg < cb_vecs && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        if (ok[k]) v[k].load(x + (((long long)img * p.H + iy) * p.W + ix) * p.C + c0 + vg * VE);
+        else v[k].zero();
+    }
+    // phase 2: affine + activation (in-image elements only: the padding is zeros of the ACTIVATED tensor) -> LDS
 #pragma unroll
-        for (int j = 0; j < VE; ++j) f[j] = 0.f;
-        if (vg < cb_vecs && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
-            Vec16<T> v;
-            v.load(x + (((long long)img * p.H + iy) * p.W + ix) * p.C + c0 + vg * VE);
-            v.unpack(f);
-            if (p.in_scale != nullptr) {
+    for (int k = 0; k < MAXV; ++k) {
+        const int hp = hp0 + k * hstep;
+        if (hp < TL::HH * TL::HW) {
+            float f[VE];
+            v[k].unpack(f);
+            if (ok[k] && aff.on) {
 #pragma unroll
                 for (int j = 0; j < VE; ++j) {
-                    float t = f[j] * p.in_scale[c0 + vg * VE + j] + p.in_shift[c0 + vg * VE + j];
+                    float t = f[j] * aff.sc[j] + aff.sh[j];
                     if (p.in_act != MPN_ACT_NONE) t = fmaxf(t, 0.f);
                     if (p.in_act == MPN_ACT_RELU6) t = fminf(t, 6.f);
                     f[j] = t;
                 }
             }
-        }
-        float* dst = tile + (hp * p.nvg + vg) * VE;
+            float* dst = tile + (hp * p.nvg + vg) * VE;
 #pragma unroll
-        for (int j = 0; j < VE; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+            for (int j = 0; j < VE; j += 4)
+                *reinterpret_cast<float4*>(dst + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+        }
     }
 }
 
+// Blocks are persistent over a strided set of tiles of ONE channel block: the 9 x VE weights stay in registers, the
+// batch-norm partial sums accumulate in registers across tiles and are reduced once per block (one partial row per
+// block keeps the finalize kernel short).
 template <typename T, int STRIDE>
-__global__ __launch_bounds__(kThreads) void dwconv_fwd_kernel(const DwParams p) {
+__global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams p, int nsplit) {
     using TL = DwTile<STRIDE>;
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* tile = smem_f;                                   // [HH*HW][nvg*VE]
-    float* red = smem_f + TL::HH * TL::HW * 8 * VE;         // [4][8][2*VE]
+    float* red = smem_f + TL::HH * TL::HW * 8 * VE;         // [4][16][8]
 
-    int b = blockIdx.x;
-    const int cb = b % p.cblocks; b /= p.cblocks;
-    const int tx = b % p.tiles_x; b /= p.tiles_x;
-    const int ty = b % p.tiles_y;
-    const int img = b / p.tiles_y;
-    const int part_idx = (img * p.tiles_y + ty) * p.tiles_x + tx;
-    const int oy0 = ty * TL::TH, ox0 = tx * TL::TW;
+    const int cb = blockIdx.x % p.cblocks;
+    const int split = blockIdx.x / p.cblocks;
     const int c0 = cb * p.nvg * VE;
     const int cb_vecs = min(p.nvg, (p.C - c0) / VE);
-
-    stage_halo<T, STRIDE>(p, tile, img, oy0, ox0, c0, cb_vecs);
-    __syncthreads();
-
-    const int vg = threadIdx.x % p.nvg;
-    const int pt = threadIdx.x / p.nvg;
-    const int npt = kThreads / p.nvg;
-    const bool vg_ok = vg < cb_vecs;
-    float wr[9][VE];
+    const int cstride = p.nvg * VE;            // channels (floats) per LDS pixel
+    const int ncg = cstride / 4;               // 4-channel compute lanes per pixel (<= 16)
+    const int cg = threadIdx.x % ncg;
+    const int pt = threadIdx.x / ncg;
+    const int npt = kThreads / ncg;
+    const bool cg_ok = cg * 4 < cb_vecs * VE;
+    float wr[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < VE; ++j)
-            wr[t][j] = vg_ok ? p.w[(p.flip ? 8 - t : t) * p.C + c0 + vg * VE + j] : 0.f;
+        for (int j = 0; j < 4; ++j)
+            wr[t][j] = cg_ok ? p.w[(p.flip ? 8 - t : t) * p.C + c0 + cg * 4 + j] : 0.f;
 
-    float st[2 * VE];
+    float st[8];
 #pragma unroll
-    for (int j = 0; j < 2 * VE; ++j) st[j] = 0.f;
+    for (int j = 0; j < 8; ++j) st[j] = 0.f;
     T* __restrict__ y = reinterpret_cast<T*>(p.y);
 
-    for (int op = pt; op < TL::TH * TL::TW; op += npt) {
-        const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
-        const int oy = oy0 + oyl, ox = ox0 + oxl;
-        float acc[VE];
+    const HaloAffine<T> aff = load_halo_affine<T>(p, c0, cb_vecs);
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    for (int t = split; t < ntiles; t += nsplit) {
+        const int tx = t % p.tiles_x;
+        const int t2 = t / p.tiles_x;
+        const int ty = t2 % p.tiles_y;
+        const int img = t2 / p.tiles_y;
+        const int oy0 = ty * TL::TH, ox0 = tx * TL::TW;
+        __syncthreads();  // previous tile's LDS reads are done
+        stage_halo<T, STRIDE>(p, aff, tile, img, oy0, ox0, c0, cb_vecs);
+        __syncthreads();
+#pragma unroll 1
+        for (int op = pt; op < TL::TH * TL::TW; op += npt) {
+            const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
+            const int oy = oy0 + oyl, ox = ox0 + oxl;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const float* src = tile + (((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * p.nvg + vg) * VE;
-#pragma unroll
-                for (int j = 0; j < VE; j += 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(src + j);
-                    acc[j] += q.x * wr[ky * 3 + kx][j];
-                    acc[j + 1] += q.y * wr[ky * 3 + kx][j + 1];
-                    acc[j + 2] += q.z * wr[ky * 3 + kx][j + 2];
-                    acc[j + 3] += q.w * wr[ky * 3 + kx][j + 3];
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 q = *reinterpret_cast<const float4*>(
+                        tile + ((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * cstride + cg * 4);
+                    acc[0] += q.x * wr[ky * 3 + kx][0];
+                    acc[1] += q.y * wr[ky * 3 + kx][1];
+                    acc[2] += q.z * wr[ky * 3 + kx][2];
+                    acc[3] += q.w * wr[ky * 3 + kx][3];
                 }
-            }
-        if (vg_ok && oy < p.OH && ox < p.OW) {
+            if (cg_ok && oy < p.OH && ox < p.OW) {
 #pragma unroll
-            for (int j = 0; j < VE; ++j) { st[j] += acc[j]; st[VE + j] += acc[j] * acc[j]; }
-            Vec16<T> ov;
-            ov.pack(acc);
-            ov.store(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + vg * VE);
+                for (int j = 0; j < 4; ++j) { st[j] += acc[j]; st[4 + j] += acc[j] * acc[j]; }
+                store4(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, acc);
+            }
         }
     }
     if (p.part != nullptr) {
-        reduce_same_vg<2 * VE>(st, p.nvg, red);
-        if ((int)threadIdx.x < cb_vecs) {
-            float* dst = p.part + (long long)part_idx * 2 * p.C + c0 + vg * VE;
+        reduce_same_vg<8>(st, ncg, red);
+        if ((int)threadIdx.x < ncg && cg_ok) {
+            float* dst = p.part + (long long)split * 2 * p.C + c0 + cg * 4;
 #pragma unroll
-            for (int j = 0; j < VE; ++j) { dst[j] = st[j]; dst[p.C + j] = st[VE + j]; }
+            for (int j = 0; j < 4; ++j) { dst[j] = st[j]; dst[p.C + j] = st[4 + j]; }
         }
     }
 }
@@ -210,27 +267,30 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_kernel(const T* __re
 // weight gradient: dw[t][c] = sum a[n, oy*S+ky-pt, ox*S+kx-pl, c] * dy[n,oy,ox,c].
 // Blocks walk many tiles of one channel block with the 9 x VE accumulators in registers and reduce once.
 template <typename T, int STRIDE>
-__global__ __launch_bounds__(kThreads) void dwconv_wgrad_kernel(const DwParams p, int nsplit) {
+__global__ __launch_bounds__(kThreads, 4) void dwconv_wgrad_kernel(const DwParams p, int nsplit) {
     using TL = DwTile<STRIDE>;
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* tile = smem_f;
-    float* red = smem_f + TL::HH * TL::HW * 8 * VE;  // [4][8][9*VE]
+    float* red = smem_f + TL::HH * TL::HW * 8 * VE;  // [4][16][36]
 
     const int cb = blockIdx.x % p.cblocks;
     const int split = blockIdx.x / p.cblocks;
     const int c0 = cb * p.nvg * VE;
     const int cb_vecs = min(p.nvg, (p.C - c0) / VE);
-    const int vg = threadIdx.x % p.nvg;
-    const int pt = threadIdx.x / p.nvg;
-    const int npt = kThreads / p.nvg;
-    const bool vg_ok = vg < cb_vecs;
+    const int cstride = p.nvg * VE;
+    const int ncg = cstride / 4;
+    const int cg = threadIdx.x % ncg;
+    const int pt = threadIdx.x / ncg;
+    const int npt = kThreads / ncg;
+    const bool cg_ok = cg * 4 < cb_vecs * VE;
     const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
 
-    float acc[9 * VE];
+    float acc[36];
 #pragma unroll
-    for (int j = 0; j < 9 * VE; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 36; ++j) acc[j] = 0.f;
 
+    const HaloAffine<T> aff = load_halo_affine<T>(p, c0, cb_vecs);
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     for (int t = split; t < ntiles; t += nsplit) {
         const int tx = t % p.tiles_x;
@@ -239,39 +299,35 @@ __global__ __launch_bounds__(kThreads) void dwconv_wgrad_kernel(const DwParams p
         const int img = t2 / p.tiles_y;
         const int oy0 = ty * TL::TH, ox0 = tx * TL::TW;
         __syncthreads();
-        stage_halo<T, STRIDE>(p, tile, img, oy0, ox0, c0, cb_vecs);
+        stage_halo<T, STRIDE>(p, aff, tile, img, oy0, ox0, c0, cb_vecs);
         __syncthreads();
+#pragma unroll 1
         for (int op = pt; op < TL::TH * TL::TW; op += npt) {
             const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
             const int oy = oy0 + oyl, ox = ox0 + oxl;
-            if (!(vg_ok && oy < p.OH && ox < p.OW)) continue;
-            Vec16<T> gv;
-            gv.load(dy + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + vg * VE);
-            float g[VE];
-            gv.unpack(g);
+            if (!(cg_ok && oy < p.OH && ox < p.OW)) continue;
+            float g[4];
+            load4(dy + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, g);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const float* src = tile + (((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * p.nvg + vg) * VE;
-#pragma unroll
-                    for (int j = 0; j < VE; j += 4) {
-                        const float4 q = *reinterpret_cast<const float4*>(src + j);
-                        acc[(ky * 3 + kx) * VE + j] += q.x * g[j];
-                        acc[(ky * 3 + kx) * VE + j + 1] += q.y * g[j + 1];
-                        acc[(ky * 3 + kx) * VE + j + 2] += q.z * g[j + 2];
-                        acc[(ky * 3 + kx) * VE + j + 3] += q.w * g[j + 3];
-                    }
+                    const float4 q = *reinterpret_cast<const float4*>(
+                        tile + ((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * cstride + cg * 4);
+                    acc[(ky * 3 + kx) * 4 + 0] += q.x * g[0];
+                    acc[(ky * 3 + kx) * 4 + 1] += q.y * g[1];
+                    acc[(ky * 3 + kx) * 4 + 2] += q.z * g[2];
+                    acc[(ky * 3 + kx) * 4 + 3] += q.w * g[3];
                 }
         }
     }
-    reduce_same_vg<9 * VE>(acc, p.nvg, red);
-    if ((int)threadIdx.x < cb_vecs) {
-        float* dst = p.part + (long long)split * 9 * p.C + c0 + vg * VE;
+    reduce_same_vg<36>(acc, ncg, red);
+    if ((int)threadIdx.x < ncg && cg_ok) {
+        float* dst = p.part + (long long)split * 9 * p.C + c0 + cg * 4;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
-            for (int j = 0; j < VE; ++j) dst[t * p.C + j] = acc[t * VE + j];
+            for (int j = 0; j < 4; ++j) dst[t * p.C + j] = acc[t * 4 + j];
     }
 }
 
@@ -291,7 +347,7 @@ int fill_params(DwParams& p, int N, int H, int W, int C, int stride, int dtype) 
     p.N = N; p.H = H; p.W = W; p.C = C;
     tf_same_pad(H, stride, &p.OH, &p.pad_t);
     tf_same_pad(W, stride, &p.OW, &p.pad_l);
-    const int th = stride == 1 ? 8 : 4, tw = 8;
+    const int th = stride == 1 ? 8 : 4, tw = stride == 1 ? 16 : 8;
     p.tiles_y = (p.OH + th - 1) / th;
     p.tiles_x = (p.OW + tw - 1) / tw;
     int nvg = 8;
@@ -303,7 +359,7 @@ int fill_params(DwParams& p, int N, int H, int W, int C, int stride, int dtype) 
 
 template <int STRIDE> size_t dw_smem(int ve, int nred) {
     using TL = DwTile<STRIDE>;
-    return (size_t)(TL::HH * TL::HW * 8 * ve + 4 * 8 * nred) * sizeof(float);
+    return (size_t)(TL::HH * TL::HW * 8 * ve + 4 * 16 * nred) * sizeof(float);
 }
 
 template <typename K> int set_smem(K kernel, size_t bytes) {
@@ -316,10 +372,19 @@ template <typename K> int set_smem(K kernel, size_t bytes) {
 
 extern "C" int mpn_dwconv_out_size(int size, int stride) { return (size + stride - 1) / stride; }
 
-extern "C" int mpn_dwconv_num_parts(int N, int H, int W, int stride) {
-    const int oh = (H + stride - 1) / stride, ow = (W + stride - 1) / stride;
-    const int th = stride == 1 ? 8 : 4;
-    return N * ((oh + th - 1) / th) * ((ow + 7) / 8);
+static int dw_fwd_nsplit(const DwParams& p) {
+    const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    int nsplit = 2048 / p.cblocks;   // ~8 blocks per CU
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    return nsplit;
+}
+
+/* rows of the stats partial slab written by mpn_dwconv_fwd */
+extern "C" int mpn_dwconv_num_parts(int N, int H, int W, int C, int stride, int dtype) {
+    DwParams p = {};
+    if (fill_params(p, N, H, W, C, stride, dtype)) return 0;
+    return dw_fwd_nsplit(p);
 }
 
 extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
@@ -332,19 +397,20 @@ extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int
     p.x = x; p.w = w; p.y = y; p.part = stats_part;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.flip = flip;
     const int ve = dtype == MPN_F32 ? 4 : 8;
-    const int grid = N * p.tiles_y * p.tiles_x * p.cblocks;
+    const int nsplit = dw_fwd_nsplit(p);
+    const int grid = nsplit * p.cblocks;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
-        const size_t sm = dw_smem<1>(ve, 2 * ve);
+        const size_t sm = dw_smem<1>(ve, 8);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_fwd_kernel<T, 1>, sm)) return rc;
-            dwconv_fwd_kernel<T, 1><<<grid, kThreads, sm, st>>>(p);
+            dwconv_fwd_kernel<T, 1><<<grid, kThreads, sm, st>>>(p, nsplit);
         });
     } else {
-        const size_t sm = dw_smem<2>(ve, 2 * ve);
+        const size_t sm = dw_smem<2>(ve, 8);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_fwd_kernel<T, 2>, sm)) return rc;
-            dwconv_fwd_kernel<T, 2><<<grid, kThreads, sm, st>>>(p);
+            dwconv_fwd_kernel<T, 2><<<grid, kThreads, sm, st>>>(p, nsplit);
         });
     }
     MPN_LAUNCH_CHECK();
@@ -394,13 +460,13 @@ extern "C" int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part,
     const int grid = nsplit * p.cblocks;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
-        const size_t sm = dw_smem<1>(ve, 9 * ve);
+        const size_t sm = dw_smem<1>(ve, 36);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_wgrad_kernel<T, 1>, sm)) return rc;
             dwconv_wgrad_kernel<T, 1><<<grid, kThreads, sm, st>>>(p, nsplit);
         });
     } else {
-        const size_t sm = dw_smem<2>(ve, 9 * ve);
+        const size_t sm = dw_smem<2>(ve, 36);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_wgrad_kernel<T, 2>, sm)) return rc;
             dwconv_wgrad_kernel<T, 2><<<grid, kThreads, sm, st>>>(p, nsplit);

@@ -77,21 +77,32 @@ __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restri
     }
 }
 
-// weight gradient: dW[27][C0] = sum_pixels patch[27] (x) dy[C0]; blocks walk tiles, each thread owns
-// up to ceil(27*C0/256) outputs in registers; partials [nblocks][27*C0] reduced by mpn_reduce_partials.
+// weight gradient: dW[27][C0] = sum_pixels patch[27] (x) dy[C0]. Register-blocked outer product out of LDS:
+// a thread owns one (ky,kx) position (its 3 input channels are 12 contiguous bytes of the patch) x 8 output
+// channels = 24 accumulators and 24 FMAs per 3 LDS reads; the 9 x C0/8 such threads form a "phase" and the 256
+// threads run as many phases as fit, each on its own share of the tile's 256 pixels. Blocks walk tiles with the
+// accumulators in registers; phases are summed through LDS once, partials [nblocks][27*C0] go to mpn_reduce_partials.
 template <typename T, bool U8>
 __global__ __launch_bounds__(kThreads) void stem_wgrad_kernel(const void* __restrict__ images, const T* __restrict__ dy,
                                                               float* __restrict__ part, int N, int H, int W, int C0, int OH,
                                                               int OW, int pad_t, int pad_l, int tiles_x, int tiles_y) {
     extern __shared__ __attribute__((aligned(16))) float dyn_smem[];
-    float* patch = dyn_smem;                  // [33*33*3]
-    float* g = dyn_smem + kIn * kIn * 3 + 1;  // [256][C0+1]
-    constexpr int kOutPerThread = (27 * kMaxC0 + kThreads - 1) / kThreads;  // 7
-    float acc[kOutPerThread];
+    float* patch = dyn_smem;                      // [33*33*3] (+ pad to 16 B)
+    float* g = dyn_smem + kIn * kIn * 3 + 1;      // [256][C0]  (16-byte aligned: 3268 floats)
+    const int ncq = C0 / 8;                       // 8-channel groups
+    const int tpp = 9 * ncq;                      // threads per phase
+    const int nphase = kThreads / tpp;
+    const int ph = threadIdx.x / tpp;
+    const int r = threadIdx.x - ph * tpp;
+    const int pos = r / ncq, cq = r - pos * ncq;  // pos = ky*3+kx
+    const int ky = pos / 3, kx = pos - ky * 3;
+    const bool active = ph < nphase;
+    float acc[3][8];
 #pragma unroll
-    for (int k = 0; k < kOutPerThread; ++k) acc[k] = 0.f;
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
     const int nout = 27 * C0;
-    const int gs = C0 + 1;
     const int ntiles = N * tiles_y * tiles_x;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int tx = t % tiles_x;
@@ -106,28 +117,39 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_kernel(const void* __rest
             const int oy = oy0 + px / kTile, ox = ox0 + px % kTile;
             float v = 0.f;
             if (oy < OH && ox < OW) v = to_f32(dy[(((long long)img * OH + oy) * OW + ox) * C0 + c]);
-            g[px * gs + c] = v;
+            g[px * C0 + c] = v;
         }
         __syncthreads();
+        if (active) {
+            for (int px = ph; px < kTile * kTile; px += nphase) {
+                const int ly = px / kTile, lx = px - ly * kTile;
+                const float* pp = patch + ((2 * ly + ky) * kIn + 2 * lx + kx) * 3;
+                const float a0 = pp[0], a1 = pp[1], a2 = pp[2];
+                const float4 g0 = *reinterpret_cast<const float4*>(g + px * C0 + cq * 8);
+                const float4 g1 = *reinterpret_cast<const float4*>(g + px * C0 + cq * 8 + 4);
+                const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
 #pragma unroll
-        for (int k = 0; k < kOutPerThread; ++k) {
-            const int o = threadIdx.x + k * kThreads;
-            if (o < nout) {
-                const int tap = o / C0, c = o % C0;  // tap = (ky*3+kx)*3+ch
-                const int ch = tap % 3, kx = (tap / 3) % 3, ky = tap / 9;
-                float s = 0.f;
-                for (int px = 0; px < kTile * kTile; ++px) {
-                    const int ly = px / kTile, lx = px % kTile;
-                    s += patch[((2 * ly + ky) * kIn + 2 * lx + kx) * 3 + ch] * g[px * gs + c];
+                for (int j = 0; j < 8; ++j) {
+                    acc[0][j] += a0 * gv[j];
+                    acc[1][j] += a1 * gv[j];
+                    acc[2][j] += a2 * gv[j];
                 }
-                acc[k] += s;
             }
         }
     }
+    // sum the phases through LDS (reuse g: nphase * 27*C0 floats <= 256*C0)
+    __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int k = 0; k < kOutPerThread; ++k) {
-        const int o = threadIdx.x + k * kThreads;
-        if (o < nout) part[(long long)blockIdx.x * nout + o] = acc[k];
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[ph * nout + (pos * 3 + a) * C0 + cq * 8 + j] = acc[a][j];
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < nout; o += kThreads) {
+        float s = 0.f;
+        for (int q = 0; q < nphase; ++q) s += g[q * nout + o];
+        part[(long long)blockIdx.x * nout + o] = s;
     }
 }
 
@@ -184,7 +206,8 @@ extern "C" int mpn_stem_conv_bwd_weight(const void* images, int images_u8, const
     const int tiles_y = (OH + kTile - 1) / kTile, tiles_x = (OW + kTile - 1) / kTile;
     const int grid = mpn_stem_conv_wgrad_num_parts(N, H, W);
     hipStream_t st = (hipStream_t)stream;
-    const size_t sm = (size_t)(kIn * kIn * 3 + 1 + kTile * kTile * (C0 + 1)) * sizeof(float);
+    MPN_REQUIRE(C0 % 8 == 0, MPN_ERR_BAD_SHAPE, "stem_wgrad: C0 must be a multiple of 8");
+    const size_t sm = (size_t)(kIn * kIn * 3 + 1 + kTile * kTile * C0) * sizeof(float);
     MPN_REQUIRE(sm <= 64 * 1024, MPN_ERR_BAD_SHAPE, "stem_wgrad: C0 too large");
     MPN_DISPATCH_DTYPE(dtype, {
         if (images_u8)

@@ -277,7 +277,7 @@ class KeypointNet:
         for i, blk in enumerate(self.blocks):
             hh, ww = b["hw"][i]
             cdw, cpw = b["dw"][i].shape[3], blk["pw"].cout
-            stat_floats = max(stat_floats, ops.dwconv_num_parts(N, hh, ww, blk["stride"]) * 2 * cdw,
+            stat_floats = max(stat_floats, ops.dwconv_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw,
                               nbn(rows(b["dw"][i])) * 2 * cdw,
                               ops.conv_num_parts(N, *b["hw"][i + 1], 1) * 2 * cpw, nbn(rows(b["pw"][i])) * 2 * cpw)
         for l in lv:
@@ -360,7 +360,8 @@ class KeypointNet:
             hin, win = b["hw"][i]
             ydw = ops.dwconv_fwd(x, blk["dw_w"], blk["stride"], aff, out=b["dw"][i], stats_part=sp if is_training else None)
             if is_training:
-                ops.bn_finalize(blk["dw_bn"], sp, ops.dwconv_num_parts(N, hin, win, blk["stride"]), ydw.numel() // ydw.shape[3])
+                ops.bn_finalize(blk["dw_bn"], sp, ops.dwconv_num_parts(N, hin, win, ydw.shape[3], blk["stride"], self.dtype),
+                                ydw.numel() // ydw.shape[3])
             h, w = b["hw"][i + 1]
             ypw = ops.conv_fwd(ydw, blk["pw"].packed.fwd, blk["pw"].cout, 1, blk["dw_bn"].affine, out=b["pw"][i],
                                stats_part=sp if is_training else None)

@@ -161,8 +161,8 @@ def dwconv_out_hw(H, W, stride):
     return l.mpn_dwconv_out_size(H, stride), l.mpn_dwconv_out_size(W, stride)
 
 
-def dwconv_num_parts(N, H, W, stride):
-    return _lib.lib().mpn_dwconv_num_parts(N, H, W, stride)
+def dwconv_num_parts(N, H, W, C, stride, dtype):
+    return _lib.lib().mpn_dwconv_num_parts(N, H, W, C, stride, _lib.dtype_code(dtype))
 
 
 def dwconv_fwd(x, w, stride, affine=None, out=None, stats_part=None):

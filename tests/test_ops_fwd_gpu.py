@@ -96,7 +96,7 @@ def test_dwconv_fwd(cuda, dtype, N, H, W, C, stride):
     sh = torch.tensor(rs.randn(C) * 0.5, dtype=torch.float32)
     a = torch.clamp(x * sc + sh, 0, 6)
     want = nhwc(onet.depthwise_conv2d_tf_same(nchw(a), torch.tensor(w), stride))
-    nparts = ops.dwconv_num_parts(N, H, W, stride)
+    nparts = ops.dwconv_num_parts(N, H, W, C, stride, dtype)
     part = torch.full((nparts, 2, C), float("nan"), device="cuda")
     y = ops.dwconv_fwd(dev(x, dtype), dev(w), stride, ops.Affine(dev(sc), dev(sh), 2), stats_part=part)
     assert tuple(y.shape) == tuple(want.shape)
