@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libmpn_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", "-munsafe-fp-atomics"]
+         "-fno-gpu-rdc", "-munsafe-fp-atomics"] + os.environ.get("MPN_EXTRA_FLAGS", "").split()   # diagnostic builds
 
 
 def _sources():

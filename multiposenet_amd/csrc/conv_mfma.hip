@@ -51,45 +51,75 @@ struct ConvParams {
     int N, H, W, Cin, Cout;
     int tiles_x, tiles_y;
     long long M;
-    int row_bytes;  // 128 or 256
+    int row_bytes;  // 128 or 256: bytes of K staged per pixel row and channel chunk
     int nchunk;
     int n_tiles;
     long long wp_tile_bytes;  // packed bytes per n-tile
+    unsigned long long* dbg;  // diagnostic builds only (env MPN_CONV_STAMPS): per-block s_memtime stamps, else NULL
 };
 
 constexpr int kThreads = 256;
 constexpr int kHaloW = 18, kHaloH = 10;
 
+// LDS pixel-row stride of the A image. Rows are PADDED instead of XOR-swizzled so that every fragment address is
+// `per-lane base + compile-time/uniform offset` (ds_read_b128 with an immediate): the tap, k-step and m-tile cost
+// no VALU in the MFMA loop. 160-byte rows (128 + 32) are conflict-free for the ds_read_b128 lane groups; 272-byte
+// rows (256 + 16) leave one 2-way pair per group (5 instead of 4 LDS cycles) and let two blocks share a CU's LDS.
+__host__ __device__ constexpr int a_row_stride(int row_bytes) { return row_bytes == 256 ? 272 : 160; }
+
+// B (weights) image: [k-step][BN rows][64 B]; the four 16-byte slots of a row are XOR-swizzled with f(row>>2),
+// f = {0,2,3,1}, which makes the 16 rows x 1 slot pattern of a ds_read_b128 lane group hit 16 distinct bank slots.
+// The swizzle is applied by the PACK kernel (the global image is the LDS image), so staging stays a linear copy.
+__host__ __device__ constexpr int b_swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
 template <typename T>
-__device__ __forceinline__ void apply_affine_act(Vec16<T>& v, const float* sc, const float* sh, int act) {
+__device__ __forceinline__ void apply_affine_act(Vec16<T>& v, const float* sc, const float* sh, float lo, float hi) {
     constexpr int VE = Vec16<T>::N;
     float f[VE];
     v.unpack(f);
 #pragma unroll
-    for (int j = 0; j < VE; ++j) {
-        float t = f[j] * sc[j] + sh[j];
-        if (act != MPN_ACT_NONE) t = fmaxf(t, 0.f);
-        if (act == MPN_ACT_RELU6) t = fminf(t, 6.f);
-        f[j] = t;
-    }
+    for (int j = 0; j < VE; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);   // clamp = 1 VALU op
     v.pack(f);
 }
 
-template <typename T, int TAPS, int BN>
+// 4 consecutive channels of the storage type <-> f32
+__device__ __forceinline__ void store4(float* p, const f32x4_t& v) { *reinterpret_cast<f32x4_t*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) {
+    const bf16_t a = (bf16_t)v[0], b = (bf16_t)v[1], c = (bf16_t)v[2], d = (bf16_t)v[3];
+    uint2 q;
+    q.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    q.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    *reinterpret_cast<uint2*>(p) = q;
+}
+__device__ __forceinline__ f32x4_t load4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
+__device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
+    const uint2 q = *reinterpret_cast<const uint2*>(p);
+    f32x4_t v;
+    v[0] = __uint_as_float(q.x << 16); v[1] = __uint_as_float(q.x & 0xffff0000u);
+    v[2] = __uint_as_float(q.y << 16); v[3] = __uint_as_float(q.y & 0xffff0000u);
+    return v;
+}
+
+template <typename T, int TAPS, int BN, int RB>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams p) {
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
     constexpr int CCE = 256 / ES;  // channels per full chunk
     constexpr int NPIX = TAPS == 9 ? kHaloW * kHaloH : 128;
-    constexpr int NT = BN / 32;                 // 16-col tiles per wave
+    constexpr int NT = BN / 32;                 // 16-channel tiles per wave
     constexpr int STAGE_BYTES = 2 * BN * 64;    // two k-steps of weights
     constexpr int BVEC = STAGE_BYTES / (kThreads * 16);
-    constexpr int AVEC = (NPIX * 16 + kThreads - 1) / kThreads;
+    constexpr int RS = a_row_stride(RB);
+    constexpr int SLOTS = RB >> 4;              // 16-byte slots per pixel row: 8 or 16
+    constexpr int KSTEPS = RB >> 6;             // 64-byte k-steps per chunk: 2 or 4
+    constexpr int SPT = RB >> 7;                // stages (2 k-steps) per tap: 1 or 2
+    constexpr int AVEC = (NPIX * SLOTS + kThreads - 1) / kThreads;
     using Frag = typename Mma<T>::Frag;
+    static_assert(KSTEPS == 2 * SPT, "a stage is exactly two k-steps");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
-    unsigned char* Bs = smem + NPIX * 256;
+    unsigned char* Bs = smem + NPIX * RS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -113,72 +143,72 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams
     } else {
         m0 = (long long)mtile * 128;
     }
-
-    const int RB = p.row_bytes;
-    const int slots = RB >> 4;              // 8 or 16
-    const int swz_shift = (slots == 16) ? 0 : 1;
-    const int ksteps = RB >> 6;             // 64-byte k-steps per chunk (2 or 4)
-    const int stages_per_tap = RB >> 7;     // 1 or 2
-    const int total_stages = p.nchunk * TAPS * stages_per_tap;
+    const int total_stages = p.nchunk * TAPS * SPT;
 
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const unsigned char* __restrict__ wsrc =
         reinterpret_cast<const unsigned char*>(p.wp) + (long long)ntile * p.wp_tile_bytes;
 
-    // ---- accumulators
+    // ---- accumulators: acc[mt][nt] holds D^T: lane (l15, lq) -> pixel mt*16+l15, channels nt*16+lq*4+{0..3}
     f32x4_t acc[4][NT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane A row -> halo pixel base (without tap offset)
-    int pbase[4];
+    // per-lane fragment base addresses: everything else is a compile-time or wave-uniform offset
+    const unsigned char* abase[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int row = wm * 64 + mt * 16 + l15;
-        pbase[mt] = (TAPS == 9) ? ((row >> 4) * kHaloW + (row & 15)) : row;
+        const int pix = (TAPS == 9) ? ((row >> 4) * kHaloW + (row & 15)) : row;
+        abase[mt] = As + pix * RS + lq * 16;
     }
-    const int b_lane_off = (wn * (BN / 2) + l15) * 64 + lq * 16;
+    const unsigned char* bbase = Bs + (wn * (BN / 2) + l15) * 64 + ((lq ^ b_swz(l15)) << 4);
 
-    // ---- weight stage 0 -> buffer 0
-    // (named registers, not an array: hipcc left a conditionally written uint4[] in scratch)
-    static_assert(BVEC == 2 || BVEC == 4, "weight stage is 2 or 4 vectors per thread");
-    uint4 br0, br1, br2, br3;
-#define MPN_BLOAD(src)                                                                    \
-    do {                                                                                  \
-        const unsigned char* s_ = (src) + (size_t)tid * 16;                               \
-        br0 = *reinterpret_cast<const uint4*>(s_);                                        \
-        br1 = *reinterpret_cast<const uint4*>(s_ + kThreads * 16);                        \
-        if (BVEC == 4) {                                                                  \
-            br2 = *reinterpret_cast<const uint4*>(s_ + 2 * kThreads * 16);                \
-            br3 = *reinterpret_cast<const uint4*>(s_ + 3 * kThreads * 16);                \
-        }                                                                                 \
-    } while (0)
-#define MPN_BSTORE(dst)                                                                   \
-    do {                                                                                  \
-        unsigned char* d_ = (dst) + (size_t)tid * 16;                                     \
-        *reinterpret_cast<uint4*>(d_) = br0;                                              \
-        *reinterpret_cast<uint4*>(d_ + kThreads * 16) = br1;                              \
-        if (BVEC == 4) {                                                                  \
-            *reinterpret_cast<uint4*>(d_ + 2 * kThreads * 16) = br2;                      \
-            *reinterpret_cast<uint4*>(d_ + 3 * kThreads * 16) = br3;                      \
-        }                                                                                 \
-    } while (0)
-    br2 = br3 = make_uint4(0u, 0u, 0u, 0u);
-    MPN_BLOAD(wsrc);
-    MPN_BSTORE(Bs);
+    // ---- weights: LDS-DMA (global_load_lds_dwordx4), no VGPR staging and no ds_write. Stage s+1 is in flight into
+    // buffer (s+1)%2 while stage s is computed from buffer s%2; the packed image is already in LDS order, so the
+    // destination of every wave-instruction is the linear 1 KB piece `wave-uniform base + lane*16`.
+    auto b_issue = [&](int stage, int buf) {
+        const unsigned char* src = wsrc + (size_t)stage * STAGE_BYTES + (size_t)tid * 16;
+        unsigned char* dst = Bs + buf * STAGE_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < BVEC; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * kThreads * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + i * kThreads * 16), 16, 0, 0);
+    };
+    b_issue(0, 0);
+
+#define MPN_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    MPN_STAMP(0);
+    const bool affine = (p.in_scale != nullptr);
+    const float act_lo = (p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float act_hi = (p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+
+    // fragment register sets (double-buffered across k-steps so LDS latency hides under the MFMAs)
+    Frag aP[4], bP[NT], aQ[4], bQ[NT];
+    auto load_frags = [&](Frag (&a)[4], Frag (&b)[NT], int a_off, int b_off) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const Frag*>(abase[mt] + a_off);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const Frag*>(bbase + b_off + nt * 1024);
+    };
+    auto mma_all = [&](const Frag (&a)[4], const Frag (&b)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(b[nt], a[mt], acc[mt][nt]);   // D^T = W^T x A^T
+    };
 
     int s = 0;
     for (int chunk = 0; chunk < p.nchunk; ++chunk) {
         __syncthreads();  // every wave has finished reading the previous A image
         // ================= stage the A image (halo or flat rows) for this channel chunk
         {
-            const int slot = tid & (slots - 1);  // kThreads % slots == 0 -> fixed per thread
+            const int slot = tid & (SLOTS - 1);  // kThreads % SLOTS == 0 -> fixed per thread
             const int ce = chunk * CCE + slot * VE;
             const bool cvalid = ce < p.Cin;
             float sc[VE], sh[VE];
-            const bool affine = (p.in_scale != nullptr);
             if (affine && cvalid) {
 #pragma unroll
                 for (int j = 0; j < VE; ++j) { sc[j] = p.in_scale[ce + j]; sh[j] = p.in_shift[ce + j]; }
@@ -186,14 +216,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams
 #pragma unroll
                 for (int j = 0; j < VE; ++j) { sc[j] = 1.f; sh[j] = 0.f; }
             }
-            const int nvec = NPIX * slots;
-            const int pix_step = kThreads / slots;
+            constexpr int nvec = NPIX * SLOTS;
+            constexpr int pix_step = kThreads / SLOTS;
             Vec16<T> v[AVEC];
             bool inb[AVEC];
 #pragma unroll
             for (int i = 0; i < AVEC; ++i) {
                 const int vi = tid + i * kThreads;
-                const int pix = (tid / slots) + i * pix_step;
+                const int pix = (tid / SLOTS) + i * pix_step;
                 bool ok = cvalid && (vi < nvec);
                 long long off = 0;
                 if (TAPS == 9) {
@@ -213,138 +243,115 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams
             for (int i = 0; i < AVEC; ++i) {
                 const int vi = tid + i * kThreads;
                 if (vi < nvec) {
-                    const int pix = (tid / slots) + i * pix_step;
-                    if (affine && inb[i]) apply_affine_act<T>(v[i], sc, sh, p.in_act);
-                    const int sslot = slot ^ ((pix >> swz_shift) & (slots - 1));
-                    *reinterpret_cast<uint4*>(As + pix * RB + (sslot << 4)) =
-                        *reinterpret_cast<const uint4*>(&v[i].raw);
+                    const int pix = (tid / SLOTS) + i * pix_step;
+                    if (affine && inb[i]) apply_affine_act<T>(v[i], sc, sh, act_lo, act_hi);
+                    *reinterpret_cast<uint4*>(As + pix * RS + (slot << 4)) = *reinterpret_cast<const uint4*>(&v[i].raw);
                 }
             }
         }
+        // the LDS-DMA of this chunk's first weight stage and the A image must both have landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (chunk == 0) MPN_STAMP(1);
 
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (TAPS == 9) ? ((tap / 3) * kHaloW + (tap % 3)) : 0;
-            for (int h = 0; h < stages_per_tap; ++h) {
-                const bool more = (s + 1 < total_stages);
-                if (more) MPN_BLOAD(wsrc + (size_t)(s + 1) * STAGE_BYTES);
-                const unsigned char* Bb = Bs + (s & 1) * STAGE_BYTES;
-#pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) {
-                    const int kstep = h * 2 + k2;
-                    if (kstep < ksteps) {
-                        Frag a[4], b[NT];
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt) {
-                            const int pix = pbase[mt] + toff;
-                            const int slot = kstep * 4 + lq;
-                            const int sslot = slot ^ ((pix >> swz_shift) & (slots - 1));
-                            a[mt] = *reinterpret_cast<const Frag*>(As + pix * RB + (sslot << 4));
-                        }
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            b[nt] = *reinterpret_cast<const Frag*>(Bb + k2 * (BN * 64) + nt * 1024 + b_lane_off);
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(a[mt], b[nt], acc[mt][nt]);
-                    }
-                }
-                if (more) MPN_BSTORE(Bs + ((s + 1) & 1) * STAGE_BYTES);
-                __syncthreads();
-                ++s;
-            }
+        for (int sl = 0; sl < TAPS * SPT; ++sl, ++s) {
+            const int tap = sl / SPT, h = sl - tap * SPT;
+            const int ky = (tap * 11) >> 5;   // tap / 3 for tap < 9
+            const int a_off = ((TAPS == 9) ? (ky * kHaloW + (tap - 3 * ky)) * RS : 0) + h * 128;   // wave-uniform
+            const int b_off = (s & 1) * STAGE_BYTES;
+            const bool more = (s + 1 < total_stages);
+            if (more) b_issue(s + 1, (s + 1) & 1);     // buffer (s+1)%2 was last read in stage s-1: all waves are past it
+            load_frags(aP, bP, a_off, b_off);
+            load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
+            mma_all(aP, bP);
+            mma_all(aQ, bQ);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
+            __syncthreads();
         }
     }
+    MPN_STAMP(2);
 
-#undef MPN_BLOAD
-#undef MPN_BSTORE
-    // ================= epilogue: accumulators -> LDS tile [128][BN] f32 (row stride padded)
-    constexpr int OST = BN * 4 + 16;  // bytes per row
-    unsigned char* Os = smem;         // all MFMA-phase LDS reads are behind the last barrier
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wm * 64 + mt * 16 + lq * 4 + r;
-                const int col = wn * (BN / 2) + nt * 16 + l15;
-                *reinterpret_cast<float*>(Os + row * OST + col * 4) = acc[mt][nt][r];
-            }
-    __syncthreads();
-
-    constexpr int VPR = BN / VE;               // 16-byte vectors per output row
-    constexpr int ROWS_PER_PASS = kThreads / VPR;
-    const int vcol = tid % VPR;
-    const int rrow = tid / VPR;
+    // ================= epilogue straight from the accumulators: each lane owns 4 consecutive output channels of one
+    // pixel per (mt, nt) tile -> one 8-byte (bf16) / 16-byte (f32) store; no LDS round trip.
     T* __restrict__ y = reinterpret_cast<T*>(p.y);
     const T* __restrict__ res = reinterpret_cast<const T*>(p.up_res);
-    float ssum[VE], ssq[VE];
+    const int cbase = n0 + wn * (BN / 2) + lq * 4;   // + nt*16
+    f32x4_t ssum[NT], ssq[NT];
 #pragma unroll
-    for (int j = 0; j < VE; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
-    const bool col_ok = (n0 + vcol * VE) < p.Cout;
-
-    for (int row = rrow; row < 128; row += ROWS_PER_PASS) {
-        bool ok = col_ok;
-        long long pixel;  // flat NHW index
+    for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = wm * 64 + mt * 16 + l15;
+        bool ok;
+        long long pixel;
         int n_i, oy, ox;
         if (TAPS == 9) {
             oy = oy0 + (row >> 4);
             ox = ox0 + (row & 15);
             n_i = img;
-            ok = ok && oy < p.H && ox < p.W;
+            ok = oy < p.H && ox < p.W;
             pixel = ((long long)img * p.H + oy) * p.W + ox;
         } else {
             pixel = m0 + row;
-            ok = ok && pixel < p.M;
+            ok = pixel < p.M;
             ox = (int)(pixel % p.W);
             const long long t = pixel / p.W;
             oy = (int)(t % p.H);
             n_i = (int)(t / p.H);
         }
-        if (!ok) continue;
-        float f[VE];
-        const float* src = reinterpret_cast<const float*>(Os + row * OST) + vcol * VE;
+        long long roff = 0;
+        if (res != nullptr) roff = (((long long)n_i * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.Cout;
 #pragma unroll
-        for (int j = 0; j < VE; j += 4) {
-            const float4 q = *reinterpret_cast<const float4*>(src + j);
-            f[j] = q.x; f[j + 1] = q.y; f[j + 2] = q.z; f[j + 3] = q.w;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = cbase + nt * 16;
+            if (ok && c < p.Cout) {
+                f32x4_t v = acc[mt][nt];
+                if (res != nullptr) v += load4(res + roff + c);
+                ssum[nt] += v;
+                ssq[nt] += v * v;
+                store4(y + pixel * p.Cout + c, v);
+            }
         }
-        if (res != nullptr) {
-            const int h2 = p.H >> 1, w2 = p.W >> 1;
-            const long long roff = (((long long)n_i * h2 + (oy >> 1)) * w2 + (ox >> 1)) * p.Cout + n0 + vcol * VE;
-            Vec16<T> rv;
-            rv.load(res + roff);
-            float g[VE];
-            rv.unpack(g);
-#pragma unroll
-            for (int j = 0; j < VE; ++j) f[j] += g[j];
-        }
-#pragma unroll
-        for (int j = 0; j < VE; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * f[j]; }
-        Vec16<T> ov;
-        ov.pack(f);
-        ov.store(y + pixel * p.Cout + n0 + vcol * VE);
     }
 
+    MPN_STAMP(3);
     if (p.stats_part != nullptr) {
-        __syncthreads();  // done reading the output tile; reuse LDS for the reduction
-        float* red = reinterpret_cast<float*>(smem);  // [ROWS_PER_PASS][2][BN]
+        // reduce over the 16 pixels (lanes l15) of each 16-lane row with DPP adds (pure VALU, no LDS crossbar):
+        // quad_perm xor1, xor2, then row_half_mirror and row_mirror complete the 16-lane sum in every lane.
+        auto row_sum16 = [](float v) -> float {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+            return v;
+        };
 #pragma unroll
-        for (int j = 0; j < VE; ++j) {
-            red[(rrow * 2 + 0) * BN + vcol * VE + j] = ssum[j];
-            red[(rrow * 2 + 1) * BN + vcol * VE + j] = ssq[j];
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ssum[nt][r] = row_sum16(ssum[nt][r]);
+                ssq[nt][r] = row_sum16(ssq[nt][r]);
+            }
+        float* red = reinterpret_cast<float*>(Bs);   // [2 wm][2][BN]; the weight buffers are dead (last barrier passed)
+        if (l15 == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int cl = wn * (BN / 2) + nt * 16 + lq * 4 + r;
+                    red[(wm * 2 + 0) * BN + cl] = ssum[nt][r];
+                    red[(wm * 2 + 1) * BN + cl] = ssq[nt][r];
+                }
         }
         __syncthreads();
         if (tid < 2 * BN) {
             const int which = tid / BN, c = tid % BN;
-            float t = 0.f;
-            for (int r = 0; r < ROWS_PER_PASS; ++r) t += red[(r * 2 + which) * BN + c];
             if (n0 + c < p.Cout)
-                p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c] = t;
+                p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c] = red[which * BN + c] + red[(2 + which) * BN + c];
         }
     }
+    MPN_STAMP(4);
+#undef MPN_STAMP
 }
 
 // ------------------------------------------------------------------ weight packing
@@ -376,7 +383,11 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
             if (!transpose) v = w[((long long)tap * Cin_o + c) * Cout_o + co];
             else v = w[((long long)(taps - 1 - tap) * Cin_o + co) * Cout_o + c];
         }
-        out[i] = from_f32<T>(v);
+        // destination slot inside the 64-byte row is XOR-swizzled (see b_swz): the global image is the LDS image
+        constexpr int EPS = 16 / ES;   // elements per 16-byte slot
+        const int q = e / EPS, within = e - q * EPS;
+        const long long dst = i - e + (long long)((q ^ b_swz(n & 15)) * EPS + within);
+        out[dst] = from_f32<T>(v);
     }
 }
 
@@ -427,26 +438,34 @@ extern "C" int mpn_conv_pack_weights(const float* w_hwio, int Cin, int Cout, int
     return MPN_OK;
 }
 
+// diagnostic hook (not part of the public header): device buffer of 8 u64 per block, or NULL
+static void* g_conv_dbg = nullptr;
+extern "C" void mpn_debug_set_conv_stamps(void* buf) { g_conv_dbg = buf; }
+
 extern "C" int mpn_conv_num_parts(int N, int H, int W, int ksize) {
     if (ksize == 3) return N * ((H + 7) / 8) * ((W + 15) / 16);
     return (int)(((long long)N * H * W + 127) / 128);
 }
 
-template <typename T, int TAPS, int BN>
-static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
+template <typename T, int TAPS, int BN, int RB>
+static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
     constexpr int NPIX = TAPS == 9 ? kHaloW * kHaloH : 128;
-    constexpr int main_bytes = NPIX * 256 + 2 * (2 * BN * 64);
-    constexpr int epi_bytes = 128 * (BN * 4 + 16);
-    constexpr int smem = main_bytes > epi_bytes ? main_bytes : epi_bytes;
+    constexpr int smem = NPIX * a_row_stride(RB) + 2 * (2 * BN * 64);
     static bool attr_set = false;
     if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN>,
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    conv_mfma_kernel<T, TAPS, BN><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
+    conv_mfma_kernel<T, TAPS, BN, RB><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
+}
+
+template <typename T, int TAPS, int BN>
+static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
+    return p.row_bytes == 256 ? launch_conv_rb<T, TAPS, BN, 256>(p, m_tiles, st)
+                              : launch_conv_rb<T, TAPS, BN, 128>(p, m_tiles, st);
 }
 
 extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
@@ -470,6 +489,7 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
     p.x = x; p.wp = w_packed; p.y = y;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
     p.stats_part = stats_part; p.up_res = up_res;
+    p.dbg = (unsigned long long*)g_conv_dbg;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
     p.M = (long long)N * H * W;
