@@ -1,0 +1,64 @@
+"""GPU: the reference-shaped Python surface (mobilenet_v1, feature_pyramid_network, KeypointSubnet, Detector)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network as onet
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(dtype=torch.float32, seed=5):
+    from multiposenet_amd.net import KeypointNet
+    params = onet.randomize_bn(onet.init_params(seed), seed + 1)
+    return KeypointNet(values=params, dtype=dtype), params
+
+
+def test_mobilenet_fpn_subnet_functions_match_oracle(cuda):
+    from multiposenet_amd.detector import KeypointSubnet, feature_pyramid_network
+    from multiposenet_amd.detector.backbones import mobilenet_v1
+    net, params = _net()
+    img = np.random.RandomState(0).rand(1, 128, 256, 3).astype(np.float32)   # non-square, multiples of 128
+    pt = {k: torch.tensor(v) for k, v in params.items()}
+    with torch.no_grad():
+        ref_feats = onet.mobilenet_v1(torch.tensor(img), pt, False)
+        ref_fpn = onet.feature_pyramid_network(ref_feats, pt)
+        ref_heat, ref_enr = onet.keypoint_subnet(ref_feats, pt, False)
+    feats = mobilenet_v1(img, False, 1.0, net=net)
+    assert sorted(feats) == ["c2", "c3", "c4", "c5"] and feats["c5"].shape == (1, 1024, 4, 8)
+    for k in feats:
+        np.testing.assert_allclose(feats[k].numpy(), ref_feats[k].numpy(), atol=2e-3, rtol=1e-3)
+    fpn = feature_pyramid_network(feats, False, 128, min_level=2, add_coarse_features=False, scope="keypoint_fpn", net=net)
+    for k in fpn:
+        np.testing.assert_allclose(fpn[k].numpy(), ref_fpn[k].numpy(), atol=2e-3, rtol=1e-3)
+    with pytest.raises(NotImplementedError):
+        feature_pyramid_network(feats, False, 256, net=net)
+    sub = KeypointSubnet(feats, False, {}, net=net)
+    assert tuple(sub.heatmaps.shape) == (1, 32, 64, 18)
+    np.testing.assert_allclose(sub.heatmaps.cpu().numpy(), ref_heat.numpy(), atol=2e-3, rtol=1e-3)
+    np.testing.assert_allclose(sub.enriched_features["p3"].float().cpu().numpy(), ref_enr["p3"].numpy(), atol=2e-3, rtol=1e-3)
+
+
+def test_detector_call_and_decode(cuda, tmp_path):
+    from multiposenet_amd.inference import Detector, get_keypoints
+    net, params = _net(seed=7)
+    path = tmp_path / "weights.npz"
+    np.savez(path, **net.state_dict())
+    det = Detector(str(path), dtype=torch.float32)
+    img = np.random.RandomState(1).randint(0, 256, (128, 128, 3)).astype(np.uint8)
+    out = det(img)
+    assert set(out) == {"boxes", "scores", "num_boxes", "keypoint_heatmaps", "segmentation_masks", "keypoint_scores",
+                        "keypoint_positions"}
+    assert out["keypoint_heatmaps"].shape == (32, 32, 17) and out["segmentation_masks"].shape == (32, 32)
+    pt = {k: torch.tensor(v) for k, v in params.items()}
+    with torch.no_grad():
+        heat, _ = onet.forward(torch.tensor(img[None].astype(np.float32) * np.float32(1 / 255.0)), pt, False)
+    np.testing.assert_allclose(out["keypoint_heatmaps"], torch.sigmoid(heat[0, ..., :17]).numpy(), atol=1e-3)
+    np.testing.assert_allclose(out["segmentation_masks"], heat[0, ..., 17].numpy(), atol=2e-3, rtol=1e-3)
+    # peak decode of the network's own heatmaps: bit-exact against the oracle decode of the SAME heatmaps
+    from oracle import decode as odec
+    box = np.array([0, 0, 128, 128])
+    np.testing.assert_array_equal(get_keypoints(out["keypoint_heatmaps"], box, 0.005),
+                                  odec.get_keypoints(out["keypoint_heatmaps"], box, 0.005))
+    with pytest.raises(AssertionError):
+        det(np.zeros((100, 128, 3), np.uint8))
