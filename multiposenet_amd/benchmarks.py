@@ -73,3 +73,43 @@ def cpu_baseline(size, budget_s=20.0):
     return {"value": round(bs * n / el, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{n} train steps of batch {bs} at {size}x{size}, f32, torch-CPU restatement of the reference "
                       f"(TF-1.15 semantics), {cores} threads"}
+
+
+def decode_benchmark(batch=32, h=128, w=128, iters=200):
+    """Second half of the BASELINE metric: heatmap peak decode, us/image, B images of [h,w,17] f32 resident in HBM
+    (sigmoid of N(-4.6, 1.5^2) logits, threshold 0.2 - SURVEY.md 8(d)). HIP events on the launch stream."""
+    from .inference.utils import KeypointDecoder
+    dec = KeypointDecoder(batch)
+    hm = torch.sigmoid(torch.randn(batch, h, w, 17, device="cuda") * 1.5 - 4.6)
+    box = torch.tensor([[4.0 * h, 4.0 * w]] * batch, dtype=torch.float64, device="cuda")
+    g = torch.cuda.CUDAGraph()
+    for _ in range(3):
+        dec(hm, box, 0.2)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):          # replayed launches: device time, not ctypes overhead
+        for _ in range(10):
+            dec(hm, box, 0.2)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters // 10):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (iters // 10 * 10)
+    byt = hm.numel() * 4
+    # CPU leg: the numpy oracle (bit-identical to the reference on the goldens), one thread, same data
+    from oracle import decode as odec
+    hm_np = hm[:8].cpu().numpy()
+    boxes = [[0, 0, 4 * h, 4 * w]] * 8
+    import numpy as np
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 2.0:
+        odec.get_keypoints_batch(hm_np, np.array(boxes), 0.2)
+        n += 8
+    cpu_us = (time.perf_counter() - t0) * 1e6 / n
+    return {"us_per_image": round(us / batch, 4), "batch": batch, "launch_us": round(us, 2),
+            "hbm_GBps": round(byt / us / 1e3, 1), "hbm_frac_of_8TBps": round(byt / us / 1e3 / 8000.0, 4),
+            "cpu_port_us_per_image": round(cpu_us, 1)}
