@@ -48,7 +48,8 @@ def cpu_baseline(size, budget_s=20.0):
     (TensorFlow 1.15 itself is not installable here - see BASELINE.md.)"""
     import numpy as np
     from oracle import network as onet   # checker used as the measured CPU baseline leg only
-    cores = os.cpu_count() or 1
+    # a 1-GPU box's CPU share is 16 cores (256 visible threads thrash torch's CPU conv: 180 s per step)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     bs = 2
     rs = np.random.RandomState(1234)

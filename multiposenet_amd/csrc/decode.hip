@@ -73,6 +73,44 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(
     const int pix_begin = s * chunks_per_block * kPix;
     const int pix_end = min(npix, pix_begin + chunks_per_block * kPix);
 
+    if constexpr (ES == 4) {
+        // f32: every lane streams "its" pixels straight from HBM - 68 contiguous bytes (4 x dwordx4 + 1 dword, dword
+        // aligned) per pixel, a wave covers 4352 contiguous bytes per pixel row so every fetched byte is used - two
+        // pixels in flight per lane, no LDS staging and no barrier in the streaming loop.
+        const float* __restrict__ img = reinterpret_cast<const float*>(hm + img_byte0);
+        for (int p0 = pix_begin + tid; p0 < pix_end; p0 += 2 * kThreads) {
+            const int p1 = p0 + kThreads;
+            const bool has1 = p1 < pix_end;
+            float v0[kC + 3], v1[kC + 3];
+            const float* s0 = img + (long long)p0 * kC;
+            const float* s1 = img + (long long)(has1 ? p1 : p0) * kC;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 a = *reinterpret_cast<const float4*>(s0 + 4 * q);
+                const float4 b = *reinterpret_cast<const float4*>(s1 + 4 * q);
+                v0[4 * q] = a.x; v0[4 * q + 1] = a.y; v0[4 * q + 2] = a.z; v0[4 * q + 3] = a.w;
+                v1[4 * q] = b.x; v1[4 * q + 1] = b.y; v1[4 * q + 2] = b.z; v1[4 * q + 3] = b.w;
+            }
+            v0[16] = s0[16];
+            v1[16] = s1[16];
+#pragma unroll
+            for (int c = 0; c < kC; ++c) {
+                const unsigned k = ordered_key(v0[c]);
+                const bool gt = k > best_hi[c];  // strict: keeps the first occurrence (pixels ascend per lane)
+                best_hi[c] = gt ? k : best_hi[c];
+                best_idx[c] = gt ? (unsigned)p0 : best_idx[c];
+            }
+            if (has1) {
+#pragma unroll
+                for (int c = 0; c < kC; ++c) {
+                    const unsigned k = ordered_key(v1[c]);
+                    const bool gt = k > best_hi[c];
+                    best_hi[c] = gt ? k : best_hi[c];
+                    best_idx[c] = gt ? (unsigned)p1 : best_idx[c];
+                }
+            }
+        }
+    } else {
     for (int p0 = pix_begin; p0 < pix_end; p0 += kPix) {
         const int np = min(kPix, pix_end - p0);
         const long long byte0 = img_byte0 + (long long)p0 * kC * ES;
@@ -107,6 +145,7 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(
                 best_idx[c] = gt ? pidx : best_idx[c];
             }
         }
+    }
     }
 
 #pragma unroll
@@ -197,7 +236,7 @@ extern "C" int mpn_heatmap_decode(const void* heatmaps, int dtype, int B, int h,
                 "decode: unsupported dtype %d", dtype);
     const int npix = h * w;
     const int nchunks = mpn_div_up(npix, kPix);
-    int splits = 2048 / B;  // aim at ~2k blocks so all 256 CUs stream
+    int splits = 1024 / B;  // ~1k blocks of >= 4 chunks: the block-level reduction is amortised over more pixels
     if (splits < 1) splits = 1;
     if (splits > nchunks) splits = nchunks;
     const int cpb = mpn_div_up(nchunks, splits);

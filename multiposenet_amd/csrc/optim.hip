@@ -51,9 +51,50 @@ __global__ __launch_bounds__(kThreads) void adam_apply_kernel(float* __restrict_
     }
 }
 
-// out[j] (+)= scale * sum_p part[p][j], fixed order
+// out[j] (+)= scale * sum_p part[p][j], fixed order. Bandwidth-bound (up to 75 MB of split-K slabs per layer): the
+// slabs are cut into `nslices` part-ranges so that >= ~2k blocks stream with 8 independent 16-byte loads in flight
+// per lane; slice sums land in a second, tiny slab [nslices][n] and are combined in fixed order by the same kernel
+// (deterministic: no atomics).
 __global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* __restrict__ part, int nparts, long long n,
-                                                                   float* __restrict__ out, int accumulate, float scale) {
+                                                                   float* __restrict__ out, int accumulate, float scale,
+                                                                   int nslices, long long out_stride) {
+    const long long n4 = n >> 2;
+    const int slice = blockIdx.y;
+    const int p0 = (int)((long long)nparts * slice / nslices), p1 = (int)((long long)nparts * (slice + 1) / nslices);
+    float* __restrict__ dst = out + (long long)slice * out_stride;
+    for (long long j = (long long)blockIdx.x * kThreads + threadIdx.x; j < n4; j += (long long)gridDim.x * kThreads) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+        int p = p0;
+        for (; p + 8 <= p1; p += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(part + (long long)(p + u) * n)[j];
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
+                b.x += v[u + 1].x; b.y += v[u + 1].y; b.z += v[u + 1].z; b.w += v[u + 1].w;
+                c.x += v[u + 2].x; c.y += v[u + 2].y; c.z += v[u + 2].z; c.w += v[u + 2].w;
+                d.x += v[u + 3].x; d.y += v[u + 3].y; d.z += v[u + 3].z; d.w += v[u + 3].w;
+            }
+        }
+        for (; p < p1; ++p) {
+            const float4 v = reinterpret_cast<const float4*>(part + (long long)p * n)[j];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float4 r;
+        r.x = ((a.x + b.x) + (c.x + d.x)) * scale; r.y = ((a.y + b.y) + (c.y + d.y)) * scale;
+        r.z = ((a.z + b.z) + (c.z + d.z)) * scale; r.w = ((a.w + b.w) + (c.w + d.w)) * scale;
+        if (accumulate) {
+            const float4 o = reinterpret_cast<const float4*>(dst)[j];
+            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        }
+        reinterpret_cast<float4*>(dst)[j] = r;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void reduce_partials_scalar_kernel(const float* __restrict__ part, int nparts,
+                                                                          long long n, float* __restrict__ out,
+                                                                          int accumulate, float scale) {
     const long long j = (long long)blockIdx.x * kThreads + threadIdx.x;
     if (j >= n) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -105,8 +146,15 @@ extern "C" int mpn_reduce_partials(const float* part, int nparts, long long n, f
                                    mpn_stream_t stream) {
     MPN_REQUIRE(part && out, MPN_ERR_BAD_ARG, "reduce_partials: null pointer");
     MPN_REQUIRE(nparts > 0 && n > 0, MPN_ERR_BAD_SHAPE, "reduce_partials: bad sizes");
-    reduce_partials_kernel<<<(int)((n + kThreads - 1) / kThreads), kThreads, 0, (hipStream_t)stream>>>(part, nparts, n, out,
-                                                                                                     accumulate, scale);
+    hipStream_t st = (hipStream_t)stream;
+    if (n % 4 == 0 && mpn_aligned16(part) && mpn_aligned16(out)) {
+        long long bx = ((n >> 2) + kThreads - 1) / kThreads;
+        if (bx > 2048) bx = 2048;
+        reduce_partials_kernel<<<dim3((unsigned)bx, 1), kThreads, 0, st>>>(part, nparts, n, out, accumulate, scale, 1, 0);
+    } else {  // rows that are not 16-byte multiples (the 64*18+18 head gradient): scalar kernel, tiny tensors only
+        reduce_partials_scalar_kernel<<<(int)((n + kThreads - 1) / kThreads), kThreads, 0, st>>>(part, nparts, n, out,
+                                                                                              accumulate, scale);
+    }
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
