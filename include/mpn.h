@@ -222,7 +222,8 @@ int mpn_adam_prepare(long long* step, float* hyper, double initial_learning_rate
 int mpn_adam_step(float* params, const float* grads, float* m, float* v, long long n,
                   const float* hyper, float beta1, float beta2, float eps, float clip,
                   float grad_scale, mpn_stream_t stream);
-/* out[j] (+)= scale * sum_p part[p][j] in a fixed order (deterministic) */
+/* out[j] (+)= scale * sum_p part[p][j] in a fixed order (deterministic). `part` is scratch: large slabs are
+ * reduced in two passes and the first pass folds range sums into the slab itself (its contents are clobbered). */
 int mpn_reduce_partials(const float* part, int nparts, long long n, float* out, int accumulate,
                         float scale, mpn_stream_t stream);
 int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream);

@@ -83,7 +83,14 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    int b = blockIdx.x;
+    // XCD-aware remap: hardware deals blocks round-robin over the 8 XCDs (block b and b+8 share an L2); work items
+    // are ordered ci-group fastest, so giving each XCD a contiguous run of work items puts the ci-groups that re-read
+    // one dY tile behind the same L2 (speed only; bijective for any grid size).
+    int b;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
     const int cg = b % p.n_cg; b /= p.n_cg;
     const int cb = b % p.n_cb;
     const int split = b / p.n_cb;
@@ -126,10 +133,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
             m0 = (long long)tile * 128;
         }
         __syncthreads();  // previous tile's fragment reads are done
-        // ---------------- stage A (activated input, halo for 3x3)
+        // ---------------- stage A (activated input, halo for 3x3) and the dY tile: ALL global loads of the tile are
+        // issued before the first one is consumed (one memory round trip per tile instead of three)
         {
             Vec16<T> v[AVEC];
             bool inb[AVEC];
+            Vec16<T> dv[DVEC];
 #pragma unroll
             for (int i = 0; i < AVEC; ++i) {
                 const int vi = tid + i * kThreads;
@@ -148,6 +157,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
                 }
                 inb[i] = ok;
                 if (ok) v[i].load(x + off); else v[i].zero();
+            }
+#pragma unroll
+            for (int i = 0; i < DVEC; ++i) {
+                const int r = (tid >> 4) + i * (kThreads / 16);
+                bool ok = dcvalid;
+                long long off = 0;
+                if (TAPS == 9) {
+                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
+                    ok = ok && oy < p.H && ox < p.W;
+                    off = (((long long)img * p.H + oy) * p.W + ox) * p.Cout + dce;
+                } else {
+                    const long long m = m0 + r;
+                    ok = ok && m < p.M;
+                    off = m * p.Cout + dce;
+                }
+                if (ok) dv[i].load(dy + off); else dv[i].zero();
             }
 #pragma unroll
             for (int i = 0; i < AVEC; ++i) {
@@ -170,32 +195,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
                         *reinterpret_cast<const uint4*>(&v[i].raw);
                 }
             }
-        }
-        // ---------------- stage dY tile [128 px][256 B]
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            Vec16<T> v[DVEC / 2];
-#pragma unroll
-            for (int i = 0; i < DVEC / 2; ++i) {
-                const int r = (tid >> 4) + (half * (DVEC / 2) + i) * (kThreads / 16);
-                bool ok = dcvalid;
-                long long off = 0;
-                if (TAPS == 9) {
-                    const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
-                    ok = ok && oy < p.H && ox < p.W;
-                    off = (((long long)img * p.H + oy) * p.W + ox) * p.Cout + dce;
-                } else {
-                    const long long m = m0 + r;
-                    ok = ok && m < p.M;
-                    off = m * p.Cout + dce;
-                }
-                if (ok) v[i].load(dy + off); else v[i].zero();
-            }
-#pragma unroll
-            for (int i = 0; i < DVEC / 2; ++i) {
-                const int r = (tid >> 4) + (half * (DVEC / 2) + i) * (kThreads / 16);
+            for (int i = 0; i < DVEC; ++i) {
+                const int r = (tid >> 4) + i * (kThreads / 16);
                 *reinterpret_cast<uint4*>(Ds + lds_off<256>(r, dslot >> 1, (dslot & 1) * 16)) =
-                    *reinterpret_cast<const uint4*>(&v[i].raw);
+                    *reinterpret_cast<const uint4*>(&dv[i].raw);
             }
         }
         __syncthreads();

@@ -51,24 +51,35 @@ __global__ __launch_bounds__(kThreads) void adam_apply_kernel(float* __restrict_
     }
 }
 
-// out[j] (+)= scale * sum_p part[p][j], fixed order. Bandwidth-bound (up to 75 MB of split-K slabs per layer): the
-// slabs are cut into `nslices` part-ranges so that >= ~2k blocks stream with 8 independent 16-byte loads in flight
-// per lane; slice sums land in a second, tiny slab [nslices][n] and are combined in fixed order by the same kernel
-// (deterministic: no atomics).
-__global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* __restrict__ part, int nparts, long long n,
+// out[j] (+)= scale * sum_p part[p][j], fixed order. Bandwidth-bound (up to 75 MB of split-K slabs per layer).
+// One pass has only n/1024 blocks (e.g. 144 for a 3x3 128->128 kernel), so big slabs are reduced in two passes:
+// pass 1 cuts the parts into `nslices` ranges (grid.y) and writes each range's sum IN PLACE over the first row of
+// its own range (only that thread reads it); pass 2 combines those nslices rows. Fixed order, no atomics.
+// MODE 0: plain rows p = 0..nparts-1 -> out.  MODE 1 (pass 1): range sums -> part row p0(slice).
+// MODE 2 (pass 2): rows p0(0..nslices-1) of the original slab -> out.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void reduce_partials_kernel(float* __restrict__ part, int nparts, long long n,
                                                                    float* __restrict__ out, int accumulate, float scale,
-                                                                   int nslices, long long out_stride) {
+                                                                   int nslices) {
     const long long n4 = n >> 2;
-    const int slice = blockIdx.y;
-    const int p0 = (int)((long long)nparts * slice / nslices), p1 = (int)((long long)nparts * (slice + 1) / nslices);
-    float* __restrict__ dst = out + (long long)slice * out_stride;
+    int p0 = 0, p1 = nparts;
+    if (MODE == 1) {
+        p0 = (int)((long long)nparts * blockIdx.y / nslices);
+        p1 = (int)((long long)nparts * (blockIdx.y + 1) / nslices);
+    } else if (MODE == 2) {
+        p1 = nslices;
+    }
+    auto row = [&](int p) -> const float4* {
+        const long long r = (MODE == 2) ? ((long long)nparts * p / nslices) : p;
+        return reinterpret_cast<const float4*>(part + r * n);
+    };
     for (long long j = (long long)blockIdx.x * kThreads + threadIdx.x; j < n4; j += (long long)gridDim.x * kThreads) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
         int p = p0;
         for (; p + 8 <= p1; p += 8) {
             float4 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(part + (long long)(p + u) * n)[j];
+            for (int u = 0; u < 8; ++u) v[u] = row(p + u)[j];
 #pragma unroll
             for (int u = 0; u < 8; u += 4) {
                 a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w;
@@ -78,17 +89,22 @@ __global__ __launch_bounds__(kThreads) void reduce_partials_kernel(const float* 
             }
         }
         for (; p < p1; ++p) {
-            const float4 v = reinterpret_cast<const float4*>(part + (long long)p * n)[j];
+            const float4 v = row(p)[j];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         float4 r;
-        r.x = ((a.x + b.x) + (c.x + d.x)) * scale; r.y = ((a.y + b.y) + (c.y + d.y)) * scale;
-        r.z = ((a.z + b.z) + (c.z + d.z)) * scale; r.w = ((a.w + b.w) + (c.w + d.w)) * scale;
-        if (accumulate) {
-            const float4 o = reinterpret_cast<const float4*>(dst)[j];
-            r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+        r.x = (a.x + b.x) + (c.x + d.x); r.y = (a.y + b.y) + (c.y + d.y);
+        r.z = (a.z + b.z) + (c.z + d.z); r.w = (a.w + b.w) + (c.w + d.w);
+        if (MODE == 1) {
+            reinterpret_cast<float4*>(part + (long long)p0 * n)[j] = r;
+        } else {
+            r.x *= scale; r.y *= scale; r.z *= scale; r.w *= scale;
+            if (accumulate) {
+                const float4 o = reinterpret_cast<const float4*>(out)[j];
+                r.x += o.x; r.y += o.y; r.z += o.z; r.w += o.w;
+            }
+            reinterpret_cast<float4*>(out)[j] = r;
         }
-        reinterpret_cast<float4*>(dst)[j] = r;
     }
 }
 
@@ -150,7 +166,19 @@ extern "C" int mpn_reduce_partials(const float* part, int nparts, long long n, f
     if (n % 4 == 0 && mpn_aligned16(part) && mpn_aligned16(out)) {
         long long bx = ((n >> 2) + kThreads - 1) / kThreads;
         if (bx > 2048) bx = 2048;
-        reduce_partials_kernel<<<dim3((unsigned)bx, 1), kThreads, 0, st>>>(part, nparts, n, out, accumulate, scale, 1, 0);
+        int nslices = (int)(1024 / bx);
+        if (nslices > 16) nslices = 16;
+        if (nslices > nparts / 8) nslices = nparts / 8;
+        float* slab = const_cast<float*>(part);   // scratch: pass 1 folds range sums into it
+        if (nslices >= 2) {
+            reduce_partials_kernel<1><<<dim3((unsigned)bx, (unsigned)nslices), kThreads, 0, st>>>(slab, nparts, n, out, 0, 1.f,
+                                                                                          nslices);
+            MPN_LAUNCH_CHECK();
+            reduce_partials_kernel<2><<<dim3((unsigned)bx, 1), kThreads, 0, st>>>(slab, nparts, n, out, accumulate, scale,
+                                                                              nslices);
+        } else {
+            reduce_partials_kernel<0><<<dim3((unsigned)bx, 1), kThreads, 0, st>>>(slab, nparts, n, out, accumulate, scale, 1);
+        }
     } else {  // rows that are not 16-byte multiples (the 64*18+18 head gradient): scalar kernel, tiny tensors only
         reduce_partials_scalar_kernel<<<(int)((n + kThreads - 1) / kThreads), kThreads, 0, st>>>(part, nparts, n, out,
                                                                                               accumulate, scale);
