@@ -44,9 +44,12 @@ __device__ __forceinline__ int fsw256(int r) { return (r & 3) | (((r >> 3) & 1) 
 // 64-byte rows stay linear: their transposed reads are at worst 2-way conflicted (rows r and r+8 of a
 // half-wave), which is noise next to the MFMAs, and linear rows make every tap a constant address offset.
 __device__ __forceinline__ int fsw64(int) { return 0; }
+// 128-byte rows (4 segments, two rows per 256-byte bank row): row parity separates neighbours, (r>>1)&1 and (r>>3)&1
+// separate the rest of the 8 rows (r..r+3, r+8..r+11) a half-wave touches per transposed read.
+__device__ __forceinline__ int fsw128(int r) { return ((r >> 1) & 1) | (((r >> 3) & 1) << 1); }
 
 template <int RB> __device__ __forceinline__ int lds_off(int row, int seg, int within) {
-    const int f = (RB == 64) ? fsw64(row) : fsw256(row);
+    const int f = (RB == 64) ? fsw64(row) : (RB == 128 ? fsw128(row) : fsw256(row));
     return row * RB + ((seg ^ f) << 5) + within;
 }
 
@@ -55,13 +58,16 @@ __device__ __forceinline__ bf16x4_t tr_read(const unsigned char* base, int off) 
         (bf16x4_t __attribute__((address_space(3)))*)(base + off));
 }
 
-template <typename T, int TAPS>
+// RBA / RBD: bytes per pixel row of the A (input-channel) and dY (output-channel) LDS images. Default geometry:
+// 3x3 -> (64, 256) = 32 ci x 128 co per block; 1x1 -> (256, 256). Layers with Cout <= 64 (final_conv3x3) use
+// (128, 128) = 64 ci x 64 co so that no MFMA column is spent on zero padding.
+template <typename T, int TAPS, int RBA, int RBD>
 __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradParams p) {
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
-    constexpr int RBA = TAPS == 9 ? 64 : 256;      // A image row bytes
     constexpr int CG = RBA / ES;                   // input channels per block
-    constexpr int BNW = 256 / ES;                  // output channels per block
+    constexpr int BNW = RBD / ES;                  // output channels per block
+    constexpr int DSLOTS = RBD / 16;
     constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int MT_TOTAL = CG / 16, NT_TOTAL = BNW / 16;
     // wave layout: 2x2 over (m-tiles, n-tiles) when there are >= 2 m-tiles, else 1x4
@@ -73,11 +79,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
     constexpr int KSTEPS = 128 / KPIX;
     constexpr int ASLOTS = RBA / 16;
     constexpr int AVEC = (NPIXA * ASLOTS + kThreads - 1) / kThreads;
-    constexpr int DVEC = 128 * 16 / kThreads;      // 8
+    constexpr int DVEC = 128 * DSLOTS / kThreads;  // 8 (or 4)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;                      // [NPIXA][RBA]
-    unsigned char* Ds = smem + NPIXA * RBA;        // [128][256]
+    unsigned char* Ds = smem + NPIXA * RBA;        // [128][RBD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
     const int ace = ci0 + aslot * VE;
     const bool acvalid = ace < p.Cin;
     const bool affine = p.in_scale != nullptr;
-    const int dslot = tid & 15;
+    const int dslot = tid % DSLOTS;
     const int dce = co0 + dslot * VE;
     const bool dcvalid = dce < p.Cout;
 
@@ -160,7 +166,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
             }
 #pragma unroll
             for (int i = 0; i < DVEC; ++i) {
-                const int r = (tid >> 4) + i * (kThreads / 16);
+                const int r = (tid / DSLOTS) + i * (kThreads / DSLOTS);
                 bool ok = dcvalid;
                 long long off = 0;
                 if (TAPS == 9) {
@@ -197,8 +203,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
             }
 #pragma unroll
             for (int i = 0; i < DVEC; ++i) {
-                const int r = (tid >> 4) + i * (kThreads / 16);
-                *reinterpret_cast<uint4*>(Ds + lds_off<256>(r, dslot >> 1, (dslot & 1) * 16)) =
+                const int r = (tid / DSLOTS) + i * (kThreads / DSLOTS);
+                *reinterpret_cast<uint4*>(Ds + lds_off<RBD>(r, dslot >> 1, (dslot & 1) * 16)) =
                     *reinterpret_cast<const uint4*>(&dv[i].raw);
             }
         }
@@ -212,8 +218,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
                 bf16x8_t bfr[NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
-                    const bf16x4_t lo = tr_read(Ds, lds_off<256>(r0, nt0 + j, pp * 8));
-                    const bf16x4_t hi = tr_read(Ds, lds_off<256>(r0 + 4, nt0 + j, pp * 8));
+                    const bf16x4_t lo = tr_read(Ds, lds_off<RBD>(r0, nt0 + j, pp * 8));
+                    const bf16x4_t hi = tr_read(Ds, lds_off<RBD>(r0 + 4, nt0 + j, pp * 8));
                     bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
                 // software-pipelined over (tap, m-tile): the fragment of step n+1 is fetched while the
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
                     const int c = (nt0 + j) * 16 + l15;  // channel (float index) in the 64-float row
-                    bfr[j] = *reinterpret_cast<const float*>(Ds + lds_off<256>(r, c >> 3, (c & 7) * 4));
+                    bfr[j] = *reinterpret_cast<const float*>(Ds + lds_off<RBD>(r, c >> 3, (c & 7) * 4));
                 }
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
@@ -292,8 +298,9 @@ struct WgradGeom {
 
 WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout, int ksize, int es) {
     WgradGeom g;
-    const int cgsz = (ksize == 3 ? 64 : 256) / es;
-    const int bnw = 256 / es;
+    const bool narrow = ksize == 3 && Cout * es <= 128;   // (128,128) geometry, see launch_wgrad
+    const int cgsz = (narrow ? 128 : (ksize == 3 ? 64 : 256)) / es;
+    const int bnw = (narrow ? 128 : 256) / es;
     g.n_cg = (Cin + cgsz - 1) / cgsz;
     g.n_cb = (Cout + bnw - 1) / bnw;
     g.ntiles = ksize == 3 ? N * ((H + 7) / 8) * ((W + 15) / 16) : (int)(((long long)N * H * W + 127) / 128);
@@ -304,21 +311,26 @@ WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout, int ksize, int es) 
     return g;
 }
 
+template <typename T, int TAPS, int RBA, int RBD>
+int launch_wgrad_g(const WgradParams& p, hipStream_t st) {
+    constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int smem = NPIXA * RBA + 128 * RBD;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, TAPS, RBA, RBD>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    conv_wgrad_kernel<T, TAPS, RBA, RBD><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(kThreads), smem, st>>>(p);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
 template <typename T, int TAPS>
 int launch_wgrad(const WgradParams& p, hipStream_t st) {
     constexpr int ES = (int)sizeof(T);
-    constexpr int RBA = TAPS == 9 ? 64 : 256;
-    constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
-    constexpr int smem = NPIXA * RBA + 128 * 256;
-    (void)ES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, TAPS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    conv_wgrad_kernel<T, TAPS><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(kThreads), smem, st>>>(p);
-    MPN_LAUNCH_CHECK();
-    return MPN_OK;
+    if (TAPS == 9 && p.Cout * ES <= 128) return launch_wgrad_g<T, TAPS, 128, 128>(p, st);
+    return launch_wgrad_g<T, TAPS, (TAPS == 9 ? 64 : 256), 256>(p, st);
 }
 
 }  // namespace
