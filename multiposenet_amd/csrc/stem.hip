@@ -16,48 +16,78 @@ template <typename T, bool U8>
 __device__ __forceinline__ void stage_patch(const void* images, float* patch, int img, int oy0, int ox0, int H, int W,
                                             int pad_t, int pad_l) {
     const int iy0 = oy0 * 2 - pad_t, ix0 = ox0 * 2 - pad_l;
-    for (int i = threadIdx.x; i < kIn * kIn * 3; i += kThreads) {
+    constexpr int NEL = kIn * kIn * 3;
+    constexpr int PER = (NEL + kThreads - 1) / kThreads;   // 13 loads per thread, all issued before the first use
+    float v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = threadIdx.x + k * kThreads;
         const int ch = i % 3;
         const int px = (i / 3) % kIn;
         const int py = i / (3 * kIn);
         const int iy = iy0 + py, ix = ix0 + px;
-        float v = 0.f;  // SAME padding: zeros of the STANDARDISED tensor
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+        float raw = 0.5f;  // 2*0.5-1 = 0: SAME padding is zeros of the STANDARDISED tensor
+        if (i < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W) {
             const long long off = (((long long)img * H + iy) * W + ix) * 3 + ch;
-            const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] * (1.0f / 255.0f)
-                                 : reinterpret_cast<const float*>(images)[off];
-            v = 2.0f * raw - 1.0f;
+            raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] * (1.0f / 255.0f)
+                     : reinterpret_cast<const float*>(images)[off];
         }
-        patch[i] = v;
+        v[k] = raw;
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int i = threadIdx.x + k * kThreads;
+        if (i < NEL) patch[i] = 2.0f * v[k] - 1.0f;
     }
 }
 
+// forward: one thread = one output pixel x all C0 channels. Its 3x3x3 input window is three runs of 9 contiguous
+// floats (36 B, dword aligned): loaded straight from global with wide loads (neighbouring lanes overlap by 1/3, served
+// by L1), no LDS patch and no barrier except for the broadcast weights.
 template <typename T, bool U8>
 __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restrict__ images, const float* __restrict__ w,
                                                             T* __restrict__ y, int N, int H, int W, int C0, int OH, int OW,
                                                             int pad_t, int pad_l, int tiles_x, int tiles_y) {
     constexpr int VE = Vec16<T>::N;
-    __shared__ float patch[kIn * kIn * 3];
     __shared__ __attribute__((aligned(16))) float wl[27 * kMaxC0];
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
     const int img = b / tiles_y;
-    const int oy0 = ty * kTile, ox0 = tx * kTile;
     for (int i = threadIdx.x; i < 27 * C0; i += kThreads) wl[i] = w[i];
-    stage_patch<T, U8>(images, patch, img, oy0, ox0, H, W, pad_t, pad_l);
     __syncthreads();
     const int lx = threadIdx.x % kTile, ly = threadIdx.x / kTile;
-    const int oy = oy0 + ly, ox = ox0 + lx;
-    float in[27];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-                in[(ky * 3 + kx) * 3 + ch] = patch[((2 * ly + ky) * kIn + 2 * lx + kx) * 3 + ch];
+    const int oy = ty * kTile + ly, ox = tx * kTile + lx;
     if (oy >= OH || ox >= OW) return;
+    float in[27];
+    const int ix0 = 2 * ox - pad_l;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy - pad_t + ky;
+        const bool row_ok = iy >= 0 && iy < H;
+        const long long base = (((long long)img * H + (row_ok ? iy : 0)) * W + ix0) * 3;
+        if (!U8 && row_ok && ix0 >= 0 && ix0 + 2 < W) {
+            const float* src = reinterpret_cast<const float*>(images) + base;
+            const float4 a = *reinterpret_cast<const float4*>(src);
+            const float4 c = *reinterpret_cast<const float4*>(src + 4);
+            const float e = src[8];
+            const float r[9] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, e};
+#pragma unroll
+            for (int j = 0; j < 9; ++j) in[ky * 9 + j] = 2.0f * r[j] - 1.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const int ix = ix0 + j / 3;
+                float v = 0.f;   // SAME padding: zeros of the STANDARDISED tensor
+                if (row_ok && ix >= 0 && ix < W) {
+                    const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[base + j] * (1.0f / 255.0f)
+                                         : reinterpret_cast<const float*>(images)[base + j];
+                    v = 2.0f * raw - 1.0f;
+                }
+                in[ky * 9 + j] = v;
+            }
+        }
+    }
     T* dst = y + (((long long)img * OH + oy) * OW + ox) * C0;
     for (int c0 = 0; c0 < C0; c0 += VE) {
         float acc[VE];
@@ -112,12 +142,24 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_kernel(const void* __rest
         const int oy0 = ty * kTile, ox0 = tx * kTile;
         __syncthreads();
         stage_patch<T, U8>(images, patch, img, oy0, ox0, H, W, pad_t, pad_l);
-        for (int i = threadIdx.x; i < kTile * kTile * C0; i += kThreads) {
-            const int c = i % C0, px = i / C0;
-            const int oy = oy0 + px / kTile, ox = ox0 + px % kTile;
-            float v = 0.f;
-            if (oy < OH && ox < OW) v = to_f32(dy[(((long long)img * OH + oy) * OW + ox) * C0 + c]);
-            g[px * C0 + c] = v;
+        {
+            constexpr int VE = Vec16<T>::N;
+            const int vpp = C0 / VE;                       // 16-byte vectors per pixel
+            for (int i = threadIdx.x; i < kTile * kTile * vpp; i += kThreads) {
+                const int vq = i % vpp, px = i / vpp;
+                const int oy = oy0 + px / kTile, ox = ox0 + px % kTile;
+                float f[VE];
+#pragma unroll
+                for (int j = 0; j < VE; ++j) f[j] = 0.f;
+                if (oy < OH && ox < OW) {
+                    Vec16<T> vv;
+                    vv.load(dy + (((long long)img * OH + oy) * OW + ox) * C0 + vq * VE);
+                    vv.unpack(f);
+                }
+#pragma unroll
+                for (int j = 0; j < VE; j += 4)
+                    *reinterpret_cast<float4*>(g + px * C0 + vq * VE + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+            }
         }
         __syncthreads();
         if (active) {
