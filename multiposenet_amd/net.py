@@ -155,6 +155,9 @@ class KeypointNet:
         self.load_state_dict(values if values is not None else initial_values(seed, depth_multiplier))
         self._build_layers()
         self._bufs = {}
+        self.overlap_wgrad = False    # opt-in: weight gradients on a second HIP stream (measured 4% SLOWER at bs32: the
+                                      # kernels already fill the chip, concurrent ones only contend; see backward)
+        self._wstream = None
 
     # ------------------------------------------------------------------ variables
     def state_dict(self):
@@ -319,7 +322,9 @@ class KeypointNet:
         wfloats = max(wfloats, ops._lib.lib().mpn_stem_conv_wgrad_num_parts(N, H, W) * self.stem_w.numel())
         wfloats = max(wfloats, ops._lib.lib().mpn_heatmap_head_bwd_num_parts(N * b["lv"][2][0] * b["lv"][2][1]) *
                       self._head_grad.numel())
-        g["wpart"] = torch.empty(wfloats, dtype=torch.float32, device=dev)
+        g["wpart"] = torch.empty(wfloats, dtype=torch.float32, device=dev)   # side-stream scratch (weight gradients)
+        g["head_part"] = torch.empty(ops._lib.lib().mpn_heatmap_head_bwd_num_parts(N * b["lv"][2][0] * b["lv"][2][1]) *
+                                     self._head_grad.numel(), dtype=torch.float32, device=dev)   # main-stream scratch
         b["g"] = g
         return g
 
@@ -429,36 +434,53 @@ class KeypointNet:
         return ops.keypoint_loss(b["logits"], labels, ps, g["dlogits"] if g else None,
                                  [g["daux"][l] for l in (2, 3, 4, 5)] if g else None, b["loss_part"], b["losses"])
 
+    def _wgrad(self, fn):
+        """Run a weight-gradient launch sequence on the side stream: it only needs dy (just produced on the main stream)
+        and forward activations, so it overlaps the main stream's critical chain (bn_backward -> dgrad -> ...).
+        Captured into the hipGraph as a fork (event wait); `backward` joins once at the end."""
+        main = torch.cuda.current_stream()
+        if self._wstream is None:
+            fn()
+            return
+        self._wstream.wait_stream(main)
+        with torch.cuda.stream(self._wstream):
+            fn()
+
     def backward(self):
-        """Gradients of the total loss w.r.t. every trainable variable -> self.grad (call after compute_losses)."""
+        """Gradients of the total loss w.r.t. every trainable variable -> self.grad (call after compute_losses).
+        Two HIP streams: the main one carries the activation-gradient chain, the side one all weight gradients
+        (MFMA split-K kernels + slab reductions), so HBM-bound batch-norm passes overlap MFMA-bound wgrad kernels."""
         b, feats, images = self._last
         g = self._grad_buffers(b)
-        N = b["shape"][0]
         sp, wp = b["stat_part"], g["wpart"]
+        if self.overlap_wgrad and self._wstream is None:
+            self._wstream = torch.cuda.Stream(device=self.device)
+        W = self._wgrad
         # ---- head + final conv
-        ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad, wp)
+        ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
+                             g["head_part"])
         ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
-        ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, wp)
+        W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, wp))
         ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm
         for l in (2, 3, 4, 5):
             ph = self.phi[l]
             ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
             ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp)
-            ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, wp)
+            W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, wp))
             ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
             ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp)
-            ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, wp)
+            W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, wp))
             ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
             ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l])
         # ---- FPN (top-down path reversed)
         for l in (2, 3, 4, 5):
-            ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, wp)
+            W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, wp))
             ops.conv_fwd(g["p"][l], self.pconv[l].packed.bwd, DEPTH, 3, None, out=g["x"][l])
             if l > 2:
                 ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample
             raw, aff = feats[f"c{l}"]
-            ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, wp)
+            W(lambda: ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, wp))
             ops.conv_fwd(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, None, out=g["c"][f"c{l}"])
         # ---- backbone
         dA = g["c"]["c5"]
@@ -467,17 +489,19 @@ class KeypointNet:
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
             ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp)
-            ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, wp)
+            W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, wp))
             ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
             ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
-            ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], wp)
+            W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], wp))
             dst = g["pw"][i - 1] if i > 0 else g["stem"]
             ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst)
             dA = dst
         ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp)
-        ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, wp)
+        W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, wp))
+        if self._wstream is not None:
+            torch.cuda.current_stream().wait_stream(self._wstream)   # join: every gradient is in the arena
 
     def add_weight_decay_gradients(self, weight_decay):
         """keypoints_model.py:129-138: + wd * l2_loss(k) for every 'weights'/'kernel' variable except depthwise."""
