@@ -37,9 +37,14 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=20):
     flops = 2.0 * batch * h * w * 128 * 128 * 9          # algorithmic FLOPs of one launch
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
     achieved = flops / sec / 1e12
+    traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
+    tj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_dominant_kernel_traffic.json")
+    if dtype == torch.bfloat16 and batch == 32 and size == 512 and os.path.exists(tj):
+        import json
+        traffic = json.load(open(tj))["hbm_bytes_per_launch"]
     return {"kernel": "conv_mfma_kernel<3x3,128->128> @ [%d,%d,%d,128]" % (batch, h, w), "bound": "mfma",
             "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None, "launch_us": round(sec * 1e6, 2)}
+            "traffic": traffic, "launch_us": round(sec * 1e6, 2)}
 
 
 def cpu_baseline(size, budget_s=20.0):
