@@ -101,50 +101,66 @@ __device__ __forceinline__ HaloAffine<T> load_halo_affine(const DwParams& p, int
     return a;
 }
 
-template <typename T, int STRIDE>
-__device__ __forceinline__ void stage_halo(const DwParams& p, const HaloAffine<T>& aff, float* tile, int img, int oy0,
-                                           int ox0, int c0, int cb_vecs) {
+// Halo staging split in two so that a persistent block can PREFETCH: `load` issues all of a tile's global loads into
+// registers (before the previous tile is computed), `commit` applies the affine + activation and writes the f32 LDS
+// tile (after the previous tile's LDS reads are done). The HBM round trip hides under the previous tile's math.
+template <typename T, int STRIDE> struct HaloRegs {
     using TL = DwTile<STRIDE>;
-    constexpr int VE = Vec16<T>::N;
-    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
-    const int iy0 = oy0 * STRIDE - p.pad_t, ix0 = ox0 * STRIDE - p.pad_l;
-    constexpr int MAXV = (TL::HH * TL::HW * 8 + kThreads - 1) / kThreads;
-    const int vg = threadIdx.x % p.nvg;
-    const int hp0 = threadIdx.x / p.nvg, hstep = kThreads / p.nvg;
-    // phase 1: issue every global load of this thread (up to MAXV 16-byte vectors in flight)
+    static constexpr int MAXV = (TL::HH * TL::HW * 8 + kThreads - 1) / kThreads;
     Vec16<T> v[MAXV];
-    bool ok[MAXV];
+    unsigned okmask;
+
+    __device__ __forceinline__ void load(const DwParams& p, int img, int oy0, int ox0, int c0, int cb_vecs) {
+        constexpr int VE = Vec16<T>::N;
+        const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+        const int iy0 = oy0 * STRIDE - p.pad_t, ix0 = ox0 * STRIDE - p.pad_l;
+        const int vg = threadIdx.x % p.nvg;
+        const int hp0 = threadIdx.x / p.nvg, hstep = kThreads / p.nvg;
+        okmask = 0u;
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-        const int hp = hp0 + k * hstep;
-        const int hy = hp / TL::HW, hx = hp - hy * TL::HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        ok[k] = hp < TL::HH * TL::HW && vg < cb_vecs && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        if (ok[k]) v[k].load(x + (((long long)img * p.H + iy) * p.W + ix) * p.C + c0 + vg * VE);
-        else v[k].zero();
-    }
-    // phase 2: affine + activation (in-image elements only: the padding is zeros of the ACTIVATED tensor) -> LDS
-#pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-        const int hp = hp0 + k * hstep;
-        if (hp < TL::HH * TL::HW) {
-            float f[VE];
-            v[k].unpack(f);
-            if (ok[k] && aff.on) {
-#pragma unroll
-                for (int j = 0; j < VE; ++j) {
-                    float t = f[j] * aff.sc[j] + aff.sh[j];
-                    if (p.in_act != MPN_ACT_NONE) t = fmaxf(t, 0.f);
-                    if (p.in_act == MPN_ACT_RELU6) t = fminf(t, 6.f);
-                    f[j] = t;
-                }
-            }
-            float* dst = tile + (hp * p.nvg + vg) * VE;
-#pragma unroll
-            for (int j = 0; j < VE; j += 4)
-                *reinterpret_cast<float4*>(dst + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+        for (int k = 0; k < MAXV; ++k) {
+            const int hp = hp0 + k * hstep;
+            const int hy = hp / TL::HW, hx = hp - hy * TL::HW;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool ok = hp < TL::HH * TL::HW && vg < cb_vecs && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            if (ok) { v[k].load(x + (((long long)img * p.H + iy) * p.W + ix) * p.C + c0 + vg * VE); okmask |= 1u << k; }
+            else v[k].zero();
         }
     }
+
+    // affine + activation on in-image elements only (the padding is zeros of the ACTIVATED tensor) -> LDS
+    __device__ __forceinline__ void commit(const DwParams& p, const HaloAffine<T>& aff, float* tile) {
+        constexpr int VE = Vec16<T>::N;
+        const int vg = threadIdx.x % p.nvg;
+        const int hp0 = threadIdx.x / p.nvg, hstep = kThreads / p.nvg;
+        const float lo = (p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+        const float hi = (p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            const int hp = hp0 + k * hstep;
+            if (hp < TL::HH * TL::HW) {
+                float f[VE];
+                v[k].unpack(f);
+                if (((okmask >> k) & 1u) && aff.on) {
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * aff.sc[j] + aff.sh[j], lo, hi);
+                }
+                float* dst = tile + (hp * p.nvg + vg) * VE;
+#pragma unroll
+                for (int j = 0; j < VE; j += 4)
+                    *reinterpret_cast<float4*>(dst + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+            }
+        }
+    }
+};
+
+__device__ __forceinline__ void dw_tile_origin(const DwParams& p, int t, int th, int tw, int& img, int& oy0, int& ox0) {
+    const int tx = t % p.tiles_x;
+    const int t2 = t / p.tiles_x;
+    const int ty = t2 % p.tiles_y;
+    img = t2 / p.tiles_y;
+    oy0 = ty * th;
+    ox0 = tx * tw;
 }
 
 // Blocks are persistent over a strided set of tiles of ONE channel block: the 9 x VE weights stay in registers, the
@@ -182,15 +198,22 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
 
     const HaloAffine<T> aff = load_halo_affine<T>(p, c0, cb_vecs);
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    HaloRegs<T, STRIDE> hr;
+    int img, oy0, ox0;
+    if (split < ntiles) {
+        dw_tile_origin(p, split, TL::TH, TL::TW, img, oy0, ox0);
+        hr.load(p, img, oy0, ox0, c0, cb_vecs);
+    }
     for (int t = split; t < ntiles; t += nsplit) {
-        const int tx = t % p.tiles_x;
-        const int t2 = t / p.tiles_x;
-        const int ty = t2 % p.tiles_y;
-        const int img = t2 / p.tiles_y;
-        const int oy0 = ty * TL::TH, ox0 = tx * TL::TW;
+        dw_tile_origin(p, t, TL::TH, TL::TW, img, oy0, ox0);
         __syncthreads();  // previous tile's LDS reads are done
-        stage_halo<T, STRIDE>(p, aff, tile, img, oy0, ox0, c0, cb_vecs);
+        hr.commit(p, aff, tile);
         __syncthreads();
+        if (t + nsplit < ntiles) {   // prefetch the next tile: its loads fly while this tile is computed
+            int img2, oy2, ox2;
+            dw_tile_origin(p, t + nsplit, TL::TH, TL::TW, img2, oy2, ox2);
+            hr.load(p, img2, oy2, ox2, c0, cb_vecs);
+        }
 #pragma unroll 1
         for (int op = pt; op < TL::TH * TL::TW; op += npt) {
             const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
@@ -292,15 +315,22 @@ __global__ __launch_bounds__(kThreads, 4) void dwconv_wgrad_kernel(const DwParam
 
     const HaloAffine<T> aff = load_halo_affine<T>(p, c0, cb_vecs);
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
+    HaloRegs<T, STRIDE> hr;
+    int img, oy0, ox0;
+    if (split < ntiles) {
+        dw_tile_origin(p, split, TL::TH, TL::TW, img, oy0, ox0);
+        hr.load(p, img, oy0, ox0, c0, cb_vecs);
+    }
     for (int t = split; t < ntiles; t += nsplit) {
-        const int tx = t % p.tiles_x;
-        const int t2 = t / p.tiles_x;
-        const int ty = t2 % p.tiles_y;
-        const int img = t2 / p.tiles_y;
-        const int oy0 = ty * TL::TH, ox0 = tx * TL::TW;
+        dw_tile_origin(p, t, TL::TH, TL::TW, img, oy0, ox0);
+        __syncthreads();  // previous tile's LDS reads are done
+        hr.commit(p, aff, tile);
         __syncthreads();
-        stage_halo<T, STRIDE>(p, aff, tile, img, oy0, ox0, c0, cb_vecs);
-        __syncthreads();
+        if (t + nsplit < ntiles) {   // prefetch the next tile: its loads fly while this tile is computed
+            int img2, oy2, ox2;
+            dw_tile_origin(p, t + nsplit, TL::TH, TL::TW, img2, oy2, ox2);
+            hr.load(p, img2, oy2, ox2, c0, cb_vecs);
+        }
 #pragma unroll 1
         for (int op = pt; op < TL::TH * TL::TW; op += npt) {
             const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
