@@ -90,6 +90,14 @@ size_t mpn_conv_packed_bytes(int Cin, int Cout, int ksize, int transpose, int dt
 /* w_hwio: f32 [ksize,ksize,Cin,Cout] in the reference's variable layout (HWIO) */
 int mpn_conv_pack_weights(const float* w_hwio, int Cin, int Cout, int ksize, int transpose,
                           int dtype, void* out, mpn_stream_t stream);
+/* Batched packing (one launch for every conv of the network after an optimizer step): fill one host descriptor
+ * per (conv, direction) with mpn_conv_pack_desc_fill (returns the job's block count; block_begin = running sum),
+ * copy the array to the device once, then launch mpn_conv_pack_weights_batched each step. */
+size_t mpn_conv_pack_desc_bytes(void);
+int mpn_conv_pack_desc_fill(void* desc_host, const float* w_hwio, int Cin, int Cout, int ksize, int transpose,
+                            int dtype, void* out, int block_begin);
+int mpn_conv_pack_weights_batched(const void* descs_device, int ndesc, int total_blocks, int dtype,
+                                  mpn_stream_t stream);
 int mpn_conv_num_parts(int N, int H, int W, int ksize);
 int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin,
                  int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,

@@ -28,6 +28,9 @@ SIGNATURES = {
     "mpn_heatmap_decode": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _Z, _P]),
     "mpn_conv_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "mpn_conv_pack_weights": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    "mpn_conv_pack_desc_bytes": (_Z, []),
+    "mpn_conv_pack_desc_fill": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I]),
+    "mpn_conv_pack_weights_batched": (_I, [_P, _I, _I, _I, _P]),
     "mpn_conv_num_parts": (_I, [_I, _I, _I, _I]),
     "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "mpn_conv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I, _I]),

@@ -18,6 +18,7 @@
 // Epilogue: accumulators -> LDS -> full 16-byte NHWC stores; optional fused nearest-2x
 // upsample-add (fpn.py:51) and per-tile batch-norm partial sums (sum, sum of squares).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -356,39 +357,66 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams
 
 // ------------------------------------------------------------------ weight packing
 // Packed order (per n-tile of BN output channels): [chunk][tap][stage][kstep(2)][BN][64 bytes].
+struct PackDesc {           // one (conv, direction) packing job; lives in device memory for the batched kernel
+    const float* w;
+    void* out;
+    int Cin_o, Cout_o, taps, transpose, BN, n_tiles, nchunk, row_bytes;
+    long long total_elems;
+    int block_begin, block_count;   // blocks [block_begin, block_begin + block_count) of the batched launch
+};
+
 template <typename T>
-__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin_o, int Cout_o,
-                                    int taps, int transpose, int BN, int n_tiles, int nchunk, int row_bytes,
-                                    long long total_elems) {
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restrict__ out, int Cin_o, int Cout_o, int taps,
+                                         int transpose, int BN, int nchunk, int row_bytes, long long i) {
     constexpr int ES = (int)sizeof(T);
     constexpr int EPK = 64 / ES;   // elements per k-step row
     constexpr int CCE = 256 / ES;
     const int Kin = transpose ? Cout_o : Cin_o;     // GEMM K channels
     const int Nout = transpose ? Cin_o : Cout_o;    // GEMM N channels
     const int stages_per_tap = row_bytes >> 7;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_elems;
-         i += (long long)gridDim.x * blockDim.x) {
-        long long r = i;
-        const int e = (int)(r % EPK); r /= EPK;
-        const int n = (int)(r % BN); r /= BN;
-        const int ks = (int)(r % 2); r /= 2;
-        const int st = (int)(r % stages_per_tap); r /= stages_per_tap;
-        const int tap = (int)(r % taps); r /= taps;
-        const int chunk = (int)(r % nchunk); r /= nchunk;
-        const int ntile = (int)r;
-        const int c = chunk * CCE + (st * 2 + ks) * EPK + e;
-        const int co = ntile * BN + n;
-        float v = 0.f;
-        if (c < Kin && co < Nout && (st * 2 + ks) * 64 < row_bytes) {
-            if (!transpose) v = w[((long long)tap * Cin_o + c) * Cout_o + co];
-            else v = w[((long long)(taps - 1 - tap) * Cin_o + co) * Cout_o + c];
-        }
-        // destination slot inside the 64-byte row is XOR-swizzled (see b_swz): the global image is the LDS image
-        constexpr int EPS = 16 / ES;   // elements per 16-byte slot
-        const int q = e / EPS, within = e - q * EPS;
-        const long long dst = i - e + (long long)((q ^ b_swz(n & 15)) * EPS + within);
-        out[dst] = from_f32<T>(v);
+    long long r = i;
+    const int e = (int)(r % EPK); r /= EPK;
+    const int n = (int)(r % BN); r /= BN;
+    const int ks = (int)(r % 2); r /= 2;
+    const int st = (int)(r % stages_per_tap); r /= stages_per_tap;
+    const int tap = (int)(r % taps); r /= taps;
+    const int chunk = (int)(r % nchunk); r /= nchunk;
+    const int ntile = (int)r;
+    const int c = chunk * CCE + (st * 2 + ks) * EPK + e;
+    const int co = ntile * BN + n;
+    float v = 0.f;
+    if (c < Kin && co < Nout && (st * 2 + ks) * 64 < row_bytes) {
+        if (!transpose) v = w[((long long)tap * Cin_o + c) * Cout_o + co];
+        else v = w[((long long)(taps - 1 - tap) * Cin_o + co) * Cout_o + c];
     }
+    // destination slot inside the 64-byte row is XOR-swizzled (see b_swz): the global image is the LDS image
+    constexpr int EPS = 16 / ES;   // elements per 16-byte slot
+    const int q = e / EPS, within = e - q * EPS;
+    const long long dst = i - e + (long long)((q ^ b_swz(n & 15)) * EPS + within);
+    out[dst] = from_f32<T>(v);
+}
+
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cin_o, int Cout_o,
+                                    int taps, int transpose, int BN, int n_tiles, int nchunk, int row_bytes,
+                                    long long total_elems) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_elems;
+         i += (long long)gridDim.x * blockDim.x)
+        pack_one<T>(w, out, Cin_o, Cout_o, taps, transpose, BN, nchunk, row_bytes, i);
+}
+
+// all packing jobs of the network in ONE launch (68 tiny launches per optimizer step otherwise)
+template <typename T>
+__global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, int ndesc) {
+    int lo = 0, hi = ndesc - 1;   // binary search of the job that owns this block
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackDesc d = descs[lo];
+    const int lb = blockIdx.x - d.block_begin;
+    for (long long i = (long long)lb * blockDim.x + threadIdx.x; i < d.total_elems; i += (long long)d.block_count * blockDim.x)
+        pack_one<T>(d.w, reinterpret_cast<T*>(d.out), d.Cin_o, d.Cout_o, d.taps, d.transpose, d.BN, d.nchunk, d.row_bytes, i);
 }
 
 struct PackGeom {
@@ -434,6 +462,42 @@ extern "C" int mpn_conv_pack_weights(const float* w_hwio, int Cin, int Cout, int
     else
         pack_weights_kernel<bf16_t><<<blocks, 256, 0, st>>>(w_hwio, (bf16_t*)out, Cin, Cout, taps, transpose, g.BN,
                                                            g.n_tiles, g.nchunk, g.row_bytes, total);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" size_t mpn_conv_pack_desc_bytes(void) { return sizeof(PackDesc); }
+
+/* Fills ONE host-side descriptor (desc_host, mpn_conv_pack_desc_bytes() bytes) for the batched packer and returns the
+ * number of blocks the job wants; block_begin = running sum over the jobs. */
+extern "C" int mpn_conv_pack_desc_fill(void* desc_host, const float* w_hwio, int Cin, int Cout, int ksize, int transpose,
+                                       int dtype, void* out, int block_begin) {
+    if (!(ksize == 1 || ksize == 3) || !desc_host || !w_hwio || !out) return -1;
+    const int es = dtype == MPN_F32 ? 4 : 2;
+    const int taps = ksize * ksize;
+    const PackGeom g = pack_geom(transpose ? Cout : Cin, transpose ? Cin : Cout, taps, es);
+    PackDesc d;
+    d.w = w_hwio; d.out = out; d.Cin_o = Cin; d.Cout_o = Cout; d.taps = taps; d.transpose = transpose;
+    d.BN = g.BN; d.n_tiles = g.n_tiles; d.nchunk = g.nchunk; d.row_bytes = g.row_bytes;
+    d.total_elems = g.total_bytes / es;
+    long long blocks = (d.total_elems + 4 * 256 - 1) / (4 * 256);   // 4 elements per thread
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    d.block_begin = block_begin;
+    d.block_count = (int)blocks;
+    memcpy(desc_host, &d, sizeof(d));
+    return (int)blocks;
+}
+
+extern "C" int mpn_conv_pack_weights_batched(const void* descs_device, int ndesc, int total_blocks, int dtype,
+                                             mpn_stream_t stream) {
+    MPN_REQUIRE(descs_device && ndesc > 0 && total_blocks > 0, MPN_ERR_BAD_ARG, "pack batched: bad arguments");
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "pack batched: dtype");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPN_F32)
+        pack_weights_batched_kernel<float><<<total_blocks, 256, 0, st>>>((const PackDesc*)descs_device, ndesc);
+    else
+        pack_weights_batched_kernel<bf16_t><<<total_blocks, 256, 0, st>>>((const PackDesc*)descs_device, ndesc);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

@@ -227,13 +227,32 @@ class KeypointNet:
         ob, nb, _ = self._train_arena.offsets["heatmaps/bias"]
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
+        self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
             [self.p_bn[l] for l in (2, 3, 4, 5)] + [self.phi[l][k] for l in (2, 3, 4, 5) for k in ("bn1", "bn2")] + [self.final_bn]
 
+    def _build_pack_table(self):
+        """Device table of packing jobs (forward + data-gradient image of every conv) for the one-launch packer."""
+        import ctypes
+        lib = ops._lib.lib()
+        nb = lib.mpn_conv_pack_desc_bytes()
+        jobs = [(c, t) for c in self.convs for t in (0, 1)]
+        host = (ctypes.c_ubyte * (nb * len(jobs)))()
+        begin = 0
+        dc = ops._lib.dtype_code(self.dtype)
+        for j, (c, t) in enumerate(jobs):
+            out = c.packed.bwd if t else c.packed.fwd
+            blocks = lib.mpn_conv_pack_desc_fill(ctypes.byref(host, j * nb), ops.ptr(c.w), c.cin, c.cout, c.ksize, t, dc,
+                                                 ops.ptr(out), begin)
+            assert blocks > 0
+            begin += blocks
+        self._pack_table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.device)
+        self._pack_jobs, self._pack_blocks = len(jobs), begin
+
     def repack_weights(self):
-        """Refresh the packed (bf16/f32, MFMA tile order) copies after the f32 masters changed."""
-        for c in self.convs:
-            c.packed.repack()
+        """Refresh the packed (bf16/f32, MFMA tile order) copies after the f32 masters changed: one launch."""
+        ops.call("mpn_conv_pack_weights_batched", ops.ptr(self._pack_table), self._pack_jobs, self._pack_blocks,
+                 ops._lib.dtype_code(self.dtype), ops.stream_ptr())
 
     # ------------------------------------------------------------------ buffers (allocated once per input shape)
     def _buffers(self, N, H, W):
