@@ -18,6 +18,7 @@
 // Epilogue: accumulators -> LDS -> full 16-byte NHWC stores; optional fused nearest-2x
 // upsample-add (fpn.py:51) and per-tile batch-norm partial sums (sum, sum of squares).
 #include "common.h"
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -101,22 +102,29 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
     return v;
 }
 
-template <typename T, int TAPS, int BN, int RB>
-__global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams p) {
+// RING = false: weight stages of 2 k-steps, 2 LDS buffers, DMA distance 1 (256-byte chunks: 2 blocks per CU).
+// RING = true (128-byte chunks only): stages of 1 k-step in a 3-slot ring, DMA distance 2 behind a COUNTED vmcnt and a
+// raw s_barrier; A image 28.8 KB + 24 KB of weights = 52.8 KB -> THREE blocks per CU, so one block's staging / epilogue
+// always has two others' MFMA phases to hide under.
+template <typename T, int TAPS, int BN, int RB, bool RING>
+__global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
-    constexpr int CCE = 256 / ES;  // channels per full chunk
+    constexpr int CCE = RB / ES;   // channels per chunk
     constexpr int NPIX = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int NT = BN / 32;                 // 16-channel tiles per wave
-    constexpr int STAGE_BYTES = 2 * BN * 64;    // two k-steps of weights
+    constexpr int KSPS = RING ? 1 : 2;          // k-steps per weight stage
+    constexpr int NBUF = RING ? 3 : 2;
+    constexpr int STAGE_BYTES = KSPS * BN * 64;
     constexpr int BVEC = STAGE_BYTES / (kThreads * 16);
+    static_assert(BVEC >= 1, "a weight stage is at least one 16-byte vector per thread");
     constexpr int RS = a_row_stride(RB);
     constexpr int SLOTS = RB >> 4;              // 16-byte slots per pixel row: 8 or 16
     constexpr int KSTEPS = RB >> 6;             // 64-byte k-steps per chunk: 2 or 4
-    constexpr int SPT = RB >> 7;                // stages (2 k-steps) per tap: 1 or 2
+    constexpr int SPT = KSTEPS / KSPS;          // weight stages per tap
     constexpr int AVEC = (NPIX * SLOTS + kThreads - 1) / kThreads;
     using Frag = typename Mma<T>::Frag;
-    static_assert(KSTEPS == 2 * SPT, "a stage is exactly two k-steps");
+    static_assert(!RING || RB == 128, "the 3-slot ring is sized for 128-byte chunks");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
@@ -179,6 +187,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams
                                              (__attribute__((address_space(3))) void*)(dst + i * kThreads * 16), 16, 0, 0);
     };
     b_issue(0, 0);
+    if (RING && total_stages > 1) b_issue(1, 1);
 
 #define MPN_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
     MPN_STAMP(0);
@@ -258,16 +267,28 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams
         for (int sl = 0; sl < TAPS * SPT; ++sl, ++s) {
             const int tap = sl / SPT, h = sl - tap * SPT;
             const int ky = (tap * 11) >> 5;   // tap / 3 for tap < 9
-            const int a_off = ((TAPS == 9) ? (ky * kHaloW + (tap - 3 * ky)) * RS : 0) + h * 128;   // wave-uniform
-            const int b_off = (s & 1) * STAGE_BYTES;
-            const bool more = (s + 1 < total_stages);
-            if (more) b_issue(s + 1, (s + 1) & 1);     // buffer (s+1)%2 was last read in stage s-1: all waves are past it
-            load_frags(aP, bP, a_off, b_off);
-            load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
-            mma_all(aP, bP);
-            mma_all(aQ, bQ);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
-            __syncthreads();
+            const int a_off = ((TAPS == 9) ? (ky * kHaloW + (tap - 3 * ky)) * RS : 0) + h * (KSPS * 64);   // wave-uniform
+            if constexpr (!RING) {
+                const int b_off = (s & 1) * STAGE_BYTES;
+                const bool more = (s + 1 < total_stages);
+                if (more) b_issue(s + 1, (s + 1) & 1);   // buffer (s+1)%2 was last read in stage s-1: all waves are past it
+                load_frags(aP, bP, a_off, b_off);
+                load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
+                mma_all(aP, bP);
+                mma_all(aQ, bQ);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
+                __syncthreads();
+            } else {
+                const int b_off = (s % 3) * STAGE_BYTES;
+                const bool more2 = (s + 2 < total_stages);
+                if (more2) b_issue(s + 2, (s + 2) % 3);   // slot (s+2)%3 was last read in stage s-1: all waves are past it
+                load_frags(aP, bP, a_off, b_off);
+                mma_all(aP, bP);
+                // stage s+1 must have landed; the BVEC pieces of stage s+2 just issued may stay in flight
+                if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BVEC) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();   // raw: __syncthreads() would drain the DMA with vmcnt(0)
+            }
         }
     }
     MPN_STAMP(2);
@@ -370,7 +391,7 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
                                          int transpose, int BN, int nchunk, int row_bytes, long long i) {
     constexpr int ES = (int)sizeof(T);
     constexpr int EPK = 64 / ES;   // elements per k-step row
-    constexpr int CCE = 256 / ES;
+    const int CCE = row_bytes / ES;   // channels per chunk
     const int Kin = transpose ? Cout_o : Cin_o;     // GEMM K channels
     const int Nout = transpose ? Cin_o : Cout_o;    // GEMM N channels
     const int stages_per_tap = row_bytes >> 7;
@@ -429,8 +450,12 @@ PackGeom pack_geom(int Kin, int Nout, int taps, int es) {
     g.BN = (Nout % 128 == 0) ? 128 : 64;
     g.n_tiles = (Nout + g.BN - 1) / g.BN;
     const int kbytes = Kin * es;
-    g.row_bytes = kbytes <= 128 ? 128 : 256;
-    g.nchunk = (kbytes + 255) / 256;
+    // chunk (= LDS pixel row) width: 128 bytes of K for 3x3 (a 28.8 KB halo image: the two co-resident blocks of a CU
+    // alternate their staging and MFMA phases at twice the granularity), 256 for 1x1 when K is that wide
+    const char* force = getenv("MPN_CONV_RB");
+    const int pref = force ? atoi(force) : (taps == 9 ? 128 : 256);
+    g.row_bytes = (kbytes <= 128 || pref == 128) ? 128 : 256;
+    g.nchunk = (kbytes + g.row_bytes - 1) / g.row_bytes;
     const int stages_per_tap = g.row_bytes >> 7;
     g.tile_bytes = (long long)g.nchunk * taps * stages_per_tap * 2 * g.BN * 64;
     g.total_bytes = g.tile_bytes * g.n_tiles;
@@ -511,25 +536,31 @@ extern "C" int mpn_conv_num_parts(int N, int H, int W, int ksize) {
     return (int)(((long long)N * H * W + 127) / 128);
 }
 
-template <typename T, int TAPS, int BN, int RB>
+template <typename T, int TAPS, int BN, int RB, bool RING>
 static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
     constexpr int NPIX = TAPS == 9 ? kHaloW * kHaloH : 128;
-    constexpr int smem = NPIX * a_row_stride(RB) + 2 * (2 * BN * 64);
+    constexpr int smem = NPIX * a_row_stride(RB) + (RING ? 3 * (BN * 64) : 2 * (2 * BN * 64));
     static bool attr_set = false;
     if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB>,
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB, RING>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    conv_mfma_kernel<T, TAPS, BN, RB><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
+    conv_mfma_kernel<T, TAPS, BN, RB, RING><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
 
 template <typename T, int TAPS, int BN>
 static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
-    return p.row_bytes == 256 ? launch_conv_rb<T, TAPS, BN, 256>(p, m_tiles, st)
-                              : launch_conv_rb<T, TAPS, BN, 128>(p, m_tiles, st);
+    // MPN_CONV_RING=1 selects the 3-blocks-per-CU ring variant for 128-byte chunks. Measured equal to the 2-buffer
+    // variant (211 vs 210 us on 3x3 128->128 @ [32,128,128]): occupancy is not what limits this kernel, so the
+    // simpler variant stays the default.
+    static int ring = -1;
+    if (ring < 0) { const char* e = getenv("MPN_CONV_RING"); ring = e ? atoi(e) : 0; }
+    if (p.row_bytes == 256) return launch_conv_rb<T, TAPS, BN, 256, false>(p, m_tiles, st);
+    if (ring && BN == 128) return launch_conv_rb<T, TAPS, BN, 128, true>(p, m_tiles, st);
+    return launch_conv_rb<T, TAPS, BN, 128, false>(p, m_tiles, st);
 }
 
 extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
