@@ -236,6 +236,33 @@ int mpn_reduce_partials(const float* part, int nparts, long long n, float* out, 
                         float scale, mpn_stream_t stream);
 int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * L1  target-heatmap rendering (label producer of the keypoint path).
+ * Replaces detector/input_pipeline/heatmap_creation.py:6-72 `get_heatmaps` (+ `get_kernel`
+ * :75-86, `create_heatmap` :89-118), which the reference runs per image under the GIL via
+ * tf.py_func (keypoints_detector_pipeline.py:86-90, prn_pipeline.py:91-95), for a whole
+ * batch of equally sized images in one launch:
+ *
+ *   out[b,y,x,j] = max(0, max over visible persons p of image b of
+ *                         float32(g_p[|y-cy_pj|] * g_p[|x-cx_pj|]),  |dy|,|dx| <= k_p)
+ *   sigma_p = clip(0.007f * sqrtf(box area), 1, 4)            (float32, :33-37)
+ *   k_p     = ceil(sqrt(-2 sigma^2 ln 0.01)), g_p[d] = exp(-d^2 / (2 sigma^2))  (float64, :78-84)
+ *   cy, cx  = rint(float32(y / (height-1)) * (h-1)), likewise x  (:23-24,57,104-107)
+ * Bit-identical to the reference (tests/golden/render_goldens.npz); peaks are exactly 1.0f.
+ *
+ *   keypoints    [P,17,3] int32 (y, x, visibility), persons of all images concatenated
+ *   boxes        [P,4] f32 (ymin, xmin, ymax, xmax), absolute
+ *   first_person [B+1] int32, device: persons of image b are first_person[b] .. first_person[b+1]-1
+ *   width,height size of the (equally sized) images; h = ceil(height/downsample), w likewise
+ *   out          [B,h,w,17] f32, every element written
+ *   workspace    mpn_heatmap_render_workspace_bytes(P) bytes of scratch (no initialisation needed)
+ * A blob whose centre lies outside the map is clipped (the numpy code raises or wraps there).
+ */
+size_t mpn_heatmap_render_workspace_bytes(int total_persons);
+int mpn_heatmap_render(const int32_t* keypoints, const float* boxes, const int32_t* first_person,
+                       int B, int total_persons, int width, int height, int downsample, float* out,
+                       void* workspace, size_t workspace_bytes, mpn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,8 @@ SIGNATURES = {
     "mpn_last_error": (_I, [_c.c_char_p, _Z]),
     "mpn_heatmap_decode_workspace_bytes": (_Z, [_I]),
     "mpn_heatmap_decode": (_I, [_P, _I, _I, _I, _I, _I, _P, _F, _P, _P, _P, _P, _Z, _P]),
+    "mpn_heatmap_render_workspace_bytes": (_Z, [_I]),
+    "mpn_heatmap_render": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P]),
     "mpn_conv_packed_bytes": (_Z, [_I, _I, _I, _I, _I]),
     "mpn_conv_pack_weights": (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     "mpn_conv_pack_desc_bytes": (_Z, []),

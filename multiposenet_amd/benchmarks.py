@@ -119,3 +119,51 @@ def decode_benchmark(batch=32, h=128, w=128, iters=200):
     return {"us_per_image": round(us / batch, 4), "batch": batch, "launch_us": round(us, 2),
             "hbm_GBps": round(byt / us / 1e3, 1), "hbm_frac_of_8TBps": round(byt / us / 1e3 / 8000.0, 4),
             "cpu_port_us_per_image": round(cpu_us, 1)}
+
+
+def render_benchmark(batch=32, width=512, height=512, downsample=4, persons_per_image=6, iters=200):
+    """Label producer: target-heatmap rendering, us/image, for `batch` images of
+    `persons_per_image` persons each (keypoints/boxes resident in HBM). Algorithmic bytes = the [B,h,w,17] f32
+    output written once. CPU leg: the numpy oracle (bit-identical to the reference on the goldens), one thread."""
+    import numpy as np
+    from .detector.input_pipeline import HeatmapRenderer
+    rs = np.random.RandomState(11)
+    P = batch * persons_per_image
+    kp = np.zeros((P, 17, 3), np.int32)
+    kp[:, :, 0] = rs.randint(0, height, size=(P, 17))
+    kp[:, :, 1] = rs.randint(0, width, size=(P, 17))
+    kp[:, :, 2] = rs.rand(P, 17) < 0.7
+    side = rs.uniform(0.1, 0.9, size=(P, 2)) * [height, width]
+    bx = np.concatenate([np.zeros((P, 2)), side], axis=1).astype(np.float32)
+    first = (np.arange(batch + 1) * persons_per_image).astype(np.int32)
+    r = HeatmapRenderer(batch, width, height, downsample, max_persons=P)
+    d_kp, d_bx, d_first = (torch.from_numpy(a).cuda() for a in (kp, bx, first))
+    for _ in range(3):
+        r(d_kp, d_bx, d_first)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(10):
+            r(d_kp, d_bx, d_first)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters // 10):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (iters // 10 * 10)
+    byt = r.out.numel() * 4
+    from oracle import heatmap_creation as oren
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < 2.0:
+        b = n % batch
+        sl = slice(first[b], first[b + 1])
+        oren.get_heatmaps(kp[sl], bx[sl], width, height, downsample)
+        n += 1
+    cpu_us = (time.perf_counter() - t0) * 1e6 / n
+    return {"us_per_image": round(us / batch, 4), "batch": batch, "persons_per_image": persons_per_image,
+            "launch_us": round(us, 2), "hbm_GBps": round(byt / us / 1e3, 1),
+            "hbm_frac_of_8TBps": round(byt / us / 1e3 / 8000.0, 4), "cpu_port_us_per_image": round(cpu_us, 1)}

@@ -56,3 +56,16 @@ def assert_close(got, want, dtype, k=1, scale=None):
     assert not bool(bad.any()), (
         f"max err {float(err.max()):.3e} (scale {scale:.3e}, {int(bad.sum())}/{bad.numel()} outside tol) "
         f"at {np.unravel_index(int(err.argmax()), tuple(err.shape))}")
+
+
+import os as _os
+
+RENDER_GOLD = np.load(_os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "golden", "render_goldens.npz"))
+
+
+def render_golden(name):
+    """Dense float32 [h,w,17] heatmaps the reference produced for a case of tests/golden/render_cases.py."""
+    shape = tuple(int(s) for s in RENDER_GOLD[f"{name}/shape"])
+    out = np.zeros(int(np.prod(shape)), np.float32)
+    out[RENDER_GOLD[f"{name}/index"]] = RENDER_GOLD[f"{name}/value"]
+    return out.reshape(shape)
