@@ -15,6 +15,7 @@
 // LDS rows are XOR-swizzled in 32-byte segments so the 8 pixel rows one half-wave touches per
 // transposed read land in 8 different bank groups.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -38,6 +39,7 @@ struct WgradParams {
     int ntiles;   // pixel tiles
     int nsplit;
     int n_cg, n_cb;
+    unsigned long long* dbg;   // diagnostics (mpn_debug_set_wgrad_stamps): per-wave phase times, else NULL
 };
 
 __device__ __forceinline__ int fsw256(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
@@ -292,23 +294,363 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
                 }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// bf16 throughput kernel: 8 waves, ONE block per CU, software-pipelined over pixel tiles.
+// The 4-wave kernel above stalls a whole memory round trip per tile (load -> LDS -> barrier -> MFMA, two blocks per CU
+// cannot cover it: measured 21 % MFMA utilisation on the 128x128-map 3x3 layers). Here a block owns twice the input
+// channels (fewer re-reads of every dY tile), the NEXT tile's global loads are issued into registers before the
+// current tile's MFMAs start and are committed (batch-norm affine + activation) into the OTHER half of a
+// double-buffered LDS image afterwards, so that one barrier per tile remains and the round trip hides under
+// ~4.6k MFMA cycles per SIMD.  Geometries (RBA, RBD bytes per LDS pixel row; WM x WN waves over m/n tiles):
+//   3x3:              (128, 256, 2x4) = 64 ci x 9 taps x 128 co, 144 accumulator registers per lane
+//   3x3, Cout <= 64:  (256, 128, 4x2) = 128 ci x 9 taps x 64 co
+//   1x1:              (256, 256, 4x2) = 128 ci x 128 co
+template <int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradParams p) {
+    using T = bf16_t;
+    constexpr int NT = 512;
+    constexpr int VE = 8;
+    constexpr int CG = RBA / 2, BNW = RBD / 2;
+    constexpr int ASLOTS = RBA / 16, DSLOTS = RBD / 16;
+    constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int MT_TOTAL = CG / 16, NT_TOTAL = BNW / 16;
+    constexpr int WN = 8 / WM;
+    constexpr int MTW = MT_TOTAL / WM, NTW = NT_TOTAL / WN;
+    static_assert(MTW * WM == MT_TOTAL && NTW * WN == NT_TOTAL, "wave layout must tile the block");
+    constexpr int AVEC = (NPIXA * ASLOTS + NT - 1) / NT;
+    constexpr int DVEC = 128 * DSLOTS / NT;
+    // LDS images: padded rows (stride = row bytes + 32, an odd number of 32-byte bank groups), NO swizzle: the 8
+    // consecutive pixel rows a half-wave touches per transposed read fall into 8 different bank groups, and every
+    // (tap, k-step, m-tile) of a fragment read is an IMMEDIATE offset from one per-lane base address. (XOR-swizzled
+    // rows cost ~10 VALU instructions per fragment read: 2 waves x 250 VALU x 4 cycles per k-step against 1152 MFMA
+    // cycles - the MFMA phase was VALU-bound.)
+    constexpr int SA = RBA + 32, SD = RBD + 32;
+    constexpr int ABYTES = NPIXA * SA, DBYTES = 128 * SD;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // [2][ABYTES] A images, [2][DBYTES] dY images, [2][CG] f32 scale / shift
+    float* aff = reinterpret_cast<float*>(smem + 2 * ABYTES + 2 * DBYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    int b;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int cg = b % p.n_cg; b /= p.n_cg;
+    const int cb = b % p.n_cb;
+    const int split = b / p.n_cb;
+    const int ci0 = cg * CG, co0 = cb * BNW;
+    const int mt0 = (wave / WN) * MTW, nt0 = (wave % WN) * NTW;
+
+    f32x4_t acc[TAPS][MTW][NTW];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) acc[t][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+    const bool affine = p.in_scale != nullptr;
+    const float lo = (affine && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (affine && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    for (int c = tid; c < CG; c += NT) {
+        const bool ok = affine && ci0 + c < p.Cin;
+        aff[c] = ok ? p.in_scale[ci0 + c] : 1.f;
+        aff[CG + c] = ok ? p.in_shift[ci0 + c] : 0.f;
+    }
+
+    const int aslot = tid % ASLOTS;
+    const int dslot = tid % DSLOTS;
+
+    Vec16<T> v[AVEC], dv[DVEC];
+    unsigned inb = 0u, inbd = 0u;
+
+    // Per-thread invariants of the staging (32-bit element offsets relative to the tile origin; the host checks that
+    // both tensors have < 2^31 elements). Halo position packed as hy << 8 | hx.
+    int relA[AVEC], hyx[AVEC], relD[DVEC];
+    {
+        const int ace = ci0 + aslot * VE, dce = co0 + dslot * VE;
+#pragma unroll
+        for (int i = 0; i < AVEC; ++i) {
+            const int vi = tid + i * NT;
+            const int pix = vi / ASLOTS;
+            const bool ok = ace < p.Cin && vi < NPIXA * ASLOTS;
+            if (TAPS == 9) {
+                const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
+                relA[i] = ((hy - 1) * p.W + (hx - 1)) * p.Cin + ace;
+                hyx[i] = ok ? (hy << 8 | hx) : 0x7fff00;        // hy = 32767: never inside an image
+            } else {
+                relA[i] = pix * p.Cin + ace;
+                hyx[i] = ok ? pix : 0x7fffffff;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DVEC; ++i) {
+            const int r = (tid / DSLOTS) + i * (NT / DSLOTS);
+            relD[i] = (TAPS == 9 ? ((r >> 4) * p.W + (r & 15)) : r) * p.Cout + dce;
+        }
+    }
+    const bool dvalid = co0 + dslot * VE < p.Cout;
+    const int drow0 = tid / DSLOTS;
+
+    // Loads are UNCONDITIONAL (out-of-image lanes read element 0 of the tensor and are zeroed at commit time): a
+    // predicated load is lowered to load + select, which waits for the data right here and defeats the prefetch.
+    // Addresses and masks first, then the loads back to back.
+    auto load_tile = [&](int tile) {
+        int oy0 = 0, ox0 = 0, baseA, baseD, mleft = 0;
+        if (TAPS == 9) {
+            const int tx = tile % p.tiles_x;
+            const int t2 = tile / p.tiles_x;
+            const int ty = t2 % p.tiles_y;
+            const int img = t2 / p.tiles_y;
+            oy0 = ty * 8;
+            ox0 = tx * 16;
+            const int pix0 = (img * p.H + oy0) * p.W + ox0;
+            baseA = pix0 * p.Cin;
+            baseD = pix0 * p.Cout;
+        } else {
+            baseA = tile * 128 * p.Cin;
+            baseD = tile * 128 * p.Cout;
+            mleft = (int)(p.M - (long long)tile * 128);      // valid pixels from the tile origin on
+        }
+        int oa[AVEC], od[DVEC];
+        unsigned ma = 0u, md = 0u;
+#pragma unroll
+        for (int i = 0; i < AVEC; ++i) {
+            bool ok;
+            if (TAPS == 9) {
+                const int iy = oy0 + (hyx[i] >> 8) - 1, ix = ox0 + (hyx[i] & 255) - 1;
+                ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            } else {
+                ok = hyx[i] < mleft;
+            }
+            oa[i] = ok ? baseA + relA[i] : 0;
+            ma |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int i = 0; i < DVEC; ++i) {
+            const int r = drow0 + i * (NT / DSLOTS);
+            bool ok = dvalid;
+            if (TAPS == 9) ok = ok && oy0 + (r >> 4) < p.H && ox0 + (r & 15) < p.W;
+            else ok = ok && r < mleft;
+            od[i] = ok ? baseD + relD[i] : 0;
+            md |= (ok ? 1u : 0u) << i;
+        }
+        inb = ma;
+        inbd = md;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < AVEC; ++i) v[i].load(x + oa[i]);
+#pragma unroll
+        for (int i = 0; i < DVEC; ++i) dv[i].load(dy + od[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    auto commit_tile = [&](unsigned char* As, unsigned char* Ds) {
+        float sc[VE], sh[VE];
+        if (affine) {
+#pragma unroll
+            for (int j = 0; j < VE; j += 4) {
+                const float4 a = *reinterpret_cast<const float4*>(aff + aslot * VE + j);
+                const float4 c = *reinterpret_cast<const float4*>(aff + CG + aslot * VE + j);
+                sc[j] = a.x; sc[j + 1] = a.y; sc[j + 2] = a.z; sc[j + 3] = a.w;
+                sh[j] = c.x; sh[j + 1] = c.y; sh[j + 2] = c.z; sh[j + 3] = c.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < AVEC; ++i) {
+            const int vi = tid + i * NT;
+            if (vi < NPIXA * ASLOTS) {
+                const int pix = vi / ASLOTS;
+                uint4 q = *reinterpret_cast<const uint4*>(&v[i].raw);
+                if (affine) {
+                    float f[VE];
+                    v[i].unpack(f);
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);
+                    Vec16<T> o;
+                    o.pack(f);
+                    q = *reinterpret_cast<const uint4*>(&o.raw);
+                }
+                if (!((inb >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
+                *reinterpret_cast<uint4*>(As + pix * SA + aslot * 16) = q;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DVEC; ++i) {
+            const int r = (tid / DSLOTS) + i * (NT / DSLOTS);
+            uint4 q = *reinterpret_cast<const uint4*>(&dv[i].raw);
+            if (!((inbd >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(Ds + r * SD + dslot * 16) = q;
+        }
+    };
+
+    unsigned long long ph[4] = {0, 0, 0, 0}, t_prev = 0;
+#define MPN_WG_STAMP(k) do { if (p.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                                          ph[k] += t_ - t_prev; t_prev = t_; } } while (0)
+    // Schedule. The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD) that run the SAME loop
+    //     load(next) ; barrier ; MFMAs(tile i) ; barrier ; commit(next)
+    // half a period apart: group 1 executes one barrier more before the loop and group 0 one more after it, so while
+    // one group multiplies, the other one commits its share of a later tile to the other LDS half and issues its next
+    // loads - the matrix pipe of every SIMD always has one wave feeding it, and staging costs no MFMA time as long
+    // as it is shorter than one tile's MFMAs of a single wave. Group 0 stages one tile ahead of its MFMAs, group 1
+    // two; a tile's image is complete one barrier before the first group reads it, and nobody writes the half that
+    // the other group still reads (see DESIGN.md 4 for the barrier-by-barrier table).
+    // The prefetch registers are written (load) and read (commit) inside ONE iteration - carried across the back
+    // edge they become PHIs whose live ranges hipcc splits with a copy right after the loads, which waits for them.
+    const int grp = STAGGER ? wave >> 2 : 0;   // !STAGGER: all waves in step (one group, two barriers per tile)
+    const int ntl = p.ntiles > split ? (p.ntiles - split + p.nsplit - 1) / p.nsplit : 0;   // tiles of this block
+    const int ahead = 1 + grp;
+    if (ntl > 0) load_tile(split);
+    __syncthreads();   // scale / shift table visible
+    if (ntl > 0) commit_tile(smem, smem + 2 * ABYTES);
+    if (grp == 1) {
+        if (ntl > 1) load_tile(split + p.nsplit);
+        __syncthreads();
+        if (ntl > 1) commit_tile(smem + ABYTES, smem + 2 * ABYTES + DBYTES);
+    }
+    if (p.dbg) t_prev = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int it = 0; it < ntl; ++it) {
+        const int buf = it & 1;
+        unsigned char* As = smem + buf * ABYTES;
+        unsigned char* Ds = smem + 2 * ABYTES + buf * DBYTES;
+        const bool more = it + ahead < ntl;
+        if (more) load_tile(split + (it + ahead) * p.nsplit);   // flies under this tile's MFMAs
+        MPN_WG_STAMP(1);
+        __syncthreads();
+        MPN_WG_STAMP(2);
+        // k (pixel) order inside a 32-pixel k-step: the first transposed read of lane group lq covers pixels
+        // 4*lq..4*lq+3 of the even tile row, the second the same columns of the odd tile row (any order works as long
+        // as A and dY agree); a half-wave therefore reads 8 consecutive pixel rows of the image.
+        const int qq = l15 >> 2, pp = l15 & 3;
+        const unsigned char* a_lane = As + (4 * lq + qq) * SA + pp * 8 + mt0 * 32;
+        const unsigned char* d_lane = Ds + (4 * lq + qq) * SD + pp * 8 + nt0 * 32;
+        // One flat, fully unrolled stream of 4 k-steps x STEPS fragment steps: the fragment ring and the double-
+        // buffered dY fragments run ACROSS k-step boundaries (a rolled k-step loop drains the LDS pipeline 4x per tile).
+        constexpr int STEPS = TAPS * MTW;
+        constexpr int TOTAL = 4 * STEPS;
+        constexpr int RING0 = NTW >= 4 ? 4 : 6;
+        constexpr int RING = RING0 < STEPS ? RING0 : STEPS;
+        constexpr int KSA = (TAPS == 9 ? 2 * kHaloW : 32) * SA, KSD = 32 * SD;
+        auto a_load = [&](int gs) -> bf16x8_t {
+            const int ks = gs / STEPS, step = gs % STEPS;
+            const int t = step / MTW, i = step % MTW;
+            const int row = TAPS == 9 ? (t / 3) * kHaloW + (t % 3) : 0;
+            const int second = TAPS == 9 ? kHaloW : 16;
+            const bf16x4_t l4 = tr_read(a_lane, ks * KSA + row * SA + i * 32);
+            const bf16x4_t h4 = tr_read(a_lane, ks * KSA + (row + second) * SA + i * 32);
+            return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto b_load = [&](int ks, int j) -> bf16x8_t {
+            const bf16x4_t l4 = tr_read(d_lane, ks * KSD + j * 32);
+            const bf16x4_t h4 = tr_read(d_lane, ks * KSD + 16 * SD + j * 32);
+            return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        bf16x8_t bfr[2][NTW];
+        bf16x8_t ar[RING];
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) bfr[0][j] = b_load(0, j);
+#pragma unroll
+        for (int r = 0; r < RING - 1; ++r) ar[r] = a_load(r);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int gs = 0; gs < TOTAL; ++gs) {
+            const int ks = gs / STEPS, step = gs % STEPS;
+            // the next k-step's dY fragments are requested one step before its first A fragment (LDS returns in order)
+            if (step == STEPS - RING && ks + 1 < 4) {
+#pragma unroll
+                for (int j = 0; j < NTW; ++j) bfr[(ks + 1) & 1][j] = b_load(ks + 1, j);
+            }
+            if (gs + RING - 1 < TOTAL) ar[(gs + RING - 1) % RING] = a_load(gs + RING - 1);
+            const int t = step / MTW, i = step % MTW;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[gs % RING], bfr[ks & 1][j], acc[t][i][j], 0, 0, 0);
+            // full fence per step: without it the scheduler sinks every read down to its use (one register set,
+            // lgkmcnt(0) before each MFMA group) and the ring degenerates to distance 0
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        MPN_WG_STAMP(3);
+        __syncthreads();
+        MPN_WG_STAMP(2);
+        if (more) {
+            const int nb = (it + ahead) & 1;
+            commit_tile(smem + nb * ABYTES, smem + 2 * ABYTES + nb * DBYTES);
+        }
+        MPN_WG_STAMP(0);
+    }
+    if (STAGGER && grp == 0) __syncthreads();
+    if (p.dbg && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 4 + k] = ph[k];
+    }
+#undef MPN_WG_STAMP
+
+    float* __restrict__ dst = p.part + (long long)split * TAPS * p.Cin * p.Cout;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int j = 0; j < NTW; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ci = ci0 + (mt0 + i) * 16 + lq * 4 + r;
+                    const int co = co0 + (nt0 + j) * 16 + l15;
+                    if (ci < p.Cin && co < p.Cout)
+                        dst[((long long)t * p.Cin + ci) * p.Cout + co] = acc[t][i][j][r];
+                }
+}
+
 struct WgradGeom {
     int n_cg, n_cb, ntiles, nsplit;
 };
 
 WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout, int ksize, int es) {
     WgradGeom g;
-    const bool narrow = ksize == 3 && Cout * es <= 128;   // (128,128) geometry, see launch_wgrad
-    const int cgsz = (narrow ? 128 : (ksize == 3 ? 64 : 256)) / es;
-    const int bnw = (narrow ? 128 : 256) / es;
+    int cgsz, bnw, blocks;
+    if (es == 2) {   // conv_wgrad_bf16_kernel: one 8-wave block per CU
+        const bool narrow = ksize == 3 && Cout <= 64;
+        cgsz = (ksize == 3 && !narrow) ? 64 : 128;
+        bnw = narrow ? 64 : 128;
+        blocks = 256;
+    } else {
+        const bool narrow = ksize == 3 && Cout * es <= 128;   // (128,128) geometry, see launch_wgrad
+        cgsz = (narrow ? 128 : (ksize == 3 ? 64 : 256)) / es;
+        bnw = (narrow ? 128 : 256) / es;
+        blocks = 512;
+    }
     g.n_cg = (Cin + cgsz - 1) / cgsz;
     g.n_cb = (Cout + bnw - 1) / bnw;
     g.ntiles = ksize == 3 ? N * ((H + 7) / 8) * ((W + 15) / 16) : (int)(((long long)N * H * W + 127) / 128);
-    int ns = 512 / (g.n_cg * g.n_cb);
+    int ns = blocks / (g.n_cg * g.n_cb);
     if (ns < 1) ns = 1;
     if (ns > g.ntiles) ns = g.ntiles;
     g.nsplit = ns;
     return g;
+}
+
+template <int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+int launch_wgrad_bf16(const WgradParams& p, hipStream_t st) {
+    constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int smem = 2 * NPIXA * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * (RBA / 2) * (int)sizeof(float);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TAPS, RBA, RBD, WM, STAGGER>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    conv_wgrad_bf16_kernel<TAPS, RBA, RBD, WM, STAGGER><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(512), smem, st>>>(p);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
 }
 
 template <typename T, int TAPS, int RBA, int RBD>
@@ -333,7 +675,12 @@ int launch_wgrad(const WgradParams& p, hipStream_t st) {
     return launch_wgrad_g<T, TAPS, (TAPS == 9 ? 64 : 256), 256>(p, st);
 }
 
+void* g_wgrad_dbg = nullptr;
+
 }  // namespace
+
+/* diagnostics only (tools/stamp_wgrad.py): buf = u64 [blocks][8 waves][4 phases] of s_memtime ticks, or NULL */
+extern "C" void mpn_debug_set_wgrad_stamps(void* buf) { g_wgrad_dbg = buf; }
 
 extern "C" int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, int ksize, int dtype) {
     return wgrad_geom(N, H, W, Cin, Cout, ksize, dtype == MPN_F32 ? 4 : 2).nsplit;
@@ -352,6 +699,8 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
     MPN_REQUIRE(x && dy && part, MPN_ERR_BAD_ARG, "conv wgrad: null pointer");
     MPN_REQUIRE(mpn_aligned16(x) && mpn_aligned16(dy), MPN_ERR_BAD_ALIGN, "conv wgrad: pointers must be 16-byte aligned");
     MPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), MPN_ERR_BAD_ARG, "conv wgrad: scale/shift mismatch");
+    MPN_REQUIRE((long long)N * H * W * Cin < (1ll << 31) && (long long)N * H * W * Cout < (1ll << 31), MPN_ERR_BAD_SHAPE,
+                "conv wgrad: tensors must have fewer than 2^31 elements");
     const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout, ksize, es);
     WgradParams p;
     p.x = x; p.dy = dy; p.part = part;
@@ -360,7 +709,13 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
     p.M = (long long)N * H * W;
     p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = g.n_cg; p.n_cb = g.n_cb;
+    p.dbg = (unsigned long long*)g_wgrad_dbg;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MPN_F32) return ksize == 3 ? launch_wgrad<float, 9>(p, st) : launch_wgrad<float, 1>(p, st);
-    return ksize == 3 ? launch_wgrad<bf16_t, 9>(p, st) : launch_wgrad<bf16_t, 1>(p, st);
+    static const int stagger = getenv("MPN_WGRAD_STAGGER") ? atoi(getenv("MPN_WGRAD_STAGGER")) : 6;   // bit per geometry (1x1, narrow 3x3, 3x3): measured best
+    if (ksize == 1)
+        return (stagger & 1) ? launch_wgrad_bf16<1, 256, 256, 4, true>(p, st) : launch_wgrad_bf16<1, 256, 256, 4, false>(p, st);
+    if (Cout <= 64)
+        return (stagger & 2) ? launch_wgrad_bf16<9, 256, 128, 4, true>(p, st) : launch_wgrad_bf16<9, 256, 128, 4, false>(p, st);
+    return (stagger & 4) ? launch_wgrad_bf16<9, 128, 256, 2, true>(p, st) : launch_wgrad_bf16<9, 128, 256, 2, false>(p, st);
 }
