@@ -64,8 +64,27 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const T* __restrict_
     }
 }
 
+__device__ __forceinline__ void store4(float* p, const float (&f)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void store4(bf16_t* p, const float (&f)[4]) {
+    const bf16_t a = (bf16_t)f[0], b = (bf16_t)f[1], c = (bf16_t)f[2], d = (bf16_t)f[3];
+    uint2 q;
+    q.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    q.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    *reinterpret_cast<uint2*>(p) = q;
+}
+
 // backward: dA[m][c] = sum_k dl[m][k] W[c][k];  dW[c][k] = sum_m a[m][c] dl[m][k];  db[k] = sum_m dl[m][k]
+// Blocks walk 128-pixel tiles staged in LDS (activated input f32 [128][Cin+4], dlogits [128][20]).
+//   data gradient:   a thread keeps the 4 x 18 weights of ITS 4-channel group in registers and walks the tile's pixels:
+//                    18 LDS reads (the pixel's dlogits, broadcast) per 72 FMAs;
+//   weight gradient: 3 pixel sets x (Cin/4 channel groups x 5 groups of 4 outputs): a thread accumulates a 4 x 4 block
+//                    of dW over every third pixel from two 16-byte LDS reads per 16 FMAs (one read per FMA operand made
+//                    the LDS the bottleneck: 2 b32 reads per FMA = 150 us of LDS time per launch); the three sets are
+//                    summed through LDS once per block; the bias gradient is 18 lanes summing dlogits columns.
 constexpr int kBwdPix = 128;
+constexpr int kDls = 20;                     // dlogits row stride in LDS (16-byte aligned groups of 4)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dl,
                                                             const float* __restrict__ w, long long M, int Cin,
@@ -73,17 +92,37 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const T* __restrict_
                                                             int act, T* __restrict__ dA, float* __restrict__ part) {
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int as = Cin + 1;
-    float* at = smem;                        // [128][Cin+1] activated input
-    float* dlt = at + kBwdPix * as;          // [128][19]
-    float* wl = dlt + kBwdPix * (kOut + 1);  // [Cin][18]
-    constexpr int kOPT = (kMaxCin * kOut + kOut + kThreads - 1) / kThreads;  // outputs per thread (<= 10)
-    float acc[kOPT];
-#pragma unroll
-    for (int k = 0; k < kOPT; ++k) acc[k] = 0.f;
+    const int as = Cin + 4;
+    float* at = smem;                        // [128][Cin+4] activated input
+    float* dlt = at + kBwdPix * as;          // [128][20]: 18 dlogits + 2 zeros
+    float* scl = dlt + kBwdPix * kDls;       // [Cin] batch-norm scale, [Cin] shift of the input
+    float* shl = scl + Cin;
     const int nout = Cin * kOut + kOut;
-    for (int i = threadIdx.x; i < Cin * kOut; i += kThreads) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cin; i += kThreads) { scl[i] = sc ? sc[i] : 1.f; shl[i] = sc ? sh[i] : 0.f; }
+    const float lo = (sc && act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (sc && act == MPN_ACT_RELU6) ? 6.f : INFINITY;
     const int cvec = Cin / VE;
+    const int ncg = Cin / 4;                 // 4-channel groups per pixel (<= 32)
+    // data-gradient role: channel group + first pixel
+    const int d_cg = threadIdx.x % ncg, d_px0 = threadIdx.x / ncg, d_step = kThreads / ncg;
+    float wreg[4][kOut];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < kOut; ++k) wreg[j][k] = w[(d_cg * 4 + j) * kOut + k];
+    // weight-gradient role: (pixel set, k group, channel group); threads beyond 3 sets idle in that phase
+    const int per_set = ncg * 5;
+    const int nsets = kThreads / per_set < 1 ? 1 : kThreads / per_set;     // 3 for Cin = 64
+    const int w_set = threadIdx.x / per_set, w_r = threadIdx.x % per_set;
+    const int w_kg = w_r / ncg, w_cg = w_r % ncg;
+    const bool w_on = w_set < nsets;
+    float acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = 0.f;
+    float accb = 0.f;
+
     const long long ntiles = (M + kBwdPix - 1) / kBwdPix;
     for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const long long m0 = t * kBwdPix;
@@ -97,67 +136,81 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const T* __restrict_
                 Vec16<T> v;
                 v.load(x + (m0 + px) * Cin + vg * VE);
                 v.unpack(f);
+                // scale / shift from their LDS copies: per-element predicated global loads (`sc ? f*sc[c]+sh[c] : f`)
+                // are issued as 2*VE strided dword loads and bound the kernel on the texture unit
 #pragma unroll
-                for (int j = 0; j < VE; ++j) {
-                    float q = sc ? f[j] * sc[vg * VE + j] + sh[vg * VE + j] : f[j];
-                    if (act != MPN_ACT_NONE) q = fmaxf(q, 0.f);
-                    if (act == MPN_ACT_RELU6) q = fminf(q, 6.f);
-                    f[j] = q;
-                }
+                for (int j = 0; j < VE; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * scl[vg * VE + j] + shl[vg * VE + j], lo, hi);
             }
 #pragma unroll
-            for (int j = 0; j < VE; ++j) at[px * as + vg * VE + j] = f[j];
+            for (int j = 0; j < VE; j += 4)
+                *reinterpret_cast<float4*>(at + px * as + vg * VE + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
         }
-        for (int i = threadIdx.x; i < kBwdPix * kOut; i += kThreads) {
-            const int px = i / kOut, k = i % kOut;
-            dlt[px * (kOut + 1) + k] = (m0 + px < M) ? dl[(m0 + px) * kOut + k] : 0.f;
+        for (int i = threadIdx.x; i < kBwdPix * kDls; i += kThreads) {
+            const int px = i / kDls, k = i % kDls;
+            dlt[i] = (k < kOut && m0 + px < M) ? dl[(m0 + px) * kOut + k] : 0.f;
         }
         __syncthreads();
-        // (1) data gradient: each thread = (pixel, channel vector) pairs
-        for (int i = threadIdx.x; i < kBwdPix * cvec; i += kThreads) {
-            const int px = i / cvec, vg = i % cvec;
-            if (m0 + px >= M) continue;
-            float o[VE];
+        // (1) data gradient
+        for (int px = d_px0; px < kBwdPix; px += d_step) {
+            if (m0 + px >= M) break;
+            float g[kDls];
 #pragma unroll
-            for (int j = 0; j < VE; ++j) {
-                float s = 0.f;
-#pragma unroll
-                for (int k = 0; k < kOut; ++k) s += dlt[px * (kOut + 1) + k] * wl[(vg * VE + j) * kOut + k];
-                o[j] = s;
+            for (int k = 0; k < kDls; k += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(dlt + px * kDls + k);
+                g[k] = q.x; g[k + 1] = q.y; g[k + 2] = q.z; g[k + 3] = q.w;
             }
-            Vec16<T> ov;
-            ov.pack(o);
-            ov.store(dA + (m0 + px) * Cin + vg * VE);
-        }
-        // (2) weight / bias gradient
+            float o[4];
 #pragma unroll
-        for (int k = 0; k < kOPT; ++k) {
-            const int o = threadIdx.x + k * kThreads;
-            if (o < nout) {
-                float s = 0.f;
-                if (o < Cin * kOut) {
-                    const int c = o / kOut, kk = o % kOut;
-                    for (int px = 0; px < kBwdPix; ++px) s += at[px * as + c] * dlt[px * (kOut + 1) + kk];
-                } else {
-                    const int kk = o - Cin * kOut;
-                    for (int px = 0; px < kBwdPix; ++px) s += dlt[px * (kOut + 1) + kk];
-                }
-                acc[k] += s;
+            for (int j = 0; j < 4; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < kOut; ++k) sum += g[k] * wreg[j][k];
+                o[j] = sum;
+            }
+            store4(dA + (m0 + px) * Cin + d_cg * 4, o);
+        }
+        // (2) weight gradient: 4 channels x 4 outputs per thread over every nsets-th pixel (zero rows beyond M)
+        if (w_on) {
+            for (int px = w_set; px < kBwdPix; px += nsets) {
+                const float4 a4 = *reinterpret_cast<const float4*>(at + px * as + w_cg * 4);
+                const float4 d4 = *reinterpret_cast<const float4*>(dlt + px * kDls + w_kg * 4);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[j][i] += av[j] * dv[i];
             }
         }
+        // bias gradient: lane k sums column k
+        if (threadIdx.x < kOut)
+            for (int px = 0; px < kBwdPix; ++px) accb += dlt[px * kDls + threadIdx.x];
     }
+    // ---- sum the pixel sets through LDS and write this block's partial row [Cin*18 dW | 18 db]
+    __syncthreads();
+    float* red = smem;                       // [nsets][per_set][16]  (<= 3 * 160 * 16 floats, fits in `at`)
+    if (w_on) {
 #pragma unroll
-    for (int k = 0; k < kOPT; ++k) {
-        const int o = threadIdx.x + k * kThreads;
-        if (o < nout) part[(long long)blockIdx.x * nout + o] = acc[k];
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(red + (w_set * per_set + w_r) * 16 + j * 4) =
+                make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
     }
+    __syncthreads();
+    float* dst = part + (long long)blockIdx.x * nout;
+    for (int o = threadIdx.x; o < Cin * kOut; o += kThreads) {
+        const int c = o / kOut, kk = o % kOut;
+        const int r = (kk >> 2) * ncg + (c >> 2), e = (c & 3) * 4 + (kk & 3);
+        float sum = 0.f;
+        for (int st = 0; st < nsets; ++st) sum += red[(st * per_set + r) * 16 + e];
+        dst[o] = sum;
+    }
+    if (threadIdx.x < kOut) dst[Cin * kOut + threadIdx.x] = accb;
 }
 
 int check(long long M, int Cin, int dtype) {
     MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "head: dtype %d", dtype);
     const int ve = dtype == MPN_F32 ? 4 : 8;
-    MPN_REQUIRE(M > 0 && Cin > 0 && Cin <= kMaxCin && Cin % ve == 0, MPN_ERR_BAD_SHAPE,
-                "head: Cin (%d) must be <= %d and a multiple of %d", Cin, kMaxCin, ve);
+    MPN_REQUIRE(M > 0 && Cin > 0 && Cin <= kMaxCin && Cin % ve == 0 && (kThreads % (Cin / 4)) == 0, MPN_ERR_BAD_SHAPE,
+                "head: Cin (%d) must be <= %d, a multiple of %d, and Cin/4 must divide %d", Cin, kMaxCin, ve, kThreads);
     return MPN_OK;
 }
 }  // namespace
@@ -190,7 +243,7 @@ extern "C" int mpn_heatmap_head_bwd(const void* x, const float* dlogits, const f
     if (int rc = check(M, Cin, dtype)) return rc;
     MPN_REQUIRE(x && dlogits && w && dA && part, MPN_ERR_BAD_ARG, "head_bwd: null pointer");
     const int grid = mpn_heatmap_head_bwd_num_parts(M);
-    const size_t sm = (size_t)(kBwdPix * (Cin + 1) + kBwdPix * (kOut + 1) + Cin * kOut) * sizeof(float);
+    const size_t sm = (size_t)(kBwdPix * (Cin + 4) + kBwdPix * kDls + 2 * Cin) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     MPN_DISPATCH_DTYPE(dtype, {
         if (sm > 48 * 1024)

@@ -29,86 +29,118 @@ __device__ __forceinline__ void load_act(const T* p, const float* sc, const floa
     }
 }
 
+// One block row of the grid = one INPUT row (n, y0): a thread owns one 16-byte channel vector of one input pixel, reads
+// the 2x2 input neighbourhood once (batch-norm affine + activation applied once per tap, scale / shift loaded once as
+// 16-byte vectors) and writes the u x u output pixels that interpolate inside it - 8 + 16/u lerps per output vector
+// instead of 4 activated taps each. The arithmetic per output is unchanged: top = a+(b-a)fx, bot = c+(d-c)fx,
+// out = top+(bot-top)fy (TF's order, resize_bilinear_op.cc), so results are bit-identical to the per-output form.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bilinear_up_fwd_kernel(
-    const T* __restrict__ x, T* __restrict__ y, int N, int h, int w, int C, int u, int y_coff, int y_ctot,
-    const float* __restrict__ sc, const float* __restrict__ sh, int act, long long total) {
+    const T* __restrict__ x, T* __restrict__ y, int h, int w, int C, int u, int y_coff, int y_ctot,
+    const float* __restrict__ sc, const float* __restrict__ sh, int act) {
     constexpr int VE = Vec16<T>::N;
-    const int cvec = C / VE;
-    const int OH = h * u, OW = w * u;
+    const unsigned cvec = C / VE;
+    const int OW = w * u;
+    const unsigned t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= (unsigned)w * cvec) return;
+    const int x0 = (int)(t / cvec), c0 = (int)(t - (unsigned)x0 * cvec) * VE;
+    const int n = blockIdx.y / h, y0 = blockIdx.y - n * h;          // scalar
+    const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
     const float inv = 1.0f / (float)u;
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
-        const int vg = (int)(i % cvec);
-        long long r = i / cvec;
-        const int ox = (int)(r % OW); r /= OW;
-        const int oy = (int)(r % OH);
-        const int n = (int)(r / OH);
-        const int y0 = oy / u, x0 = ox / u;
-        const int y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-        const float fy = (float)(oy - y0 * u) * inv, fx = (float)(ox - x0 * u) * inv;
-        const int c0 = vg * VE;
-        const T* base = x + (long long)n * h * w * C + c0;
-        float a[VE], b[VE], c[VE], d[VE];
-        load_act<T>(base + ((long long)y0 * w + x0) * C, sc, sh, act, c0, a);
-        load_act<T>(base + ((long long)y0 * w + x1) * C, sc, sh, act, c0, b);
-        load_act<T>(base + ((long long)y1 * w + x0) * C, sc, sh, act, c0, c);
-        load_act<T>(base + ((long long)y1 * w + x1) * C, sc, sh, act, c0, d);
-        float o[VE];
+    float s_[VE], b_[VE];
+    const bool aff = sc != nullptr;
+    // unconditional 16-byte loads under ONE branch: a per-element `aff ? sc[c] : 1.f` compiles to 2*VE predicated dword
+    // loads with a 32-byte lane stride, and the texture unit then bounds the kernel (232 us vs 46 us per level)
+    if (aff) {
+#pragma unroll
+        for (int j = 0; j < VE; j += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(sc + c0 + j);
+            const float4 b4 = *reinterpret_cast<const float4*>(sh + c0 + j);
+            s_[j] = a4.x; s_[j + 1] = a4.y; s_[j + 2] = a4.z; s_[j + 3] = a4.w;
+            b_[j] = b4.x; b_[j + 1] = b4.y; b_[j + 2] = b4.z; b_[j + 3] = b4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { s_[j] = 1.f; b_[j] = 0.f; }
+    }
+    const float lo = (aff && act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (aff && act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    float a[VE], b[VE], c[VE], d[VE];
+#define MPN_TAP(yy, xx, f)                                                                        \
+    do {                                                                                          \
+        Vec16<T> v_;                                                                              \
+        v_.load(x + (((long long)n * h + (yy)) * w + (xx)) * C + c0);                             \
+        v_.unpack(f);                                                                             \
+        _Pragma("unroll") for (int j = 0; j < VE; ++j)                                            \
+            f[j] = __builtin_amdgcn_fmed3f(f[j] * s_[j] + b_[j], lo, hi);                         \
+    } while (0)
+    MPN_TAP(y0, x0, a);
+    MPN_TAP(y0, x1, b);
+    MPN_TAP(y1, x0, c);
+    MPN_TAP(y1, x1, d);
+#undef MPN_TAP
+    T* out = y + (((long long)n * h * u + (long long)y0 * u) * OW + (long long)x0 * u) * y_ctot + y_coff + c0;
+    for (int k = 0; k < u; ++k) {
+        const float fx = (float)k * inv;
+        float top[VE], bot[VE];
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
-            const float top = a[j] + (b[j] - a[j]) * fx;
-            const float bot = c[j] + (d[j] - c[j]) * fx;
-            o[j] = top + (bot - top) * fy;
+            top[j] = a[j] + (b[j] - a[j]) * fx;
+            bot[j] = c[j] + (d[j] - c[j]) * fx;
         }
-        Vec16<T> ov;
-        ov.pack(o);
-        ov.store(y + (((long long)n * OH + oy) * OW + ox) * y_ctot + y_coff + c0);
+        for (int m = 0; m < u; ++m) {
+            const float fy = (float)m * inv;
+            float o[VE];
+#pragma unroll
+            for (int j = 0; j < VE; ++j) o[j] = top[j] + (bot[j] - top[j]) * fy;
+            Vec16<T> ov;
+            ov.pack(o);
+            ov.store(out + ((long long)m * OW + k) * y_ctot);
+        }
     }
 }
 
-// dX[n,iy,ix,c] = sum over output pixels of wy*wx*dY (gather form)
+// dX[n,iy,ix,c] = sum over output pixels of wy*wx*dY (gather form, deterministic). The weight of output row oy for
+// input row iy is the tent 1 - |oy - iy*u| / u over |oy - iy*u| < u, except that the last input row also owns the
+// clamped rows oy >= (h-1)*u with weight 1 (y0 == y1 == h-1 there); same in x. No divisions in the loops.
 template <typename T>
-__global__ __launch_bounds__(kThreads) void bilinear_up_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N,
-                                                                   int h, int w, int C, int u, int y_coff, int y_ctot,
-                                                                   long long total) {
+__global__ __launch_bounds__(kThreads) void bilinear_up_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int h,
+                                                                   int w, int C, int u, int y_coff, int y_ctot) {
     constexpr int VE = Vec16<T>::N;
-    const int cvec = C / VE;
+    const unsigned cvec = C / VE;
     const int OH = h * u, OW = w * u;
+    const unsigned t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= (unsigned)w * cvec) return;
+    const int ix = (int)(t / cvec), c0 = (int)(t - (unsigned)ix * cvec) * VE;
+    const int n = blockIdx.y / h, iy = blockIdx.y - n * h;          // scalar
     const float inv = 1.0f / (float)u;
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
-        const int vg = (int)(i % cvec);
-        long long r = i / cvec;
-        const int ix = (int)(r % w); r /= w;
-        const int iy = (int)(r % h);
-        const int n = (int)(r / h);
-        float acc[VE];
+    float acc[VE];
 #pragma unroll
-        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
-        const int oy_lo = max(0, (iy - 1) * u), oy_hi = iy * u + u - 1;
-        const int ox_lo = max(0, (ix - 1) * u), ox_hi = ix * u + u - 1;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            const int y0 = oy / u, y1 = min(y0 + 1, h - 1);
-            const float fy = (float)(oy - y0 * u) * inv;
-            const float wy = (y0 == iy ? 1.f - fy : 0.f) + (y1 == iy ? fy : 0.f);
-            if (wy == 0.f) continue;
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                const int x0 = ox / u, x1 = min(x0 + 1, w - 1);
-                const float fx = (float)(ox - x0 * u) * inv;
-                const float wx = (x0 == ix ? 1.f - fx : 0.f) + (x1 == ix ? fx : 0.f);
-                if (wx == 0.f) continue;
-                Vec16<T> v;
-                v.load(dy + (((long long)n * OH + oy) * OW + ox) * y_ctot + y_coff + vg * VE);
-                float f[VE];
-                v.unpack(f);
-                const float wgt = wy * wx;
+    for (int j = 0; j < VE; ++j) acc[j] = 0.f;
+    const int dy_lo = iy == 0 ? 0 : -(u - 1), dx_lo = ix == 0 ? 0 : -(u - 1);
+    const bool last_y = iy == h - 1, last_x = ix == w - 1;
+    const T* base = dy + (long long)n * OH * OW * y_ctot + y_coff + c0;
+    for (int dyo = dy_lo; dyo < u; ++dyo) {
+        const int oy = iy * u + dyo;
+        const float fy = (float)(dyo >= 0 ? dyo : u + dyo) * inv;   // forward's fraction of output row oy
+        const float wy = dyo < 0 ? fy : (last_y ? (1.f - fy) + fy : 1.f - fy);
+        const T* row = base + (long long)oy * OW * y_ctot;
+        for (int dxo = dx_lo; dxo < u; ++dxo) {
+            const int ox = ix * u + dxo;
+            const float fx = (float)(dxo >= 0 ? dxo : u + dxo) * inv;
+            const float wx = dxo < 0 ? fx : (last_x ? (1.f - fx) + fx : 1.f - fx);
+            Vec16<T> v;
+            v.load(row + (long long)ox * y_ctot);
+            float f[VE];
+            v.unpack(f);
+            const float wgt = wy * wx;
 #pragma unroll
-                for (int j = 0; j < VE; ++j) acc[j] += wgt * f[j];
-            }
+            for (int j = 0; j < VE; ++j) acc[j] += wgt * f[j];
         }
-        Vec16<T> ov;
-        ov.pack(acc);
-        ov.store(dx + i * VE);
     }
+    Vec16<T> ov;
+    ov.pack(acc);
+    ov.store(dx + (((long long)n * h + iy) * w + ix) * C + c0);
 }
 
 // dst[n,y,x,c] (+)= sum_{dy,dx in 0..1} src[n,2y+dy,2x+dx,c]
@@ -190,11 +222,13 @@ extern "C" int mpn_bilinear_up_fwd(const void* x, void* y, int N, int h, int w, 
     MPN_REQUIRE(y_channel_offset % ve == 0 && y_channels_total % ve == 0 && y_channel_offset + C <= y_channels_total,
                 MPN_ERR_BAD_SHAPE, "bilinear: bad channel slice");
     MPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), MPN_ERR_BAD_ARG, "bilinear: scale/shift mismatch");
-    const long long total = (long long)N * h * upsample * w * upsample * (C / ve);
+    MPN_REQUIRE(mpn_aligned16(in_scale) && mpn_aligned16(in_shift), MPN_ERR_BAD_ALIGN, "bilinear: scale/shift must be 16-byte aligned");
+    MPN_REQUIRE((long long)N * h <= 65535, MPN_ERR_BAD_SHAPE, "bilinear: N * height must be <= 65535");
+    const dim3 grid((unsigned)mpn_div_up((long long)w * (C / ve), kThreads), (unsigned)(N * h));
     hipStream_t st = (hipStream_t)stream;
-    MPN_DISPATCH_DTYPE(dtype, (bilinear_up_fwd_kernel<T><<<blocks_for(total), kThreads, 0, st>>>(
-                                  (const T*)x, (T*)y, N, h, w, C, upsample, y_channel_offset, y_channels_total, in_scale,
-                                  in_shift, in_act, total)));
+    MPN_DISPATCH_DTYPE(dtype, (bilinear_up_fwd_kernel<T><<<grid, kThreads, 0, st>>>(
+                                  (const T*)x, (T*)y, h, w, C, upsample, y_channel_offset, y_channels_total, in_scale,
+                                  in_shift, in_act)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -207,10 +241,11 @@ extern "C" int mpn_bilinear_up_bwd(const void* dy, void* dx, int N, int h, int w
     MPN_REQUIRE(upsample >= 1 && upsample <= 64, MPN_ERR_BAD_SHAPE, "bilinear: integer upsample factor expected");
     MPN_REQUIRE(y_channel_offset % ve == 0 && y_channels_total % ve == 0 && y_channel_offset + C <= y_channels_total,
                 MPN_ERR_BAD_SHAPE, "bilinear: bad channel slice");
-    const long long total = (long long)N * h * w * (C / ve);
+    MPN_REQUIRE((long long)N * h <= 65535, MPN_ERR_BAD_SHAPE, "bilinear: N * height must be <= 65535");
+    const dim3 grid((unsigned)mpn_div_up((long long)w * (C / ve), kThreads), (unsigned)(N * h));
     hipStream_t st = (hipStream_t)stream;
-    MPN_DISPATCH_DTYPE(dtype, (bilinear_up_bwd_kernel<T><<<blocks_for(total), kThreads, 0, st>>>(
-                                  (const T*)dy, (T*)dx, N, h, w, C, upsample, y_channel_offset, y_channels_total, total)));
+    MPN_DISPATCH_DTYPE(dtype, (bilinear_up_bwd_kernel<T><<<grid, kThreads, 0, st>>>(
+                                  (const T*)dy, (T*)dx, h, w, C, upsample, y_channel_offset, y_channels_total)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
