@@ -114,8 +114,12 @@ template <typename T, int STRIDE> struct HaloRegs {
         constexpr int VE = Vec16<T>::N;
         const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
         const int iy0 = oy0 * STRIDE - p.pad_t, ix0 = ox0 * STRIDE - p.pad_l;
-        const int vg = threadIdx.x % p.nvg;
-        const int hp0 = threadIdx.x / p.nvg, hstep = kThreads / p.nvg;
+        // decode from an OPAQUE copy of the thread index: hoisted out of the tile loop the per-vector pixel decode
+        // costs ~20 registers that hipcc spills (and a scratch reload waits on vmcnt, i.e. on the prefetch)
+        int tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        const int vg = tid_ % p.nvg;
+        const int hp0 = tid_ / p.nvg, hstep = kThreads / p.nvg;
         okmask = 0u;
 #pragma unroll
         for (int k = 0; k < MAXV; ++k) {
@@ -123,16 +127,20 @@ template <typename T, int STRIDE> struct HaloRegs {
             const int hy = hp / TL::HW, hx = hp - hy * TL::HW;
             const int iy = iy0 + hy, ix = ix0 + hx;
             const bool ok = hp < TL::HH * TL::HW && vg < cb_vecs && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            if (ok) { v[k].load(x + (((long long)img * p.H + iy) * p.W + ix) * p.C + c0 + vg * VE); okmask |= 1u << k; }
-            else v[k].zero();
+            // UNPREDICATED load from a clamped address (zeroed at commit time): `if (ok) load else zero` is lowered to
+            // load + select, which waits for the data right here - the prefetch then hides nothing
+            v[k].load(x + (ok ? (((long long)img * p.H + iy) * p.W + ix) * p.C + c0 + vg * VE : 0));
+            okmask |= (ok ? 1u : 0u) << k;
         }
     }
 
     // affine + activation on in-image elements only (the padding is zeros of the ACTIVATED tensor) -> LDS
     __device__ __forceinline__ void commit(const DwParams& p, const HaloAffine<T>& aff, float* tile) {
         constexpr int VE = Vec16<T>::N;
-        const int vg = threadIdx.x % p.nvg;
-        const int hp0 = threadIdx.x / p.nvg, hstep = kThreads / p.nvg;
+        int tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        const int vg = tid_ % p.nvg;
+        const int hp0 = tid_ / p.nvg, hstep = kThreads / p.nvg;
         const float lo = (p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
         const float hi = (p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
 #pragma unroll
@@ -141,9 +149,14 @@ template <typename T, int STRIDE> struct HaloRegs {
             if (hp < TL::HH * TL::HW) {
                 float f[VE];
                 v[k].unpack(f);
-                if (((okmask >> k) & 1u) && aff.on) {
+                const bool ok = (okmask >> k) & 1u;
+                if (aff.on) {
 #pragma unroll
                     for (int j = 0; j < VE; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * aff.sc[j] + aff.sh[j], lo, hi);
+                }
+                if (!ok) {
+#pragma unroll
+                    for (int j = 0; j < VE; ++j) f[j] = 0.f;
                 }
                 float* dst = tile + (hp * p.nvg + vg) * VE;
 #pragma unroll
@@ -200,20 +213,22 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     HaloRegs<T, STRIDE> hr;
     int img, oy0, ox0;
+    // loop shape: load(next) ; barrier ; compute(this) ; barrier ; commit(next) - the prefetch registers are written
+    // and read inside ONE iteration (carried across the back edge, hipcc copies them right after the loads and waits)
     if (split < ntiles) {
         dw_tile_origin(p, split, TL::TH, TL::TW, img, oy0, ox0);
         hr.load(p, img, oy0, ox0, c0, cb_vecs);
+        hr.commit(p, aff, tile);
     }
     for (int t = split; t < ntiles; t += nsplit) {
         dw_tile_origin(p, t, TL::TH, TL::TW, img, oy0, ox0);
-        __syncthreads();  // previous tile's LDS reads are done
-        hr.commit(p, aff, tile);
-        __syncthreads();
-        if (t + nsplit < ntiles) {   // prefetch the next tile: its loads fly while this tile is computed
+        const bool more = t + nsplit < ntiles;
+        if (more) {   // prefetch the next tile: its loads fly while this tile is computed
             int img2, oy2, ox2;
             dw_tile_origin(p, t + nsplit, TL::TH, TL::TW, img2, oy2, ox2);
             hr.load(p, img2, oy2, ox2, c0, cb_vecs);
         }
+        __syncthreads();  // this tile's halo image is complete
 #pragma unroll 1
         for (int op = pt; op < TL::TH * TL::TW; op += npt) {
             const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
@@ -236,6 +251,8 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
                 store4(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, acc);
             }
         }
+        __syncthreads();  // everybody is done reading this tile
+        if (more) hr.commit(p, aff, tile);
     }
     if (p.part != nullptr) {
         reduce_same_vg<8>(st, ncg, red);
@@ -290,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_kernel(const T* __re
 // weight gradient: dw[t][c] = sum a[n, oy*S+ky-pt, ox*S+kx-pl, c] * dy[n,oy,ox,c].
 // Blocks walk many tiles of one channel block with the 9 x VE accumulators in registers and reduce once.
 template <typename T, int STRIDE>
-__global__ __launch_bounds__(kThreads, 4) void dwconv_wgrad_kernel(const DwParams p, int nsplit) {
+__global__ __launch_bounds__(kThreads, 2) void dwconv_wgrad_kernel(const DwParams p, int nsplit) {
     using TL = DwTile<STRIDE>;
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
@@ -317,27 +334,40 @@ __global__ __launch_bounds__(kThreads, 4) void dwconv_wgrad_kernel(const DwParam
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     HaloRegs<T, STRIDE> hr;
     int img, oy0, ox0;
+    // same loop shape as the forward kernel; the tile's dY values (one 4-channel piece per owned output pixel) are
+    // ALL requested before the first barrier instead of one exposed global load per pixel inside the loop
+    constexpr int NOP = TL::TH * TL::TW / (kThreads / 16);   // owned output pixels per thread at most (ncg <= 16)
     if (split < ntiles) {
         dw_tile_origin(p, split, TL::TH, TL::TW, img, oy0, ox0);
         hr.load(p, img, oy0, ox0, c0, cb_vecs);
+        hr.commit(p, aff, tile);
     }
     for (int t = split; t < ntiles; t += nsplit) {
         dw_tile_origin(p, t, TL::TH, TL::TW, img, oy0, ox0);
-        __syncthreads();  // previous tile's LDS reads are done
-        hr.commit(p, aff, tile);
-        __syncthreads();
-        if (t + nsplit < ntiles) {   // prefetch the next tile: its loads fly while this tile is computed
+        float g_all[NOP][4];
+        unsigned gmask = 0u;
+#pragma unroll
+        for (int k = 0; k < NOP; ++k) {
+            const int op = pt + k * npt;
+            const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
+            const int oy = oy0 + oyl, ox = ox0 + oxl;
+            const bool ok = op < TL::TH * TL::TW && cg_ok && oy < p.OH && ox < p.OW;
+            load4(dy + (ok ? (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4 : 0), g_all[k]);
+            gmask |= (ok ? 1u : 0u) << k;
+        }
+        const bool more = t + nsplit < ntiles;
+        if (more) {   // prefetch the next tile: its loads fly while this tile is computed
             int img2, oy2, ox2;
             dw_tile_origin(p, t + nsplit, TL::TH, TL::TW, img2, oy2, ox2);
             hr.load(p, img2, oy2, ox2, c0, cb_vecs);
         }
-#pragma unroll 1
-        for (int op = pt; op < TL::TH * TL::TW; op += npt) {
+        __syncthreads();  // this tile's halo image is complete
+#pragma unroll
+        for (int k = 0; k < NOP; ++k) {
+            const int op = pt + k * npt;
             const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
-            const int oy = oy0 + oyl, ox = ox0 + oxl;
-            if (!(cg_ok && oy < p.OH && ox < p.OW)) continue;
-            float g[4];
-            load4(dy + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, g);
+            if (!((gmask >> k) & 1u)) continue;
+            const float (&g)[4] = g_all[k];
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -350,6 +380,8 @@ __global__ __launch_bounds__(kThreads, 4) void dwconv_wgrad_kernel(const DwParam
                     acc[(ky * 3 + kx) * 4 + 3] += q.w * g[3];
                 }
         }
+        __syncthreads();  // everybody is done reading this tile
+        if (more) hr.commit(p, aff, tile);
     }
     reduce_same_vg<36>(acc, ncg, red);
     if ((int)threadIdx.x < ncg && cg_ok) {

@@ -43,13 +43,20 @@ __device__ __forceinline__ void stage_patch(const void* images, float* patch, in
 
 // forward: one thread = one output pixel x all C0 channels. Its 3x3x3 input window is three runs of 9 contiguous
 // floats (36 B, dword aligned): loaded straight from global with wide loads (neighbouring lanes overlap by 1/3, served
-// by L1), no LDS patch and no barrier except for the broadcast weights.
+// by L1). Weights are broadcast from LDS and multiplied with packed FP32 FMAs (v_pk_fma_f32: two channels per
+// instruction). The outputs leave through an LDS tile so that every store instruction writes whole 1 KB rows of the
+// NHWC tensor: per-thread stores of 16 bytes at the 64-byte pixel stride cost as much as the rest of the kernel.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 template <typename T, bool U8>
 __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restrict__ images, const float* __restrict__ w,
                                                             T* __restrict__ y, int N, int H, int W, int C0, int OH, int OW,
                                                             int pad_t, int pad_l, int tiles_x, int tiles_y) {
     constexpr int VE = Vec16<T>::N;
-    __shared__ __attribute__((aligned(16))) float wl[27 * kMaxC0];
+    extern __shared__ __attribute__((aligned(16))) unsigned char stem_smem[];
+    float* wl = reinterpret_cast<float*>(stem_smem);                        // [27][C0]
+    unsigned char* otile = stem_smem + 27 * kMaxC0 * sizeof(float);         // [256 px][C0 * sizeof(T) + 16]
+    const int orow = C0 * (int)sizeof(T) + 16;
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
@@ -58,52 +65,68 @@ __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restri
     __syncthreads();
     const int lx = threadIdx.x % kTile, ly = threadIdx.x / kTile;
     const int oy = ty * kTile + ly, ox = tx * kTile + lx;
-    if (oy >= OH || ox >= OW) return;
-    float in[27];
-    const int ix0 = 2 * ox - pad_l;
+    if (oy < OH && ox < OW) {
+        float in[27];
+        const int ix0 = 2 * ox - pad_l;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * oy - pad_t + ky;
-        const bool row_ok = iy >= 0 && iy < H;
-        const long long base = (((long long)img * H + (row_ok ? iy : 0)) * W + ix0) * 3;
-        if (!U8 && row_ok && ix0 >= 0 && ix0 + 2 < W) {
-            const float* src = reinterpret_cast<const float*>(images) + base;
-            const float4 a = *reinterpret_cast<const float4*>(src);
-            const float4 c = *reinterpret_cast<const float4*>(src + 4);
-            const float e = src[8];
-            const float r[9] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, e};
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - pad_t + ky;
+            const bool row_ok = iy >= 0 && iy < H;
+            const long long base = (((long long)img * H + (row_ok ? iy : 0)) * W + ix0) * 3;
+            if (!U8 && row_ok && ix0 >= 0 && ix0 + 2 < W) {
+                const float* src = reinterpret_cast<const float*>(images) + base;
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 c = *reinterpret_cast<const float4*>(src + 4);
+                const float e = src[8];
+                const float r[9] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, e};
 #pragma unroll
-            for (int j = 0; j < 9; ++j) in[ky * 9 + j] = 2.0f * r[j] - 1.0f;
-        } else {
+                for (int j = 0; j < 9; ++j) in[ky * 9 + j] = 2.0f * r[j] - 1.0f;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const int ix = ix0 + j / 3;
-                float v = 0.f;   // SAME padding: zeros of the STANDARDISED tensor
-                if (row_ok && ix >= 0 && ix < W) {
-                    const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[base + j] * (1.0f / 255.0f)
-                                         : reinterpret_cast<const float*>(images)[base + j];
-                    v = 2.0f * raw - 1.0f;
+                for (int j = 0; j < 9; ++j) {
+                    const int ix = ix0 + j / 3;
+                    float v = 0.f;   // SAME padding: zeros of the STANDARDISED tensor
+                    if (row_ok && ix >= 0 && ix < W) {
+                        const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[base + j] * (1.0f / 255.0f)
+                                             : reinterpret_cast<const float*>(images)[base + j];
+                        v = 2.0f * raw - 1.0f;
+                    }
+                    in[ky * 9 + j] = v;
                 }
-                in[ky * 9 + j] = v;
             }
+        }
+        for (int c0 = 0; c0 < C0; c0 += VE) {
+            f32x2_t acc2[VE / 2];
+#pragma unroll
+            for (int j = 0; j < VE / 2; ++j) acc2[j] = (f32x2_t){0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 27; ++t) {
+                const f32x2_t iv = (f32x2_t){in[t], in[t]};
+#pragma unroll
+                for (int j = 0; j < VE; j += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(&wl[t * C0 + c0 + j]);  // LDS broadcast
+                    acc2[j / 2] += iv * (f32x2_t){q.x, q.y};
+                    acc2[j / 2 + 1] += iv * (f32x2_t){q.z, q.w};
+                }
+            }
+            float acc[VE];
+#pragma unroll
+            for (int j = 0; j < VE / 2; ++j) { acc[2 * j] = acc2[j].x; acc[2 * j + 1] = acc2[j].y; }
+            Vec16<T> ov;
+            ov.pack(acc);
+            *reinterpret_cast<uint4*>(otile + threadIdx.x * orow + c0 * (int)sizeof(T)) = *reinterpret_cast<const uint4*>(&ov.raw);
         }
     }
-    T* dst = y + (((long long)img * OH + oy) * OW + ox) * C0;
-    for (int c0 = 0; c0 < C0; c0 += VE) {
-        float acc[VE];
-#pragma unroll
-        for (int j = 0; j < VE; ++j) acc[j] = 0.f;
-#pragma unroll
-        for (int t = 0; t < 27; ++t) {
-#pragma unroll
-            for (int j = 0; j < VE; j += 4) {
-                const float4 q = *reinterpret_cast<const float4*>(&wl[t * C0 + c0 + j]);  // LDS broadcast
-                acc[j] += in[t] * q.x; acc[j + 1] += in[t] * q.y; acc[j + 2] += in[t] * q.z; acc[j + 3] += in[t] * q.w;
-            }
-        }
-        Vec16<T> ov;
-        ov.pack(acc);
-        ov.store(dst + c0);
+    __syncthreads();
+    // copy-out: tile row r = 16 pixels x C0 channels = one contiguous run of the output tensor
+    const int ppr = C0 * (int)sizeof(T) / 16;            // 16-byte pieces per pixel
+    for (int i = threadIdx.x; i < kTile * kTile * ppr; i += kThreads) {
+        const int pxl = i / ppr, piece = i - pxl * ppr;
+        const int r = pxl / kTile, cx = pxl - r * kTile;
+        const int yy = ty * kTile + r, xx = tx * kTile + cx;
+        if (yy < OH && xx < OW)
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(y + (((long long)img * OH + yy) * OW + xx) * C0) + piece * 16) =
+                *reinterpret_cast<const uint4*>(otile + pxl * orow + piece * 16);
     }
 }
 
@@ -134,34 +157,85 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_kernel(const void* __rest
         for (int j = 0; j < 8; ++j) acc[a][j] = 0.f;
     const int nout = 27 * C0;
     const int ntiles = N * tiles_y * tiles_x;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // Software pipeline over tiles: the NEXT tile's image patch and dy vectors are loaded into registers (unpredicated
+    // loads from clamped addresses + validity masks) before this tile is multiplied, and committed to LDS afterwards -
+    // one HBM round trip per tile is hidden under the outer products instead of being waited for at every barrier.
+    constexpr int NEL = kIn * kIn * 3;
+    constexpr int PER = (NEL + kThreads - 1) / kThreads;   // 13 patch elements per thread
+    constexpr int VE = Vec16<T>::N;
+    constexpr int DPER = kTile * kTile * (kMaxC0 / VE) / kThreads;   // <= 8 (bf16) / 16 (f32) dy vectors per thread
+    const int vpp = C0 / VE;                       // 16-byte vectors per pixel
+    const int ndv = kTile * kTile * vpp / kThreads; // dy vectors per thread actually used (C0 multiple of VE, <= DPER)
+    float pv[PER];
+    Vec16<T> dvv[DPER];
+    unsigned pmask = 0u, dmask = 0u;
+
+    auto load_tile = [&](int t) {
         const int tx = t % tiles_x;
         const int t2 = t / tiles_x;
         const int ty = t2 % tiles_y;
         const int img = t2 / tiles_y;
         const int oy0 = ty * kTile, ox0 = tx * kTile;
-        __syncthreads();
-        stage_patch<T, U8>(images, patch, img, oy0, ox0, H, W, pad_t, pad_l);
-        {
-            constexpr int VE = Vec16<T>::N;
-            const int vpp = C0 / VE;                       // 16-byte vectors per pixel
-            for (int i = threadIdx.x; i < kTile * kTile * vpp; i += kThreads) {
+        const int iy0 = oy0 * 2 - pad_t, ix0 = ox0 * 2 - pad_l;
+        pmask = 0u;
+        dmask = 0u;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            const int ch = i % 3;
+            const int px = (i / 3) % kIn;
+            const int py = i / (3 * kIn);
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool ok = i < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const long long off = ok ? (((long long)img * H + iy) * W + ix) * 3 + ch : 0;
+            pv[k] = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] * (1.0f / 255.0f)
+                       : reinterpret_cast<const float*>(images)[off];
+            pmask |= (ok ? 1u : 0u) << k;
+        }
+#pragma unroll
+        for (int k = 0; k < DPER; ++k) {
+            if (k < ndv) {
+                const int i = threadIdx.x + k * kThreads;
                 const int vq = i % vpp, px = i / vpp;
                 const int oy = oy0 + px / kTile, ox = ox0 + px % kTile;
-                float f[VE];
-#pragma unroll
-                for (int j = 0; j < VE; ++j) f[j] = 0.f;
-                if (oy < OH && ox < OW) {
-                    Vec16<T> vv;
-                    vv.load(dy + (((long long)img * OH + oy) * OW + ox) * C0 + vq * VE);
-                    vv.unpack(f);
-                }
-#pragma unroll
-                for (int j = 0; j < VE; j += 4)
-                    *reinterpret_cast<float4*>(g + px * C0 + vq * VE + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+                const bool ok = oy < OH && ox < OW;
+                dvv[k].load(dy + (ok ? (((long long)img * OH + oy) * OW + ox) * C0 + vq * VE : 0));
+                dmask |= (ok ? 1u : 0u) << k;
             }
         }
-        __syncthreads();
+    };
+    auto commit_tile = [&]() {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int i = threadIdx.x + k * kThreads;
+            // SAME padding is zeros of the STANDARDISED tensor (2*0.5-1)
+            if (i < NEL) patch[i] = ((pmask >> k) & 1u) ? 2.0f * pv[k] - 1.0f : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < DPER; ++k) {
+            if (k < ndv) {
+                const int i = threadIdx.x + k * kThreads;
+                const int vq = i % vpp, px = i / vpp;
+                float f[VE];
+                dvv[k].unpack(f);
+                const bool ok = (dmask >> k) & 1u;
+#pragma unroll
+                for (int j = 0; j < VE; j += 4)
+                    *reinterpret_cast<float4*>(g + px * C0 + vq * VE + j) =
+                        ok ? make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    int t = blockIdx.x;
+    if (t < ntiles) {
+        load_tile(t);
+        commit_tile();
+    }
+    for (; t < ntiles; t += gridDim.x) {
+        const bool more = t + (int)gridDim.x < ntiles;
+        if (more) load_tile(t + gridDim.x);
+        __syncthreads();   // this tile's patch / dy are complete
         if (active) {
             for (int px = ph; px < kTile * kTile; px += nphase) {
                 const int ly = px / kTile, lx = px - ly * kTile;
@@ -178,6 +252,8 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_kernel(const void* __rest
                 }
             }
         }
+        __syncthreads();   // everybody is done reading this tile
+        if (more) commit_tile();
     }
     // sum the phases through LDS (reuse g: nphase * 27*C0 floats <= 256*C0)
     __syncthreads();
@@ -224,10 +300,16 @@ extern "C" int mpn_stem_conv_fwd(const void* images, int images_u8, const float*
     const int grid = N * tiles_y * tiles_x;
     hipStream_t st = (hipStream_t)stream;
     MPN_DISPATCH_DTYPE(dtype, {
-        if (images_u8)
-            stem_fwd_kernel<T, true><<<grid, kThreads, 0, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
-        else
-            stem_fwd_kernel<T, false><<<grid, kThreads, 0, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+        const int sm = 27 * kMaxC0 * (int)sizeof(float) + kThreads * (C0 * (int)sizeof(T) + 16);
+        if (images_u8) {
+            if (sm > 48 * 1024)
+                MPN_HIP(hipFuncSetAttribute((const void*)stem_fwd_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm));
+            stem_fwd_kernel<T, true><<<grid, kThreads, sm, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+        } else {
+            if (sm > 48 * 1024)
+                MPN_HIP(hipFuncSetAttribute((const void*)stem_fwd_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm));
+            stem_fwd_kernel<T, false><<<grid, kThreads, sm, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+        }
     });
     MPN_LAUNCH_CHECK();
     return MPN_OK;
@@ -235,7 +317,7 @@ extern "C" int mpn_stem_conv_fwd(const void* images, int images_u8, const float*
 
 extern "C" int mpn_stem_conv_wgrad_num_parts(int N, int H, int W) {
     const int ntiles = N * (((H + 1) / 2 + kTile - 1) / kTile) * (((W + 1) / 2 + kTile - 1) / kTile);
-    return ntiles < 1024 ? ntiles : 1024;
+    return ntiles < 512 ? ntiles : 512;   // 2 resident blocks per CU (register-bound): one balanced round
 }
 
 extern "C" int mpn_stem_conv_bwd_weight(const void* images, int images_u8, const void* dy, float* part, int N, int H, int W,

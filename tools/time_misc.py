@@ -56,3 +56,13 @@ dwdb = torch.empty(64 * 18 + 18, device='cuda')
 aff64 = ops.Affine(sc64, sh64, 1)
 us = timeit(lambda: ops.heatmap_head_bwd(xh4, dl, wh, aff64, dA, dwdb))
 print(f"head_bwd (+reduce): {us:7.1f} us")
+img = torch.rand(N, 512, 512, 3, device='cuda')
+w0 = torch.randn(3, 3, 3, 32, device='cuda') * 0.1
+y0 = torch.empty(N, 256, 256, 32, device='cuda', dtype=dt)
+us = timeit(lambda: ops.stem_conv_fwd(img, w0, 32, dt, out=y0))
+print(f"stem fwd: {us:7.1f} us")
+dy0 = torch.randn(N, 256, 256, 32, device='cuda').to(dt)
+dw0 = torch.empty(3, 3, 3, 32, device='cuda')
+import inspect
+us = timeit(lambda: ops.stem_conv_bwd_weight(img, dy0, dw0))
+print(f"stem wgrad (+reduce): {us:7.1f} us")
