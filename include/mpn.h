@@ -234,6 +234,14 @@ int mpn_adam_step(float* params, const float* grads, float* m, float* v, long lo
  * reduced in two passes and the first pass folds range sums into the slab itself (its contents are clobbered). */
 int mpn_reduce_partials(const float* part, int nparts, long long n, float* out, int accumulate,
                         float scale, mpn_stream_t stream);
+/* All slab reductions of a training step in ONE launch (every weight-gradient kernel leaves a slab; 46 per step).
+ * mpn_reduce_desc_fill writes one host-side job descriptor (mpn_reduce_desc_bytes() bytes; block_begin = running sum
+ * of the returned block counts), the caller copies the table to the device once, mpn_reduce_partials_batched runs
+ * out[j] = scale * sum_p part[p][j] for every job (fixed summation order; slabs are left intact). */
+size_t mpn_reduce_desc_bytes(void);
+int mpn_reduce_desc_fill(void* desc_host, const float* part, int nparts, long long n, float* out, float scale,
+                         int block_begin);
+int mpn_reduce_partials_batched(const void* descs_device, int ndesc, int total_blocks, mpn_stream_t stream);
 int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------

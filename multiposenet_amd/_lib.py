@@ -66,6 +66,9 @@ SIGNATURES = {
     "mpn_adam_prepare": (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),
     "mpn_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
     "mpn_reduce_partials": (_I, [_P, _I, _L, _P, _I, _F, _P]),
+    "mpn_reduce_desc_bytes": (_Z, []),
+    "mpn_reduce_desc_fill": (_I, [_P, _P, _I, _L, _P, _F, _I]),
+    "mpn_reduce_partials_batched": (_I, [_P, _I, _I, _P]),
     "mpn_axpy": (_I, [_L, _F, _P, _P, _P]),
 }
 

@@ -632,7 +632,10 @@ WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout, int ksize, int es) 
     g.ntiles = ksize == 3 ? N * ((H + 7) / 8) * ((W + 15) / 16) : (int)(((long long)N * H * W + 127) / 128);
     int ns = blocks / (g.n_cg * g.n_cb);
     if (ns < 1) ns = 1;
-    if (ns > g.ntiles) ns = g.ntiles;
+    // small maps: at least 4 pixel tiles per block - a slab per tile costs more HBM traffic than the layer's inputs
+    const int min_tiles = es == 2 ? 4 : 1;
+    if (ns > g.ntiles / min_tiles) ns = g.ntiles / min_tiles;
+    if (ns < 1) ns = 1;
     g.nsplit = ns;
     return g;
 }

@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 template <int STRIDE> struct DwTile;
 template <> struct DwTile<1> { static constexpr int TH = 8, TW = 16, HH = 10, HW = 18; };
@@ -204,9 +205,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
         for (int j = 0; j < 4; ++j)
             wr[t][j] = cg_ok ? p.w[(p.flip ? 8 - t : t) * p.C + c0 + cg * 4 + j] : 0.f;
 
-    float st[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) st[j] = 0.f;
+    f32x2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};   // sum / sum of squares
     T* __restrict__ y = reinterpret_cast<T*>(p.y);
 
     const HaloAffine<T> aff = load_halo_affine<T>(p, c0, cb_vecs);
@@ -233,21 +232,21 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
         for (int op = pt; op < TL::TH * TL::TW; op += npt) {
             const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
             const int oy = oy0 + oyl, ox = ox0 + oxl;
-            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            // packed FP32 FMAs (v_pk_fma_f32): two channels per instruction
+            f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const float4 q = *reinterpret_cast<const float4*>(
                         tile + ((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * cstride + cg * 4);
-                    acc[0] += q.x * wr[ky * 3 + kx][0];
-                    acc[1] += q.y * wr[ky * 3 + kx][1];
-                    acc[2] += q.z * wr[ky * 3 + kx][2];
-                    acc[3] += q.w * wr[ky * 3 + kx][3];
+                    a01 += (f32x2_t){q.x, q.y} * (f32x2_t){wr[ky * 3 + kx][0], wr[ky * 3 + kx][1]};
+                    a23 += (f32x2_t){q.z, q.w} * (f32x2_t){wr[ky * 3 + kx][2], wr[ky * 3 + kx][3]};
                 }
             if (cg_ok && oy < p.OH && ox < p.OW) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { st[j] += acc[j]; st[4 + j] += acc[j] * acc[j]; }
+                const float acc[4] = {a01.x, a01.y, a23.x, a23.y};
+                s01 += a01; s23 += a23;
+                q01 += a01 * a01; q23 += a23 * a23;
                 store4(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, acc);
             }
         }
@@ -255,6 +254,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
         if (more) hr.commit(p, aff, tile);
     }
     if (p.part != nullptr) {
+        float st[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
         reduce_same_vg<8>(st, ncg, red);
         if ((int)threadIdx.x < ncg && cg_ok) {
             float* dst = p.part + (long long)split * 2 * p.C + c0 + cg * 4;
@@ -326,9 +326,9 @@ __global__ __launch_bounds__(kThreads, 2) void dwconv_wgrad_kernel(const DwParam
     const bool cg_ok = cg * 4 < cb_vecs * VE;
     const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
 
-    float acc[36];
+    f32x2_t acc2[18];   // [tap][channel pair]: packed FP32 FMAs
 #pragma unroll
-    for (int j = 0; j < 36; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 18; ++j) acc2[j] = (f32x2_t){0.f, 0.f};
 
     const HaloAffine<T> aff = load_halo_affine<T>(p, c0, cb_vecs);
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
@@ -374,15 +374,16 @@ __global__ __launch_bounds__(kThreads, 2) void dwconv_wgrad_kernel(const DwParam
                 for (int kx = 0; kx < 3; ++kx) {
                     const float4 q = *reinterpret_cast<const float4*>(
                         tile + ((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * cstride + cg * 4);
-                    acc[(ky * 3 + kx) * 4 + 0] += q.x * g[0];
-                    acc[(ky * 3 + kx) * 4 + 1] += q.y * g[1];
-                    acc[(ky * 3 + kx) * 4 + 2] += q.z * g[2];
-                    acc[(ky * 3 + kx) * 4 + 3] += q.w * g[3];
+                    acc2[(ky * 3 + kx) * 2 + 0] += (f32x2_t){q.x, q.y} * (f32x2_t){g[0], g[1]};
+                    acc2[(ky * 3 + kx) * 2 + 1] += (f32x2_t){q.z, q.w} * (f32x2_t){g[2], g[3]};
                 }
         }
         __syncthreads();  // everybody is done reading this tile
         if (more) hr.commit(p, aff, tile);
     }
+    float acc[36];
+#pragma unroll
+    for (int j = 0; j < 18; ++j) { acc[2 * j] = acc2[j].x; acc[2 * j + 1] = acc2[j].y; }
     reduce_same_vg<36>(acc, ncg, red);
     if ((int)threadIdx.x < ncg && cg_ok) {
         float* dst = p.part + (long long)split * 9 * p.C + c0 + cg * 4;

@@ -5,6 +5,7 @@
 // with lr from tf.train.cosine_decay(alpha=1e-4). Step count and learning rate live in device memory so the
 // whole training step can be replayed from a hipGraph. Also: deterministic reduction of partial slabs, axpy.
 #include "common.h"
+#include <string.h>
 
 namespace {
 constexpr int kThreads = 256;
@@ -126,6 +127,73 @@ __global__ __launch_bounds__(kThreads) void reduce_partials_scalar_kernel(const 
     out[j] = accumulate ? out[j] + s : s;
 }
 
+// ---- all slab reductions of a training step in ONE launch (46 slabs -> 87 launches of ~5 us each otherwise).
+// A block owns `cols` consecutive columns (float4 or float) of one slab and splits the slab's rows over 256/cols row
+// slices; slices are combined through LDS in a fixed order, so the result is deterministic.
+struct ReduceDesc {
+    const float* part;
+    float* out;
+    long long n;          // floats per row
+    int nparts;
+    int cols;             // power of two <= 256
+    int vec;              // 1: columns are float4 (n % 4 == 0), 0: floats
+    int block_begin, block_count;
+    float scale;
+    int pad_;
+};
+
+__global__ __launch_bounds__(kThreads) void reduce_partials_batched_kernel(const ReduceDesc* __restrict__ descs, int ndesc) {
+    __shared__ float4 red[kThreads];
+    int lo = 0, hi = ndesc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ReduceDesc d = descs[lo];
+    const int lb = blockIdx.x - d.block_begin;
+    const int c = threadIdx.x & (d.cols - 1), sl = threadIdx.x / d.cols, nsl = kThreads / d.cols;
+    const long long ncol = d.vec ? (d.n >> 2) : d.n;
+    const long long j = (long long)lb * d.cols + c;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (j < ncol) {
+        if (d.vec) {
+            int p = sl;
+            for (; p + 3 * nsl < d.nparts; p += 4 * nsl) {
+                const float4 v0 = reinterpret_cast<const float4*>(d.part + (long long)p * d.n)[j];
+                const float4 v1 = reinterpret_cast<const float4*>(d.part + (long long)(p + nsl) * d.n)[j];
+                const float4 v2 = reinterpret_cast<const float4*>(d.part + (long long)(p + 2 * nsl) * d.n)[j];
+                const float4 v3 = reinterpret_cast<const float4*>(d.part + (long long)(p + 3 * nsl) * d.n)[j];
+                a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+                b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
+                a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
+                b.x += v3.x; b.y += v3.y; b.z += v3.z; b.w += v3.w;
+            }
+            for (; p < d.nparts; p += nsl) {
+                const float4 v = reinterpret_cast<const float4*>(d.part + (long long)p * d.n)[j];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        } else {
+            for (int p = sl; p < d.nparts; p += nsl) a.x += d.part[(long long)p * d.n + j];
+        }
+    }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    if (sl == 0 && j < ncol) {
+        float4 r = red[c];
+        for (int q = 1; q < nsl; ++q) {
+            const float4 v = red[q * d.cols + c];
+            r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
+        }
+        if (d.vec) {
+            r.x *= d.scale; r.y *= d.scale; r.z *= d.scale; r.w *= d.scale;
+            reinterpret_cast<float4*>(d.out)[j] = r;
+        } else {
+            d.out[j] = r.x * d.scale;
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void axpy_kernel(long long n, float a, const float* __restrict__ x, float* __restrict__ y) {
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
         y[i] += a * x[i];
@@ -183,6 +251,35 @@ extern "C" int mpn_reduce_partials(const float* part, int nparts, long long n, f
         reduce_partials_scalar_kernel<<<(int)((n + kThreads - 1) / kThreads), kThreads, 0, st>>>(part, nparts, n, out,
                                                                                               accumulate, scale);
     }
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" size_t mpn_reduce_desc_bytes(void) { return sizeof(ReduceDesc); }
+
+/* Fills ONE host-side descriptor (mpn_reduce_desc_bytes() bytes) of the batched slab reduction
+ * out[j] = scale * sum_p part[p][j] and returns the number of blocks the job needs; block_begin = running sum. */
+extern "C" int mpn_reduce_desc_fill(void* desc_host, const float* part, int nparts, long long n, float* out, float scale,
+                                    int block_begin) {
+    if (!desc_host || !part || !out || nparts <= 0 || n <= 0) return -1;
+    ReduceDesc d;
+    d.part = part; d.out = out; d.n = n; d.nparts = nparts; d.scale = scale; d.pad_ = 0;
+    d.vec = (n % 4 == 0 && mpn_aligned16(part) && mpn_aligned16(out)) ? 1 : 0;
+    const long long ncol = d.vec ? n / 4 : n;
+    int slices = 1;                       // ~32 rows per thread, at least 16 columns per block
+    while (slices < 16 && nparts / slices > 32) slices <<= 1;
+    int cols = kThreads / slices;
+    while (cols > 16 && (long long)cols / 2 >= ncol) cols >>= 1;   // tiny slabs: fewer columns, more row slices
+    d.cols = cols;
+    d.block_begin = block_begin;
+    d.block_count = (int)((ncol + cols - 1) / cols);
+    memcpy(desc_host, &d, sizeof(d));
+    return d.block_count;
+}
+
+extern "C" int mpn_reduce_partials_batched(const void* descs_device, int ndesc, int total_blocks, mpn_stream_t stream) {
+    MPN_REQUIRE(descs_device && ndesc > 0 && total_blocks > 0, MPN_ERR_BAD_ARG, "reduce batched: bad arguments");
+    reduce_partials_batched_kernel<<<total_blocks, kThreads, 0, (hipStream_t)stream>>>((const ReduceDesc*)descs_device, ndesc);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

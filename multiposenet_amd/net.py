@@ -328,22 +328,29 @@ class KeypointNet:
         g["pw"] = [torch.empty_like(t) for t in b["pw"]]
         g["dw"] = [torch.empty_like(t) for t in b["dw"]]
         g["stem"] = torch.empty_like(b["stem"])
-        # weight-gradient partial slabs: the largest layer decides
-        wfloats = 0
+        # weight-gradient split-K slabs: every layer gets its own region of one buffer, and ONE batched launch at the
+        # end of backward reduces all of them into the gradient arena (ops.SlabReducer; 46 slabs = 87 launches otherwise)
+        lib, dc = ops._lib.lib(), ops._lib.dtype_code(dt)
+        sites = []   # (key, nparts, n, out)
         for c in self.convs:
             hw = self._conv_hw(b, c)
-            wfloats = max(wfloats, ops.conv_wgrad_num_parts(N, hw[0], hw[1], c.cin, c.cout, c.ksize, dt) * c.w.numel())
+            sites.append((id(c.dw), ops.conv_wgrad_num_parts(N, hw[0], hw[1], c.cin, c.cout, c.ksize, dt), c.w.numel(), c.dw))
         for i, blk in enumerate(self.blocks):
             hh, ww = b["hw"][i]
             cc = b["dw"][i].shape[3]
-            wfloats = max(wfloats, ops._lib.lib().mpn_dwconv_wgrad_num_parts(N, hh, ww, cc, blk["stride"],
-                                                                           ops._lib.dtype_code(dt)) * 9 * cc)
-        wfloats = max(wfloats, ops._lib.lib().mpn_stem_conv_wgrad_num_parts(N, H, W) * self.stem_w.numel())
-        wfloats = max(wfloats, ops._lib.lib().mpn_heatmap_head_bwd_num_parts(N * b["lv"][2][0] * b["lv"][2][1]) *
-                      self._head_grad.numel())
-        g["wpart"] = torch.empty(wfloats, dtype=torch.float32, device=dev)   # side-stream scratch (weight gradients)
-        g["head_part"] = torch.empty(ops._lib.lib().mpn_heatmap_head_bwd_num_parts(N * b["lv"][2][0] * b["lv"][2][1]) *
-                                     self._head_grad.numel(), dtype=torch.float32, device=dev)   # main-stream scratch
+            sites.append((id(blk["dw_dw"]), lib.mpn_dwconv_wgrad_num_parts(N, hh, ww, cc, blk["stride"], dc), 9 * cc, blk["dw_dw"]))
+        sites.append((id(self.stem_dw), lib.mpn_stem_conv_wgrad_num_parts(N, H, W), self.stem_w.numel(), self.stem_dw))
+        sites.append((id(self._head_grad), lib.mpn_heatmap_head_bwd_num_parts(N * b["lv"][2][0] * b["lv"][2][1]),
+                      self._head_grad.numel(), self._head_grad))
+        total = sum(((np_ * n + 3) // 4) * 4 for _, np_, n, _ in sites)
+        slab = torch.empty(total, dtype=torch.float32, device=dev)
+        g["slab"], jobs, off = {}, [], 0
+        for key, np_, n, out in sites:
+            view = slab[off:off + np_ * n]
+            g["slab"][key] = view
+            jobs.append((view, np_, n, out.view(-1)))
+            off += ((np_ * n + 3) // 4) * 4
+        g["reducer"] = ops.SlabReducer(jobs, dev)
         b["g"] = g
         return g
 
@@ -471,35 +478,35 @@ class KeypointNet:
         (MFMA split-K kernels + slab reductions), so HBM-bound batch-norm passes overlap MFMA-bound wgrad kernels."""
         b, feats, images = self._last
         g = self._grad_buffers(b)
-        sp, wp = b["stat_part"], g["wpart"]
+        sp, slab = b["stat_part"], g["slab"]
         if self.overlap_wgrad and self._wstream is None:
             self._wstream = torch.cuda.Stream(device=self.device)
         W = self._wgrad
         # ---- head + final conv
         ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
-                             g["head_part"])
+                             slab[id(self._head_grad)], reduce=False)
         ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
-        W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, wp))
+        W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
         ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm
         for l in (2, 3, 4, 5):
             ph = self.phi[l]
             ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
             ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp)
-            W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, wp))
+            W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
             ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
             ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp)
-            W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, wp))
+            W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
             ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
             ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l])
         # ---- FPN (top-down path reversed)
         for l in (2, 3, 4, 5):
-            W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, wp))
+            W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, slab[id(self.pconv[l].dw)], reduce=False))
             ops.conv_fwd(g["p"][l], self.pconv[l].packed.bwd, DEPTH, 3, None, out=g["x"][l])
             if l > 2:
                 ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample
             raw, aff = feats[f"c{l}"]
-            W(lambda: ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, wp))
+            W(lambda: ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, slab[id(self.lateral[l].dw)], reduce=False))
             ops.conv_fwd(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, None, out=g["c"][f"c{l}"])
         # ---- backbone
         dA = g["c"]["c5"]
@@ -508,19 +515,20 @@ class KeypointNet:
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
             ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp)
-            W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, wp))
+            W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
             ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
             ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
-            W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], wp))
+            W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))
             dst = g["pw"][i - 1] if i > 0 else g["stem"]
             ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst)
             dA = dst
         ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp)
-        W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, wp))
+        W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, slab[id(self.stem_dw)], reduce=False))
         if self._wstream is not None:
-            torch.cuda.current_stream().wait_stream(self._wstream)   # join: every gradient is in the arena
+            torch.cuda.current_stream().wait_stream(self._wstream)   # join: every slab is written
+        g["reducer"].run()   # every gradient is in the arena
 
     def add_weight_decay_gradients(self, weight_decay):
         """keypoints_model.py:129-138: + wd * l2_loss(k) for every 'weights'/'kernel' variable except depthwise."""

@@ -78,8 +78,9 @@ def conv_wgrad_num_parts(N, H, W, cin, cout, ksize, dtype):
     return _lib.lib().mpn_conv_wgrad_num_parts(N, H, W, cin, cout, ksize, _lib.dtype_code(dtype))
 
 
-def conv_bwd_weight(x, dy, ksize, affine, dw_out, part=None):
-    """dw_out (f32 HWIO view, [k,k,Cin,Cout]) <- sum over pixels of act(bn(x)) (x) dy."""
+def conv_bwd_weight(x, dy, ksize, affine, dw_out, part=None, reduce=True):
+    """dw_out (f32 HWIO view, [k,k,Cin,Cout]) <- sum over pixels of act(bn(x)) (x) dy.
+    reduce=False leaves the split-K slab in `part` for a later batched reduction (SlabReducer)."""
     N, H, W, cin = x.shape
     cout = dy.shape[3]
     nparts = conv_wgrad_num_parts(N, H, W, cin, cout, ksize, x.dtype)
@@ -89,8 +90,32 @@ def conv_bwd_weight(x, dy, ksize, affine, dw_out, part=None):
     sc, sh, act = _aff(affine)
     call("mpn_conv_bwd_weight", ptr(x), ptr(dy), ptr(part), N, H, W, cin, cout, ksize, _lib.dtype_code(x.dtype),
          sc, sh, act, stream_ptr())
-    call("mpn_reduce_partials", ptr(part), nparts, n, ptr(dw_out), 0, 1.0, stream_ptr())
+    if reduce:
+        call("mpn_reduce_partials", ptr(part), nparts, n, ptr(dw_out), 0, 1.0, stream_ptr())
     return dw_out
+
+
+class SlabReducer:
+    """All weight-gradient slab reductions of a step in one launch (mpn_reduce_partials_batched).
+    `jobs`: list of (part tensor, nparts, n, out tensor); the device table is built once."""
+
+    def __init__(self, jobs, device):
+        import ctypes
+        lib = _lib.lib()
+        nb = lib.mpn_reduce_desc_bytes()
+        host = (ctypes.c_ubyte * (nb * len(jobs)))()
+        begin = 0
+        for j, (part, nparts, n, out) in enumerate(jobs):
+            blocks = lib.mpn_reduce_desc_fill(ctypes.byref(host, j * nb), ptr(part), int(nparts), int(n), ptr(out), 1.0, begin)
+            if blocks <= 0:
+                raise ValueError("bad slab reduction job")
+            begin += blocks
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+        self.njobs, self.blocks = len(jobs), begin
+        self._keep = jobs   # the tensors the table points at
+
+    def run(self):
+        call("mpn_reduce_partials_batched", ptr(self.table), self.njobs, self.blocks, stream_ptr())
 
 
 # ----------------------------------------------------------------------------- batch norm
@@ -186,7 +211,7 @@ def dwconv_bwd_data(dy, w, in_hw, stride, out=None):
     return out
 
 
-def dwconv_bwd_weight(x, dy, stride, affine, dw_out, part=None):
+def dwconv_bwd_weight(x, dy, stride, affine, dw_out, part=None, reduce=True):
     N, H, W, C = x.shape
     dc = _lib.dtype_code(x.dtype)
     nparts = _lib.lib().mpn_dwconv_wgrad_num_parts(N, H, W, C, stride, dc)
@@ -194,7 +219,8 @@ def dwconv_bwd_weight(x, dy, stride, affine, dw_out, part=None):
         part = _f32(nparts * 9 * C, x.device)
     sc, sh, act = _aff(affine)
     call("mpn_dwconv_bwd_weight", ptr(x), ptr(dy), ptr(part), N, H, W, C, stride, dc, sc, sh, act, stream_ptr())
-    call("mpn_reduce_partials", ptr(part), nparts, 9 * C, ptr(dw_out), 0, 1.0, stream_ptr())
+    if reduce:
+        call("mpn_reduce_partials", ptr(part), nparts, 9 * C, ptr(dw_out), 0, 1.0, stream_ptr())
     return dw_out
 
 
@@ -212,7 +238,7 @@ def stem_conv_fwd(images, w, c0, dtype, out=None):
     return out
 
 
-def stem_conv_bwd_weight(images, dy, dw_out, part=None):
+def stem_conv_bwd_weight(images, dy, dw_out, part=None, reduce=True):
     N, H, W, _ = images.shape
     c0 = dy.shape[3]
     nparts = _lib.lib().mpn_stem_conv_wgrad_num_parts(N, H, W)
@@ -220,7 +246,8 @@ def stem_conv_bwd_weight(images, dy, dw_out, part=None):
         part = _f32(nparts * 27 * c0, dy.device)
     call("mpn_stem_conv_bwd_weight", ptr(images), int(images.dtype == torch.uint8), ptr(dy), ptr(part), N, H, W, c0,
          _lib.dtype_code(dy.dtype), stream_ptr())
-    call("mpn_reduce_partials", ptr(part), nparts, 27 * c0, ptr(dw_out), 0, 1.0, stream_ptr())
+    if reduce:
+        call("mpn_reduce_partials", ptr(part), nparts, 27 * c0, ptr(dw_out), 0, 1.0, stream_ptr())
     return dw_out
 
 
@@ -275,7 +302,7 @@ def heatmap_head_fwd(x, w, bias, affine, inference=False, out=None, out_seg=None
     return (out, out_seg) if inference else out
 
 
-def heatmap_head_bwd(x, dlogits, w, affine, dA, dw_db_out, part=None):
+def heatmap_head_bwd(x, dlogits, w, affine, dA, dw_db_out, part=None, reduce=True):
     """dA <- gradient w.r.t. the activated input; dw_db_out: flat f32 view [Cin*18 + 18]."""
     N, H, W, cin = x.shape
     M = N * H * W
@@ -286,7 +313,8 @@ def heatmap_head_bwd(x, dlogits, w, affine, dA, dw_db_out, part=None):
     sc, sh, act = _aff(affine)
     call("mpn_heatmap_head_bwd", ptr(x), ptr(dlogits), ptr(w), M, cin, _lib.dtype_code(x.dtype), sc, sh, act, ptr(dA),
          ptr(part), stream_ptr())
-    call("mpn_reduce_partials", ptr(part), nparts, nout, ptr(dw_db_out), 0, 1.0, stream_ptr())
+    if reduce:
+        call("mpn_reduce_partials", ptr(part), nparts, nout, ptr(dw_db_out), 0, 1.0, stream_ptr())
     return dA
 
 
