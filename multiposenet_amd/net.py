@@ -344,13 +344,15 @@ class KeypointNet:
                       self._head_grad.numel(), self._head_grad))
         total = sum(((np_ * n + 3) // 4) * 4 for _, np_, n, _ in sites)
         slab = torch.empty(total, dtype=torch.float32, device=dev)
-        g["slab"], jobs, off = {}, [], 0
+        backbone_keys = {id(blk["pw"].dw) for blk in self.blocks} | {id(blk["dw_dw"]) for blk in self.blocks} | {id(self.stem_dw)}
+        g["slab"], jobs, off = {}, ([], []), 0
         for key, np_, n, out in sites:
             view = slab[off:off + np_ * n]
             g["slab"][key] = view
-            jobs.append((view, np_, n, out.view(-1)))
+            jobs[1 if key in backbone_keys else 0].append((view, np_, n, out.view(-1)))
             off += ((np_ * n + 3) // 4) * 4
-        g["reducer"] = ops.SlabReducer(jobs, dev)
+        # two launches: the head / FPN gradients are complete (and can be all-reduced) while the backbone still runs
+        g["reducer"] = (ops.SlabReducer(jobs[0], dev), ops.SlabReducer(jobs[1], dev))
         b["g"] = g
         return g
 
@@ -472,8 +474,19 @@ class KeypointNet:
         with torch.cuda.stream(self._wstream):
             fn()
 
-    def backward(self):
+    @property
+    def backbone_grad_end(self):
+        """Offset in the flat gradient arena where the backbone's variables end (the arena is laid out backbone first)."""
+        end = 0
+        for k, (o, n, _) in self._train_arena.offsets.items():
+            if k.startswith("MobilenetV1/"):
+                end = max(end, o + (n + 3) // 4 * 4)
+        return end
+
+    def backward(self, part=None):
         """Gradients of the total loss w.r.t. every trainable variable -> self.grad (call after compute_losses).
+        part=0: head + subnet + FPN only (their gradients are final when it returns); part=1: the backbone, after
+        part 0; None: both. Data-parallel training all-reduces the part-0 gradients while part 1 runs.
         Two HIP streams: the main one carries the activation-gradient chain, the side one all weight gradients
         (MFMA split-K kernels + slab reductions), so HBM-bound batch-norm passes overlap MFMA-bound wgrad kernels."""
         b, feats, images = self._last
@@ -482,6 +495,18 @@ class KeypointNet:
         if self.overlap_wgrad and self._wstream is None:
             self._wstream = torch.cuda.Stream(device=self.device)
         W = self._wgrad
+        if part in (None, 0):
+            self._backward_head(b, g, feats, sp, slab, W)
+            if self._wstream is not None:
+                torch.cuda.current_stream().wait_stream(self._wstream)
+            g["reducer"][0].run()
+        if part in (None, 1):
+            self._backward_backbone(b, g, images, sp, slab, W)
+            if self._wstream is not None:
+                torch.cuda.current_stream().wait_stream(self._wstream)   # join: every slab is written
+            g["reducer"][1].run()   # every gradient is in the arena
+
+    def _backward_head(self, b, g, feats, sp, slab, W):
         # ---- head + final conv
         ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
                              slab[id(self._head_grad)], reduce=False)
@@ -508,7 +533,8 @@ class KeypointNet:
             raw, aff = feats[f"c{l}"]
             W(lambda: ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, slab[id(self.lateral[l].dw)], reduce=False))
             ops.conv_fwd(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, None, out=g["c"][f"c{l}"])
-        # ---- backbone
+
+    def _backward_backbone(self, b, g, images, sp, slab, W):
         dA = g["c"]["c5"]
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
@@ -526,9 +552,6 @@ class KeypointNet:
             dA = dst
         ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp)
         W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, slab[id(self.stem_dw)], reduce=False))
-        if self._wstream is not None:
-            torch.cuda.current_stream().wait_stream(self._wstream)   # join: every slab is written
-        g["reducer"].run()   # every gradient is in the arena
 
     def add_weight_decay_gradients(self, weight_decay):
         """keypoints_model.py:129-138: + wd * l2_loss(k) for every 'weights'/'kernel' variable except depthwise."""

@@ -18,7 +18,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("MPN_DP_FORCE_COLLECTIVE", "0") == "1"   # 1-rank rehearsal of the RCCL path
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -51,17 +52,23 @@ class GradientAllReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bounds = bucket_bounds(flat_grad.numel(), bucket_bytes // flat_grad.element_size())
         self._handles = []
+        # MPN_DP_FORCE_COLLECTIVE=1: run the collectives even with one rank (exercises the RCCL path on a 1-GPU box)
+        self.force = os.environ.get("MPN_DP_FORCE_COLLECTIVE", "0") == "1" and dist.is_initialized()
 
     @property
     def grad_scale(self):
         """Factor the optimizer applies to the summed gradient (mean over replicas)."""
         return 1.0 / self.world
 
-    def start(self):
-        if self.world == 1:
+    def start(self, lo=0, hi=None):
+        """Launch the (async) all-reduce of elements [lo, hi) of the arena, bucket by bucket from the top."""
+        if self.world == 1 and not self.force:
             return
+        hi = self.flat.numel() if hi is None else hi
         for (a, b) in self.bounds:
-            self._handles.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            a, b = max(a, lo), min(b, hi)
+            if a < b:
+                self._handles.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):
         for h in self._handles:

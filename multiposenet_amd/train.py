@@ -19,27 +19,37 @@ class Trainer:
         self.reducer = GradientAllReducer(net.grad, bucket_bytes=bucket_bytes) if distributed else None
         self._static = None
         self._graph_fb = None
+        self._graph_bb = None
         self._graph_opt = None
 
     # ---- pieces
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, part=None):
+        """part None: everything; 0: forward + losses + head/FPN backward; 1: backbone backward (+ weight decay)."""
         s = self._static
-        self.net.forward(s["images"], True)
-        self.net.compute_losses(s["labels"])
-        self.net.backward()
-        if self.weight_decay > 0.0:
+        if part in (None, 0):
+            self.net.forward(s["images"], True)
+            self.net.compute_losses(s["labels"])
+        self.net.backward(part)
+        if part in (None, 1) and self.weight_decay > 0.0:
             self.net.add_weight_decay_gradients(self.weight_decay)
 
     def _opt(self):
         scale = self.reducer.grad_scale if self.reducer else 1.0
         self.net.optimizer_step(self.lr0, self.num_steps, grad_scale=scale)
 
+    def input_buffers(self, features, labels):
+        """The static device buffers a replayed step reads: (features, labels) dicts shaped like the arguments.
+        A loader that writes its batches straight into them (and passes them to `step`) saves the device-to-device
+        copy that `step` otherwise makes of every batch (100 MB of images + 38 MB of labels at bs32 @ 512x512)."""
+        self._bind(features, labels)
+        return {"images": self._static["images"]}, self._static["labels"]
+
     def _bind(self, features, labels):
         imgs = features["images"]
         s = self._static
         if s is None or s["images"].shape != imgs.shape or s["images"].dtype != imgs.dtype:
             self._static = {"images": imgs.clone(), "labels": {k: v.clone() for k, v in labels.items()}}
-            self._graph_fb = self._graph_opt = None
+            self._graph_fb = self._graph_bb = self._graph_opt = None
             return
         if s["images"].data_ptr() != imgs.data_ptr():
             s["images"].copy_(imgs)
@@ -56,11 +66,18 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._graph_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph_fb):
-            self._fwd_bwd()
-            if self.reducer is None:
+        if self.reducer is None:
+            with torch.cuda.graph(self._graph_fb):
+                self._fwd_bwd()
                 self._opt()
-        if self.reducer is not None:
+        else:
+            # data parallel: three graphs around the two RCCL exchanges (head/FPN gradients travel while the backbone's
+            # backward still runs; weight decay touches every gradient, so with it the exchange waits for the end)
+            with torch.cuda.graph(self._graph_fb):
+                self._fwd_bwd(0)
+            self._graph_bb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_bb):
+                self._fwd_bwd(1)
             self._graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_opt):
                 self._opt()
@@ -85,7 +102,13 @@ class Trainer:
                 self.net.repack_weights()
             self._graph_fb.replay()
             if self.reducer is not None:
-                self.reducer.all_reduce()
+                split = self.net.backbone_grad_end
+                early = self.weight_decay == 0.0
+                if early:
+                    self.reducer.start(split, None)      # head + FPN gradients: overlapped with the backbone's backward
+                self._graph_bb.replay()
+                self.reducer.start(0, split if early else None)
+                self.reducer.finish()
                 self._graph_opt.replay()
         return self.net._last[0]["losses"]
 

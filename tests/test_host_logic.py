@@ -67,7 +67,12 @@ def _worker(rank, world, port, out):
     flat = torch.randn(100003 * 4)           # rank-dependent "gradients"
     mine = flat.clone()
     red = GradientAllReducer(flat, bucket_bytes=64 << 10)
-    red.all_reduce()
+    # the two-phase exchange of train.Trainer: the head end of the arena first (while the backbone's backward would
+    # still run), then the rest; every element exactly once
+    split = 123456
+    red.start(split, None)
+    red.start(0, split)
+    red.finish()
     out[rank] = (mine.numpy(), flat.numpy().copy(), red.grad_scale, len(red.bounds))
     torch.distributed.destroy_process_group()
 
