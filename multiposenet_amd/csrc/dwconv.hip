@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* tile = smem_f;                                   // [HH*HW][nvg*VE]
-    float* red = smem_f + TL::HH * TL::HW * 8 * VE;         // [4][16][8]
+    float* red = smem_f + TL::HH * TL::HW * p.nvg * VE;         // [4][16][8]
 
     const int cb = blockIdx.x % p.cblocks;
     const int split = blockIdx.x / p.cblocks;
@@ -228,26 +228,38 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
             hr.load(p, img2, oy2, ox2, c0, cb_vecs);
         }
         __syncthreads();  // this tile's halo image is complete
+        // ALL 9 LDS reads of an output pixel issued before its first FMA (fenced): left to itself hipcc
+        // emits read / lgkmcnt(0) / FMA nine times per pixel - nine exposed LDS round trips - and the phase runs at a
+        // third of its instruction-issue rate.
 #pragma unroll 1
         for (int op = pt; op < TL::TH * TL::TW; op += npt) {
-            const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
-            const int oy = oy0 + oyl, ox = ox0 + oxl;
-            // packed FP32 FMAs (v_pk_fma_f32): two channels per instruction
-            f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+            float4 q[1][9];
+            int oyl_[1], oxl_[1];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int u = 0; u < 1; ++u) {
+                const int o = min(op + u * npt, TL::TH * TL::TW - 1);
+                oyl_[u] = o / TL::TW;
+                oxl_[u] = o - oyl_[u] * TL::TW;
+                const float* base = tile + ((oyl_[u] * STRIDE) * TL::HW + oxl_[u] * STRIDE) * cstride + cg * 4;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float4 q = *reinterpret_cast<const float4*>(
-                        tile + ((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * cstride + cg * 4);
-                    a01 += (f32x2_t){q.x, q.y} * (f32x2_t){wr[ky * 3 + kx][0], wr[ky * 3 + kx][1]};
-                    a23 += (f32x2_t){q.z, q.w} * (f32x2_t){wr[ky * 3 + kx][2], wr[ky * 3 + kx][3]};
+                for (int t = 0; t < 9; ++t) q[u][t] = *reinterpret_cast<const float4*>(base + ((t / 3) * TL::HW + (t % 3)) * cstride);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 1; ++u) {
+                f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};   // packed FP32 FMAs (v_pk_fma_f32): two channels per instruction
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    a01 += (f32x2_t){q[u][t].x, q[u][t].y} * (f32x2_t){wr[t][0], wr[t][1]};
+                    a23 += (f32x2_t){q[u][t].z, q[u][t].w} * (f32x2_t){wr[t][2], wr[t][3]};
                 }
-            if (cg_ok && oy < p.OH && ox < p.OW) {
-                const float acc[4] = {a01.x, a01.y, a23.x, a23.y};
-                s01 += a01; s23 += a23;
-                q01 += a01 * a01; q23 += a23 * a23;
-                store4(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, acc);
+                const int oy = oy0 + oyl_[u], ox = ox0 + oxl_[u];
+                if (op + u * npt < TL::TH * TL::TW && cg_ok && oy < p.OH && ox < p.OW) {
+                    const float acc[4] = {a01.x, a01.y, a23.x, a23.y};
+                    s01 += a01; s23 += a23;
+                    q01 += a01 * a01; q23 += a23 * a23;
+                    store4(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, acc);
+                }
             }
         }
         __syncthreads();  // everybody is done reading this tile
@@ -312,7 +324,7 @@ __global__ __launch_bounds__(kThreads, 2) void dwconv_wgrad_kernel(const DwParam
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     float* tile = smem_f;
-    float* red = smem_f + TL::HH * TL::HW * 8 * VE;  // [4][16][36]
+    float* red = smem_f + TL::HH * TL::HW * p.nvg * VE;  // [4][16][36]
 
     const int cb = blockIdx.x % p.cblocks;
     const int split = blockIdx.x / p.cblocks;
@@ -368,15 +380,18 @@ __global__ __launch_bounds__(kThreads, 2) void dwconv_wgrad_kernel(const DwParam
             const int oyl = op / TL::TW, oxl = op - oyl * TL::TW;
             if (!((gmask >> k) & 1u)) continue;
             const float (&g)[4] = g_all[k];
+            // all 9 LDS reads before the first FMA (fenced): see the forward kernel
+            float4 q[9];
+            const float* base = tile + ((oyl * STRIDE) * TL::HW + oxl * STRIDE) * cstride + cg * 4;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int t = 0; t < 9; ++t) q[t] = *reinterpret_cast<const float4*>(base + ((t / 3) * TL::HW + (t % 3)) * cstride);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float4 q = *reinterpret_cast<const float4*>(
-                        tile + ((oyl * STRIDE + ky) * TL::HW + oxl * STRIDE + kx) * cstride + cg * 4);
-                    acc2[(ky * 3 + kx) * 2 + 0] += (f32x2_t){q.x, q.y} * (f32x2_t){g[0], g[1]};
-                    acc2[(ky * 3 + kx) * 2 + 1] += (f32x2_t){q.z, q.w} * (f32x2_t){g[2], g[3]};
-                }
+            for (int t = 0; t < 9; ++t) {
+                acc2[t * 2 + 0] += (f32x2_t){q[t].x, q[t].y} * (f32x2_t){g[0], g[1]};
+                acc2[t * 2 + 1] += (f32x2_t){q[t].z, q[t].w} * (f32x2_t){g[2], g[3]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();  // everybody is done reading this tile
         if (more) hr.commit(p, aff, tile);
@@ -420,9 +435,9 @@ int fill_params(DwParams& p, int N, int H, int W, int C, int stride, int dtype) 
     return MPN_OK;
 }
 
-template <int STRIDE> size_t dw_smem(int ve, int nred) {
+template <int STRIDE> size_t dw_smem(int ve, int nred, int nvg) {
     using TL = DwTile<STRIDE>;
-    return (size_t)(TL::HH * TL::HW * 8 * ve + 4 * 16 * nred) * sizeof(float);
+    return (size_t)(TL::HH * TL::HW * nvg * ve + 4 * 16 * nred) * sizeof(float);   // halo tile + reduction scratch
 }
 
 template <typename K> int set_smem(K kernel, size_t bytes) {
@@ -464,13 +479,13 @@ extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int
     const int grid = nsplit * p.cblocks;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
-        const size_t sm = dw_smem<1>(ve, 8);
+        const size_t sm = dw_smem<1>(ve, 8, p.nvg);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_fwd_kernel<T, 1>, sm)) return rc;
             dwconv_fwd_kernel<T, 1><<<grid, kThreads, sm, st>>>(p, nsplit);
         });
     } else {
-        const size_t sm = dw_smem<2>(ve, 8);
+        const size_t sm = dw_smem<2>(ve, 8, p.nvg);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_fwd_kernel<T, 2>, sm)) return rc;
             dwconv_fwd_kernel<T, 2><<<grid, kThreads, sm, st>>>(p, nsplit);
@@ -523,13 +538,13 @@ extern "C" int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part,
     const int grid = nsplit * p.cblocks;
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
-        const size_t sm = dw_smem<1>(ve, 36);
+        const size_t sm = dw_smem<1>(ve, 36, p.nvg);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_wgrad_kernel<T, 1>, sm)) return rc;
             dwconv_wgrad_kernel<T, 1><<<grid, kThreads, sm, st>>>(p, nsplit);
         });
     } else {
-        const size_t sm = dw_smem<2>(ve, 36);
+        const size_t sm = dw_smem<2>(ve, 36, p.nvg);
         MPN_DISPATCH_DTYPE(dtype, {
             if (int rc = set_smem(dwconv_wgrad_kernel<T, 2>, sm)) return rc;
             dwconv_wgrad_kernel<T, 2><<<grid, kThreads, sm, st>>>(p, nsplit);
