@@ -45,6 +45,23 @@ enum { MPN_ACT_NONE = 0, MPN_ACT_RELU = 1, MPN_ACT_RELU6 = 2 };
 
 typedef void* mpn_stream_t; /* hipStream_t */
 
+/* Optional "tail" of a statistics-producing launch (mpn_conv_fwd_fin, mpn_dwconv_fwd_fin, mpn_bn_stats_fin,
+ * mpn_bn_bwd_reduce_fin): the last-finishing blocks reduce the partial rows (two levels, f64, fixed order ->
+ * deterministic) and do the work of mpn_bn_finalize (mode 1) or mpn_bn_bwd_finalize (mode 2) inside the same launch.
+ * Host struct, read at launch time. workspace: mpn_bn_tail_workspace_bytes(C) bytes of device memory, zero-filled ONCE
+ * by the caller (the tickets in it reset themselves); it may be shared by launches that do not overlap in time. */
+typedef struct mpn_bn_tail_t {
+    int mode;                 /* 0 = none, 1 = forward statistics -> scale/shift (+ moving stats), 2 = backward sums */
+    long long count;          /* elements per channel (N*H*W) */
+    float momentum, eps;      /* mode 1 */
+    const float* gamma; const float* beta;                                    /* mode 1 */
+    float* moving_mean; float* moving_var;                                    /* mode 1, may be NULL */
+    float* scale; float* shift; float* save_mean; float* save_invstd;         /* mode 1 outputs (save_* may be NULL) */
+    float* dgamma; float* dbeta; float* k1; float* k2;                        /* mode 2 outputs */
+    void* workspace; size_t workspace_bytes;
+} mpn_bn_tail_t;
+size_t mpn_bn_tail_workspace_bytes(int C);
+
 int mpn_version(void);
 /* copies the calling thread's last error message into buf (host), returns its length */
 int mpn_last_error(char* buf, size_t n);
@@ -102,6 +119,11 @@ int mpn_conv_num_parts(int N, int H, int W, int ksize);
 int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin,
                  int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,
                  int in_act, float* stats_part, const void* up_res, mpn_stream_t stream);
+/* same + the following batch-norm's finalize inside the launch (tail may be NULL; needs stats_part) */
+int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin,
+                     int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,
+                     int in_act, float* stats_part, const void* up_res, const mpn_bn_tail_t* tail,
+                     mpn_stream_t stream);
 
 /* Weight gradient of mpn_conv_fwd: dW[tap][ci][co] = sum_pixels act(bn(x))[pixel+tap][ci]*dy[pixel][co].
  * Split-K over pixel tiles: part [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (one HWIO slab
@@ -121,6 +143,8 @@ int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H
  */
 int mpn_bn_stats_num_parts(long long M);
 int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream);
+int mpn_bn_stats_fin(const void* x, long long M, int C, int dtype, float* part, const mpn_bn_tail_t* tail,
+                     mpn_stream_t stream);
 int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
                     const float* beta, float* moving_mean, float* moving_var, float momentum,
                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
@@ -136,6 +160,10 @@ int mpn_bn_act_apply(const void* x, void* y, long long M, int C, int dtype, cons
 int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dtype,
                       const float* scale, const float* shift, const float* mean,
                       const float* invstd, int act, float* part, mpn_stream_t stream);
+int mpn_bn_bwd_reduce_fin(const void* dA, const void* x, long long M, int C, int dtype,
+                          const float* scale, const float* shift, const float* mean,
+                          const float* invstd, int act, float* part, const mpn_bn_tail_t* tail,
+                          mpn_stream_t stream);
 int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
                         float* dbeta, float* k1, float* k2, mpn_stream_t stream);
 /* dA <- scale*(g - k1 - xhat*k2) in place; add_ch0 (NULL or [M] f32) is added to channel 0 */
@@ -154,6 +182,9 @@ int mpn_dwconv_num_parts(int N, int H, int W, int C, int stride, int dtype);
 int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
                    int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
                    float* stats_part, mpn_stream_t stream);
+int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
+                       int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
+                       float* stats_part, const mpn_bn_tail_t* tail, mpn_stream_t stream);
 /* dy [N,OH,OW,C] -> dx [N,H,W,C]  (H, W: forward input size) */
 int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C,
                         int stride, int dtype, mpn_stream_t stream);

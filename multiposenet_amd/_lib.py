@@ -35,19 +35,24 @@ SIGNATURES = {
     "mpn_conv_pack_weights_batched": (_I, [_P, _I, _I, _I, _P]),
     "mpn_conv_num_parts": (_I, [_I, _I, _I, _I]),
     "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "mpn_conv_fwd_fin": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "mpn_bn_tail_workspace_bytes": (_Z, [_I]),
     "mpn_conv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mpn_conv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_bn_stats_num_parts": (_I, [_L]),
     "mpn_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
+    "mpn_bn_stats_fin": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "mpn_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mpn_bn_inference_affine": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mpn_bn_act_apply": (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P]),
     "mpn_bn_bwd_reduce": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mpn_bn_bwd_reduce_fin": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mpn_bn_bwd_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P]),
     "mpn_bn_bwd_apply": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "mpn_dwconv_out_size": (_I, [_I, _I]),
     "mpn_dwconv_num_parts": (_I, [_I, _I, _I, _I, _I, _I]),
     "mpn_dwconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
+    "mpn_dwconv_fwd_fin": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "mpn_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mpn_dwconv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I]),
     "mpn_dwconv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

@@ -10,6 +10,7 @@
 // bn_bwd_finalize (dgamma, dbeta, per-channel coefficients), bn_bwd_apply (dx, in place).
 // All reductions are deterministic: partial slabs + fixed-order f64 finalisation, no atomics.
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -38,7 +39,7 @@ __device__ __forceinline__ RowMap make_rowmap(int C, int VE) {
 // out (per block) is written by the first `cvec` threads: part[which][c].
 template <int NV, int VE>
 __device__ __forceinline__ void block_reduce_store(const RowMap& m, float (&v)[NV][VE], float* smem,
-                                                   float* __restrict__ dst, long long which_stride) {
+                                                   float* __restrict__ dst, long long which_stride, bool sc1 = false) {
     // smem: [kThreads][NV*VE]
     __syncthreads();
 #pragma unroll
@@ -53,7 +54,8 @@ __device__ __forceinline__ void block_reduce_store(const RowMap& m, float (&v)[N
             for (int j = 0; j < VE; ++j) {
                 float t = 0.f;
                 for (int r = 0; r < m.ppb; ++r) t += smem[(r * m.cvec + m.vg) * (NV * VE) + k * VE + j];
-                dst[k * which_stride + m.vg * VE + j] = t;
+                if (sc1) st_sc1(&dst[k * which_stride + m.vg * VE + j], t);   // read by other blocks' bn_tail: sc1 hand-off
+                else dst[k * which_stride + m.vg * VE + j] = t;
             }
     }
 }
@@ -61,9 +63,11 @@ __device__ __forceinline__ void block_reduce_store(const RowMap& m, float (&v)[N
 // ---------------------------------------------------------------- forward statistics (standalone)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict__ x, long long M, int C,
-                                                            float* __restrict__ part, int rows_per_block) {
+                                                            float* __restrict__ part, int rows_per_block,
+                                                            const BnTailDev tail) {
     constexpr int VE = Vec16<T>::N;
     __shared__ float smem[kThreads * 2 * VE];
+    __shared__ int tail_flag;
     const RowMap m = make_rowmap(C, VE);
     float acc[2][VE];
 #pragma unroll
@@ -88,7 +92,8 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
             }
         }
     }
-    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C);
+    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C, tail.mode != 0);
+    if (tail.mode) bn_tail(tail, part, C, blockIdx.x, 0, C, 0, threadIdx.x, kThreads, &tail_flag);
 }
 
 // ---------------------------------------------------------------- finalize
@@ -196,9 +201,10 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-    float* __restrict__ part, int rows_per_block) {
+    float* __restrict__ part, int rows_per_block, const BnTailDev tail) {
     constexpr int VE = Vec16<T>::N;
     __shared__ float smem[kThreads * 2 * VE];
+    __shared__ int tail_flag;
     const RowMap m = make_rowmap(C, VE);
     float acc[2][VE];
     float sc[VE], sh[VE], is[VE], nmi[VE];
@@ -243,7 +249,8 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
             }
         }
     }
-    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C);
+    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C, tail.mode != 0);
+    if (tail.mode) bn_tail(tail, part, C, blockIdx.x, 0, C, 0, threadIdx.x, kThreads, &tail_flag);
 }
 
 // part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
@@ -329,16 +336,40 @@ extern "C" int mpn_bn_stats_num_parts(long long M) {
 
 static long long rows_per_block_for(long long M, int nparts) { return (M + nparts - 1) / nparts; }
 
-extern "C" int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream) {
+extern "C" size_t mpn_bn_tail_workspace_bytes(int C) { return C > 0 ? bn_tail_workspace_bytes_for(C) : 0; }
+
+int bn_tail_check(const mpn_bn_tail_t* t, int C, const char* who) {
+    if (t == nullptr || t->mode == 0) return MPN_OK;
+    MPN_REQUIRE(t->mode == 1 || t->mode == 2, MPN_ERR_BAD_ARG, "%s: bn tail mode %d", who, t->mode);
+    MPN_REQUIRE(t->count > 0 && t->workspace, MPN_ERR_BAD_ARG, "%s: bn tail needs count and workspace", who);
+    MPN_REQUIRE(t->workspace_bytes >= bn_tail_workspace_bytes_for(C), MPN_ERR_WORKSPACE, "%s: bn tail workspace too small", who);
+    if (t->mode == 1) {
+        MPN_REQUIRE(t->gamma && t->beta && t->scale && t->shift, MPN_ERR_BAD_ARG, "%s: bn tail (forward) null pointer", who);
+        MPN_REQUIRE((t->moving_mean == nullptr) == (t->moving_var == nullptr), MPN_ERR_BAD_ARG, "%s: bn tail moving stats", who);
+    } else {
+        MPN_REQUIRE(t->dgamma && t->dbeta && t->k1 && t->k2, MPN_ERR_BAD_ARG, "%s: bn tail (backward) null pointer", who);
+    }
+    return MPN_OK;
+}
+
+extern "C" int mpn_bn_stats_fin(const void* x, long long M, int C, int dtype, float* part, const mpn_bn_tail_t* tail,
+                                mpn_stream_t stream) {
     int ve;
     if (int rc = check_rows(M, C, dtype, &ve)) return rc;
     MPN_REQUIRE(x && part, MPN_ERR_BAD_ARG, "bn_stats: null pointer");
+    if (int rc = bn_tail_check(tail, C, "bn_stats")) return rc;
     const int nparts = mpn_bn_stats_num_parts(M);
     const int rpb = (int)rows_per_block_for(M, nparts);
+    BnTailDev td;
+    bn_tail_prepare(tail, nparts, C, &td);
     hipStream_t st = (hipStream_t)stream;
-    MPN_DISPATCH_DTYPE(dtype, (bn_stats_kernel<T><<<nparts, kThreads, 0, st>>>((const T*)x, M, C, part, rpb)));
+    MPN_DISPATCH_DTYPE(dtype, (bn_stats_kernel<T><<<nparts, kThreads, 0, st>>>((const T*)x, M, C, part, rpb, td)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
+}
+
+extern "C" int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream) {
+    return mpn_bn_stats_fin(x, M, C, dtype, part, nullptr, stream);
 }
 
 extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
@@ -379,19 +410,28 @@ extern "C" int mpn_bn_act_apply(const void* x, void* y, long long M, int C, int 
     return MPN_OK;
 }
 
-extern "C" int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dtype, const float* scale,
-                                 const float* shift, const float* mean, const float* invstd, int act, float* part,
-                                 mpn_stream_t stream) {
+extern "C" int mpn_bn_bwd_reduce_fin(const void* dA, const void* x, long long M, int C, int dtype, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd, int act, float* part,
+                                     const mpn_bn_tail_t* tail, mpn_stream_t stream) {
     int ve;
     if (int rc = check_rows(M, C, dtype, &ve)) return rc;
     MPN_REQUIRE(dA && x && scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "bn_bwd_reduce: null pointer");
+    if (int rc = bn_tail_check(tail, C, "bn_bwd_reduce")) return rc;
     const int nparts = mpn_bn_stats_num_parts(M);
     const int rpb = (int)rows_per_block_for(M, nparts);
+    BnTailDev td;
+    bn_tail_prepare(tail, nparts, C, &td);
     hipStream_t st = (hipStream_t)stream;
     MPN_DISPATCH_DTYPE(dtype, (bn_bwd_reduce_kernel<T><<<nparts, kThreads, 0, st>>>(
-                                  (const T*)dA, (const T*)x, M, C, scale, shift, mean, invstd, act, part, rpb)));
+                                  (const T*)dA, (const T*)x, M, C, scale, shift, mean, invstd, act, part, rpb, td)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
+}
+
+extern "C" int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dtype, const float* scale,
+                                 const float* shift, const float* mean, const float* invstd, int act, float* part,
+                                 mpn_stream_t stream) {
+    return mpn_bn_bwd_reduce_fin(dA, x, M, C, dtype, scale, shift, mean, invstd, act, part, nullptr, stream);
 }
 
 extern "C" int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,

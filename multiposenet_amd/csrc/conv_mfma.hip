@@ -18,6 +18,7 @@
 // Epilogue: accumulators -> LDS -> full 16-byte NHWC stores; optional fused nearest-2x
 // upsample-add (fpn.py:51) and per-tile batch-norm partial sums (sum, sum of squares).
 #include "common.h"
+#include "bn_tail.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -57,6 +58,7 @@ struct ConvParams {
     int nchunk;
     int n_tiles;
     long long wp_tile_bytes;  // packed bytes per n-tile
+    BnTailDev tail;           // batch-norm finalize fused into the last-finishing blocks (mode 0: off)
     unsigned long long* dbg;  // diagnostic builds only (env MPN_CONV_STAMPS): per-block s_memtime stamps, else NULL
 };
 
@@ -368,8 +370,15 @@ __global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const
         __syncthreads();
         if (tid < 2 * BN) {
             const int which = tid / BN, c = tid % BN;
-            if (n0 + c < p.Cout)
-                p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c] = red[which * BN + c] + red[(2 + which) * BN + c];
+            if (n0 + c < p.Cout) {
+                float* dstp = &p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c];
+                const float val = red[which * BN + c] + red[(2 + which) * BN + c];
+                if (p.tail.mode) st_sc1(dstp, val); else *dstp = val;
+            }
+        }
+        if (p.tail.mode) {
+            int* flag = reinterpret_cast<int*>(Bs + 4 * BN * sizeof(float));   // one word behind `red`
+            bn_tail(p.tail, p.stats_part, p.Cout, mtile, n0, BN, ntile, tid, kThreads, flag);
         }
     }
     MPN_STAMP(4);
@@ -566,6 +575,13 @@ static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
 extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
                             int ksize, int dtype, const float* in_scale, const float* in_shift, int in_act,
                             float* stats_part, const void* up_res, mpn_stream_t stream) {
+    return mpn_conv_fwd_fin(x, w_packed, y, N, H, W, Cin, Cout, ksize, dtype, in_scale, in_shift, in_act, stats_part, up_res,
+                            nullptr, stream);
+}
+
+extern "C" int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
+                                int ksize, int dtype, const float* in_scale, const float* in_shift, int in_act,
+                                float* stats_part, const void* up_res, const mpn_bn_tail_t* tail, mpn_stream_t stream) {
     MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv: ksize must be 1 or 3 (got %d)", ksize);
     MPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, MPN_ERR_BAD_SHAPE, "conv: bad shape");
     MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "conv: dtype %d", dtype);
@@ -590,6 +606,9 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
     p.M = (long long)N * H * W;
     p.row_bytes = g.row_bytes; p.nchunk = g.nchunk; p.n_tiles = g.n_tiles; p.wp_tile_bytes = g.tile_bytes;
     const int m_tiles = mpn_conv_num_parts(N, H, W, ksize);
+    MPN_REQUIRE(tail == nullptr || tail->mode == 0 || stats_part != nullptr, MPN_ERR_BAD_ARG, "conv: a bn tail needs stats_part");
+    if (int rc = bn_tail_check(tail, Cout, "conv")) return rc;
+    bn_tail_prepare(tail, m_tiles, Cout, &p.tail);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MPN_F32) {
         if (ksize == 3) return g.BN == 128 ? launch_conv<float, 9, 128>(p, m_tiles, st) : launch_conv<float, 9, 64>(p, m_tiles, st);

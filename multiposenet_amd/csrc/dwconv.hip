@@ -9,6 +9,7 @@
 // The following batch-norm's partial statistics come out of the same pass (wave shuffles over
 // the lanes that share a channel vector, then one LDS hop across the 4 waves).
 #include "common.h"
+#include "bn_tail.h"
 
 namespace {
 
@@ -34,6 +35,7 @@ struct DwParams {
     int tiles_x, tiles_y;
     int nvg;            // channel vectors handled per block (<= 8)
     int cblocks;        // channel blocks
+    BnTailDev tail;     // batch-norm finalize fused into the last-finishing blocks (forward kernel, mode 0: off)
 };
 
 // 4-channel (one LDS float4) accessors of the storage type: the COMPUTE granule. 72 weight registers per thread
@@ -271,8 +273,12 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
         if ((int)threadIdx.x < ncg && cg_ok) {
             float* dst = p.part + (long long)split * 2 * p.C + c0 + cg * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { dst[j] = st[j]; dst[p.C + j] = st[4 + j]; }
+            for (int j = 0; j < 4; ++j) {
+                if (p.tail.mode) { st_sc1(&dst[j], st[j]); st_sc1(&dst[p.C + j], st[4 + j]); }
+                else { dst[j] = st[j]; dst[p.C + j] = st[4 + j]; }
+            }
         }
+        if (p.tail.mode) bn_tail(p.tail, p.part, p.C, split, c0, cstride, cb, threadIdx.x, kThreads, reinterpret_cast<int*>(red));
     }
 }
 
@@ -468,8 +474,16 @@ extern "C" int mpn_dwconv_num_parts(int N, int H, int W, int C, int stride, int 
 extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
                               int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
                               float* stats_part, mpn_stream_t stream) {
+    return mpn_dwconv_fwd_fin(x, w, y, N, H, W, C, stride, dtype, in_scale, in_shift, in_act, flip, stats_part, nullptr, stream);
+}
+
+extern "C" int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
+                                  int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
+                                  float* stats_part, const mpn_bn_tail_t* tail, mpn_stream_t stream) {
     DwParams p = {};
     if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
+    MPN_REQUIRE(tail == nullptr || tail->mode == 0 || stats_part != nullptr, MPN_ERR_BAD_ARG, "dwconv_fwd: a bn tail needs stats_part");
+    if (int rc = bn_tail_check(tail, C, "dwconv_fwd")) return rc;
     MPN_REQUIRE(x && w && y, MPN_ERR_BAD_ARG, "dwconv_fwd: null pointer");
     MPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), MPN_ERR_BAD_ARG, "dwconv_fwd: scale/shift mismatch");
     p.x = x; p.w = w; p.y = y; p.part = stats_part;
@@ -477,6 +491,7 @@ extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int
     const int ve = dtype == MPN_F32 ? 4 : 8;
     const int nsplit = dw_fwd_nsplit(p);
     const int grid = nsplit * p.cblocks;
+    bn_tail_prepare(tail, nsplit, C, &p.tail);
     hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
         const size_t sm = dw_smem<1>(ve, 8, p.nvg);

@@ -227,6 +227,10 @@ class KeypointNet:
         ob, nb, _ = self._train_arena.offsets["heatmaps/bias"]
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
+        # batch-norm finalizes inside the producing launches (mpn_*_fin, 80 launches fewer per step): implemented and
+        # tested, but SLOWER on MI355X (13.1 vs 12.0 ms/step): the fence-free sc1 hand-off costs >= 4 dependent
+        # memory round trips (~2 us each) at the tail of every producer, more than the ~5 us launch it replaces
+        self.fuse_bn = False
         self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
             [self.p_bn[l] for l in (2, 3, 4, 5)] + [self.phi[l][k] for l in (2, 3, 4, 5) for k in ("bn1", "bn2")] + [self.final_bn]
@@ -371,6 +375,10 @@ class KeypointNet:
         if training:
             ops.bn_finalize(bn, b["stat_part"], nparts, count, training=True)
 
+    def _tail(self, bn, count):
+        """Descriptor that makes a statistics-producing launch finalize `bn` itself (None: separate mpn_bn_finalize)."""
+        return ops.bn_tail_fwd(bn, count, training=True) if self.fuse_bn else None
+
     def prepare_inference(self):
         """is_training=False: every batch-norm becomes the affine of its moving statistics."""
         for bn in self.all_bn:
@@ -384,21 +392,25 @@ class KeypointNet:
             self.prepare_inference()
         sp = b["stat_part"]
         stem = ops.stem_conv_fwd(images, self.stem_w, self.stem_w.shape[3], self.dtype, out=b["stem"])
+        T = self._tail if is_training else (lambda bn, count: None)
         if is_training:
-            _, nparts = ops.bn_stats(stem, sp)
-            ops.bn_finalize(self.stem_bn, sp, nparts, stem.numel() // stem.shape[3])
+            cnt = stem.numel() // stem.shape[3]
+            _, nparts = ops.bn_stats(stem, sp, tail=T(self.stem_bn, cnt))
+            if not self.fuse_bn:
+                ops.bn_finalize(self.stem_bn, sp, nparts, cnt)
         x, aff = stem, self.stem_bn.affine
         feats = {}
         for i, blk in enumerate(self.blocks):
             hin, win = b["hw"][i]
-            ydw = ops.dwconv_fwd(x, blk["dw_w"], blk["stride"], aff, out=b["dw"][i], stats_part=sp if is_training else None)
-            if is_training:
+            h, w = b["hw"][i + 1]
+            ydw = ops.dwconv_fwd(x, blk["dw_w"], blk["stride"], aff, out=b["dw"][i], stats_part=sp if is_training else None,
+                                 tail=T(blk["dw_bn"], N * h * w))
+            if is_training and not self.fuse_bn:
                 ops.bn_finalize(blk["dw_bn"], sp, ops.dwconv_num_parts(N, hin, win, ydw.shape[3], blk["stride"], self.dtype),
                                 ydw.numel() // ydw.shape[3])
-            h, w = b["hw"][i + 1]
             ypw = ops.conv_fwd(ydw, blk["pw"].packed.fwd, blk["pw"].cout, 1, blk["dw_bn"].affine, out=b["pw"][i],
-                               stats_part=sp if is_training else None)
-            if is_training:
+                               stats_part=sp if is_training else None, tail=T(blk["pw_bn"], N * h * w))
+            if is_training and not self.fuse_bn:
                 ops.bn_finalize(blk["pw_bn"], sp, ops.conv_num_parts(N, h, w, 1), N * h * w)
             x, aff = ypw, blk["pw_bn"].affine
             if blk["i"] in FEATURE_BLOCKS:
@@ -409,29 +421,35 @@ class KeypointNet:
         """KeypointSubnet (detector/keypoint_subnet.py:11-62) on top of feature_pyramid_network (detector/fpn.py:36-55)."""
         N = b["shape"][0]
         sp = b["stat_part"] if is_training else None
+        T = self._tail if is_training else (lambda bn, count: None)
+        sep = is_training and not self.fuse_bn     # separate mpn_bn_finalize launches (the unfused reference path)
         prev = None
         for l in (5, 4, 3, 2):
             raw, aff = feats[f"c{l}"]
             h, w = b["lv"][l]
             ops.conv_fwd(raw, self.lateral[l].packed.fwd, DEPTH, 1, aff, out=b["x"][l], up_res=prev)    # fpn.py:38,50-51
             prev = b["x"][l]
-            ops.conv_fwd(prev, self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=sp)    # fpn.py:39,52
-            if is_training:
+            ops.conv_fwd(prev, self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=sp,
+                         tail=T(self.p_bn[l], N * h * w))                                                  # fpn.py:39,52
+            if sep:
                 ops.bn_finalize(self.p_bn[l], sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
         for l in (2, 3, 4, 5):
             ph = self.phi[l]
             h, w = b["lv"][l]
             nparts, cnt = ops.conv_num_parts(N, h, w, 3), N * h * w
-            ops.conv_fwd(b["p"][l], ph["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=sp)
-            if is_training:
+            ops.conv_fwd(b["p"][l], ph["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=sp,
+                         tail=T(ph["bn1"], cnt))
+            if sep:
                 ops.bn_finalize(ph["bn1"], sp, nparts, cnt)
-            ops.conv_fwd(b["y1"][l], ph["conv2"].packed.fwd, DEPTH, 3, ph["bn1"].affine, out=b["y2"][l], stats_part=sp)
-            if is_training:
+            ops.conv_fwd(b["y1"][l], ph["conv2"].packed.fwd, DEPTH, 3, ph["bn1"].affine, out=b["y2"][l], stats_part=sp,
+                         tail=T(ph["bn2"], cnt))
+            if sep:
                 ops.bn_finalize(ph["bn2"], sp, nparts, cnt)
             ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, ph["bn2"].affine)   # :86 + :37
         h, w = b["lv"][2]
-        ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, None, out=b["final"], stats_part=sp)   # :38
-        if is_training:
+        ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, None, out=b["final"], stats_part=sp,
+                     tail=T(self.final_bn, N * h * w))                                                     # :38
+        if sep:
             ops.bn_finalize(self.final_bn, sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
         if inference_outputs:
             return ops.heatmap_head_fwd(b["final"], self.heat_w, self.heat_b, self.final_bn.affine, inference=True)
@@ -510,20 +528,20 @@ class KeypointNet:
         # ---- head + final conv
         ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
                              slab[id(self._head_grad)], reduce=False)
-        ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
+        ops.bn_backward(self.final_bn, g["final"], b["final"], sp, fused=self.fuse_bn)
         W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
         ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm
         for l in (2, 3, 4, 5):
             ph = self.phi[l]
             ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
-            ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp)
+            ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp, fused=self.fuse_bn)
             W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
             ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
-            ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp)
+            ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp, fused=self.fuse_bn)
             W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
             ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
-            ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l])
+            ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l], fused=self.fuse_bn)
         # ---- FPN (top-down path reversed)
         for l in (2, 3, 4, 5):
             W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, slab[id(self.pconv[l].dw)], reduce=False))
@@ -540,17 +558,17 @@ class KeypointNet:
             blk = self.blocks[i]
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
-            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp)
+            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, fused=self.fuse_bn)
             W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
             ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
-            ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
+            ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, fused=self.fuse_bn)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
             W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))
             dst = g["pw"][i - 1] if i > 0 else g["stem"]
             ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst)
             dA = dst
-        ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp)
+        ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp, fused=self.fuse_bn)
         W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, slab[id(self.stem_dw)], reduce=False))
 
     def add_weight_decay_gradients(self, weight_decay):

@@ -4,6 +4,7 @@ Tensors are torch CUDA tensors used purely as device-memory owners; activations 
 (`[N, H, W, C]`, contiguous) in float32 or bfloat16. Nothing here computes on the host and
 nothing falls back to PyTorch ops: every function ends in a `_lib.call` into libmpn_hip.so.
 """
+import ctypes
 from collections import namedtuple
 
 import torch
@@ -62,15 +63,16 @@ def conv_num_parts(N, H, W, ksize):
     return _lib.lib().mpn_conv_num_parts(N, H, W, ksize)
 
 
-def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_res=None):
-    """y = conv(act(bn(x))) [+ nearest2x(up_res)]; optional per-tile BN partial sums."""
+def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_res=None, tail=None):
+    """y = conv(act(bn(x))) [+ nearest2x(up_res)]; optional per-tile BN partial sums; `tail` (bn_tail_fwd) makes the
+    launch finalize the following batch-norm too."""
     _check_nhwc(x)
     N, H, W, cin = x.shape
     if out is None:
         out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device)
     sc, sh, act = _aff(affine)
-    call("mpn_conv_fwd", ptr(x), ptr(packed), ptr(out), N, H, W, cin, cout, ksize, _lib.dtype_code(x.dtype),
-         sc, sh, act, ptr(stats_part), ptr(up_res), stream_ptr())
+    call("mpn_conv_fwd_fin", ptr(x), ptr(packed), ptr(out), N, H, W, cin, cout, ksize, _lib.dtype_code(x.dtype),
+         sc, sh, act, ptr(stats_part), ptr(up_res), _tail_arg(tail), stream_ptr())
     return out
 
 
@@ -137,12 +139,59 @@ class BNState:
         return Affine(self.scale, self.shift, self.act)
 
 
-def bn_stats(x, part=None):
+class _BnTailStruct(ctypes.Structure):
+    """mpn_bn_tail_t (include/mpn.h)."""
+    _fields_ = [("mode", ctypes.c_int), ("count", ctypes.c_longlong), ("momentum", ctypes.c_float), ("eps", ctypes.c_float),
+                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("moving_mean", ctypes.c_void_p),
+                ("moving_var", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
+                ("save_mean", ctypes.c_void_p), ("save_invstd", ctypes.c_void_p), ("dgamma", ctypes.c_void_p),
+                ("dbeta", ctypes.c_void_p), ("k1", ctypes.c_void_p), ("k2", ctypes.c_void_p),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+
+
+_tail_ws = {}
+
+
+def bn_tail_workspace(device, C=1024):
+    """Zero-filled once; shared by every fused finalize on this device (launches on one stream never overlap)."""
+    key = str(device)
+    ws = _tail_ws.get(key)
+    need = _lib.lib().mpn_bn_tail_workspace_bytes(C)
+    if ws is None or ws.numel() < need:
+        ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        _tail_ws[key] = ws
+    return ws
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def bn_tail_fwd(bn, count, training=True):
+    """Tail descriptor: the statistics-producing launch also does mpn_bn_finalize for `bn` (ops.bn_finalize)."""
+    ws = bn_tail_workspace(bn.gamma.device, max(1024, bn.C))
+    return _BnTailStruct(1, int(count), BN_MOMENTUM, BN_EPSILON, _p(bn.gamma), _p(bn.beta),
+                         _p(bn.moving_mean) if training else None, _p(bn.moving_var) if training else None,
+                         _p(bn.scale), _p(bn.shift), _p(bn.mean), _p(bn.invstd), None, None, None, None,
+                         ws.data_ptr(), ws.numel())
+
+
+def bn_tail_bwd(bn, count):
+    ws = bn_tail_workspace(bn.gamma.device, max(1024, bn.C))
+    return _BnTailStruct(2, int(count), 0.0, 0.0, None, None, None, None, None, None, None, None,
+                         _p(bn.dgamma), _p(bn.dbeta), _p(bn.k1), _p(bn.k2), ws.data_ptr(), ws.numel())
+
+
+def _tail_arg(tail):
+    return None if tail is None else ctypes.addressof(tail)
+
+
+def bn_stats(x, part=None, tail=None):
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     nparts = _lib.lib().mpn_bn_stats_num_parts(M)
     if part is None:
         part = _f32(nparts * 2 * C, x.device)
-    call("mpn_bn_stats", ptr(x), M, C, _lib.dtype_code(x.dtype), ptr(part), stream_ptr())
+    call("mpn_bn_stats_fin", ptr(x), M, C, _lib.dtype_code(x.dtype), ptr(part), _tail_arg(tail), stream_ptr())
     return part, nparts
 
 
@@ -166,15 +215,21 @@ def bn_act_apply(x, affine, out=None):
     return out
 
 
-def bn_backward(bn, dA, x, part, add_ch0=None):
+def bn_backward(bn, dA, x, part, add_ch0=None, fused=True):
     """In place: dA (gradient w.r.t. act(bn(x))) -> gradient w.r.t. the raw conv output x.
-    Writes bn.dgamma / bn.dbeta. `part` must hold mpn_bn_stats_num_parts(M)*2*C floats."""
+    Writes bn.dgamma / bn.dbeta. `part` must hold mpn_bn_stats_num_parts(M)*2*C floats.
+    fused: the reduction launch finalizes too (last-finishing blocks) instead of a separate mpn_bn_bwd_finalize."""
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     dc = _lib.dtype_code(x.dtype)
     nparts = _lib.lib().mpn_bn_stats_num_parts(M)
-    call("mpn_bn_bwd_reduce", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
-         int(bn.act), ptr(part), stream_ptr())
-    call("mpn_bn_bwd_finalize", ptr(part), nparts, C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), stream_ptr())
+    if fused:
+        tail = bn_tail_bwd(bn, M)
+        call("mpn_bn_bwd_reduce_fin", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean),
+             ptr(bn.invstd), int(bn.act), ptr(part), _tail_arg(tail), stream_ptr())
+    else:
+        call("mpn_bn_bwd_reduce", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
+             int(bn.act), ptr(part), stream_ptr())
+        call("mpn_bn_bwd_finalize", ptr(part), nparts, C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), stream_ptr())
     call("mpn_bn_bwd_apply", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
          ptr(bn.k1), ptr(bn.k2), int(bn.act), ptr(add_ch0), stream_ptr())
     return dA
@@ -190,15 +245,15 @@ def dwconv_num_parts(N, H, W, C, stride, dtype):
     return _lib.lib().mpn_dwconv_num_parts(N, H, W, C, stride, _lib.dtype_code(dtype))
 
 
-def dwconv_fwd(x, w, stride, affine=None, out=None, stats_part=None):
+def dwconv_fwd(x, w, stride, affine=None, out=None, stats_part=None, tail=None):
     _check_nhwc(x)
     N, H, W, C = x.shape
     OH, OW = dwconv_out_hw(H, W, stride)
     if out is None:
         out = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
     sc, sh, act = _aff(affine)
-    call("mpn_dwconv_fwd", ptr(x), ptr(w), ptr(out), N, H, W, C, stride, _lib.dtype_code(x.dtype), sc, sh, act, 0,
-         ptr(stats_part), stream_ptr())
+    call("mpn_dwconv_fwd_fin", ptr(x), ptr(w), ptr(out), N, H, W, C, stride, _lib.dtype_code(x.dtype), sc, sh, act, 0,
+         ptr(stats_part), _tail_arg(tail), stream_ptr())
     return out
 
 
