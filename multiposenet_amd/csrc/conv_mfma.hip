@@ -385,6 +385,358 @@ __global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const
 #undef MPN_STAMP
 }
 
+// ------------------------------------------------------------------ warp-specialised 3x3 kernel (bf16)
+// ONE persistent 8-wave block per CU. Waves 0-3 ("consumers", 2x2 over 128 pixels x BN channels, one per SIMD) only
+// read LDS and issue MFMAs; waves 4-7 ("producers") move everything: weight stages by LDS-DMA into a 5-deep ring
+// (issued 4 stages ahead: 2 in flight + 2 complete), the NEXT 64-channel chunk's halo by LDS-DMA into a raw ring and,
+// two stages later, through batch-norm affine + activation + zero padding into the other half of a double-buffered A
+// image. One s_barrier per stage (= one tap of one 64-channel chunk, 32 MFMAs per consumer wave) is the only
+// synchronisation: at barrier B(i) weight stage i+2 and every A piece issued two stages earlier are complete, so a
+// consumer reads stage i, prefetches the first fragments of stage i+1 ACROSS the barrier, and never waits for memory.
+// The sequence of (unit, chunk, tap) stages is flat over the block's units, so the first chunk of the next tile is
+// staged during the last chunk of the current one. (The 4-wave kernel above re-reads the 295 KB weight image per
+// 128-pixel tile with 4 LDS-DMA pieces per consumer wave and stage - a third of its main loop)
+// one weight stage's share of a producer lane (2 or 4 x 16 bytes) in NAMED registers (indexed arrays that live across the
+// producer's chunk loop end up in scratch)
+template <int N> struct WsSet {
+    uint4 v0, v1, v2, v3;
+    __device__ __forceinline__ void load(const uint4* src) {
+        v0 = src[0]; v1 = src[64];
+        if constexpr (N > 2) { v2 = src[128]; v3 = src[192]; }
+    }
+    __device__ __forceinline__ void store(uint4* dst) const {
+        dst[0] = v0; dst[64] = v1;
+        if constexpr (N > 2) { dst[128] = v2; dst[192] = v3; }
+    }
+};
+
+constexpr int kWsThreads = 512;
+constexpr int kWsNbuf = 5;
+constexpr int kWsRawSlots = 12;
+
+template <int BN>
+__global__ __launch_bounds__(kWsThreads, 1) void conv_ws_kernel(const ConvParams p, int units_total) {
+    using T = bf16_t;
+    using Frag = Mma<T>::Frag;
+    constexpr int RS = 160, NPIX = kHaloW * kHaloH, ABYTES = NPIX * RS;
+    constexpr int STAGE = 2 * BN * 64, NT = BN / 32;
+    constexpr int WPIECES = STAGE / 1024 / 4;            // LDS-DMA pieces per producer wave and stage (4 or 2)
+    constexpr int NRAW = (NPIX + 7) / 8;                  // 23 raw pieces of 8 pixels x 128 bytes per chunk
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* Aimg = smem;                                   // [2][ABYTES]
+    unsigned char* Wring = smem + 2 * ABYTES;                     // [kWsNbuf][STAGE]
+    float* Red = reinterpret_cast<float*>(Wring + kWsNbuf * STAGE);   // [2 wm][2][BN] per-wave-row stats of the last unit
+    float* Aff = Red + 4 * BN;                                    // [Cin] scale, [Cin] shift (producers only)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const int nunits = units_total > (int)blockIdx.x ? (units_total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int nchunk = p.nchunk;
+    const int TS = nunits * nchunk * 9;                           // stages of this block
+    if (TS == 0) return;
+    auto unit_coords = [&](int j, int& ntile, int& mtile, int& img, int& oy0, int& ox0) {
+        const int u = (int)blockIdx.x + j * (int)gridDim.x;
+        ntile = u % p.n_tiles;
+        mtile = u / p.n_tiles;
+        const int tx = mtile % p.tiles_x;
+        const int t2 = mtile / p.tiles_x;
+        const int ty = t2 % p.tiles_y;
+        img = t2 / p.tiles_y;
+        oy0 = ty * 8;
+        ox0 = tx * 16;
+    };
+
+    if (wave >= 4) {
+        // =========================================================== producers
+        const int pw = wave - 4;
+        const bool affine = p.in_scale != nullptr;
+        const float act_lo = (affine && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+        const float act_hi = (affine && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+        const int nq = nunits * nchunk;                      // flat chunks of this block
+        const unsigned char* wp8 = reinterpret_cast<const unsigned char*>(p.wp);
+        // All global -> LDS traffic goes through REGISTERS (global_load_dwordx4 ... ds_write_b128), three stages in
+        // flight: an LDS-DMA piece blocks the SIMD's issue port for 60-185 cycles, i.e. it is paid by the consumer wave
+        // on the same SIMD (measured: 1060 instead of 512 cycles per stage). Index arithmetic is incremental / scalar: a
+        // producer interval has ~500 cycles, a division by a run-time value costs ~40 instructions.
+        struct UnitPos { int ntile, mtile, img, oy0, ox0; };
+        auto unit_pos = [&](int j) -> UnitPos {
+            UnitPos r;
+            int ntile, mtile, img, oy0, ox0;
+            unit_coords(j, ntile, mtile, img, oy0, ox0);
+            r.ntile = ntile; r.mtile = mtile; r.img = img; r.oy0 = oy0; r.ox0 = ox0;
+            return r;
+        };
+        // source of the next weight stage to load, stages left in its unit, units started
+        const unsigned char* w_src = nullptr;
+        int w_st = 0, w_j = 0, w_left = 0;
+        auto w_next_src = [&]() -> const uint4* {              // per-lane source of the next stage (clamped past the end)
+            if (w_st < TS && w_left == 0) {
+                const int u = (int)blockIdx.x + w_j * (int)gridDim.x;
+                w_src = wp8 + (long long)(u % p.n_tiles) * p.wp_tile_bytes;
+                w_left = nchunk * 9;
+                ++w_j;
+            }
+            const unsigned char* r = w_src + (size_t)(pw * WPIECES) * 1024 + lane * 16;
+            if (w_st < TS) { w_src += STAGE; --w_left; }
+            ++w_st;
+            return reinterpret_cast<const uint4*>(r);
+        };
+        auto a_src = [&](const UnitPos& up, int c, int k) -> const uint4* {   // halo piece k: pixel 8k + lane/8, slot lane%8
+            const int hp = min(8 * k + (lane >> 3), NPIX - 1);
+            const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
+            const int iy = min(max(up.oy0 + hy - 1, 0), p.H - 1), ix = min(max(up.ox0 + hx - 1, 0), p.W - 1);   // clamped: zeroed at commit
+            const int ce = min(c * 64 + (lane & 7) * 8, p.Cin - 8);
+            return reinterpret_cast<const uint4*>(x + (long long)up.img * p.H * p.W * p.Cin + ((iy * p.W + ix) * p.Cin + ce));
+        };
+        // registers -> A image (affine + activation; zero outside the image / beyond Cin). lds_aff: scale / shift from
+        // the LDS table (steady state: a global load here would sit in vmcnt behind the loads just issued) or from
+        // global memory (prologue: the table is complete only after the prologue barrier)
+        auto a_commit = [&](const uint4 raw, const UnitPos& up, int c, int k, unsigned char* abuf, bool lds_aff) {
+            const int hp = 8 * k + (lane >> 3), slot = lane & 7;
+            if (hp >= NPIX) return;
+            const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
+            const int iy = up.oy0 + hy - 1, ix = up.ox0 + hx - 1;
+            const int ce = c * 64 + slot * 8;
+            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ce < p.Cin;
+            Vec16<T> v;
+            v.raw = raw;
+            if (ok && affine) {
+                float sc[8], sh[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj += 4) {
+                    float4 a4, b4;
+                    if (lds_aff) {
+                        a4 = *reinterpret_cast<const float4*>(Aff + ce + jj);
+                        b4 = *reinterpret_cast<const float4*>(Aff + p.Cin + ce + jj);
+                    } else {
+                        a4 = *reinterpret_cast<const float4*>(p.in_scale + ce + jj);
+                        b4 = *reinterpret_cast<const float4*>(p.in_shift + ce + jj);
+                    }
+                    sc[jj] = a4.x; sc[jj + 1] = a4.y; sc[jj + 2] = a4.z; sc[jj + 3] = a4.w;
+                    sh[jj] = b4.x; sh[jj + 1] = b4.y; sh[jj + 2] = b4.z; sh[jj + 3] = b4.w;
+                }
+                apply_affine_act<T>(v, sc, sh, act_lo, act_hi);
+            }
+            if (!ok) v.zero();
+            *reinterpret_cast<uint4*>(abuf + hp * RS + slot * 16) = v.raw;
+        };
+        auto write_stats = [&](const UnitPos& up) {
+            for (int t = lane; t < 2 * BN; t += 64) {
+                const int which = t / BN, c = t - which * BN;
+                if (up.ntile * BN + c < p.Cout)
+                    p.stats_part[((long long)up.mtile * 2 + which) * p.Cout + up.ntile * BN + c] = Red[which * BN + c] + Red[(2 + which) * BN + c];
+            }
+        };
+
+        // weight stage X lives in register set X % 3 (wA, wB, wC) while in flight, halo piece kk of the next chunk in set
+        // kk % 3 (aA, aB, aC). Named sets + a macro per interval with literal set names: indexed arrays end up in scratch.
+        uint4 wA0 = {}, wA1 = {}, wA2 = {}, wA3 = {}, wB0 = {}, wB1 = {}, wB2 = {}, wB3 = {}, wC0 = {}, wC1 = {}, wC2 = {}, wC3 = {};
+#define MPN_WS_WLOAD(S, src)  do { const uint4* s_ = (src); S##0 = s_[0]; S##1 = s_[64]; if (WPIECES > 2) { S##2 = s_[128]; S##3 = s_[192]; } } while (0)
+#define MPN_WS_WSTORE(S, dst) do { uint4* d_ = (dst); d_[0] = S##0; d_[64] = S##1; if (WPIECES > 2) { d_[128] = S##2; d_[192] = S##3; } } while (0)
+        uint4 aA = {}, aB = {}, aC = {};
+        // ---- prologue: scale / shift table; weight stages 0, 1 into the ring, 2..4 into the sets; A image of chunk 0
+        if (affine)
+            for (int c = tid - 256; c < p.Cin; c += 256) { Aff[c] = p.in_scale[c]; Aff[p.Cin + c] = p.in_shift[c]; }
+        UnitPos cur_up = unit_pos(0);                        // unit of the chunk being multiplied
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            const uint4* src = w_next_src();
+            uint4* dst = reinterpret_cast<uint4*>(Wring + st * STAGE + (pw * WPIECES) * 1024) + lane;
+#pragma unroll
+            for (int k = 0; k < WPIECES; ++k) dst[k * 64] = src[k * 64];
+        }
+        for (int k = pw; k < NRAW; k += 4) {
+            const uint4 raw = *a_src(cur_up, 0, k);
+            a_commit(raw, cur_up, 0, k, Aimg, false);
+        }
+        {
+            MPN_WS_WLOAD(wC, w_next_src());   // stage 2
+            MPN_WS_WLOAD(wA, w_next_src());   // stage 3
+            MPN_WS_WLOAD(wB, w_next_src());   // stage 4
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // prologue barrier: stages 0, 1, A(0), Aff are complete
+
+        // ---- steady state: interval i = 9q + sl sits between barriers B(i-1) and B(i)
+        UnitPos nxt_up = cur_up;                              // unit / channel chunk of flat chunk q+1
+        int nxt_c = 1;
+        if (nchunk == 1) { nxt_c = 0; if (1 < nunits) nxt_up = unit_pos(1); }
+        bool stats_due = false;                               // the previous interval ended a unit
+        UnitPos done_up = cur_up;
+        int c = 0, wslot = 2;                                 // ring slot of stage i+2
+        unsigned long long t_work = 0, t_bar = 0, t_vm = 0, t0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+#define MPN_WS_STAMP(accu) do { if (p.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); accu += t_ - t0; t0 = t_; } } while (0)
+        for (int q = 0; q < nq; ++q) {
+            const bool nxt_real = q + 1 < nq;
+            unsigned char* nxt_img = Aimg + ((q + 1) & 1) * ABYTES;
+            // one interval: weight stage i+2 from its set into the ring, the set reloaded with stage i+5; halo piece
+            // SL-2 of the next chunk from its set into the A image, piece SL loaded
+#define MPN_WS_INTERVAL(SL, WSET, ACOMMIT, ALOAD)                                                              \
+            {                                                                                                  \
+                uint4* dst_ = reinterpret_cast<uint4*>(Wring + wslot * STAGE + (pw * WPIECES) * 1024) + lane;  \
+                MPN_WS_WSTORE(WSET, dst_);                                                                     \
+                MPN_WS_WLOAD(WSET, w_next_src());                                                              \
+                wslot = wslot + 1 == kWsNbuf ? 0 : wslot + 1;                                                  \
+                if ((SL) >= 2 && (SL) < 8) {                                                                   \
+                    const int k_ = 4 * ((SL)-2) + pw;                                                          \
+                    if (nxt_real && k_ < NRAW) a_commit(ACOMMIT, nxt_up, nxt_c, k_, nxt_img, true);            \
+                }                                                                                              \
+                if ((SL) < 6) ALOAD = *a_src(nxt_up, nxt_c, min(4 * (SL) + pw, NRAW - 1));                     \
+                if ((SL) == 0) {                                                                               \
+                    if (stats_due && pw == 0 && p.stats_part != nullptr) write_stats(done_up);                 \
+                    stats_due = false;                                                                         \
+                }                                                                                              \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+                MPN_WS_STAMP(t_work);                                                                          \
+                __builtin_amdgcn_s_barrier();                                                                  \
+                MPN_WS_STAMP(t_bar);                                                                           \
+            }
+            MPN_WS_INTERVAL(0, wC, aA, aA)
+            MPN_WS_INTERVAL(1, wA, aA, aB)
+            MPN_WS_INTERVAL(2, wB, aA, aC)
+            MPN_WS_INTERVAL(3, wC, aB, aA)
+            MPN_WS_INTERVAL(4, wA, aC, aB)
+            MPN_WS_INTERVAL(5, wB, aA, aC)
+            MPN_WS_INTERVAL(6, wC, aB, aA)
+            MPN_WS_INTERVAL(7, wA, aC, aA)
+            MPN_WS_INTERVAL(8, wB, aA, aA)
+#undef MPN_WS_INTERVAL
+#undef MPN_WS_WLOAD
+#undef MPN_WS_WSTORE
+            if (++c == nchunk) { c = 0; stats_due = true; done_up = cur_up; }
+            cur_up = nxt_up;
+            if (++nxt_c == nchunk) nxt_c = 0;
+            if (nxt_c == 0 && q + 2 < nq) nxt_up = unit_pos((q + 2) / nchunk);
+        }
+        if (p.stats_part != nullptr && pw == 0) write_stats(done_up);   // the block's last unit (Red complete at B(TS-1))
+        if (p.dbg && tid == 256) { p.dbg[blockIdx.x * 8 + 3] = t_work; p.dbg[blockIdx.x * 8 + 4] = t_bar; p.dbg[blockIdx.x * 8 + 5] = t_vm; }
+        return;
+    }
+
+    // =============================================================== consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    f32x4_t acc[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int aoff[4];                                                   // per-lane fragment base offsets inside an A image
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int row = wm * 64 + mt * 16 + l15;
+        aoff[mt] = ((row >> 4) * kHaloW + (row & 15)) * RS + lq * 16;
+    }
+    const int boff = (wn * (BN / 2) + l15) * 64 + ((lq ^ b_swz(l15)) << 4);
+    Frag aP[4], bP[NT], aQ[4], bQ[NT];
+    auto load_frags = [&](Frag (&a)[4], Frag (&b)[NT], const unsigned char* Ab, int a_off, const unsigned char* Wb, int b_off) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const Frag*>(Ab + aoff[mt] + a_off);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const Frag*>(Wb + boff + b_off + nt * 1024);
+    };
+    auto mma_all = [&](const Frag (&a)[4], const Frag (&b)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(b[nt], a[mt], acc[mt][nt]);   // D^T = W^T x A^T
+    };
+    auto tap_off = [&](int sl) -> int {
+        const int ky = (sl * 11) >> 5;
+        return (ky * kHaloW + (sl - 3 * ky)) * RS;
+    };
+    T* __restrict__ y = reinterpret_cast<T*>(p.y);
+
+    __builtin_amdgcn_s_barrier();                                  // prologue barrier
+    load_frags(aP, bP, Aimg, tap_off(0), Wring, 0);
+    int q = 0, sl = 0, c = 0, j = 0, wslot = 0;                  // flat chunk, tap, chunk in unit, unit, weight ring slot
+    unsigned long long c_work = 0, c_bar = 0, c_epi = 0, t0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
+    for (int i = 0; i < TS; ++i) {
+        const unsigned char* Ab = Aimg + (q & 1) * ABYTES;
+        const unsigned char* Wb = Wring + wslot * STAGE;
+        const int wslot1 = wslot + 1 == kWsNbuf ? 0 : wslot + 1;
+        load_frags(aQ, bQ, Ab, tap_off(sl) + 64, Wb, BN * 64);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_all(aP, bP);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i + 1 < TS) {                                          // first fragments of the next stage, across the barrier
+            const int q1 = sl == 8 ? q + 1 : q, sl1 = sl == 8 ? 0 : sl + 1;
+            load_frags(aP, bP, Aimg + (q1 & 1) * ABYTES, tap_off(sl1), Wring + wslot1 * STAGE, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_all(aQ, bQ);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool unit_end = sl == 8 && c == nchunk - 1;
+        MPN_WS_STAMP(c_work);
+        if (unit_end) {
+            // ---------------- epilogue of unit j: accumulators -> global, per-wave-row statistics -> Red
+            int ntile, mtile, img, oy0, ox0;
+            unit_coords(j, ntile, mtile, img, oy0, ox0);
+            const int cbase = ntile * BN + wn * (BN / 2) + lq * 4;
+            f32x4_t ssum[NT], ssq[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int row = wm * 64 + mt * 16 + l15;
+                const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+                const bool ok = oy < p.H && ox < p.W;
+                const long long pixel = ((long long)img * p.H + oy) * p.W + ox;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c = cbase + nt * 16;
+                    if (ok && c < p.Cout) {
+                        const f32x4_t v = acc[mt][nt];
+                        ssum[nt] += v;
+                        ssq[nt] += v * v;
+                        store4(y + pixel * p.Cout + c, v);
+                    }
+                    acc[mt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (p.stats_part != nullptr) {
+                auto row_sum16 = [](float v) -> float {
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+                    return v;
+                };
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ssum[nt][r] = row_sum16(ssum[nt][r]);
+                        ssq[nt][r] = row_sum16(ssq[nt][r]);
+                    }
+                if (l15 == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int cl = wn * (BN / 2) + nt * 16 + lq * 4 + r;
+                            Red[(wm * 2 + 0) * BN + cl] = ssum[nt][r];
+                            Red[(wm * 2 + 1) * BN + cl] = ssq[nt][r];
+                        }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        MPN_WS_STAMP(c_epi);
+        __builtin_amdgcn_s_barrier();                              // B(i)
+        MPN_WS_STAMP(c_bar);
+        wslot = wslot1;
+        if (++sl == 9) {
+            sl = 0;
+            ++q;
+            if (++c == nchunk) { c = 0; ++j; }
+        }
+    }
+    if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 8 + 0] = c_work; p.dbg[blockIdx.x * 8 + 1] = c_bar; p.dbg[blockIdx.x * 8 + 2] = c_epi; }
+#undef MPN_WS_STAMP
+}
+
 // ------------------------------------------------------------------ weight packing
 // Packed order (per n-tile of BN output channels): [chunk][tap][stage][kstep(2)][BN][64 bytes].
 struct PackDesc {           // one (conv, direction) packing job; lives in device memory for the batched kernel
@@ -560,8 +912,34 @@ static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
     return MPN_OK;
 }
 
+template <int BN>
+static int launch_conv_ws(const ConvParams& p, int m_tiles, hipStream_t st) {
+    const int smem = 2 * (kHaloW * kHaloH * 160) + kWsNbuf * (2 * BN * 64) + 16 * BN + 8 * p.Cin;
+    if (smem > 160 * 1024) return -100;   // caller falls back to the 4-wave kernel
+    static int attr_set = 0;
+    if (attr_set < smem) {
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_ws_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = smem;
+    }
+    const int units = m_tiles * p.n_tiles;
+    const int grid = units < 256 ? units : 256;
+    conv_ws_kernel<BN><<<dim3((unsigned)grid), dim3(kWsThreads), smem, st>>>(p, units);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
 template <typename T, int TAPS, int BN>
 static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
+    // MPN_CONV_WS=<min units>: the warp-specialised persistent kernel for bf16 3x3 layers with at least that many tiles
+    if constexpr (sizeof(T) == 2 && TAPS == 9) {
+        static int ws_min = -1;
+        if (ws_min < 0) { const char* e = getenv("MPN_CONV_WS"); ws_min = e ? atoi(e) : 0; }
+        if (ws_min > 0 && m_tiles * p.n_tiles >= ws_min && p.row_bytes == 128 && p.up_res == nullptr && p.tail.mode == 0 &&
+            p.Cin % 8 == 0) {
+            const int rc = launch_conv_ws<BN>(p, m_tiles, st);
+            if (rc != -100) return rc;
+        }
+    }
     // MPN_CONV_RING=1 selects the 3-blocks-per-CU ring variant for 128-byte chunks. Measured equal to the 2-buffer
     // variant (211 vs 210 us on 3x3 128->128 @ [32,128,128]): occupancy is not what limits this kernel, so the
     // simpler variant stays the default.
