@@ -61,6 +61,19 @@ __device__ __forceinline__ void store4(bf16_t* p, const float (&f)[4]) {
     *reinterpret_cast<uint2*>(p) = q;
 }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two packed channel pairs -> 4 consecutive channels of the storage type (one v_cvt_pk_bf16_f32 per pair)
+__device__ __forceinline__ void store4x2(float* p, f32x2_t a, f32x2_t b) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void store4x2(bf16_t* p, f32x2_t a, f32x2_t b) {
+    const bf16x2_t lo = __builtin_convertvector(a, bf16x2_t), hi = __builtin_convertvector(b, bf16x2_t);
+    uint2 q;
+    q.x = __builtin_bit_cast(unsigned, lo);
+    q.y = __builtin_bit_cast(unsigned, hi);
+    *reinterpret_cast<uint2*>(p) = q;
+}
+
 // reduce over the lanes/waves that share this thread's channel vector; result valid in threads
 // with pt == 0 (pixel lane 0). nvg is a power of two <= 8.
 template <int NV>
@@ -230,37 +243,37 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
             hr.load(p, img2, oy2, ox2, c0, cb_vecs);
         }
         __syncthreads();  // this tile's halo image is complete
-        // ALL 9 LDS reads of an output pixel issued before its first FMA (fenced): left to itself hipcc
-        // emits read / lgkmcnt(0) / FMA nine times per pixel - nine exposed LDS round trips - and the phase runs at a
-        // third of its instruction-issue rate.
+        // The phase is bound by vector INSTRUCTION ISSUE (~80 instructions per 4-channel output before this rewrite,
+        // 27 of them the 9 LDS reads + 18 packed FMAs): a thread's column (oxl) and its LDS / output offsets are fixed
+        // across its pixels (npt is a multiple of the tile width), rows advance by constant strides, the output address
+        // is a per-tile scalar base + a 32-bit per-thread offset, and interior tiles skip the bounds tests. All 9 LDS
+        // reads of a pixel are issued before its first FMA (fenced: hipcc otherwise emits read / lgkmcnt(0) / FMA nine
+        // times - nine exposed LDS round trips).
+        {
+            const int oxl = pt % TL::TW, oyl0 = pt / TL::TW, dyl = npt / TL::TW;      // npt % TW == 0 (host-checked)
+            const float* lbase = tile + ((oyl0 * STRIDE) * TL::HW + oxl * STRIDE) * cstride + cg * 4;
+            const int lstep = dyl * STRIDE * TL::HW * cstride;
+            T* ytile = y + (((long long)img * p.OH + oy0) * p.OW + ox0) * p.C + c0;   // scalar
+            int yoff = (oyl0 * p.OW + oxl) * p.C + cg * 4;
+            const int ystep = dyl * p.OW * p.C;
+            const bool full = oy0 + TL::TH <= p.OH && ox0 + TL::TW <= p.OW;          // scalar
+            const bool col_ok = cg_ok && ox0 + oxl < p.OW;
 #pragma unroll 1
-        for (int op = pt; op < TL::TH * TL::TW; op += npt) {
-            float4 q[1][9];
-            int oyl_[1], oxl_[1];
+            for (int oyl = oyl0; oyl < TL::TH; oyl += dyl, lbase += lstep, yoff += ystep) {
+                float4 q[9];
 #pragma unroll
-            for (int u = 0; u < 1; ++u) {
-                const int o = min(op + u * npt, TL::TH * TL::TW - 1);
-                oyl_[u] = o / TL::TW;
-                oxl_[u] = o - oyl_[u] * TL::TW;
-                const float* base = tile + ((oyl_[u] * STRIDE) * TL::HW + oxl_[u] * STRIDE) * cstride + cg * 4;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) q[u][t] = *reinterpret_cast<const float4*>(base + ((t / 3) * TL::HW + (t % 3)) * cstride);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 1; ++u) {
+                for (int t = 0; t < 9; ++t) q[t] = *reinterpret_cast<const float4*>(lbase + ((t / 3) * TL::HW + (t % 3)) * cstride);
+                __builtin_amdgcn_sched_barrier(0);
                 f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};   // packed FP32 FMAs (v_pk_fma_f32): two channels per instruction
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    a01 += (f32x2_t){q[u][t].x, q[u][t].y} * (f32x2_t){wr[t][0], wr[t][1]};
-                    a23 += (f32x2_t){q[u][t].z, q[u][t].w} * (f32x2_t){wr[t][2], wr[t][3]};
+                    a01 += (f32x2_t){q[t].x, q[t].y} * (f32x2_t){wr[t][0], wr[t][1]};
+                    a23 += (f32x2_t){q[t].z, q[t].w} * (f32x2_t){wr[t][2], wr[t][3]};
                 }
-                const int oy = oy0 + oyl_[u], ox = ox0 + oxl_[u];
-                if (op + u * npt < TL::TH * TL::TW && cg_ok && oy < p.OH && ox < p.OW) {
-                    const float acc[4] = {a01.x, a01.y, a23.x, a23.y};
+                if (full ? cg_ok : (col_ok && oy0 + oyl < p.OH)) {
                     s01 += a01; s23 += a23;
                     q01 += a01 * a01; q23 += a23 * a23;
-                    store4(y + (((long long)img * p.OH + oy) * p.OW + ox) * p.C + c0 + cg * 4, acc);
+                    store4x2(ytile + yoff, a01, a23);
                 }
             }
         }
