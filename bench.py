@@ -89,10 +89,13 @@ def main():
         out["roofline"] = dominant_kernel_roofline(net, args.batch, args.size, dt)
         out["config"]["step_mfma_frac_of_peak"] = whole_step_mfma_fraction(args.batch, args.size, dt_s / args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from multiposenet_amd.benchmarks import cpu_baseline, decode_benchmark, render_benchmark
+        from multiposenet_amd.benchmarks import cpu_baseline, decode_benchmark, render_benchmark, prn_benchmark
         out["cpu_baseline"] = cpu_baseline(args.size)
         out["decode"] = decode_benchmark(32)
         out["label_render"] = render_benchmark(args.batch, args.size, args.size)
+        del trainer, net
+        torch.cuda.empty_cache()
+        out["prn"] = prn_benchmark(128)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

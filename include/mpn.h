@@ -302,6 +302,22 @@ int mpn_heatmap_render(const int32_t* keypoints, const float* boxes, const int32
                        int B, int total_persons, int width, int height, int downsample, float* out,
                        void* workspace, size_t workspace_bytes, mpn_stream_t stream);
 
+/* ------------------------------------------------------------------------------------
+ * L2  PRN - pose residual network (BASELINE config 5).
+ * Replaces detector/prn.py:5-25 (flatten -> fc1 34272->1024 + ReLU -> fc2 1024->34272 + ReLU -> x + y) and the loss of
+ * prn_model.py:16-30 (softmax over h*w per keypoint channel, tf.losses.log_loss eps 1e-7, mean). The four GEMMs of a
+ * training step run on mpn_conv_fwd / mpn_conv_bwd_weight (K = 34272 contractions as split-K "weight gradients" whose
+ * pixel axis is K); these entry points are the glue: K-major operand copies, bias + ReLU, the loss and its gradient.
+ */
+int mpn_transpose_cast(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, mpn_stream_t stream);
+int mpn_cast(const void* in, int in_dtype, void* out, int out_dtype, long long n, mpn_stream_t stream);
+int mpn_bias_relu_fwd(const void* pre, int pre_dtype, const float* bias, void* y, int out_dtype, int R, int C,
+                      mpn_stream_t stream);
+int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, void* dpre, int dpre_dtype, float* dbias, int R,
+                      int C, mpn_stream_t stream);
+int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const float* labels, int B, int P, int C,
+                 float* logits, float* dlogits, float* loss_part, mpn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

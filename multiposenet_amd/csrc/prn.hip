@@ -1,0 +1,216 @@
+// PRN (pose residual network) helpers - SURVEY 8(f) rank 2, BASELINE config 5.
+// Replaces detector/prn.py:5-25 (`prn`: flatten -> fc1 34272->1024 + ReLU -> fc2 1024->34272 + ReLU -> residual) and the
+// loss of prn_model.py:16-30 (softmax over the h*w axis per keypoint channel + tf.losses.log_loss, mean).
+// The four GEMMs run on the MFMA kernels that already exist (the two with K = 34272 as split-K "weight gradients" of a
+// 1x1 convolution whose pixel axis is K, the other two as a 1x1 convolution / its weight gradient); this file holds what
+// is left: transposes / casts that put an operand K-major, bias + ReLU forward / backward, and the loss with its gradient.
+#include "common.h"
+
+namespace {
+constexpr int kThreads = 256;
+
+template <typename T> __device__ __forceinline__ float ld_f32(const T* p, long long i) { return to_f32(p[i]); }
+
+// out[c][r] = (TO) in[r][c]   (in: [R][C], out: [C][R]); 32x32 tiles through LDS, coalesced both ways
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kThreads) void transpose_cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int r = r0 + ty + k, c = c0 + tx;
+        tile[ty + k][tx] = (r < R && c < C) ? to_f32(in[(long long)r * C + c]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 32; k += 8) {
+        const int c = c0 + ty + k, r = r0 + tx;
+        if (c < C && r < R) out[(long long)c * R + r] = from_f32<TO>(tile[tx][ty + k]);
+    }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kThreads) void cast_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+        out[i] = from_f32<TO>(to_f32(in[i]));
+}
+
+// y[r][c] = relu(pre[r][c] + bias[c])      (pre: f32 partial-reduced GEMM output or storage type)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kThreads) void bias_relu_fwd_kernel(const TI* __restrict__ pre, const float* __restrict__ bias,
+                                                                TO* __restrict__ y, long long n, int C) {
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const float v = to_f32(pre[i]) + bias[i % C];
+        y[i] = from_f32<TO>(fmaxf(v, 0.f));
+    }
+}
+
+// dpre[r][c] = y[r][c] > 0 ? dy[r][c] : 0;  dbias[c] = sum_r dpre[r][c]   (one thread per column, R rows: tiny R)
+template <typename TY, typename TD>
+__global__ __launch_bounds__(kThreads) void bias_relu_bwd_kernel(const TY* __restrict__ y, const float* __restrict__ dy,
+                                                                TD* __restrict__ dpre, float* __restrict__ dbias, int R, int C) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const long long i = (long long)r * C + c;
+        const float g = to_f32(y[i]) > 0.f ? dy[i] : 0.f;
+        dpre[i] = from_f32<TD>(g);
+        s += g;   // dbias from the unrounded gradient
+    }
+    dbias[c] = s;
+}
+
+// logits[b][p][c] = x[b][p][c] + y2[b][p][c];  prob = softmax over p;  loss = mean(log_loss(labels, prob, eps=1e-7));
+// dlogits = d loss / d logits.  One block per image: thread (c, lane) walks pixels lane, lane+LP, ...
+constexpr int kPL = 15;   // pixel lanes per channel: 17 channels x 15 = 255 threads
+template <typename TY>
+__global__ __launch_bounds__(kThreads) void prn_loss_kernel(const float* __restrict__ x, const TY* __restrict__ y2,
+                                                           const float* __restrict__ labels, int P, int C, float inv_total,
+                                                           float* __restrict__ logits, float* __restrict__ dlogits,
+                                                           float* __restrict__ loss_part) {
+    __shared__ float red[kThreads];
+    __shared__ float stat[2][32];
+    const int b = blockIdx.x;
+    const int c = threadIdx.x / kPL, pl = threadIdx.x % kPL;
+    const bool on = c < C;
+    const long long base = (long long)b * P * C;
+    auto reduce_c = [&](float v, bool is_max) -> float {   // over the kPL lanes of this channel
+        red[threadIdx.x] = v;
+        __syncthreads();
+        float r = is_max ? -INFINITY : 0.f;
+        if (on) {
+            for (int k = 0; k < kPL; ++k) {
+                const float t = red[c * kPL + k];
+                r = is_max ? fmaxf(r, t) : r + t;
+            }
+        }
+        __syncthreads();
+        return r;
+    };
+    float m = -INFINITY;
+    if (on)
+        for (int p = pl; p < P; p += kPL) {
+            const long long i = base + (long long)p * C + c;
+            const float z = x[i] + to_f32(y2[i]);
+            logits[i] = z;
+            m = fmaxf(m, z);
+        }
+    m = reduce_c(m, true);
+    float se = 0.f;
+    if (on)
+        for (int p = pl; p < P; p += kPL) se += expf(logits[base + (long long)p * C + c] - m);
+    se = reduce_c(se, false);
+    const float inv_se = on ? 1.f / se : 0.f;
+    // loss and sum_j g_j p_j
+    const float eps = 1e-7f;
+    float l = 0.f, gp = 0.f;
+    if (on)
+        for (int p = pl; p < P; p += kPL) {
+            const long long i = base + (long long)p * C + c;
+            const float pr = expf(logits[i] - m) * inv_se;
+            const float yv = labels[i];
+            l += -yv * logf(pr + eps) - (1.f - yv) * logf(1.f - pr + eps);
+            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * inv_total;
+            gp += g * pr;
+        }
+    gp = reduce_c(gp, false);
+    if (on && dlogits != nullptr)
+        for (int p = pl; p < P; p += kPL) {
+            const long long i = base + (long long)p * C + c;
+            const float pr = expf(logits[i] - m) * inv_se;
+            const float yv = labels[i];
+            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * inv_total;
+            dlogits[i] = pr * (g - gp);
+        }
+    // block loss partial (fixed order)
+    red[threadIdx.x] = on ? l : 0.f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int k = 0; k < kThreads; ++k) s += red[k];
+        loss_part[b] = s * inv_total;
+    }
+    (void)stat;
+}
+
+int blocks_for(long long n) {
+    long long b = (n + kThreads - 1) / kThreads;
+    if (b > 8192) b = 8192;
+    return (int)(b < 1 ? 1 : b);
+}
+}  // namespace
+
+/* out[C][R] = cast(in[R][C]); in_dtype / out_dtype: MPN_F32 or MPN_BF16 */
+extern "C" int mpn_transpose_cast(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, mpn_stream_t stream) {
+    MPN_REQUIRE(in && out && R > 0 && C > 0, MPN_ERR_BAD_ARG, "transpose_cast: bad arguments");
+    MPN_REQUIRE((in_dtype == MPN_F32 || in_dtype == MPN_BF16) && (out_dtype == MPN_F32 || out_dtype == MPN_BF16), MPN_ERR_BAD_DTYPE,
+                "transpose_cast: dtype");
+    const dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32));
+    hipStream_t st = (hipStream_t)stream;
+    if (in_dtype == MPN_F32 && out_dtype == MPN_F32) transpose_cast_kernel<float, float><<<grid, kThreads, 0, st>>>((const float*)in, (float*)out, R, C);
+    else if (in_dtype == MPN_F32) transpose_cast_kernel<float, bf16_t><<<grid, kThreads, 0, st>>>((const float*)in, (bf16_t*)out, R, C);
+    else if (out_dtype == MPN_F32) transpose_cast_kernel<bf16_t, float><<<grid, kThreads, 0, st>>>((const bf16_t*)in, (float*)out, R, C);
+    else transpose_cast_kernel<bf16_t, bf16_t><<<grid, kThreads, 0, st>>>((const bf16_t*)in, (bf16_t*)out, R, C);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* out[i] = cast(in[i]) */
+extern "C" int mpn_cast(const void* in, int in_dtype, void* out, int out_dtype, long long n, mpn_stream_t stream) {
+    MPN_REQUIRE(in && out && n > 0, MPN_ERR_BAD_ARG, "cast: bad arguments");
+    MPN_REQUIRE((in_dtype == MPN_F32 || in_dtype == MPN_BF16) && (out_dtype == MPN_F32 || out_dtype == MPN_BF16), MPN_ERR_BAD_DTYPE, "cast: dtype");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = blocks_for(n);
+    if (in_dtype == MPN_F32 && out_dtype == MPN_BF16) cast_kernel<float, bf16_t><<<g, kThreads, 0, st>>>((const float*)in, (bf16_t*)out, n);
+    else if (in_dtype == MPN_BF16 && out_dtype == MPN_F32) cast_kernel<bf16_t, float><<<g, kThreads, 0, st>>>((const bf16_t*)in, (float*)out, n);
+    else if (in_dtype == MPN_F32) cast_kernel<float, float><<<g, kThreads, 0, st>>>((const float*)in, (float*)out, n);
+    else cast_kernel<bf16_t, bf16_t><<<g, kThreads, 0, st>>>((const bf16_t*)in, (bf16_t*)out, n);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* y[R][C] = relu(pre + bias[c]);  pre: f32 (pre_dtype MPN_F32) or storage type, y: out_dtype */
+extern "C" int mpn_bias_relu_fwd(const void* pre, int pre_dtype, const float* bias, void* y, int out_dtype, int R, int C,
+                                 mpn_stream_t stream) {
+    MPN_REQUIRE(pre && bias && y && R > 0 && C > 0, MPN_ERR_BAD_ARG, "bias_relu_fwd: bad arguments");
+    const long long n = (long long)R * C;
+    hipStream_t st = (hipStream_t)stream;
+    const int g = blocks_for(n);
+    if (pre_dtype == MPN_F32 && out_dtype == MPN_F32) bias_relu_fwd_kernel<float, float><<<g, kThreads, 0, st>>>((const float*)pre, bias, (float*)y, n, C);
+    else if (pre_dtype == MPN_F32 && out_dtype == MPN_BF16) bias_relu_fwd_kernel<float, bf16_t><<<g, kThreads, 0, st>>>((const float*)pre, bias, (bf16_t*)y, n, C);
+    else if (pre_dtype == MPN_BF16 && out_dtype == MPN_BF16) bias_relu_fwd_kernel<bf16_t, bf16_t><<<g, kThreads, 0, st>>>((const bf16_t*)pre, bias, (bf16_t*)y, n, C);
+    else if (pre_dtype == MPN_BF16 && out_dtype == MPN_F32) bias_relu_fwd_kernel<bf16_t, float><<<g, kThreads, 0, st>>>((const bf16_t*)pre, bias, (float*)y, n, C);
+    else MPN_FAIL(MPN_ERR_BAD_DTYPE, "bias_relu_fwd: dtype");
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* dpre = (y > 0) * dy (storage dtype of the GEMM operand), dbias[c] = column sums; dy f32 */
+extern "C" int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, void* dpre, int dpre_dtype, float* dbias, int R,
+                                 int C, mpn_stream_t stream) {
+    MPN_REQUIRE(y && dy && dpre && dbias && R > 0 && C > 0, MPN_ERR_BAD_ARG, "bias_relu_bwd: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = (C + kThreads - 1) / kThreads;
+    if (y_dtype == MPN_F32 && dpre_dtype == MPN_F32) bias_relu_bwd_kernel<float, float><<<g, kThreads, 0, st>>>((const float*)y, dy, (float*)dpre, dbias, R, C);
+    else if (y_dtype == MPN_BF16 && dpre_dtype == MPN_BF16) bias_relu_bwd_kernel<bf16_t, bf16_t><<<g, kThreads, 0, st>>>((const bf16_t*)y, dy, (bf16_t*)dpre, dbias, R, C);
+    else MPN_FAIL(MPN_ERR_BAD_DTYPE, "bias_relu_bwd: dtype");
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* PRN loss (prn_model.py:16-30): logits = x + y2 [B][P][C]; softmax over P; mean log_loss; C <= 17.
+ * logits, dlogits (may be NULL): f32 [B][P][C]; loss_part: f32 [B] (sum = loss). */
+extern "C" int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const float* labels, int B, int P, int C,
+                            float* logits, float* dlogits, float* loss_part, mpn_stream_t stream) {
+    MPN_REQUIRE(x && y2 && labels && logits && loss_part, MPN_ERR_BAD_ARG, "prn_loss: null pointer");
+    MPN_REQUIRE(B > 0 && P > 0 && C > 0 && C * kPL <= kThreads, MPN_ERR_BAD_SHAPE, "prn_loss: C must be <= %d", kThreads / kPL);
+    const float inv_total = 1.0f / ((float)B * (float)P * (float)C);
+    hipStream_t st = (hipStream_t)stream;
+    if (y2_dtype == MPN_F32) prn_loss_kernel<float><<<B, kThreads, 0, st>>>(x, (const float*)y2, labels, P, C, inv_total, logits, dlogits, loss_part);
+    else if (y2_dtype == MPN_BF16) prn_loss_kernel<bf16_t><<<B, kThreads, 0, st>>>(x, (const bf16_t*)y2, labels, P, C, inv_total, logits, dlogits, loss_part);
+    else MPN_FAIL(MPN_ERR_BAD_DTYPE, "prn_loss: dtype");
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}

@@ -1,0 +1,167 @@
+"""Pose residual network on the HIP kernels - `prn` (reference detector/prn.py:5-25) and the TRAIN / EVAL step of
+prn_model.py:5-57 (softmax-over-space log loss, cosine LR, TF-Adam without clipping).
+
+GEMM mapping (b = number of crops, n = h*w*c = 34272, hidden = 1024):
+    fc1 forward   pre1[b,1024] = X[b,n] W1[n,1024]        K = n: split-K "weight gradient" of a 1x1 conv whose pixel
+    fc2 dgrad     dH[b,1024]   = dPre2[b,n] W2^T[n,1024]   axis is K (operands K-major: X^T / dPre2^T, W1 / W2^T)
+    fc2 forward   pre2[b,n]    = H[b,1024] W2[1024,n]      1x1 conv, 1024 -> n channels over b "pixels"
+    fc1 / fc2 wgrad                                        1x1 conv weight gradients over b "pixels" (one slab each)
+"""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import call, ptr, stream_ptr
+from .net import _Arena
+
+NUM_KEYPOINTS = 17
+CROP_SIZE = (56, 36)     # detector/constants.py
+HIDDEN = 1024
+
+
+def variable_shapes(h=CROP_SIZE[0], w=CROP_SIZE[1], c=NUM_KEYPOINTS, hidden=HIDDEN):
+    n = h * w * c
+    return OrderedDict([("PRN/fc1/weights", (n, hidden)), ("PRN/fc1/biases", (hidden,)),
+                        ("PRN/fc2/weights", (hidden, n)), ("PRN/fc2/biases", (n,))])
+
+
+def initial_values(seed=0, **kw):
+    rs = np.random.RandomState(seed)
+    out = OrderedDict()
+    for k, shp in variable_shapes(**kw).items():
+        if k.endswith("weights"):       # tf.variance_scaling_initializer(): truncated normal, fan_in
+            std = np.sqrt(1.0 / shp[0]) / 0.87962566103423978
+            out[k] = (np.clip(rs.randn(*shp), -2, 2) * std).astype(np.float32)
+        else:
+            out[k] = np.zeros(shp, np.float32)
+    return out
+
+
+class PoseResidualNet:
+    def __init__(self, values=None, batch=128, h=CROP_SIZE[0], w=CROP_SIZE[1], c=NUM_KEYPOINTS, hidden=HIDDEN,
+                 dtype=torch.bfloat16, device="cuda:0", seed=0):
+        _lib.lib()   # fail loudly without the HIP library
+        self.B, self.h, self.w, self.c, self.hidden = int(batch), h, w, c, hidden
+        self.n = h * w * c
+        if self.n % 8 or hidden % 8:
+            raise ValueError("h*w*c and hidden must be multiples of 8")
+        self.dtype, self.device = dtype, torch.device(device)
+        shapes = variable_shapes(h, w, c, hidden)
+        self._arena = _Arena(shapes, self.device)
+        self.theta, self.grad = self._arena.new(), self._arena.new()
+        self.adam_m, self.adam_v = self._arena.new(), self._arena.new()
+        self.vars, self.grads = self._arena.views(self.theta), self._arena.views(self.grad)
+        self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
+        self.load_state_dict(values if values is not None else initial_values(seed, h=h, w=w, c=c, hidden=hidden))
+        dev, B, n = self.device, self.B, self.n
+        W1, W2 = self.vars["PRN/fc1/weights"], self.vars["PRN/fc2/weights"]
+        # operand copies in the storage dtype: W1 [n,1024] (K-major as stored), W2^T [n,1024], W2 packed for conv_fwd
+        self.w1_op = W1 if dtype == torch.float32 else torch.empty((n, hidden), dtype=dtype, device=dev)
+        self.w2t_op = torch.empty((n, hidden), dtype=dtype, device=dev)
+        self.w2_conv = ops.PackedConv(W2.view(1, 1, hidden, n), dtype)
+        f32 = torch.float32
+        self.xt = torch.empty((n, B), dtype=dtype, device=dev)            # X^T
+        self.x_op = torch.empty((B, n), dtype=dtype, device=dev)          # X in the storage dtype (fc1 wgrad operand)
+        self.pre1 = torch.empty((B, hidden), dtype=f32, device=dev)
+        self.hid = torch.empty((B, hidden), dtype=dtype, device=dev)
+        self.pre2 = torch.empty((B, n), dtype=dtype, device=dev)
+        self.y2 = torch.empty((B, n), dtype=dtype, device=dev)
+        self.logits = torch.empty((B, n), dtype=f32, device=dev)
+        self.dlogits = torch.empty((B, n), dtype=f32, device=dev)
+        self.dpre2 = torch.empty((B, n), dtype=dtype, device=dev)
+        self.dpre2t = torch.empty((n, B), dtype=dtype, device=dev)
+        self.dhid = torch.empty((B, hidden), dtype=f32, device=dev)
+        self.dpre1 = torch.empty((B, hidden), dtype=dtype, device=dev)
+        self.loss_part = torch.empty(B, dtype=f32, device=dev)
+        nparts = ops.conv_wgrad_num_parts(1, 1, n, B, hidden, 1, dtype)   # the two K = n contractions
+        self.kslab = torch.empty(nparts * B * hidden, dtype=f32, device=dev)
+        self._kparts = nparts
+        for name, cin, cout in (("PRN/fc1/weights", n, hidden), ("PRN/fc2/weights", hidden, n)):
+            if ops.conv_wgrad_num_parts(1, 1, B, cin, cout, 1, dtype) != 1:
+                raise RuntimeError("weight-gradient geometry changed: expected one slab for " + name)
+        self.refresh_operands()
+
+    # ---------------------------------------------------------------- state
+    def state_dict(self):
+        return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.vars.items())
+
+    def load_state_dict(self, values):
+        for k, v in self.vars.items():
+            a = np.asarray(values[k], np.float32)
+            if a.shape != tuple(v.shape):
+                raise ValueError(f"{k}: shape {a.shape} != {tuple(v.shape)}")
+            v.copy_(torch.from_numpy(a))
+
+    def refresh_operands(self):
+        """Operand copies of the f32 masters (after every optimizer step)."""
+        dc = _lib.dtype_code(self.dtype)
+        W1, W2 = self.vars["PRN/fc1/weights"], self.vars["PRN/fc2/weights"]
+        if self.dtype != torch.float32:
+            call("mpn_cast", ptr(W1), _lib.dtype_code(torch.float32), ptr(self.w1_op), dc, W1.numel(), stream_ptr())
+        call("mpn_transpose_cast", ptr(W2), _lib.dtype_code(torch.float32), ptr(self.w2t_op), dc, self.hidden, self.n, stream_ptr())
+        self.w2_conv.repack(with_bwd=False)
+
+    # ---------------------------------------------------------------- forward / loss / backward
+    def _kgemm(self, at, bmat, out):
+        """out[B? rows = at.shape[1], cols = bmat.shape[1]] = at^T @ bmat with the contraction over the n rows."""
+        n, rows = at.shape
+        cols = bmat.shape[1]
+        ops.conv_bwd_weight(at.view(1, 1, n, rows), bmat.view(1, 1, n, cols), 1, None, out.view(1, 1, rows, cols), self.kslab)
+
+    def forward(self, x):
+        """x: f32 [b,h,w,c] device tensor (b == batch). Returns y2 = relu(fc2(relu(fc1(x)))) [b, n] (storage dtype);
+        logits = x + y2 are formed by `loss` / `predict`."""
+        B, n, dc = self.B, self.n, _lib.dtype_code(self.dtype)
+        if tuple(x.shape) != (B, self.h, self.w, self.c) or x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError(f"x must be contiguous float32 [{B},{self.h},{self.w},{self.c}]")
+        f32c = _lib.dtype_code(torch.float32)
+        call("mpn_transpose_cast", ptr(x), f32c, ptr(self.xt), dc, B, n, stream_ptr())
+        call("mpn_cast", ptr(x), f32c, ptr(self.x_op), dc, B * n, stream_ptr())
+        self._kgemm(self.xt, self.w1_op, self.pre1)
+        call("mpn_bias_relu_fwd", ptr(self.pre1), f32c, ptr(self.vars["PRN/fc1/biases"]), ptr(self.hid), dc, B, self.hidden, stream_ptr())
+        ops.conv_fwd(self.hid.view(1, 1, B, self.hidden), self.w2_conv.fwd, n, 1, None, out=self.pre2.view(1, 1, B, n))
+        call("mpn_bias_relu_fwd", ptr(self.pre2), dc, ptr(self.vars["PRN/fc2/biases"]), ptr(self.y2), dc, B, n, stream_ptr())
+        self._x = x
+        return self.y2
+
+    def loss(self, labels, with_grad=True):
+        """labels f32 [b,h,w,c]. Returns the device scalar loss (prn_model.py:29); fills logits (and dlogits)."""
+        B = self.B
+        call("mpn_prn_loss", ptr(self._x), ptr(self.y2), _lib.dtype_code(self.dtype), ptr(labels), B, self.h * self.w, self.c,
+             ptr(self.logits), ptr(self.dlogits) if with_grad else None, ptr(self.loss_part), stream_ptr())
+        return self.loss_part.sum()
+
+    def predict(self, x):
+        """Inference: logits [b,h,w,c] f32 (create_pb.py:112)."""
+        self.forward(x)
+        return (x.reshape(self.B, self.n) + self.y2.float()).view(self.B, self.h, self.w, self.c)
+
+    def backward(self):
+        B, n, hidden, dc = self.B, self.n, self.hidden, _lib.dtype_code(self.dtype)
+        g = self.grads
+        call("mpn_bias_relu_bwd", ptr(self.y2), dc, ptr(self.dlogits), ptr(self.dpre2), dc, ptr(g["PRN/fc2/biases"]), B, n, stream_ptr())
+        # fc2 weight gradient: dW2[1024,n] = H^T dPre2 (one slab = the gradient itself)
+        ops.conv_bwd_weight(self.hid.view(1, 1, B, hidden), self.dpre2.view(1, 1, B, n), 1, None,
+                            g["PRN/fc2/weights"].view(1, 1, hidden, n), g["PRN/fc2/weights"].view(-1), reduce=False)
+        # fc2 data gradient: dH = dPre2 W2^T (K = n)
+        call("mpn_transpose_cast", ptr(self.dpre2), dc, ptr(self.dpre2t), dc, B, n, stream_ptr())
+        self._kgemm(self.dpre2t, self.w2t_op, self.dhid)
+        call("mpn_bias_relu_bwd", ptr(self.hid), dc, ptr(self.dhid), ptr(self.dpre1), dc, ptr(g["PRN/fc1/biases"]), B, hidden, stream_ptr())
+        # fc1 weight gradient: dW1[n,1024] = X^T dPre1
+        ops.conv_bwd_weight(self.x_op.view(1, 1, B, n), self.dpre1.view(1, 1, B, hidden), 1, None,
+                            g["PRN/fc1/weights"].view(1, 1, n, hidden), g["PRN/fc1/weights"].view(-1), reduce=False)
+
+    def optimizer_step(self, initial_learning_rate, num_steps):
+        ops.adam_prepare(self.global_step, self.hyper, initial_learning_rate, num_steps)
+        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, clip=float("inf"))
+        self.refresh_operands()
+
+    def train_step(self, x, labels, initial_learning_rate, num_steps):
+        self.forward(x)
+        loss = self.loss(labels)
+        self.backward()
+        self.optimizer_step(initial_learning_rate, num_steps)
+        return loss

@@ -1,0 +1,41 @@
+"""`model_fn(features, labels, mode, params)` of the reference's prn_model.py:5-57 on the HIP kernels.
+
+features: float32 [b, 56, 36, 17] person-crop heatmaps (numpy or CUDA tensor), labels: the same shape (one-hot peaks per
+visible keypoint, prn_pipeline.py); mode: ModeKeys.TRAIN | EVAL; params: {'initial_learning_rate', 'num_steps'} (+ optional
+'dtype': 'bf16' | 'f32', 'values': initial variables by reference name). TRAIN performs the optimizer step.
+"""
+import numpy as np
+import torch
+
+from .keypoints_model import EstimatorSpec, ModeKeys
+from .prn import PoseResidualNet
+
+_models = {}
+
+
+def _model(params, batch, shape):
+    key = (id(params), batch, shape)
+    if key not in _models:
+        dt = torch.float32 if params.get("dtype", "bf16") == "f32" else torch.bfloat16
+        _models[key] = PoseResidualNet(values=params.get("values"), batch=batch, h=shape[0], w=shape[1], c=shape[2], dtype=dt)
+    return _models[key]
+
+
+def _dev(a):
+    if isinstance(a, np.ndarray):
+        a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return a.to("cuda:0", torch.float32).contiguous()
+
+
+def model_fn(features, labels, mode, params):
+    assert mode != ModeKeys.PREDICT                       # prn_model.py:7
+    x, y = _dev(features), _dev(labels)
+    if x.dim() != 4 or x.shape != y.shape:
+        raise ValueError(f"features and labels must be [b, h, w, c] of equal shape, got {tuple(x.shape)} / {tuple(y.shape)}")
+    net = _model(params, x.shape[0], tuple(x.shape[1:]))
+    if mode == ModeKeys.TRAIN:
+        loss = net.train_step(x, y, float(params["initial_learning_rate"]), int(params["num_steps"]))
+        return EstimatorSpec(mode=mode, loss=loss, train_op=net.global_step, eval_metric_ops=None, losses={"logloss": loss})
+    net.forward(x)
+    loss = net.loss(y, with_grad=False)
+    return EstimatorSpec(mode=mode, loss=loss, train_op=None, eval_metric_ops={"eval_loss": loss}, losses={"logloss": loss})
