@@ -10,6 +10,7 @@
 // the lanes that share a channel vector, then one LDS hop across the 4 waves).
 #include "common.h"
 #include "bn_tail.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -295,6 +296,189 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward, register sliding window ("sw"): no LDS tile, no barrier in the loop. A thread owns 4 channels of ONE output
+// column and walks down a strip of SWR output rows; the 3x3 window of activated inputs lives in registers, each step
+// loads the 3 (stride 1) or 6 (stride 2) new 8-byte pieces straight from global memory (neighbouring columns overlap
+// and hit in L1), applies the producer's batch-norm affine + activation, and emits one 4-channel output. Memory latency
+// is hidden by occupancy (~70 registers) and by requesting the next row's pieces before the current row is multiplied.
+// Lanes run over (column, 4-channel group) with channels fastest, so every wave access is a contiguous run of pixels.
+constexpr int SWR = 16;   // output rows per thread
+
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { float4 v; };
+template <> struct Raw4<bf16_t> { uint2 v; };
+__device__ __forceinline__ void raw_load(Raw4<float>& r, const float* p) { r.v = *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void raw_load(Raw4<bf16_t>& r, const bf16_t* p) { r.v = *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ void raw_unpack(const Raw4<float>& r, float (&f)[4]) { f[0] = r.v.x; f[1] = r.v.y; f[2] = r.v.z; f[3] = r.v.w; }
+__device__ __forceinline__ void raw_unpack(const Raw4<bf16_t>& r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.v.x << 16); f[1] = __uint_as_float(r.v.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.v.y << 16); f[3] = __uint_as_float(r.v.y & 0xffff0000u);
+}
+
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams p, int ncg, int cols, int xblocks, int yblocks) {
+    __shared__ float red[kThreads * 8];
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    T* __restrict__ y = reinterpret_cast<T*>(p.y);
+    int b = blockIdx.x;
+    const int xb = b % xblocks; b /= xblocks;
+    const int yb = b % yblocks; b /= yblocks;
+    const int cgb = b % p.cblocks;
+    const int img = b / p.cblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;       // 4-channel group inside the block, column
+    const int c = (cgb * ncg + cgl) * 4;
+    const int ox = xb * cols + col;
+    const bool lane_ok = c < p.C && ox < p.OW && col < cols;
+    const int cc = lane_ok ? c : 0;
+    float wr[9][4], sc[4], sh[4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[t][j] = p.w[(p.flip ? 8 - t : t) * p.C + cc + j];
+    const bool aff = p.in_scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = aff ? p.in_scale[cc + j] : 1.f; sh[j] = aff ? p.in_shift[cc + j] : 0.f; }
+    const float lo = (aff && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (aff && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+
+    const int oy_begin = yb * SWR, oy_end = min(oy_begin + SWR, p.OH);
+    const int ix0 = ox * STRIDE - p.pad_l;                            // leftmost input column of the window
+    const T* ximg = x + (long long)img * p.H * p.W * p.C + cc;
+    bool xok[3];
+    int xoff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ix = ix0 + k;
+        xok[k] = lane_ok && ix >= 0 && ix < p.W;
+        xoff[k] = (xok[k] ? ix : 0) * p.C;
+    }
+    // one input row: 3 raw pieces (unpredicated loads from clamped addresses) -> activated f32, zero outside the image
+    auto row_load = [&](Raw4<T> (&r)[3], int iy) {
+        const int iyc = min(max(iy, 0), p.H - 1);
+        const T* rowp = ximg + (long long)iyc * p.W * p.C;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) raw_load(r[k], rowp + xoff[k]);
+    };
+    // (row validity is uniform over the block: a scalar branch; only the outer columns of the window can fall outside
+    //  the image in x, so the centre column of a stride-1 window needs no select at all)
+    auto row_act = [&](const Raw4<T> (&r)[3], int iy, f32x2_t (&a)[3][2]) {
+        if (iy < 0 || iy >= p.H) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a[k][0] = (f32x2_t){0.f, 0.f}; a[k][1] = (f32x2_t){0.f, 0.f}; }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float f[4];
+            raw_unpack(r[k], f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);
+            if (STRIDE != 1 || k != 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = xok[k] ? f[j] : 0.f;
+            }
+            a[k][0] = (f32x2_t){f[0], f[1]};
+            a[k][1] = (f32x2_t){f[2], f[3]};
+        }
+    };
+    f32x2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+    f32x2_t w01[9], w23[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { w01[t] = (f32x2_t){wr[t][0], wr[t][1]}; w23[t] = (f32x2_t){wr[t][2], wr[t][3]}; }
+
+    f32x2_t r0[3][2], r1[3][2], r2[3][2];                             // window rows (activated), [column][channel pair]
+    T* yp = y + (((long long)img * p.OH + oy_begin) * p.OW + ox) * p.C + cc;
+    const long long ystep = (long long)p.OW * p.C;
+    auto emit = [&](const f32x2_t (&a)[3][2], const f32x2_t (&bb)[3][2], const f32x2_t (&cr)[3][2]) {
+        f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a01 += a[k][0] * w01[k];      a23 += a[k][1] * w23[k];
+            a01 += bb[k][0] * w01[3 + k]; a23 += bb[k][1] * w23[3 + k];
+            a01 += cr[k][0] * w01[6 + k]; a23 += cr[k][1] * w23[6 + k];
+        }
+        if (lane_ok) {
+            s01 += a01; s23 += a23;
+            q01 += a01 * a01; q23 += a23 * a23;
+            store4x2(yp, a01, a23);
+        }
+        yp += ystep;
+    };
+    if (STRIDE == 1) {
+        // rows iy = oy-1, oy, oy+1: prime two rows, then one new row per output row (unrolled by 3: the window registers
+        // rotate roles). The load of the following row is issued right after the current one is activated and flies
+        // while the output row is multiplied and stored.
+        // THREE raw row buffers rotate with the window: a buffer is re-requested (3 rows ahead) as soon as it has been
+        // activated, so three rows (9 pieces = 72 bytes per thread, ~70 KB per CU) are always in flight - with one row in
+        // flight the kernel ran at 3.4 TB/s, exactly what its bytes in flight allow.
+        Raw4<T> ra[3], rb[3], rc[3];
+        int iy = oy_begin - p.pad_t;
+        row_load(ra, iy);
+        row_load(rb, iy + 1);
+        row_load(rc, iy + 2);
+        row_act(ra, iy, r0);
+        row_load(ra, iy + 3);
+        row_act(rb, iy + 1, r1);
+        row_load(rb, iy + 4);
+        iy += 2;
+        for (int oy = oy_begin; oy < oy_end; oy += 3, iy += 3) {
+            row_act(rc, iy, r2);
+            row_load(rc, iy + 3);
+            emit(r0, r1, r2);
+            if (oy + 1 < oy_end) {
+                row_act(ra, iy + 1, r0);
+                row_load(ra, iy + 4);
+                emit(r1, r2, r0);
+            }
+            if (oy + 2 < oy_end) {
+                row_act(rb, iy + 2, r1);
+                row_load(rb, iy + 5);
+                emit(r2, r0, r1);
+            }
+        }
+    } else {
+        // rows iy = 2*oy - pad_t + {0,1,2}; consecutive outputs share one row (the third becomes the first)
+        Raw4<T> ra[3], rb[3];
+        int iy = oy_begin * 2 - p.pad_t;
+        row_load(ra, iy);
+        row_act(ra, iy, r0);
+        row_load(ra, iy + 1);
+        row_load(rb, iy + 2);
+        for (int oy = oy_begin; oy < oy_end; oy += 2, iy += 4) {
+            row_act(ra, iy + 1, r1);
+            row_act(rb, iy + 2, r2);
+            row_load(ra, iy + 3);
+            row_load(rb, iy + 4);
+            emit(r0, r1, r2);
+            if (oy + 1 < oy_end) {
+                row_act(ra, iy + 3, r1);
+                row_act(rb, iy + 4, r0);
+                row_load(ra, iy + 5);
+                row_load(rb, iy + 6);
+                emit(r2, r1, r0);
+            }
+        }
+    }
+    if (p.part != nullptr) {
+        // partial row of this block: sum over the block's columns per 4-channel group (fixed order)
+        float st[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = lane_ok ? st[j] : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < ncg && (cgb * ncg + (int)threadIdx.x) * 4 < p.C) {
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int cidx = 0; cidx < cols; ++cidx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += red[(cidx * ncg + threadIdx.x) * 8 + j];
+            const int prow = (img * yblocks + yb) * xblocks + xb;
+            float* dst = p.part + (long long)prow * 2 * p.C + (cgb * ncg + threadIdx.x) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[j] = acc8[j]; dst[p.C + j] = acc8[4 + j]; }
+        }
+    }
+}
+
 // stride-2 data gradient (gather form): dx[iy,ix,c] = sum_{ky,kx} dy[(iy+pt-ky)/2,(ix+pl-kx)/2,c]*w[ky,kx,c]
 // over the taps for which the division is exact. One thread = one input pixel x 16 bytes of channels.
 template <typename T>
@@ -469,7 +653,29 @@ template <typename K> int set_smem(K kernel, size_t bytes) {
 
 extern "C" int mpn_dwconv_out_size(int size, int stride) { return (size + stride - 1) / stride; }
 
-static int dw_fwd_nsplit(const DwParams& p) {
+// register sliding-window forward kernel (default) vs the LDS-tile kernel (MPN_DW_SW=0)
+static int g_dw_sw = -1;
+static bool dw_use_sw() {
+    if (g_dw_sw < 0) { const char* e = getenv("MPN_DW_SW"); g_dw_sw = e ? atoi(e) : 1; }
+    return g_dw_sw != 0;
+}
+/* diagnostic hook (not part of the public header): 1 = sliding-window forward kernel, 0 = LDS-tile kernel, -1 = MPN_DW_SW / default.
+   Only call between steps: the stats slab geometry (mpn_dwconv_fwd_num_parts) follows the choice. */
+extern "C" void mpn_debug_set_dw_kernel(int sw) { g_dw_sw = sw; }
+struct DwSwGeom { int ncg, cols, xblocks, yblocks, cblocks; };
+static DwSwGeom dw_sw_geom(const DwParams& p) {
+    DwSwGeom g;
+    const int cg_total = p.C / 4;
+    g.ncg = cg_total < kThreads ? cg_total : kThreads;
+    g.cols = kThreads / g.ncg;
+    g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
+    g.xblocks = (p.OW + g.cols - 1) / g.cols;
+    g.yblocks = (p.OH + SWR - 1) / SWR;
+    return g;
+}
+
+static int dw_fwd_nsplit(const DwParams& p, bool lds_kernel = false) {
+    if (dw_use_sw() && !lds_kernel) { const DwSwGeom g = dw_sw_geom(p); return p.N * g.yblocks * g.xblocks; }
     const int ntiles = p.N * p.tiles_y * p.tiles_x;
     int nsplit = 2048 / p.cblocks;   // ~8 blocks per CU
     if (nsplit < 1) nsplit = 1;
@@ -502,10 +708,23 @@ extern "C" int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N,
     p.x = x; p.w = w; p.y = y; p.part = stats_part;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.flip = flip;
     const int ve = dtype == MPN_F32 ? 4 : 8;
-    const int nsplit = dw_fwd_nsplit(p);
+    const bool want_tail = tail != nullptr && tail->mode != 0;   // the fused finalize lives in the LDS-tile kernel only
+    const int nsplit = dw_fwd_nsplit(p, want_tail);
+    hipStream_t st = (hipStream_t)stream;
+    if (dw_use_sw() && !want_tail) {
+        const DwSwGeom g = dw_sw_geom(p);
+        p.cblocks = g.cblocks;
+        const long long blocks = (long long)p.N * g.cblocks * g.yblocks * g.xblocks;
+        MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_fwd: grid too large");
+        MPN_DISPATCH_DTYPE(dtype, {
+            if (stride == 1) dwconv_fwd_sw_kernel<T, 1><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
+            else dwconv_fwd_sw_kernel<T, 2><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
+        });
+        MPN_LAUNCH_CHECK();
+        return MPN_OK;
+    }
     const int grid = nsplit * p.cblocks;
     bn_tail_prepare(tail, nsplit, C, &p.tail);
-    hipStream_t st = (hipStream_t)stream;
     if (stride == 1) {
         const size_t sm = dw_smem<1>(ve, 8, p.nvg);
         MPN_DISPATCH_DTYPE(dtype, {
