@@ -279,6 +279,69 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ k1, const float* __restrict__ k2, int act, const float* __restrict__ add_ch0) {
     constexpr int VE = Vec16<T>::N;
+    constexpr int U = 4;   // 16-byte vectors of each operand in flight per thread
+    const int cvec = C / VE;
+    // the grid stride (a multiple of kThreads) is a multiple of cvec (a power of two <= kThreads, checked by the launcher):
+    // a thread keeps its channel vector, so the six per-channel parameters fold into registers ONCE:
+    //   out = sc*(g - k1 - xhat*k2) = sc*g + cb*x + cc,  cb = -sc*k2*invstd,  cc = -sc*(k1 - mean*invstd*k2)
+    // (re-loading them per element was 48 dword loads per 16-byte vector: bound by the texture unit, not by HBM)
+    const long long i0 = (long long)blockIdx.x * kThreads + threadIdx.x;
+    const int vg = (int)(i0 % cvec);
+    float sc[VE], sh[VE], cb[VE], cc[VE];
+#pragma unroll
+    for (int j4 = 0; j4 < VE; j4 += 4) {
+        const int c = vg * VE + j4;
+        const float4 s4 = *reinterpret_cast<const float4*>(scale + c), h4 = *reinterpret_cast<const float4*>(shift + c);
+        const float4 m4 = *reinterpret_cast<const float4*>(mean + c), i4 = *reinterpret_cast<const float4*>(invstd + c);
+        const float4 a4 = *reinterpret_cast<const float4*>(k1 + c), b4 = *reinterpret_cast<const float4*>(k2 + c);
+        const float ss[4] = {s4.x, s4.y, s4.z, s4.w}, hh[4] = {h4.x, h4.y, h4.z, h4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w};
+        const float ii[4] = {i4.x, i4.y, i4.z, i4.w}, aa[4] = {a4.x, a4.y, a4.z, a4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sc[j4 + j] = ss[j];
+            sh[j4 + j] = hh[j];
+            cb[j4 + j] = -ss[j] * bb[j] * ii[j];
+            cc[j4 + j] = -ss[j] * (aa[j] - mm[j] * ii[j] * bb[j]);
+        }
+    }
+    const float lo = (act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = i0; i < nvec; i += U * stride) {
+        Vec16<T> vd[U], vx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long ii = i + u * stride;
+            const long long ic = ii < nvec ? ii : i;   // unconditional loads from a valid address (a predicated load waits)
+            vd[u].load(dA + ic * VE);
+            vx[u].load(x + ic * VE);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long ii = i + u * stride;
+            float d[VE], f[VE];
+            vd[u].unpack(d);
+            vx[u].unpack(f);
+#pragma unroll
+            for (int j = 0; j < VE; ++j) {
+                const float pre = f[j] * sc[j] + sh[j];
+                const float g = (pre > lo && pre < hi) ? d[j] : 0.f;
+                d[j] = sc[j] * g + (cb[j] * f[j] + cc[j]);
+            }
+            if (add_ch0 != nullptr && vg == 0 && ii < nvec) d[0] += add_ch0[ii / cvec];
+            vd[u].pack(d);
+            if (ii < nvec) vd[u].store(dA + ii * VE);
+        }
+    }
+}
+
+// any C (a channel vector per thread changes from iteration to iteration: parameters re-loaded per element)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_generic_kernel(
+    T* __restrict__ dA, const T* __restrict__ x, long long nvec, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ k1, const float* __restrict__ k2, int act, const float* __restrict__ add_ch0) {
+    constexpr int VE = Vec16<T>::N;
     const int cvec = C / VE;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += (long long)gridDim.x * kThreads) {
         const int vg = (int)(i % cvec);
@@ -326,10 +389,15 @@ int check_rows(long long M, int C, int dtype, int* ve_out) {
 }  // namespace
 
 extern "C" int mpn_bn_stats_num_parts(long long M) {
-    // >= 128 rows per block, at most 2048 blocks (8 waves per SIMD on 256 CUs)
-    long long rows = 128;
-    long long parts = (M + rows - 1) / rows;
+    // 128 rows per block, at most 2048 blocks (8 waves per SIMD on 256 CUs); small tensors (the 32x32 and 16x16 maps)
+    // go down to 32 rows per block for up to 1024 blocks: at 128 rows they occupied 64-256 CUs with ONE block each
+    // (32 KB of loads in flight per CU, 0.9-3 TB/s)
+    long long parts = (M + 127) / 128;
     if (parts > 2048) parts = 2048;
+    if (parts < 1024) {
+        parts = (M + 31) / 32;
+        if (parts > 1024) parts = 1024;
+    }
     if (parts < 1) parts = 1;
     return (int)parts;
 }
@@ -452,8 +520,15 @@ extern "C" int mpn_bn_bwd_apply(void* dA, const void* x, long long M, int C, int
     MPN_REQUIRE(dA && x && scale && shift && mean && invstd && k1 && k2, MPN_ERR_BAD_ARG, "bn_bwd_apply: null pointer");
     const long long nvec = M * (C / ve);
     hipStream_t st = (hipStream_t)stream;
-    MPN_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<stream_blocks(nvec), kThreads, 0, st>>>(
-                                  (T*)dA, (const T*)x, nvec, C, scale, shift, mean, invstd, k1, k2, act, add_ch0)));
+    if (kThreads % (C / ve) == 0) {
+        long long blocks = (nvec + 4 * kThreads - 1) / (4 * kThreads);   // 4 vectors per thread and iteration
+        if (blocks > 2048) blocks = 2048;
+        MPN_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                      (T*)dA, (const T*)x, nvec, C, scale, shift, mean, invstd, k1, k2, act, add_ch0)));
+    } else {
+        MPN_DISPATCH_DTYPE(dtype, (bn_bwd_apply_generic_kernel<T><<<stream_blocks(nvec), kThreads, 0, st>>>(
+                                      (T*)dA, (const T*)x, nvec, C, scale, shift, mean, invstd, k1, k2, act, add_ch0)));
+    }
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

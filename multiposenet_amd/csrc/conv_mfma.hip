@@ -25,6 +25,7 @@
 namespace {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 template <typename T> struct Mma;
@@ -41,6 +42,10 @@ template <> struct Mma<float> {
         for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], c, 0, 0, 0);
     }
 };
+
+__device__ __forceinline__ bf16x4_t o_tr_read(const unsigned char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4_t __attribute__((address_space(3)))*)(p));
+}
 
 struct ConvParams {
     const void* x;
@@ -60,6 +65,7 @@ struct ConvParams {
     long long wp_tile_bytes;  // packed bytes per n-tile
     BnTailDev tail;           // batch-norm finalize fused into the last-finishing blocks (mode 0: off)
     unsigned long long* dbg;  // diagnostic builds only (env MPN_CONV_STAMPS): per-block s_memtime stamps, else NULL
+    int lds_epilogue;         // bf16: output tile through LDS + MFMA statistics (default) or the direct epilogue
 };
 
 constexpr int kThreads = 256;
@@ -108,12 +114,18 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
 // RING = true (128-byte chunks only): stages of 1 k-step in a 3-slot ring, DMA distance 2 behind a COUNTED vmcnt and a
 // raw s_barrier; A image 28.8 KB + 24 KB of weights = 52.8 KB -> THREE blocks per CU, so one block's staging / epilogue
 // always has two others' MFMA phases to hide under.
-template <typename T, int TAPS, int BN, int RB, bool RING>
-__global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {
+// MT = 16-pixel m-tiles per wave: 4 -> a block owns 128 pixels (8 x 16 for 3x3), 8 -> 256 pixels (16 x 16, bf16 3x3 with
+// the ring only): the weight image - 295 KB per n-tile of a 128 -> 128 layer, re-read from L2 by EVERY block - then
+// serves twice the pixels, and the halo overhead drops from 1.41 to 1.27. Its statistics rows are those of the two
+// 128-pixel tiles it covers (wave row wm = upper / lower half), so mpn_conv_num_parts does not depend on the variant.
+template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4>
+__global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {
+    static_assert(MT == 4 || (MT == 8 && TAPS == 9 && RING && sizeof(T) == 2), "256-pixel tiles: bf16 3x3 ring variant only");
+    constexpr int HALO_H = MT * 2 + 2;
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
     constexpr int CCE = RB / ES;   // channels per chunk
-    constexpr int NPIX = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int NPIX = TAPS == 9 ? kHaloW * HALO_H : MT * 32;
     constexpr int NT = BN / 32;                 // 16-channel tiles per wave
     constexpr int KSPS = RING ? 1 : 2;          // k-steps per weight stage
     constexpr int NBUF = RING ? 3 : 2;
@@ -147,12 +159,13 @@ __global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const
     if (TAPS == 9) {
         const int tx = mtile % p.tiles_x;
         const int t2 = mtile / p.tiles_x;
-        const int ty = t2 % p.tiles_y;
-        img = t2 / p.tiles_y;
-        oy0 = ty * 8;
+        const int tiles_y = (MT == 8) ? ((p.tiles_y + 1) >> 1) : p.tiles_y;
+        const int ty = t2 % tiles_y;
+        img = t2 / tiles_y;
+        oy0 = ty * (MT * 2);
         ox0 = tx * 16;
     } else {
-        m0 = (long long)mtile * 128;
+        m0 = (long long)mtile * (MT * 32);
     }
     const int total_stages = p.nchunk * TAPS * SPT;
 
@@ -161,17 +174,17 @@ __global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const
         reinterpret_cast<const unsigned char*>(p.wp) + (long long)ntile * p.wp_tile_bytes;
 
     // ---- accumulators: acc[mt][nt] holds D^T: lane (l15, lq) -> pixel mt*16+l15, channels nt*16+lq*4+{0..3}
-    f32x4_t acc[4][NT];
+    f32x4_t acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     // per-lane fragment base addresses: everything else is a compile-time or wave-uniform offset
-    const unsigned char* abase[4];
+    const unsigned char* abase[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = wm * 64 + mt * 16 + l15;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = wm * (MT * 16) + mt * 16 + l15;
         const int pix = (TAPS == 9) ? ((row >> 4) * kHaloW + (row & 15)) : row;
         abase[mt] = As + pix * RS + lq * 16;
     }
@@ -198,16 +211,16 @@ __global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const
     const float act_hi = (p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
 
     // fragment register sets (double-buffered across k-steps so LDS latency hides under the MFMAs)
-    Frag aP[4], bP[NT], aQ[4], bQ[NT];
-    auto load_frags = [&](Frag (&a)[4], Frag (&b)[NT], int a_off, int b_off) {
+    Frag aP[MT], bP[NT], aQ[MT], bQ[NT];
+    auto load_frags = [&](auto& a, auto& b, int a_off, int b_off) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const Frag*>(abase[mt] + a_off);
+        for (int mt = 0; mt < MT; ++mt) a[mt] = *reinterpret_cast<const Frag*>(abase[mt] + a_off);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const Frag*>(bbase + b_off + nt * 1024);
     };
-    auto mma_all = [&](const Frag (&a)[4], const Frag (&b)[NT]) {
+    auto mma_all = [&](const auto& a, const auto& b) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(b[nt], a[mt], acc[mt][nt]);   // D^T = W^T x A^T
     };
@@ -295,10 +308,132 @@ __global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_kernel(const
     }
     MPN_STAMP(2);
 
-    // ================= epilogue straight from the accumulators: each lane owns 4 consecutive output channels of one
-    // pixel per (mt, nt) tile -> one 8-byte (bf16) / 16-byte (f32) store; no LDS round trip.
     T* __restrict__ y = reinterpret_cast<T*>(p.y);
     const T* __restrict__ res = reinterpret_cast<const T*>(p.up_res);
+
+    // ================= bf16 epilogue through an LDS image of the output tile (the staging buffers are dead: every wave
+    // is past the last stage's barrier). The direct epilogue below costs the vector issue port more than the MFMAs of
+    // the tile do: 16 stores per wave that each touch 16 x 32-byte segments, and 128 DPP adds for the statistics.
+    // Here: (1) each wave writes its 64 px x BN/2 ch as bf16 into O[128 px][BN ch] (ds_write_b64, conflict-free with
+    // 8 bytes of row padding); (2) the per-channel sum and sum of squares come from the MATRIX unit: the wave reads
+    // its own part of O back with the transposing ds_read_b64_tr_b16 as 16x16x32 operands F[k = pixel][channel] and
+    // accumulates ones x F (column sums) and F^T x F (Gram matrix: the diagonal is the sum of squares, products of
+    // bf16 values are exact in f32) - 2 reads + 2 MFMAs per 32 px x 16 ch, no cross-lane VALU work; the k order is
+    // free (both operands are the same registers), so each 32-lane half reads 8 rows 4 apart = 8 distinct bank
+    // windows; (3) after one barrier, whole 16-byte pieces of pixel rows go to global memory, 256 contiguous bytes per
+    // 16 lanes. The statistics are those of the ROUNDED outputs - exactly the tensor the consumer normalises.
+    if constexpr (sizeof(T) == 2) {
+        if (MT == 8 || (res == nullptr && p.lds_epilogue)) {
+            constexpr int RSO = BN * 2 + 8;
+            constexpr int ROWS = MT * 32;
+            unsigned char* O = smem;
+            float* red = reinterpret_cast<float*>(smem + ROWS * RSO);   // [2 wm][2][BN] (+ the tail's flag word)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = wm * (MT * 16) + mt * 16 + l15;
+                bool ok;
+                if (TAPS == 9) ok = (oy0 + (row >> 4)) < p.H && (ox0 + (row & 15)) < p.W;
+                else ok = (m0 + row) < p.M;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    f32x4_t v = acc[mt][nt];
+                    if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // out-of-image pixels must not count in the statistics
+                    store4(reinterpret_cast<bf16_t*>(O + row * RSO + (wn * (BN / 2) + nt * 16 + lq * 4) * 2), v);
+                }
+            }
+            MPN_STAMP(3);
+            if (p.stats_part != nullptr) {
+                f32x4_t sa[NT], ga[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { sa[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ga[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+                bf16x8_t ones;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+                // lane 4q+pp of a 16-lane group supplies the address of block row q, channels 4pp..4pp+3
+                const unsigned char* tb = O + (wm * (MT * 16) + (lq >> 1) * 2 + 4 * ((lq & 1) * 4 + (l15 >> 2))) * RSO +
+                                          (wn * (BN / 2) + 4 * (l15 & 3)) * 2;
+#pragma unroll
+                for (int ks = 0; ks < MT / 2; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const bf16x4_t lo = o_tr_read(tb + ks * 32 * RSO + nt * 32);
+                        const bf16x4_t hi = o_tr_read(tb + (ks * 32 + 1) * RSO + nt * 32);
+                        const bf16x8_t f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        sa[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f, sa[nt], 0, 0, 0);
+                        ga[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, ga[nt], 0, 0, 0);
+                    }
+                // D layout: lane (l15 = column, lq) holds rows 4 lq + r. Column sums: every row; Gram diagonal: row == column
+                const int r = l15 & 3;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float q = r == 0 ? ga[nt][0] : (r == 1 ? ga[nt][1] : (r == 2 ? ga[nt][2] : ga[nt][3]));
+                    if (lq == (l15 >> 2)) {
+                        const int cl = wn * (BN / 2) + nt * 16 + l15;
+                        red[(wm * 2 + 0) * BN + cl] = sa[nt][0];
+                        red[(wm * 2 + 1) * BN + cl] = q;
+                    }
+                }
+            }
+            __syncthreads();
+            {
+                constexpr int SL = BN / 8;            // 16-byte pieces per pixel row
+                constexpr int PPP = kThreads / SL;    // pixel rows per pass
+                const int slot = tid % SL;
+                const bool cok = n0 + slot * 8 < p.Cout;
+#pragma unroll
+                for (int i = 0; i < ROWS / PPP; ++i) {
+                    const int row = tid / SL + i * PPP;
+                    bool ok;
+                    long long pixel;
+                    if (TAPS == 9) {
+                        const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
+                        ok = oy < p.H && ox < p.W;
+                        pixel = ((long long)img * p.H + oy) * p.W + ox;
+                    } else {
+                        pixel = m0 + row;
+                        ok = pixel < p.M;
+                    }
+                    if (ok && cok) {
+                        const uint2 a = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16);
+                        const uint2 b = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16 + 8);
+                        *reinterpret_cast<uint4*>(y + pixel * p.Cout + n0 + slot * 8) = make_uint4(a.x, a.y, b.x, b.y);
+                    }
+                }
+            }
+            if (p.stats_part != nullptr) {
+                if constexpr (MT == 8) {
+                    // wave row wm = the 128-pixel tile (ty*2 + wm, tx): one statistics row each, nothing to combine
+                    const int tx = mtile % p.tiles_x;
+                    const int ty8 = (oy0 >> 3);
+                    for (int v = tid; v < 4 * BN; v += kThreads) {
+                        const int half = v / (2 * BN), which = (v / BN) & 1, c = v % BN;
+                        if (ty8 + half < p.tiles_y && n0 + c < p.Cout) {
+                            const long long mt128 = ((long long)img * p.tiles_y + ty8 + half) * p.tiles_x + tx;
+                            p.stats_part[(mt128 * 2 + which) * p.Cout + n0 + c] = red[(half * 2 + which) * BN + c];
+                        }
+                    }
+                } else {
+                    if (tid < 2 * BN) {
+                        const int which = tid / BN, c = tid % BN;
+                        if (n0 + c < p.Cout) {
+                            float* dstp = &p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c];
+                            const float val = red[which * BN + c] + red[(2 + which) * BN + c];
+                            if (p.tail.mode) st_sc1(dstp, val); else *dstp = val;
+                        }
+                    }
+                    if (p.tail.mode) {
+                        int* flag = reinterpret_cast<int*>(red + 4 * BN);
+                        bn_tail(p.tail, p.stats_part, p.Cout, mtile, n0, BN, ntile, tid, kThreads, flag);
+                    }
+                }
+            }
+            MPN_STAMP(4);
+            return;
+        }
+    }
+
+    // ================= direct epilogue (f32 parity build, and the upsample-add variant): each lane owns 4 consecutive
+    // output channels of one pixel per (mt, nt) tile -> one 8-byte (bf16) / 16-byte (f32) store; no LDS round trip.
     const int cbase = n0 + wn * (BN / 2) + lq * 4;   // + nt*16
     f32x4_t ssum[NT], ssq[NT];
 #pragma unroll
@@ -891,23 +1026,26 @@ extern "C" int mpn_conv_pack_weights_batched(const void* descs_device, int ndesc
 // diagnostic hook (not part of the public header): device buffer of 8 u64 per block, or NULL
 static void* g_conv_dbg = nullptr;
 extern "C" void mpn_debug_set_conv_stamps(void* buf) { g_conv_dbg = buf; }
+static int g_conv_lds_epilogue = -1;   // MPN_CONV_LDS_EPILOGUE=0 / mpn_debug_set_conv_epilogue(0): the direct epilogue
+extern "C" void mpn_debug_set_conv_epilogue(int on) { g_conv_lds_epilogue = on; }
 
 extern "C" int mpn_conv_num_parts(int N, int H, int W, int ksize) {
     if (ksize == 3) return N * ((H + 7) / 8) * ((W + 15) / 16);
     return (int)(((long long)N * H * W + 127) / 128);
 }
 
-template <typename T, int TAPS, int BN, int RB, bool RING>
+template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4>
 static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
-    constexpr int NPIX = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int NPIX = TAPS == 9 ? kHaloW * (MT * 2 + 2) : MT * 32;
     constexpr int smem = NPIX * a_row_stride(RB) + (RING ? 3 * (BN * 64) : 2 * (2 * BN * 64));
+    static_assert(sizeof(T) != 2 || smem >= MT * 32 * (BN * 2 + 8) + 4 * BN * 4 + 16, "the output image of the epilogue fits");
     static bool attr_set = false;
     if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB, RING>,
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB, RING, MT>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    conv_mfma_kernel<T, TAPS, BN, RB, RING><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
+    conv_mfma_kernel<T, TAPS, BN, RB, RING, MT><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -945,6 +1083,14 @@ static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
     // simpler variant stays the default.
     static int ring = -1;
     if (ring < 0) { const char* e = getenv("MPN_CONV_RING"); ring = e ? atoi(e) : 0; }
+    // 256-pixel tiles (MPN_CONV_BIG=<min blocks>; off by default - measured equal to the 128-pixel tiles)
+    if constexpr (sizeof(T) == 2 && TAPS == 9) {
+        static int big_min = -1;
+        if (big_min < 0) { const char* e = getenv("MPN_CONV_BIG"); big_min = e ? atoi(e) : 0; }
+        const int m_big = p.N * ((p.tiles_y + 1) >> 1) * p.tiles_x;
+        if (big_min > 0 && m_big * p.n_tiles >= big_min && p.row_bytes == 128 && p.up_res == nullptr && p.tail.mode == 0)
+            return launch_conv_rb<T, TAPS, BN, 128, true, 8>(p, m_big, st);
+    }
     if (p.row_bytes == 256) return launch_conv_rb<T, TAPS, BN, 256, false>(p, m_tiles, st);
     if (ring && BN == 128) return launch_conv_rb<T, TAPS, BN, 128, true>(p, m_tiles, st);
     return launch_conv_rb<T, TAPS, BN, 128, false>(p, m_tiles, st);
@@ -979,6 +1125,8 @@ extern "C" int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, in
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
     p.stats_part = stats_part; p.up_res = up_res;
     p.dbg = (unsigned long long*)g_conv_dbg;
+    if (g_conv_lds_epilogue < 0) { const char* e = getenv("MPN_CONV_LDS_EPILOGUE"); g_conv_lds_epilogue = e ? atoi(e) : 1; }
+    p.lds_epilogue = g_conv_lds_epilogue;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
     p.M = (long long)N * H * W;
