@@ -15,7 +15,7 @@ def t(fn, n=20):
 
 dt = torch.bfloat16
 N = 32
-for (H, Cin, Cout, k) in [(128, 128, 128, 3), (128, 512, 64, 3), (128, 64, 512, 3), (256, 32, 64, 1), (32, 512, 512, 1), (64, 128, 128, 3)]:
+for (H, Cin, Cout, k) in [(128, 128, 128, 3), (128, 512, 64, 3), (128, 64, 512, 3), (64, 128, 128, 3), (256, 32, 64, 1), (128, 128, 128, 1), (64, 256, 256, 1), (32, 256, 512, 1), (32, 512, 512, 1), (16, 512, 1024, 1), (16, 1024, 1024, 1), (16, 1024, 128, 1)]:
     x = torch.randn(N, H, H, Cin, device='cuda').to(dt)
     w = torch.randn(k, k, Cin, Cout, device='cuda') * 0.05
     pc = ops.PackedConv(w, dt)
