@@ -214,7 +214,10 @@ __global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma
     b_issue(0, 0);
     if (RING && total_stages > 1) b_issue(1, 1);
 
-#define MPN_STAMP(k) do { if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// slots 0-4: s_memtime (shader clock) at the phase boundaries; slots 5, 6: s_memrealtime (100 MHz) at the first and last one
+#define MPN_STAMP(k) do { if (p.dbg && tid == 0) { p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    if ((k) == 0) p.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) == 4) p.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } } while (0)
     MPN_STAMP(0);
     const bool affine = (p.in_scale != nullptr);
     const float act_lo = (p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
@@ -299,8 +302,20 @@ __global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma
                 if (more) b_issue(s + 1, (s + 1) & 1);   // buffer (s+1)%2 was last read in stage s-1: all waves are past it
                 load_frags(aP, bP, a_off, b_off);
                 load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
+#if defined(MPN_EXP_SCHED)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+#if defined(MPN_EXP_PRIO)
+                __builtin_amdgcn_s_setprio(1);
+#endif
                 mma_all(aP, bP);
                 mma_all(aQ, bQ);
+#if defined(MPN_EXP_PRIO)
+                __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(MPN_EXP_SCHED)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
                 __syncthreads();
             } else {

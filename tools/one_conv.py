@@ -1,7 +1,8 @@
 """Run ONE conv shape a few times (for rocprofv3 --pmc). usage: python tools/one_conv.py [fwd|wgrad] H Cin Cout k"""
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multiposenet_amd import ops
 mode, H, Cin, Cout, k = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 dt = torch.bfloat16

@@ -25,4 +25,9 @@ t0 = d[:, 0].min()
 ph = np.diff(d[:, :5], axis=1)   # stage A, main loop, epilogue, stats
 print("blocks", nblk, "kernel span (ticks of 100MHz?)", (d[:, 4].max() - t0))
 print("mean phase ticks: stageA %.0f  main %.0f  epilogue %.0f  stats %.0f  | total %.0f" % (*ph.mean(0), (d[:, 4] - d[:, 0]).mean()))
+rt = (d[:, 6] - d[:, 5])
+ok = rt > 0
+clk = np.median((d[ok, 4] - d[ok, 0]) / rt[ok]) * 100e6
+mfma_cycles = 4 * max(1, Cout // 128 and 4 or 2) * (k * k * Cin // 32) * 16   # per wave and tile: (64 px x BN/2 ch) x K
+print("in-kernel clock %.2f GHz (s_memtime / s_memrealtime x 100 MHz, median over blocks); block time %.1f us" % (clk / 1e9, np.median(rt[ok]) / 100.0))
 print("start-time spread of blocks (first/last start):", d[:, 0].min() - t0, d[:, 0].max() - t0)
