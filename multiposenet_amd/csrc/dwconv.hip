@@ -479,6 +479,172 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient, register sliding window: the forward kernel's walk (a thread = 4 channels of one output column,
+// the 3x3 window of activated inputs in registers, three raw rows in flight) with the output row's dY piece in place
+// of the store: acc[tap] += window[tap] * dY, 18 packed FMAs per output pixel, 36 accumulators per thread. One block
+// = one (image, row strip, column block, channel block) unit = one row of the partial slab; blocks are at most 128
+// channels wide (ncg <= 32) so that small maps with many channels still make hundreds of blocks with small slabs.
+template <typename T, int STRIDE>
+__global__ __launch_bounds__(kThreads) void dwconv_wgrad_sw_kernel(const DwParams p, int ncg, int cols, int xblocks, int yblocks,
+                                                                  int rows) {
+    __shared__ __attribute__((aligned(16))) float red[9 * kThreads * 4];   // [tap][thread][4 channels]
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+    int b = blockIdx.x;
+    const int cgb = b % p.cblocks; b /= p.cblocks;
+    const int unit = b;                                               // partial-slab row
+    const int xb = b % xblocks; b /= xblocks;
+    const int yb = b % yblocks;
+    const int img = b / yblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;
+    const int c = (cgb * ncg + cgl) * 4;
+    const int ox = xb * cols + col;
+    const bool lane_ok = c < p.C && ox < p.OW && col < cols;
+    const int cc = lane_ok ? c : 0;
+    const int oxc = lane_ok ? ox : 0;
+    float sc[4], sh[4];
+    const bool aff = p.in_scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = aff ? p.in_scale[cc + j] : 1.f; sh[j] = aff ? p.in_shift[cc + j] : 0.f; }
+    const float lo = (aff && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (aff && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+
+    const int oy_begin = yb * rows, oy_end = min(oy_begin + rows, p.OH);
+    const int ix0 = oxc * STRIDE - p.pad_l;
+    const T* ximg = x + (long long)img * p.H * p.W * p.C + cc;
+    const T* dyimg = dy + ((long long)img * p.OH * p.OW + oxc) * p.C + cc;
+    bool xok[3];
+    int xoff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int ix = ix0 + k;
+        xok[k] = lane_ok && ix >= 0 && ix < p.W;
+        xoff[k] = (xok[k] ? ix : 0) * p.C;
+    }
+    auto row_load = [&](Raw4<T> (&r)[3], int iy) {
+        const int iyc = min(max(iy, 0), p.H - 1);
+        const T* rowp = ximg + (long long)iyc * p.W * p.C;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) raw_load(r[k], rowp + xoff[k]);
+    };
+    auto dy_load = [&](Raw4<T>& r, int oy) {
+        const int oyc = min(oy, p.OH - 1);
+        raw_load(r, dyimg + (long long)oyc * p.OW * p.C);
+    };
+    auto row_act = [&](const Raw4<T> (&r)[3], int iy, f32x2_t (&a)[3][2]) {
+        if (iy < 0 || iy >= p.H) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { a[k][0] = (f32x2_t){0.f, 0.f}; a[k][1] = (f32x2_t){0.f, 0.f}; }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float f[4];
+            raw_unpack(r[k], f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);
+            if (STRIDE != 1 || k != 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = xok[k] ? f[j] : 0.f;
+            }
+            a[k][0] = (f32x2_t){f[0], f[1]};
+            a[k][1] = (f32x2_t){f[2], f[3]};
+        }
+    };
+    f32x2_t a01[9], a23[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { a01[t] = (f32x2_t){0.f, 0.f}; a23[t] = (f32x2_t){0.f, 0.f}; }
+    auto accum = [&](const f32x2_t (&ra_)[3][2], const f32x2_t (&rb_)[3][2], const f32x2_t (&rc_)[3][2], const Raw4<T>& d) {
+        float g[4];
+        raw_unpack(d, g);
+        const f32x2_t g01 = {g[0], g[1]}, g23 = {g[2], g[3]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a01[k] += ra_[k][0] * g01;     a23[k] += ra_[k][1] * g23;
+            a01[3 + k] += rb_[k][0] * g01; a23[3 + k] += rb_[k][1] * g23;
+            a01[6 + k] += rc_[k][0] * g01; a23[6 + k] += rc_[k][1] * g23;
+        }
+    };
+    f32x2_t r0[3][2], r1[3][2], r2[3][2];
+    if (STRIDE == 1) {
+        Raw4<T> ra[3], rb[3], rc[3], da, db, dc;
+        int iy = oy_begin - p.pad_t;
+        row_load(ra, iy);
+        row_load(rb, iy + 1);
+        row_load(rc, iy + 2);
+        dy_load(da, oy_begin);
+        dy_load(db, oy_begin + 1);
+        dy_load(dc, oy_begin + 2);
+        row_act(ra, iy, r0);
+        row_load(ra, iy + 3);
+        row_act(rb, iy + 1, r1);
+        row_load(rb, iy + 4);
+        iy += 2;
+        for (int oy = oy_begin; oy < oy_end; oy += 3, iy += 3) {
+            row_act(rc, iy, r2);
+            row_load(rc, iy + 3);
+            accum(r0, r1, r2, da);
+            dy_load(da, oy + 3);
+            if (oy + 1 < oy_end) {
+                row_act(ra, iy + 1, r0);
+                row_load(ra, iy + 4);
+                accum(r1, r2, r0, db);
+                dy_load(db, oy + 4);
+            }
+            if (oy + 2 < oy_end) {
+                row_act(rb, iy + 2, r1);
+                row_load(rb, iy + 5);
+                accum(r2, r0, r1, dc);
+                dy_load(dc, oy + 5);
+            }
+        }
+    } else {
+        Raw4<T> ra[3], rb[3], da, db;
+        int iy = oy_begin * 2 - p.pad_t;
+        row_load(ra, iy);
+        dy_load(da, oy_begin);
+        dy_load(db, oy_begin + 1);
+        row_act(ra, iy, r0);
+        row_load(ra, iy + 1);
+        row_load(rb, iy + 2);
+        for (int oy = oy_begin; oy < oy_end; oy += 2, iy += 4) {
+            row_act(ra, iy + 1, r1);
+            row_act(rb, iy + 2, r2);
+            row_load(ra, iy + 3);
+            row_load(rb, iy + 4);
+            accum(r0, r1, r2, da);
+            dy_load(da, oy + 2);
+            if (oy + 1 < oy_end) {
+                row_act(ra, iy + 3, r1);
+                row_act(rb, iy + 4, r0);
+                row_load(ra, iy + 5);
+                row_load(rb, iy + 6);
+                accum(r2, r1, r0, db);
+                dy_load(db, oy + 3);
+            }
+        }
+    }
+    // block reduction over the columns that share a 4-channel group (fixed order), one partial-slab row per block
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float4 v = make_float4(a01[t].x, a01[t].y, a23[t].x, a23[t].y);
+        if (!lane_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&red[(t * kThreads + threadIdx.x) * 4]) = v;
+    }
+    __syncthreads();
+    const int nch = ncg * 4;
+    float* dst = p.part + (long long)unit * 9 * p.C + cgb * nch;
+    for (int o = threadIdx.x; o < 9 * nch; o += kThreads) {
+        const int t = o / nch, cj = o - t * nch;
+        if (cgb * nch + cj < p.C) {
+            float sum = 0.f;
+            for (int cidx = 0; cidx < cols; ++cidx) sum += red[(t * kThreads + cidx * ncg) * 4 + cj];
+            dst[t * p.C + cj] = sum;
+        }
+    }
+}
+
 // stride-2 data gradient (gather form): dx[iy,ix,c] = sum_{ky,kx} dy[(iy+pt-ky)/2,(ix+pl-kx)/2,c]*w[ky,kx,c]
 // over the taps for which the division is exact. One thread = one input pixel x 16 bytes of channels.
 template <typename T>
@@ -666,7 +832,9 @@ struct DwSwGeom { int ncg, cols, xblocks, yblocks, cblocks; };
 static DwSwGeom dw_sw_geom(const DwParams& p) {
     DwSwGeom g;
     const int cg_total = p.C / 4;
-    g.ncg = cg_total < kThreads ? cg_total : kThreads;
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("MPN_DW_SW_NCG"); cap = e ? atoi(e) : 32; }   // blocks of <= 128 channels: more columns per block, 4x fewer statistics rows on the 512 / 1024-channel maps (21.6 -> 18.8, 15.4 -> 13.0 us)
+    g.ncg = cg_total < cap ? cg_total : cap;
     g.cols = kThreads / g.ncg;
     g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
     g.xblocks = (p.OW + g.cols - 1) / g.cols;
@@ -761,9 +929,33 @@ extern "C" int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int
     return MPN_OK;
 }
 
+// sliding-window weight gradient: blocks of at most 128 channels; strips of 32 output rows on the large maps, 16 below
+struct DwWgSwGeom { int ncg, cols, xblocks, yblocks, cblocks, rows, units; };
+static DwWgSwGeom dw_wg_sw_geom(const DwParams& p) {
+    DwWgSwGeom g;
+    const int cg_total = p.C / 4;
+    g.ncg = cg_total < 32 ? cg_total : 32;
+    g.cols = kThreads / g.ncg;
+    g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
+    g.rows = p.OH >= 64 ? 32 : 16;
+    g.xblocks = (p.OW + g.cols - 1) / g.cols;
+    g.yblocks = (p.OH + g.rows - 1) / g.rows;
+    g.units = p.N * g.yblocks * g.xblocks;
+    return g;
+}
+static bool dw_wg_use_sw(const DwParams& p) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MPN_DW_WGRAD_SW"); v = e ? atoi(e) : 1; }
+    const int cg_total = p.C / 4;
+    // (the thread map needs a power-of-two group count per block; other channel counts keep the LDS-tile kernel)
+    const int ncg = cg_total < 32 ? cg_total : 32;
+    return v != 0 && (ncg & (ncg - 1)) == 0 && kThreads % ncg == 0;
+}
+
 extern "C" int mpn_dwconv_wgrad_num_parts(int N, int H, int W, int C, int stride, int dtype) {
     DwParams p = {};
     if (fill_params(p, N, H, W, C, stride, dtype)) return 0;
+    if (dw_wg_use_sw(p)) return dw_wg_sw_geom(p).units;
     const int ntiles = N * p.tiles_y * p.tiles_x;
     int nsplit = 2048 / p.cblocks;
     if (nsplit < 1) nsplit = 1;
@@ -782,8 +974,20 @@ extern "C" int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part,
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
     const int ve = dtype == MPN_F32 ? 4 : 8;
     const int nsplit = mpn_dwconv_wgrad_num_parts(N, H, W, C, stride, dtype);
-    const int grid = nsplit * p.cblocks;
     hipStream_t st = (hipStream_t)stream;
+    if (dw_wg_use_sw(p)) {
+        const DwWgSwGeom g = dw_wg_sw_geom(p);
+        p.cblocks = g.cblocks;
+        const long long blocks = (long long)g.units * g.cblocks;
+        MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_weight: grid too large");
+        MPN_DISPATCH_DTYPE(dtype, {
+            if (stride == 1) dwconv_wgrad_sw_kernel<T, 1><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+            else dwconv_wgrad_sw_kernel<T, 2><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+        });
+        MPN_LAUNCH_CHECK();
+        return MPN_OK;
+    }
+    const int grid = nsplit * p.cblocks;
     if (stride == 1) {
         const size_t sm = dw_smem<1>(ve, 36, p.nvg);
         MPN_DISPATCH_DTYPE(dtype, {

@@ -238,8 +238,11 @@ def test_graph_replay_equals_eager_and_bf16_tracks_f32(cuda):
     # as few samples: 40% (observed 8-26%, depending on kernel summation order and on whether the batch statistics are
     # those of the f32 accumulators or of the rounded bf16 outputs)
     np.testing.assert_allclose(bf16_steps[0][4:6], f32_steps[0][4:6], rtol=0.4)
-    for a, b in zip(f32_steps, bf16_steps):   # later steps: the dominant terms keep tracking
-        np.testing.assert_allclose(b[[0, 6]], a[[0, 6]], rtol=5e-2)
+    # later steps: the dominant terms keep tracking. Adam's sign-like first updates amplify rounding differences on this
+    # 2-image batch: over seeds and kernel variants the bf16 run sits within -2 .. +8 % of the f32 run after 3-4 steps,
+    # with no systematic sign (tools/track_bf16.py)
+    for a, b in zip(f32_steps, bf16_steps):
+        np.testing.assert_allclose(b[[0, 6]], a[[0, 6]], rtol=0.12)
 
 
 def test_fused_bn_finalize_equals_separate_launches(cuda):

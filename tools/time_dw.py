@@ -8,7 +8,7 @@ from time_misc_util import timeit
 
 dt = torch.bfloat16
 N = 32
-for (H, C, s) in [(256, 32, 1), (256, 64, 2), (128, 128, 1), (128, 128, 2), (64, 256, 1), (32, 512, 1), (16, 1024, 1)]:
+for (H, C, s) in [(256, 32, 1), (256, 64, 2), (128, 128, 1), (128, 128, 2), (64, 256, 1), (64, 256, 2), (32, 512, 1), (32, 512, 2), (16, 1024, 1)]:
     x = torch.randn(N, H, H, C, device='cuda').to(dt)
     w = torch.randn(3, 3, C, device='cuda') * 0.2
     sc = torch.rand(C, device='cuda') + 0.5
