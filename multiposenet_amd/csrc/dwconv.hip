@@ -819,6 +819,95 @@ template <typename K> int set_smem(K kernel, size_t bytes) {
 
 extern "C" int mpn_dwconv_out_size(int size, int stride) { return (size + stride - 1) / stride; }
 
+namespace {
+// stride-2 data gradient, sliding-window form for even H, W (pad_t = pad_l = 0): a thread owns 4 channels of one dY column
+// b and walks down the dY rows a; with the previous row's two pieces in registers, dY[a-1..a][b-1..b] gives the 2x2 block
+// dx[2a..2a+1][2b..2b+1] (4 + 2 + 2 + 1 taps): 2 loads and 4 stores per step, no parity branches (the gather kernel above
+// issues all 9 tap loads with a quarter of the lanes active each).
+constexpr int SWR_DG = 16;   // dY rows per thread
+template <typename T>
+__global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                                      T* __restrict__ dx, int H, int W, int C, int OH, int OW,
+                                                                      int ncg, int cols, int xblocks, int yblocks, int cblocks) {
+    int bi = blockIdx.x;
+    const int xb = bi % xblocks; bi /= xblocks;
+    const int yb = bi % yblocks; bi /= yblocks;
+    const int cgb = bi % cblocks;
+    const int img = bi / cblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;
+    const int c = (cgb * ncg + cgl) * 4;
+    const int b = xb * cols + col;
+    const bool lane_ok = c < C && b < OW && col < cols;
+    const int cc = lane_ok ? c : 0, bc = lane_ok ? b : 0;
+    f32x2_t w01[9], w23[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 q = *reinterpret_cast<const float4*>(w + t * C + cc);
+        w01[t] = (f32x2_t){q.x, q.y};
+        w23[t] = (f32x2_t){q.z, q.w};
+    }
+    const int a_begin = yb * SWR_DG, a_end = min(a_begin + SWR_DG, OH);
+    const bool left_ok = bc > 0;
+    const T* dyimg = dy + ((long long)img * OH * OW) * C + cc;
+    const int off_c = bc * C, off_l = (left_ok ? bc - 1 : 0) * C;
+    auto row_load = [&](Raw4<T> (&r)[2], int a) {
+        const int ac = min(max(a, 0), OH - 1);
+        const T* rowp = dyimg + (long long)ac * OW * C;
+        raw_load(r[0], rowp + off_l);
+        raw_load(r[1], rowp + off_c);
+    };
+    auto row_cvt = [&](const Raw4<T> (&r)[2], int a, f32x2_t (&v)[2][2]) {   // [left, centre][channel pair]; zero outside
+        if (a < 0) {
+            v[0][0] = v[0][1] = v[1][0] = v[1][1] = (f32x2_t){0.f, 0.f};
+            return;
+        }
+        float f[4];
+        raw_unpack(r[0], f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = left_ok ? f[j] : 0.f;
+        v[0][0] = (f32x2_t){f[0], f[1]}; v[0][1] = (f32x2_t){f[2], f[3]};
+        raw_unpack(r[1], f);
+        v[1][0] = (f32x2_t){f[0], f[1]}; v[1][1] = (f32x2_t){f[2], f[3]};
+    };
+    T* xp = dx + (((long long)img * H + 2 * a_begin) * W + 2 * bc) * C + cc;
+    const long long xrow = (long long)W * C;
+    auto emit = [&](const f32x2_t (&pv)[2][2], const f32x2_t (&cv)[2][2]) {   // previous row a-1, current row a
+        // taps t = ky*3 + kx
+        const f32x2_t e01 = cv[1][0] * w01[0] + pv[1][0] * w01[6] + cv[0][0] * w01[2] + pv[0][0] * w01[8];
+        const f32x2_t e23 = cv[1][1] * w23[0] + pv[1][1] * w23[6] + cv[0][1] * w23[2] + pv[0][1] * w23[8];
+        const f32x2_t f01 = cv[1][0] * w01[1] + pv[1][0] * w01[7];
+        const f32x2_t f23 = cv[1][1] * w23[1] + pv[1][1] * w23[7];
+        const f32x2_t g01 = cv[1][0] * w01[3] + cv[0][0] * w01[5];
+        const f32x2_t g23 = cv[1][1] * w23[3] + cv[0][1] * w23[5];
+        const f32x2_t h01 = cv[1][0] * w01[4];
+        const f32x2_t h23 = cv[1][1] * w23[4];
+        if (lane_ok) {
+            store4x2(xp, e01, e23);
+            store4x2(xp + C, f01, f23);
+            store4x2(xp + xrow, g01, g23);
+            store4x2(xp + xrow + C, h01, h23);
+        }
+        xp += 2 * xrow;
+    };
+    Raw4<T> ra[2], rb[2], rc[2];
+    f32x2_t v0[2][2], v1[2][2];
+    row_load(ra, a_begin - 1);
+    row_load(rb, a_begin);
+    row_load(rc, a_begin + 1);
+    row_cvt(ra, a_begin - 1, v0);
+    row_load(ra, a_begin + 2);
+    // the three raw buffers rotate; the converted rows alternate between v0 and v1
+    for (int a = a_begin; a < a_end; a += 6) {
+        row_cvt(rb, a, v1);     row_load(rb, a + 3); emit(v0, v1);
+        if (a + 1 < a_end) { row_cvt(rc, a + 1, v0); row_load(rc, a + 4); emit(v1, v0); }
+        if (a + 2 < a_end) { row_cvt(ra, a + 2, v1); row_load(ra, a + 5); emit(v0, v1); }
+        if (a + 3 < a_end) { row_cvt(rb, a + 3, v0); row_load(rb, a + 6); emit(v1, v0); }
+        if (a + 4 < a_end) { row_cvt(rc, a + 4, v1); row_load(rc, a + 7); emit(v0, v1); }
+        if (a + 5 < a_end) { row_cvt(ra, a + 5, v0); row_load(ra, a + 8); emit(v1, v0); }
+    }
+}
+}  // namespace
+
 // register sliding-window forward kernel (default) vs the LDS-tile kernel (MPN_DW_SW=0)
 static int g_dw_sw = -1;
 static bool dw_use_sw() {
@@ -918,11 +1007,27 @@ extern "C" int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int
     DwParams p = {};
     if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
     MPN_REQUIRE(dy && w && dx, MPN_ERR_BAD_ARG, "dwconv_bwd_data: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    {
+        static int sw = -1;
+        if (sw < 0) { const char* e = getenv("MPN_DW_DGRAD_SW"); sw = e ? atoi(e) : 1; }
+        const int cg_total = C / 4;
+        const int ncg = cg_total < 32 ? cg_total : 32;
+        if (sw && p.pad_t == 0 && p.pad_l == 0 && H == 2 * p.OH && W == 2 * p.OW && (ncg & (ncg - 1)) == 0) {
+            const int cols = kThreads / ncg, cblocks = (cg_total + ncg - 1) / ncg;
+            const int xblocks = (p.OW + cols - 1) / cols, yblocks = (p.OH + SWR_DG - 1) / SWR_DG;
+            const long long blocks = (long long)N * cblocks * yblocks * xblocks;
+            MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_data: grid too large");
+            MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, ncg, cols, xblocks, yblocks, cblocks)));
+            MPN_LAUNCH_CHECK();
+            return MPN_OK;
+        }
+    }
     const int ve = dtype == MPN_F32 ? 4 : 8;
     const long long total_vec = (long long)N * H * W * (C / ve);
     long long blocks = (total_vec + kThreads - 1) / kThreads;
     if (blocks > 8192) blocks = 8192;
-    hipStream_t st = (hipStream_t)stream;
     MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_kernel<T><<<(int)blocks, kThreads, 0, st>>>(
                                   (const T*)dy, w, (T*)dx, N, H, W, C, p.OH, p.OW, p.pad_t, p.pad_l, total_vec)));
     MPN_LAUNCH_CHECK();

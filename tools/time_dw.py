@@ -22,4 +22,6 @@ for (H, C, s) in [(256, 32, 1), (256, 64, 2), (128, 128, 1), (128, 128, 2), (64,
     dy = torch.randn(N, OH, OH, C, device='cuda').to(dt)
     dw = torch.empty(3, 3, C, device='cuda')
     us2 = timeit(lambda: ops.dwconv_bwd_weight(x, dy, s, aff, dw))
-    print(f"dw {C:4d}ch @{H} s{s}: fwd {us:6.1f} us {byt / us / 1e3:6.0f} GB/s | wgrad(+reduce) {us2:6.1f} us {byt / us2 / 1e3:6.0f} GB/s")
+    dx = torch.empty_like(x)
+    us3 = timeit(lambda: ops.dwconv_bwd_data(dy, w, (H, H), s, out=dx))
+    print(f"dw {C:4d}ch @{H} s{s}: dgrad {us3:6.1f} us {byt / us3 / 1e3:6.0f} GB/s | fwd {us:6.1f} us {byt / us / 1e3:6.0f} GB/s | wgrad(+reduce) {us2:6.1f} us {byt / us2 / 1e3:6.0f} GB/s")
