@@ -103,37 +103,49 @@ __global__ __launch_bounds__(kThreads) void bilinear_up_fwd_kernel(
 // dX[n,iy,ix,c] = sum over output pixels of wy*wx*dY (gather form, deterministic). The weight of output row oy for
 // input row iy is the tent 1 - |oy - iy*u| / u over |oy - iy*u| < u, except that the last input row also owns the
 // clamped rows oy >= (h-1)*u with weight 1 (y0 == y1 == h-1 there); same in x. No divisions in the loops.
-template <typename T>
+template <typename T, int U>
 __global__ __launch_bounds__(kThreads) void bilinear_up_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int h,
-                                                                   int w, int C, int u, int y_coff, int y_ctot) {
+                                                                   int w, int C, int y_coff, int y_ctot) {
     constexpr int VE = Vec16<T>::N;
+    constexpr int u = U;
+    constexpr int NT = 2 * U - 1;                                    // taps per axis
     const unsigned cvec = C / VE;
     const int OH = h * u, OW = w * u;
     const unsigned t = blockIdx.x * kThreads + threadIdx.x;
     if (t >= (unsigned)w * cvec) return;
     const int ix = (int)(t / cvec), c0 = (int)(t - (unsigned)ix * cvec) * VE;
     const int n = blockIdx.y / h, iy = blockIdx.y - n * h;          // scalar
-    const float inv = 1.0f / (float)u;
+    constexpr float inv = 1.0f / (float)U;
     float acc[VE];
 #pragma unroll
     for (int j = 0; j < VE; ++j) acc[j] = 0.f;
-    const int dy_lo = iy == 0 ? 0 : -(u - 1), dx_lo = ix == 0 ? 0 : -(u - 1);
     const bool last_y = iy == h - 1, last_x = ix == w - 1;
+    // the x taps of this thread: weights and (clamped) offsets once, so that the row loop is NT independent loads
+    float wxs[NT];
+    int xoffs[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        const int dxo = k - (U - 1);
+        const bool ok = dxo >= 0 || ix > 0;
+        const float fx = (float)(dxo >= 0 ? dxo : u + dxo) * inv;
+        wxs[k] = !ok ? 0.f : (dxo < 0 ? fx : (last_x ? (1.f - fx) + fx : 1.f - fx));
+        xoffs[k] = (ix * u + (ok ? dxo : 0)) * y_ctot;
+    }
+    const int dy_lo = iy == 0 ? 0 : -(u - 1);
     const T* base = dy + (long long)n * OH * OW * y_ctot + y_coff + c0;
     for (int dyo = dy_lo; dyo < u; ++dyo) {
         const int oy = iy * u + dyo;
         const float fy = (float)(dyo >= 0 ? dyo : u + dyo) * inv;   // forward's fraction of output row oy
         const float wy = dyo < 0 ? fy : (last_y ? (1.f - fy) + fy : 1.f - fy);
         const T* row = base + (long long)oy * OW * y_ctot;
-        for (int dxo = dx_lo; dxo < u; ++dxo) {
-            const int ox = ix * u + dxo;
-            const float fx = (float)(dxo >= 0 ? dxo : u + dxo) * inv;
-            const float wx = dxo < 0 ? fx : (last_x ? (1.f - fx) + fx : 1.f - fx);
-            Vec16<T> v;
-            v.load(row + (long long)ox * y_ctot);
+        Vec16<T> v[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) v[k].load(row + xoffs[k]);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
             float f[VE];
-            v.unpack(f);
-            const float wgt = wy * wx;
+            v[k].unpack(f);
+            const float wgt = wy * wxs[k];
 #pragma unroll
             for (int j = 0; j < VE; ++j) acc[j] += wgt * f[j];
         }
@@ -141,6 +153,76 @@ __global__ __launch_bounds__(kThreads) void bilinear_up_bwd_kernel(const T* __re
     Vec16<T> ov;
     ov.pack(acc);
     ov.store(dx + (((long long)n * h + iy) * w + ix) * C + c0);
+}
+
+// upsample 1 forward: act(x * scale + shift) written into the concat slice (the general kernel loads all four taps of
+// every output although fx = fy = 0), 4 vectors in flight per thread
+template <typename T>
+__global__ __launch_bounds__(kThreads) void slice_affine_store_kernel(const T* __restrict__ x, T* __restrict__ y, long long nvec,
+                                                                      int C, int coff, int ctot, const float* __restrict__ sc,
+                                                                      const float* __restrict__ sh, int act) {
+    constexpr int VE = Vec16<T>::N;
+    constexpr int U = 4;
+    const unsigned cvec = C / VE;
+    const long long stride = (long long)gridDim.x * kThreads;   // a multiple of cvec (checked by the launcher)
+    const long long i0 = (long long)blockIdx.x * kThreads + threadIdx.x;
+    const int c0 = (int)(i0 % cvec) * VE;
+    float s_[VE], b_[VE];
+    const bool aff = sc != nullptr;
+    if (aff) {
+#pragma unroll
+        for (int j = 0; j < VE; j += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(sc + c0 + j);
+            const float4 b4 = *reinterpret_cast<const float4*>(sh + c0 + j);
+            s_[j] = a4.x; s_[j + 1] = a4.y; s_[j + 2] = a4.z; s_[j + 3] = a4.w;
+            b_[j] = b4.x; b_[j + 1] = b4.y; b_[j + 2] = b4.z; b_[j + 3] = b4.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { s_[j] = 1.f; b_[j] = 0.f; }
+    }
+    const float lo = (aff && act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (aff && act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    for (long long i = i0; i < nvec; i += U * stride) {
+        Vec16<T> v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k].load(x + (i + k * stride < nvec ? i + k * stride : i) * VE);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const long long ii = i + k * stride;
+            if (ii < nvec) {
+                float f[VE];
+                v[k].unpack(f);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * s_[j] + b_[j], lo, hi);
+                v[k].pack(f);
+                v[k].store(y + (ii / cvec) * ctot + coff + c0);
+            }
+        }
+    }
+}
+
+// upsample 1: the gradient of a concat slice is the slice itself - a strided copy, 4 vectors in flight per thread
+// (the tent kernel above ran it as 32 768 blocks of one load + one store per thread: 2.2 TB/s)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void slice_copy_kernel(const T* __restrict__ src, T* __restrict__ dst, long long nvec,
+                                                              int C, int coff, int ctot) {
+    constexpr int VE = Vec16<T>::N;
+    constexpr int U = 4;
+    const unsigned cvec = C / VE;
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < nvec; i += U * stride) {
+        Vec16<T> v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const long long ii = i + k * stride < nvec ? i + k * stride : i;
+            const long long pix = ii / cvec;
+            v[k].load(src + pix * ctot + coff + (ii - pix * cvec) * VE);
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k)
+            if (i + k * stride < nvec) v[k].store(dst + (i + k * stride) * VE);
+    }
 }
 
 // dst[n,y,x,c] (+)= sum_{dy,dx in 0..1} src[n,2y+dy,2x+dx,c]
@@ -226,6 +308,15 @@ extern "C" int mpn_bilinear_up_fwd(const void* x, void* y, int N, int h, int w, 
     MPN_REQUIRE((long long)N * h <= 65535, MPN_ERR_BAD_SHAPE, "bilinear: N * height must be <= 65535");
     const dim3 grid((unsigned)mpn_div_up((long long)w * (C / ve), kThreads), (unsigned)(N * h));
     hipStream_t st = (hipStream_t)stream;
+    if (upsample == 1 && kThreads % (C / ve) == 0) {
+        const long long nvec = (long long)N * h * w * (C / ve);
+        long long blocks = mpn_div_up(nvec, 4 * kThreads);
+        if (blocks > 4096) blocks = 4096;
+        MPN_DISPATCH_DTYPE(dtype, (slice_affine_store_kernel<T><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                      (const T*)x, (T*)y, nvec, C, y_channel_offset, y_channels_total, in_scale, in_shift, in_act)));
+        MPN_LAUNCH_CHECK();
+        return MPN_OK;
+    }
     MPN_DISPATCH_DTYPE(dtype, (bilinear_up_fwd_kernel<T><<<grid, kThreads, 0, st>>>(
                                   (const T*)x, (T*)y, h, w, C, upsample, y_channel_offset, y_channels_total, in_scale,
                                   in_shift, in_act)));
@@ -244,8 +335,21 @@ extern "C" int mpn_bilinear_up_bwd(const void* dy, void* dx, int N, int h, int w
     MPN_REQUIRE((long long)N * h <= 65535, MPN_ERR_BAD_SHAPE, "bilinear: N * height must be <= 65535");
     const dim3 grid((unsigned)mpn_div_up((long long)w * (C / ve), kThreads), (unsigned)(N * h));
     hipStream_t st = (hipStream_t)stream;
-    MPN_DISPATCH_DTYPE(dtype, (bilinear_up_bwd_kernel<T><<<grid, kThreads, 0, st>>>(
-                                  (const T*)dy, (T*)dx, h, w, C, upsample, y_channel_offset, y_channels_total)));
+    if (upsample == 1) {
+        const long long nvec = (long long)N * h * w * (C / ve);
+        long long blocks = mpn_div_up(nvec, 4 * kThreads);
+        if (blocks > 4096) blocks = 4096;
+        MPN_DISPATCH_DTYPE(dtype, (slice_copy_kernel<T><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                      (const T*)dy, (T*)dx, nvec, C, y_channel_offset, y_channels_total)));
+        MPN_LAUNCH_CHECK();
+        return MPN_OK;
+    }
+    MPN_REQUIRE(upsample == 2 || upsample == 4 || upsample == 8, MPN_ERR_BAD_SHAPE, "bilinear bwd: upsample must be 1, 2, 4 or 8");
+    MPN_DISPATCH_DTYPE(dtype, {
+        if (upsample == 2) bilinear_up_bwd_kernel<T, 2><<<grid, kThreads, 0, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total);
+        else if (upsample == 4) bilinear_up_bwd_kernel<T, 4><<<grid, kThreads, 0, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total);
+        else bilinear_up_bwd_kernel<T, 8><<<grid, kThreads, 0, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total);
+    });
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
