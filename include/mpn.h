@@ -318,6 +318,23 @@ int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, void* dpre, i
 int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const float* labels, int B, int P, int C,
                  float* logits, float* dlogits, float* loss_part, mpn_stream_t stream);
 
+/* PRN inference glue (create_pb.py:86-142): what sits between the sigmoid heatmaps / the detector's boxes and the
+ * network, and between its logits and the exported `keypoint_scores` / `keypoint_positions`.
+ *   mpn_heatmap_minmax  per (image, channel) min and max over the map (create_pb.py:90-92: M, m). minmax_keys: B*C*2
+ *                       32-bit words (opaque order-preserving keys, decoded by mpn_prn_crop). heatmaps f32 [B,h,w,C], C <= 17.
+ *   mpn_prn_crop        (heatmaps - m) / (M - m) * (M > threshold), then tf.image.crop_and_resize (bilinear, extrapolation
+ *                       value 0; create_pb.py:93-109) of box n of image box_ind[n]: boxes f32 [nb,4] normalised
+ *                       (y1,x1,y2,x2) -> crops f32 [nb,crop_h,crop_w,C]. box_ind outside [0,B) gives a zero crop.
+ *   mpn_prn_decode      logits f32 [nb,crop_h,crop_w,C] -> softmax over the crop_h*crop_w positions of each channel
+ *                       (create_pb.py:114-117): scores f32 [nb,C] = its maximum, positions f32 [nb,C,2] =
+ *                       (y / crop_h, x / crop_w) of the first maximum (argmax_2d + scaler, create_pb.py:119-138).
+ */
+int mpn_heatmap_minmax(const float* heatmaps, int B, int h, int w, int C, void* minmax_keys, mpn_stream_t stream);
+int mpn_prn_crop(const float* heatmaps, const void* minmax_keys, const float* boxes, const int* box_ind, int nb, int B,
+                 int h, int w, int C, int crop_h, int crop_w, float threshold, float* crops, mpn_stream_t stream);
+int mpn_prn_decode(const float* logits, int nb, int crop_h, int crop_w, int C, float* scores, float* positions,
+                   mpn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,9 @@ SIGNATURES = {
     "mpn_bias_relu_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "mpn_bias_relu_bwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
     "mpn_prn_loss": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mpn_heatmap_minmax": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "mpn_prn_crop": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "mpn_prn_decode": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mpn_axpy": (_I, [_L, _F, _P, _P, _P]),
 }
 

@@ -196,6 +196,55 @@ def prn_benchmark(batch=128, iters=20):
     ms = e0.elapsed_time(e1) / iters
     nw = 2 * net.n * net.hidden
     byt = nw * (2 * 3 + 4 + 5 * 4 + 3 * (4 + 2))      # operand reads, f32 grads, Adam, refreshes
-    return {"ms_per_step": round(ms, 3), "crops_per_s": round(batch / ms * 1e3, 1), "batch": batch,
-            "alg_GB_per_step": round(byt / 1e9, 3), "hbm_GBps": round(byt / ms / 1e6, 1),
-            "hbm_frac_of_8TBps": round(byt / ms / 1e6 / 8000.0, 4), "final_loss": round(float(loss), 5)}
+    out = {"ms_per_step": round(ms, 3), "crops_per_s": round(batch / ms * 1e3, 1), "batch": batch,
+           "alg_GB_per_step": round(byt / 1e9, 3), "hbm_GBps": round(byt / ms / 1e6, 1),
+           "hbm_frac_of_8TBps": round(byt / ms / 1e6 / 8000.0, 4), "final_loss": round(float(loss), 5)}
+    out["assign"] = prn_assign_benchmark(net, iters=iters)
+    return out
+
+
+def prn_assign_benchmark(net, images=32, h=128, w=128, iters=20):
+    """Inference side of the same model (create_pb.py:86-142): per-channel min/max of `images` heatmaps, normalise +
+    crop_and_resize of net.B person boxes to 56x36, PRN forward, softmax / argmax decode - one hipGraph.
+    Algorithmic bytes: heatmaps read once for min/max, the crops written + read, the two weight matrices read as bf16
+    operands, the logits written + read."""
+    from .prn_inference import KeypointAssigner
+    import numpy as np
+    rs = np.random.RandomState(0)
+    B = net.B
+    hm = torch.sigmoid(torch.randn(images, h, w, net.c, device="cuda") * 1.5 - 3.0)
+    y1, x1 = rs.rand(B) * 0.5, rs.rand(B) * 0.5
+    boxes = torch.tensor(np.stack([y1, x1, y1 + 0.2 + rs.rand(B) * 0.3, x1 + 0.1 + rs.rand(B) * 0.3], 1).astype(np.float32)).cuda()
+    ind = torch.tensor(rs.randint(0, images, B).astype(np.int32)).cuda()
+    a = KeypointAssigner(net)
+
+    def run():
+        return a.decode(net.predict(a.crops(hm, boxes, ind)))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        run()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    byt = hm.numel() * 4 + 4 * B * net.n * 4 + 2 * net.n * net.hidden * 2
+    # CPU restatement of the glue (oracle, numpy): normalise + crop of 8 boxes + decode
+    import time
+    from oracle import prn_post as opost   # checker used as the measured CPU baseline leg only
+    hm_np, bx, bi = hm.cpu().numpy(), boxes.cpu().numpy()[:8], ind.cpu().numpy()[:8]
+    t0 = time.perf_counter()
+    norm, _, _ = opost.normalize_heatmaps(hm_np)
+    cr = opost.crop_and_resize(norm, bx, bi, (net.h, net.w))
+    opost.decode(cr)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    return {"ms_per_batch": round(ms, 3), "persons_per_s": round(B / ms * 1e3, 1), "persons": B, "images": images,
+            "alg_MB": round(byt / 1e6, 1), "hbm_GBps": round(byt / ms / 1e6, 1),
+            "cpu_port_ms_glue_8_persons": round(cpu_ms, 1)}
