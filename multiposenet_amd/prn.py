@@ -88,12 +88,18 @@ class PoseResidualNet:
     def state_dict(self):
         return OrderedDict((k, v.detach().cpu().numpy().copy()) for k, v in self.vars.items())
 
-    def load_state_dict(self, values):
+    def load_state_dict(self, values, strict=True):
         for k, v in self.vars.items():
+            if k not in values:
+                if strict:
+                    raise KeyError(f"missing variable {k}")
+                continue
             a = np.asarray(values[k], np.float32)
             if a.shape != tuple(v.shape):
                 raise ValueError(f"{k}: shape {a.shape} != {tuple(v.shape)}")
             v.copy_(torch.from_numpy(a))
+        if hasattr(self, "w2_conv"):
+            self.refresh_operands()
 
     def refresh_operands(self):
         """Operand copies of the f32 masters (after every optimizer step)."""

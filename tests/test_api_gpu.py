@@ -62,3 +62,32 @@ def test_detector_call_and_decode(cuda, tmp_path):
                                   odec.get_keypoints(out["keypoint_heatmaps"], box, 0.005))
     with pytest.raises(AssertionError):
         det(np.zeros((100, 128, 3), np.uint8))
+
+
+def test_detector_with_prn_assigns_keypoints_to_given_boxes(cuda, tmp_path):
+    """Detector(model_path, prn_path=...)(image, boxes=...) = create_pb.py:86-142 on caller-provided person boxes."""
+    from multiposenet_amd.inference import Detector
+    from multiposenet_amd.prn import initial_values
+    from oracle import prn_post as opost, prn as oprn
+    net, params = _net(seed=7)
+    wpath, ppath = tmp_path / "weights.npz", tmp_path / "prn.npz"
+    np.savez(wpath, **net.state_dict())
+    pvals = initial_values(seed=5)
+    np.savez(ppath, **pvals)
+    det = Detector(str(wpath), dtype=torch.float32, prn_path=str(ppath), max_boxes=8)
+    img = np.random.RandomState(2).randint(0, 256, (128, 128, 3)).astype(np.uint8)
+    boxes = np.array([[0.1, 0.1, 0.9, 0.6], [0.3, 0.4, 0.8, 0.95], [0.0, 0.0, 1.0, 1.0]], np.float32)
+    scores = np.array([0.9, 0.01, 0.5], np.float32)
+    out = det(img, score_threshold=0.05, boxes=boxes, scores=scores)
+    assert out["num_boxes"] == 2 and out["boxes"].shape == (2, 4)            # the 0.01 box is filtered (detector.py:55-60)
+    assert out["keypoint_scores"].shape == (2, 17) and out["keypoint_positions"].shape == (2, 17, 2)
+    # the same chain on the CPU restatements, from the detector's own heatmaps
+    hm = out["keypoint_heatmaps"][None]
+    norm, _, _ = opost.normalize_heatmaps(hm)
+    crops = opost.crop_and_resize(norm, out["boxes"], np.zeros(2, np.int32), (56, 36))
+    pt = {k: torch.tensor(v, dtype=torch.float64) for k, v in pvals.items()}
+    logits = oprn.prn(torch.tensor(crops, dtype=torch.float64), pt).numpy().astype(np.float32)
+    ws, wp = opost.decode(logits)
+    np.testing.assert_allclose(out["keypoint_scores"], ws, rtol=5e-3)
+    assert np.mean(np.all(out["keypoint_positions"] == wp, axis=-1)) >= 0.9
+    assert det(img)["keypoint_positions"].shape == (0, 17, 2)                # without boxes: empty, as before
