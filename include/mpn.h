@@ -188,6 +188,15 @@ int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N, int H, int
 /* dy [N,OH,OW,C] -> dx [N,H,W,C]  (H, W: forward input size) */
 int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C,
                         int stride, int dtype, mpn_stream_t stream);
+/* The same with the batch-norm backward REDUCTION of the layer that dx feeds fused in (the pointwise conv + batch-norm whose
+ * activated output the depthwise conv read, mobilenet_v1.py:88-110): dx is that layer's dA, x_bn its raw conv output
+ * [N,H,W,C]; part [mpn_dwconv_bwd_data_bn_num_parts][2][C] receives sum(g) and sum(g*xhat) per block in the layout of
+ * mpn_bn_bwd_reduce (finish with mpn_bn_bwd_finalize(part, rows, C, N*H*W, ...), then mpn_bn_bwd_apply) - one tensor read
+ * and one launch less than reducing afterwards. num_parts == 0: not available for this shape (odd H / W at stride 2). */
+int mpn_dwconv_bwd_data_bn_num_parts(int N, int H, int W, int C, int stride, int dtype);
+int mpn_dwconv_bwd_data_bn(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride, int dtype,
+                           const void* x_bn, const float* scale, const float* shift, const float* mean,
+                           const float* invstd, int act, float* part, mpn_stream_t stream);
 int mpn_dwconv_wgrad_num_parts(int N, int H, int W, int C, int stride, int dtype);
 /* part [mpn_dwconv_wgrad_num_parts()][9][C]; finish with mpn_reduce_partials */
 int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int C,

@@ -37,6 +37,14 @@ struct DwParams {
     int nvg;            // channel vectors handled per block (<= 8)
     int cblocks;        // channel blocks
     BnTailDev tail;     // batch-norm finalize fused into the last-finishing blocks (forward kernel, mode 0: off)
+    // data-gradient kernels with the batch-norm backward reduction of the layer they feed fused in (BNR): the output is
+    // dA of that layer, bnr_x its raw conv output; part then receives sum(g), sum(g * xhat) instead of the forward statistics
+    const void* bnr_x;
+    const float* bnr_scale;
+    const float* bnr_shift;
+    const float* bnr_mean;
+    const float* bnr_invstd;
+    int bnr_act;
 };
 
 // 4-channel (one LDS float4) accessors of the storage type: the COMPUTE granule. 72 weight registers per thread
@@ -73,6 +81,13 @@ __device__ __forceinline__ void store4x2(bf16_t* p, f32x2_t a, f32x2_t b) {
     q.x = __builtin_bit_cast(unsigned, lo);
     q.y = __builtin_bit_cast(unsigned, hi);
     *reinterpret_cast<uint2*>(p) = q;
+}
+
+// the value a consumer reads back after the store (bf16 storage rounds, f32 does not)
+template <typename T> __device__ __forceinline__ f32x2_t round_storage(f32x2_t a);
+template <> __device__ __forceinline__ f32x2_t round_storage<float>(f32x2_t a) { return a; }
+template <> __device__ __forceinline__ f32x2_t round_storage<bf16_t>(f32x2_t a) {
+    return __builtin_convertvector(__builtin_convertvector(a, bf16x2_t), f32x2_t);
 }
 
 // reduce over the lanes/waves that share this thread's channel vector; result valid in threads
@@ -316,8 +331,9 @@ __device__ __forceinline__ void raw_unpack(const Raw4<bf16_t>& r, float (&f)[4])
     f[2] = __uint_as_float(r.v.y << 16); f[3] = __uint_as_float(r.v.y & 0xffff0000u);
 }
 
-template <typename T, int STRIDE>
+template <typename T, int STRIDE, bool BNR = false>
 __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams p, int ncg, int cols, int xblocks, int yblocks) {
+    static_assert(!BNR || STRIDE == 1, "the fused batch-norm backward reduction rides on the stride-1 data gradient");
     __shared__ float red[kThreads * 8];
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     T* __restrict__ y = reinterpret_cast<T*>(p.y);
@@ -390,7 +406,26 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
     f32x2_t r0[3][2], r1[3][2], r2[3][2];                             // window rows (activated), [column][channel pair]
     T* yp = y + (((long long)img * p.OH + oy_begin) * p.OW + ox) * p.C + cc;
     const long long ystep = (long long)p.OW * p.C;
-    auto emit = [&](const f32x2_t (&a)[3][2], const f32x2_t (&bb)[3][2], const f32x2_t (&cr)[3][2]) {
+    // BNR: per-channel constants of the batch-norm whose input gradient this kernel produces
+    f32x2_t bsc01 = {0.f, 0.f}, bsc23 = {0.f, 0.f}, bsh01 = {0.f, 0.f}, bsh23 = {0.f, 0.f};
+    f32x2_t bis01 = {0.f, 0.f}, bis23 = {0.f, 0.f}, bnm01 = {0.f, 0.f}, bnm23 = {0.f, 0.f};
+    float blo = -INFINITY, bhi = INFINITY;
+    const T* bxp = nullptr;
+    if constexpr (BNR) {
+        const float4 s4 = *reinterpret_cast<const float4*>(p.bnr_scale + cc), h4 = *reinterpret_cast<const float4*>(p.bnr_shift + cc);
+        const float4 m4 = *reinterpret_cast<const float4*>(p.bnr_mean + cc), i4 = *reinterpret_cast<const float4*>(p.bnr_invstd + cc);
+        bsc01 = (f32x2_t){s4.x, s4.y}; bsc23 = (f32x2_t){s4.z, s4.w};
+        bsh01 = (f32x2_t){h4.x, h4.y}; bsh23 = (f32x2_t){h4.z, h4.w};
+        bis01 = (f32x2_t){i4.x, i4.y}; bis23 = (f32x2_t){i4.z, i4.w};
+        bnm01 = (f32x2_t){-m4.x * i4.x, -m4.y * i4.y}; bnm23 = (f32x2_t){-m4.z * i4.z, -m4.w * i4.w};
+        blo = (p.bnr_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+        bhi = (p.bnr_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+        bxp = reinterpret_cast<const T*>(p.bnr_x) + ((long long)img * p.OH * p.OW + (lane_ok ? ox : 0)) * p.C + cc;
+    }
+    auto bnr_load = [&](Raw4<T>& r, int oy) {
+        if constexpr (BNR) raw_load(r, bxp + (long long)min(oy, p.OH - 1) * p.OW * p.C);
+    };
+    auto emit = [&](const f32x2_t (&a)[3][2], const f32x2_t (&bb)[3][2], const f32x2_t (&cr)[3][2], const Raw4<T>& yr) {
         f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -399,8 +434,22 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
             a01 += cr[k][0] * w01[6 + k]; a23 += cr[k][1] * w23[6 + k];
         }
         if (lane_ok) {
-            s01 += a01; s23 += a23;
-            q01 += a01 * a01; q23 += a23 * a23;
+            if constexpr (BNR) {
+                // g = dA * act'(x * scale + shift), computed from the ROUNDED dA the separate reduction would read
+                float f[4];
+                raw_unpack(yr, f);
+                const f32x2_t x01 = {f[0], f[1]}, x23 = {f[2], f[3]};
+                const f32x2_t p01 = x01 * bsc01 + bsh01, p23 = x23 * bsc23 + bsh23;
+                const f32x2_t d01 = round_storage<T>(a01), d23 = round_storage<T>(a23);
+                f32x2_t g01, g23;
+                g01.x = (p01.x > blo && p01.x < bhi) ? d01.x : 0.f; g01.y = (p01.y > blo && p01.y < bhi) ? d01.y : 0.f;
+                g23.x = (p23.x > blo && p23.x < bhi) ? d23.x : 0.f; g23.y = (p23.y > blo && p23.y < bhi) ? d23.y : 0.f;
+                s01 += g01; s23 += g23;
+                q01 += g01 * (x01 * bis01 + bnm01); q23 += g23 * (x23 * bis23 + bnm23);
+            } else {
+                s01 += a01; s23 += a23;
+                q01 += a01 * a01; q23 += a23 * a23;
+            }
             store4x2(yp, a01, a23);
         }
         yp += ystep;
@@ -412,11 +461,14 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
         // THREE raw row buffers rotate with the window: a buffer is re-requested (3 rows ahead) as soon as it has been
         // activated, so three rows (9 pieces = 72 bytes per thread, ~70 KB per CU) are always in flight - with one row in
         // flight the kernel ran at 3.4 TB/s, exactly what its bytes in flight allow.
-        Raw4<T> ra[3], rb[3], rc[3];
+        Raw4<T> ra[3], rb[3], rc[3], ya, yb, yc;
         int iy = oy_begin - p.pad_t;
         row_load(ra, iy);
         row_load(rb, iy + 1);
         row_load(rc, iy + 2);
+        bnr_load(ya, oy_begin);
+        bnr_load(yb, oy_begin + 1);
+        bnr_load(yc, oy_begin + 2);
         row_act(ra, iy, r0);
         row_load(ra, iy + 3);
         row_act(rb, iy + 1, r1);
@@ -425,16 +477,19 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
         for (int oy = oy_begin; oy < oy_end; oy += 3, iy += 3) {
             row_act(rc, iy, r2);
             row_load(rc, iy + 3);
-            emit(r0, r1, r2);
+            emit(r0, r1, r2, ya);
+            bnr_load(ya, oy + 3);
             if (oy + 1 < oy_end) {
                 row_act(ra, iy + 1, r0);
                 row_load(ra, iy + 4);
-                emit(r1, r2, r0);
+                emit(r1, r2, r0, yb);
+                bnr_load(yb, oy + 4);
             }
             if (oy + 2 < oy_end) {
                 row_act(rb, iy + 2, r1);
                 row_load(rb, iy + 5);
-                emit(r2, r0, r1);
+                emit(r2, r0, r1, yc);
+                bnr_load(yc, oy + 5);
             }
         }
     } else {
@@ -450,13 +505,13 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
             row_act(rb, iy + 2, r2);
             row_load(ra, iy + 3);
             row_load(rb, iy + 4);
-            emit(r0, r1, r2);
+            emit(r0, r1, r2, ra[0]);
             if (oy + 1 < oy_end) {
                 row_act(ra, iy + 3, r1);
                 row_act(rb, iy + 4, r0);
                 row_load(ra, iy + 5);
                 row_load(rb, iy + 6);
-                emit(r2, r1, r0);
+                emit(r2, r1, r0, ra[0]);
             }
         }
     }
@@ -825,10 +880,12 @@ namespace {
 // dx[2a..2a+1][2b..2b+1] (4 + 2 + 2 + 1 taps): 2 loads and 4 stores per step, no parity branches (the gather kernel above
 // issues all 9 tap loads with a quarter of the lanes active each).
 constexpr int SWR_DG = 16;   // dY rows per thread
-template <typename T>
+template <typename T, bool BNR>
 __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* __restrict__ dy, const float* __restrict__ w,
                                                                       T* __restrict__ dx, int H, int W, int C, int OH, int OW,
-                                                                      int ncg, int cols, int xblocks, int yblocks, int cblocks) {
+                                                                      int ncg, int cols, int xblocks, int yblocks, int cblocks,
+                                                                      const DwParams p) {
+    __shared__ float red[BNR ? kThreads * 8 : 1];
     int bi = blockIdx.x;
     const int xb = bi % xblocks; bi /= xblocks;
     const int yb = bi % yblocks; bi /= yblocks;
@@ -871,6 +928,43 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
     };
     T* xp = dx + (((long long)img * H + 2 * a_begin) * W + 2 * bc) * C + cc;
     const long long xrow = (long long)W * C;
+    // BNR: batch-norm backward reduction of the layer whose input gradient dx is (see dwconv_fwd_sw_kernel)
+    f32x2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+    f32x2_t bsc01 = {0.f, 0.f}, bsc23 = {0.f, 0.f}, bsh01 = {0.f, 0.f}, bsh23 = {0.f, 0.f};
+    f32x2_t bis01 = {0.f, 0.f}, bis23 = {0.f, 0.f}, bnm01 = {0.f, 0.f}, bnm23 = {0.f, 0.f};
+    float blo = -INFINITY, bhi = INFINITY;
+    const T* bxp = nullptr;
+    if constexpr (BNR) {
+        const float4 s4 = *reinterpret_cast<const float4*>(p.bnr_scale + cc), h4 = *reinterpret_cast<const float4*>(p.bnr_shift + cc);
+        const float4 m4 = *reinterpret_cast<const float4*>(p.bnr_mean + cc), i4 = *reinterpret_cast<const float4*>(p.bnr_invstd + cc);
+        bsc01 = (f32x2_t){s4.x, s4.y}; bsc23 = (f32x2_t){s4.z, s4.w};
+        bsh01 = (f32x2_t){h4.x, h4.y}; bsh23 = (f32x2_t){h4.z, h4.w};
+        bis01 = (f32x2_t){i4.x, i4.y}; bis23 = (f32x2_t){i4.z, i4.w};
+        bnm01 = (f32x2_t){-m4.x * i4.x, -m4.y * i4.y}; bnm23 = (f32x2_t){-m4.z * i4.z, -m4.w * i4.w};
+        blo = (p.bnr_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+        bhi = (p.bnr_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+        bxp = reinterpret_cast<const T*>(p.bnr_x) + (((long long)img * H + 2 * a_begin) * W + 2 * bc) * C + cc;
+    }
+    Raw4<T> yq[4];   // the raw outputs of that layer at the 2x2 block of the NEXT emit (requested one step ahead)
+    auto bnr_load = [&](int a) {
+        if constexpr (BNR) {
+            const T* q = bxp + (long long)(2 * (min(a, OH - 1) - a_begin)) * xrow;
+            raw_load(yq[0], q); raw_load(yq[1], q + C); raw_load(yq[2], q + xrow); raw_load(yq[3], q + xrow + C);
+        }
+    };
+    auto bnr_acc = [&](const Raw4<T>& yr, f32x2_t o01, f32x2_t o23) {
+        float f[4];
+        raw_unpack(yr, f);
+        const f32x2_t x01 = {f[0], f[1]}, x23 = {f[2], f[3]};
+        const f32x2_t p01 = x01 * bsc01 + bsh01, p23 = x23 * bsc23 + bsh23;
+        const f32x2_t d01 = round_storage<T>(o01), d23 = round_storage<T>(o23);
+        f32x2_t g01, g23;
+        g01.x = (p01.x > blo && p01.x < bhi) ? d01.x : 0.f; g01.y = (p01.y > blo && p01.y < bhi) ? d01.y : 0.f;
+        g23.x = (p23.x > blo && p23.x < bhi) ? d23.x : 0.f; g23.y = (p23.y > blo && p23.y < bhi) ? d23.y : 0.f;
+        s01 += g01; s23 += g23;
+        q01 += g01 * (x01 * bis01 + bnm01); q23 += g23 * (x23 * bis23 + bnm23);
+    };
+    int a_cur = a_begin;
     auto emit = [&](const f32x2_t (&pv)[2][2], const f32x2_t (&cv)[2][2]) {   // previous row a-1, current row a
         // taps t = ky*3 + kx
         const f32x2_t e01 = cv[1][0] * w01[0] + pv[1][0] * w01[6] + cv[0][0] * w01[2] + pv[0][0] * w01[8];
@@ -886,9 +980,18 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
             store4x2(xp + C, f01, f23);
             store4x2(xp + xrow, g01, g23);
             store4x2(xp + xrow + C, h01, h23);
+            if constexpr (BNR) {
+                bnr_acc(yq[0], e01, e23);
+                bnr_acc(yq[1], f01, f23);
+                bnr_acc(yq[2], g01, g23);
+                bnr_acc(yq[3], h01, h23);
+            }
         }
         xp += 2 * xrow;
+        ++a_cur;
+        bnr_load(a_cur);
     };
+    bnr_load(a_begin);
     Raw4<T> ra[2], rb[2], rc[2];
     f32x2_t v0[2][2], v1[2][2];
     row_load(ra, a_begin - 1);
@@ -904,6 +1007,22 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
         if (a + 3 < a_end) { row_cvt(rb, a + 3, v0); row_load(rb, a + 6); emit(v1, v0); }
         if (a + 4 < a_end) { row_cvt(rc, a + 4, v1); row_load(rc, a + 7); emit(v0, v1); }
         if (a + 5 < a_end) { row_cvt(ra, a + 5, v0); row_load(ra, a + 8); emit(v1, v0); }
+    }
+    if constexpr (BNR) {
+        float st[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = lane_ok ? st[j] : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < ncg && (cgb * ncg + (int)threadIdx.x) * 4 < C) {
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int cidx = 0; cidx < cols; ++cidx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += red[(cidx * ncg + threadIdx.x) * 8 + j];
+            const int prow = (img * yblocks + yb) * xblocks + xb;
+            float* dst = p.part + (long long)prow * 2 * C + (cgb * ncg + threadIdx.x) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[j] = acc8[j]; dst[C + j] = acc8[4 + j]; }
+        }
     }
 }
 }  // namespace
@@ -999,31 +1118,59 @@ extern "C" int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N,
     return MPN_OK;
 }
 
-/* data gradient: dy [N,OH,OW,C] -> dx [N,H,W,C] (H, W = the forward INPUT size) */
-extern "C" int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
-                                   int dtype, mpn_stream_t stream) {
-    if (stride == 1)  // correlation with the flipped kernel, pad 1
-        return mpn_dwconv_fwd(dy, w, dx, N, H, W, C, 1, dtype, nullptr, nullptr, MPN_ACT_NONE, 1, nullptr, stream);
+// stride-2 sliding-window data gradient: geometry (even H, W only; else the gather kernel)
+struct DwDgS2Geom { bool ok; int ncg, cols, cblocks, xblocks, yblocks; };
+static DwDgS2Geom dw_dg_s2_geom(const DwParams& p) {
+    static int sw = -1;
+    if (sw < 0) { const char* e = getenv("MPN_DW_DGRAD_SW"); sw = e ? atoi(e) : 1; }
+    DwDgS2Geom g = {};
+    const int cg_total = p.C / 4;
+    g.ncg = cg_total < 32 ? cg_total : 32;
+    g.ok = sw && p.pad_t == 0 && p.pad_l == 0 && p.H == 2 * p.OH && p.W == 2 * p.OW && (g.ncg & (g.ncg - 1)) == 0;
+    g.cols = kThreads / g.ncg;
+    g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
+    g.xblocks = (p.OW + g.cols - 1) / g.cols;
+    g.yblocks = (p.OH + SWR_DG - 1) / SWR_DG;
+    return g;
+}
+
+// bnr: fuse the batch-norm backward reduction of the layer that dx feeds (p.bnr_* and p.part set); needs the sliding-window kernels
+static int dw_bwd_data_impl(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride, int dtype,
+                            const DwParams* bnr, mpn_stream_t stream) {
     DwParams p = {};
     if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
     MPN_REQUIRE(dy && w && dx, MPN_ERR_BAD_ARG, "dwconv_bwd_data: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    {
-        static int sw = -1;
-        if (sw < 0) { const char* e = getenv("MPN_DW_DGRAD_SW"); sw = e ? atoi(e) : 1; }
-        const int cg_total = C / 4;
-        const int ncg = cg_total < 32 ? cg_total : 32;
-        if (sw && p.pad_t == 0 && p.pad_l == 0 && H == 2 * p.OH && W == 2 * p.OW && (ncg & (ncg - 1)) == 0) {
-            const int cols = kThreads / ncg, cblocks = (cg_total + ncg - 1) / ncg;
-            const int xblocks = (p.OW + cols - 1) / cols, yblocks = (p.OH + SWR_DG - 1) / SWR_DG;
-            const long long blocks = (long long)N * cblocks * yblocks * xblocks;
-            MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_data: grid too large");
-            MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T><<<(unsigned)blocks, kThreads, 0, st>>>(
-                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, ncg, cols, xblocks, yblocks, cblocks)));
-            MPN_LAUNCH_CHECK();
-            return MPN_OK;
-        }
+    if (stride == 1) {   // correlation with the flipped kernel, pad 1
+        if (bnr == nullptr)
+            return mpn_dwconv_fwd(dy, w, dx, N, H, W, C, 1, dtype, nullptr, nullptr, MPN_ACT_NONE, 1, nullptr, stream);
+        MPN_REQUIRE(dw_use_sw(), MPN_ERR_BAD_ARG, "dwconv_bwd_data_bn: needs the sliding-window kernel");
+        p.x = dy; p.w = w; p.y = dx; p.flip = 1; p.in_act = MPN_ACT_NONE;
+        p.part = bnr->part; p.bnr_x = bnr->bnr_x; p.bnr_scale = bnr->bnr_scale; p.bnr_shift = bnr->bnr_shift;
+        p.bnr_mean = bnr->bnr_mean; p.bnr_invstd = bnr->bnr_invstd; p.bnr_act = bnr->bnr_act;
+        const DwSwGeom g = dw_sw_geom(p);
+        p.cblocks = g.cblocks;
+        const long long blocks = (long long)p.N * g.cblocks * g.yblocks * g.xblocks;
+        MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_data: grid too large");
+        MPN_DISPATCH_DTYPE(dtype, (dwconv_fwd_sw_kernel<T, 1, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks)));
+        MPN_LAUNCH_CHECK();
+        return MPN_OK;
     }
+    const DwDgS2Geom g = dw_dg_s2_geom(p);
+    if (g.ok) {
+        const long long blocks = (long long)N * g.cblocks * g.yblocks * g.xblocks;
+        MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_data: grid too large");
+        if (bnr != nullptr) {
+            MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T, true><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, *bnr)));
+        } else {
+            MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T, false><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p)));
+        }
+        MPN_LAUNCH_CHECK();
+        return MPN_OK;
+    }
+    MPN_REQUIRE(bnr == nullptr, MPN_ERR_BAD_SHAPE, "dwconv_bwd_data_bn: shape not supported (mpn_dwconv_bwd_data_bn_num_parts == 0)");
     const int ve = dtype == MPN_F32 ? 4 : 8;
     const long long total_vec = (long long)N * H * W * (C / ve);
     long long blocks = (total_vec + kThreads - 1) / kThreads;
@@ -1032,6 +1179,44 @@ extern "C" int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int
                                   (const T*)dy, w, (T*)dx, N, H, W, C, p.OH, p.OW, p.pad_t, p.pad_l, total_vec)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
+}
+
+/* data gradient: dy [N,OH,OW,C] -> dx [N,H,W,C] (H, W = the forward INPUT size) */
+extern "C" int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
+                                   int dtype, mpn_stream_t stream) {
+    return dw_bwd_data_impl(dy, w, dx, N, H, W, C, stride, dtype, nullptr, stream);
+}
+
+/* rows of the partial slab mpn_dwconv_bwd_data_bn writes ([rows][2][C], the layout of mpn_bn_bwd_reduce: finish with
+ * mpn_bn_bwd_finalize(part, rows, C, N*H*W, ...)); 0 = the fused form is not available for this shape */
+extern "C" int mpn_dwconv_bwd_data_bn_num_parts(int N, int H, int W, int C, int stride, int dtype) {
+    DwParams p = {};
+    if (fill_params(p, N, H, W, C, stride, dtype)) return 0;
+    if (C % 4 != 0) return 0;
+    if (stride == 1) {
+        if (!dw_use_sw()) return 0;
+        const DwSwGeom g = dw_sw_geom(p);
+        if (kThreads % g.ncg != 0) return 0;
+        return p.N * g.yblocks * g.xblocks;
+    }
+    const DwDgS2Geom g = dw_dg_s2_geom(p);
+    return g.ok ? N * g.yblocks * g.xblocks : 0;
+}
+
+/* mpn_dwconv_bwd_data + the batch-norm backward REDUCTION of the layer whose activated output the depthwise conv read:
+ * dx is that layer's dA, x_bn its raw conv output [N,H,W,C]; part receives sum(g), sum(g*xhat) per block
+ * (g = dA * act'(x_bn*scale+shift), xhat = (x_bn-mean)*invstd) - one tensor read and one launch less than
+ * mpn_bn_bwd_reduce(dx, x_bn, ...) after the fact. */
+extern "C" int mpn_dwconv_bwd_data_bn(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
+                                      int dtype, const void* x_bn, const float* scale, const float* shift, const float* mean,
+                                      const float* invstd, int act, float* part, mpn_stream_t stream) {
+    MPN_REQUIRE(x_bn && scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "dwconv_bwd_data_bn: null pointer");
+    MPN_REQUIRE(mpn_dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, dtype) > 0, MPN_ERR_BAD_SHAPE,
+                "dwconv_bwd_data_bn: shape not supported (mpn_dwconv_bwd_data_bn_num_parts == 0)");
+    DwParams b = {};
+    b.part = part; b.bnr_x = x_bn; b.bnr_scale = scale; b.bnr_shift = shift; b.bnr_mean = mean; b.bnr_invstd = invstd;
+    b.bnr_act = act;
+    return dw_bwd_data_impl(dy, w, dx, N, H, W, C, stride, dtype, &b, stream);
 }
 
 // sliding-window weight gradient: blocks of at most 128 channels; strips of 32 output rows on the large maps, 16 below

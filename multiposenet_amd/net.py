@@ -231,6 +231,7 @@ class KeypointNet:
         # tested, but SLOWER on MI355X (13.1 vs 12.0 ms/step): the fence-free sc1 hand-off costs >= 4 dependent
         # memory round trips (~2 us each) at the tail of every producer, more than the ~5 us launch it replaces
         self.fuse_bn = False
+        self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
         self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
             [self.p_bn[l] for l in (2, 3, 4, 5)] + [self.phi[l][k] for l in (2, 3, 4, 5) for k in ("bn1", "bn2")] + [self.final_bn]
@@ -305,7 +306,8 @@ class KeypointNet:
             cdw, cpw = b["dw"][i].shape[3], blk["pw"].cout
             stat_floats = max(stat_floats, ops.dwconv_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw,
                               nbn(rows(b["dw"][i])) * 2 * cdw,
-                              ops.conv_num_parts(N, *b["hw"][i + 1], 1) * 2 * cpw, nbn(rows(b["pw"][i])) * 2 * cpw)
+                              ops.conv_num_parts(N, *b["hw"][i + 1], 1) * 2 * cpw, nbn(rows(b["pw"][i])) * 2 * cpw,
+                              ops.dwconv_bwd_data_bn_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw)
         for l in lv:
             stat_floats = max(stat_floats, ops.conv_num_parts(N, *lv[l], 3) * 2 * DEPTH, nbn(N * lv[l][0] * lv[l][1]) * 2 * DEPTH)
         b["stat_part"] = torch.empty(stat_floats, dtype=torch.float32, device=dev)
@@ -554,11 +556,12 @@ class KeypointNet:
 
     def _backward_backbone(self, b, g, images, sp, slab, W):
         dA = g["c"]["c5"]
+        reduced = 0
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
-            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, fused=self.fuse_bn)
+            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, fused=self.fuse_bn, reduced_parts=reduced)
             W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
             ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
             ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, fused=self.fuse_bn)
@@ -566,9 +569,20 @@ class KeypointNet:
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
             W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))
             dst = g["pw"][i - 1] if i > 0 else g["stem"]
-            ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst)
+            # the data gradient also reduces for the batch-norm it feeds (one read of dA and one launch less), unless a
+            # lateral's gradient still has to be added to dA first or the fused finalize (fuse_bn) owns the reduction
+            prev_bn = self.blocks[i - 1]["pw_bn"] if i > 0 else self.stem_bn
+            prev_x = b["pw"][i - 1] if i > 0 else b["stem"]
+            prev_feature = i > 0 and self.blocks[i - 1]["i"] in FEATURE_BLOCKS
+            reduced = 0
+            if self.fuse_dw_bn and not self.fuse_bn and not prev_feature and \
+                    ops.dwconv_bwd_data_bn_num_parts(dst.shape[0], *b["hw"][i], dst.shape[3], blk["stride"], dst.dtype) > 0:
+                _, reduced = ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst, bn=prev_bn,
+                                                 x_bn=prev_x, part=sp)
+            else:
+                ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst)
             dA = dst
-        ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp, fused=self.fuse_bn)
+        ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp, fused=self.fuse_bn, reduced_parts=reduced)
         W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, slab[id(self.stem_dw)], reduce=False))
 
     def add_weight_decay_gradients(self, weight_decay):

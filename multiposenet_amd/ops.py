@@ -215,14 +215,17 @@ def bn_act_apply(x, affine, out=None):
     return out
 
 
-def bn_backward(bn, dA, x, part, add_ch0=None, fused=True):
+def bn_backward(bn, dA, x, part, add_ch0=None, fused=True, reduced_parts=0):
     """In place: dA (gradient w.r.t. act(bn(x))) -> gradient w.r.t. the raw conv output x.
     Writes bn.dgamma / bn.dbeta. `part` must hold mpn_bn_stats_num_parts(M)*2*C floats.
-    fused: the reduction launch finalizes too (last-finishing blocks) instead of a separate mpn_bn_bwd_finalize."""
+    fused: the reduction launch finalizes too (last-finishing blocks) instead of a separate mpn_bn_bwd_finalize.
+    reduced_parts > 0: the producer of dA already wrote that many partial rows into `part` (dwconv_bwd_data(..., bn=...))."""
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     dc = _lib.dtype_code(x.dtype)
     nparts = _lib.lib().mpn_bn_stats_num_parts(M)
-    if fused:
+    if reduced_parts:
+        call("mpn_bn_bwd_finalize", ptr(part), int(reduced_parts), C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), stream_ptr())
+    elif fused:
         tail = bn_tail_bwd(bn, M)
         call("mpn_bn_bwd_reduce_fin", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean),
              ptr(bn.invstd), int(bn.act), ptr(part), _tail_arg(tail), stream_ptr())
@@ -257,12 +260,31 @@ def dwconv_fwd(x, w, stride, affine=None, out=None, stats_part=None, tail=None):
     return out
 
 
-def dwconv_bwd_data(dy, w, in_hw, stride, out=None):
+def dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, dtype):
+    """Partial rows of the fused data gradient + batch-norm reduction; 0 = not available for this shape."""
+    return _lib.lib().mpn_dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, _lib.dtype_code(dtype))
+
+
+def dwconv_bwd_data(dy, w, in_hw, stride, out=None, bn=None, x_bn=None, part=None):
+    """bn / x_bn / part: fuse the batch-norm backward reduction of the layer that the result feeds (x_bn = that layer's raw
+    conv output, same shape as the result); returns (out, rows) then - pass rows to bn_backward(reduced_parts=rows)."""
     N, OH, OW, C = dy.shape
     H, W = in_hw
     if out is None:
         out = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
-    call("mpn_dwconv_bwd_data", ptr(dy), ptr(w), ptr(out), N, H, W, C, stride, _lib.dtype_code(dy.dtype), stream_ptr())
+    dc = _lib.dtype_code(dy.dtype)
+    if bn is not None:
+        rows = dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, dy.dtype)
+        if rows <= 0:
+            raise ValueError("dwconv_bwd_data: fused batch-norm reduction not available for this shape")
+        if part is None:
+            part = _f32(rows * 2 * C, dy.device)
+        if part.numel() < rows * 2 * C:
+            raise ValueError("dwconv_bwd_data: partial slab too small")
+        call("mpn_dwconv_bwd_data_bn", ptr(dy), ptr(w), ptr(out), N, H, W, C, stride, dc, ptr(x_bn), ptr(bn.scale), ptr(bn.shift),
+             ptr(bn.mean), ptr(bn.invstd), int(bn.act), ptr(part), stream_ptr())
+        return out, rows
+    call("mpn_dwconv_bwd_data", ptr(dy), ptr(w), ptr(out), N, H, W, C, stride, dc, stream_ptr())
     return out
 
 

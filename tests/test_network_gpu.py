@@ -270,6 +270,7 @@ def test_fused_bn_finalize_equals_separate_launches(cuda):
             for dt in (torch.float32, torch.bfloat16):
                 net = KeypointNet(values=params, dtype=dt)
                 net.fuse_bn = fused
+                net.fuse_dw_bn = False     # (that fusion replaces the reduction launch the fused finalize rides on)
                 tr = Trainer(net, hp, use_graph=False)
                 losses = [tr.step({"images": img}, dlab).cpu().numpy().copy() for _ in range(2)]   # 2 steps: tickets reset
                 out[(fused, dt)] = (losses, net.state_dict(), net.grad.cpu().numpy().copy())
@@ -307,3 +308,30 @@ def test_model_fn_contract(cuda):
     with pytest.raises(ValueError):
         bad = {"images": feats["images"][:, :100]}
         km.model_fn(bad, labels, km.ModeKeys.EVAL, params)
+
+
+def test_dw_dgrad_fused_bn_reduction_equals_separate_reduction(cuda):
+    """mpn_dwconv_bwd_data_bn (data gradient + batch-norm backward reduction in one launch) against the separate
+    mpn_bn_bwd_reduce: same partial sums up to the summation order, so the same gradients and the same step."""
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
+    rs = np.random.RandomState(12)
+    B, H, W = 2, 128, 128
+    params = _params(6)
+    img = torch.tensor(rs.rand(B, H, W, 3).astype(np.float32)).cuda()
+    dlab = {k: torch.tensor(val).cuda() for k, val in _labels(rs, B, H // 4, W // 4).items()}
+    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
+    for dt in (torch.float32, torch.bfloat16):
+        out = {}
+        for fused in (False, True):
+            net = KeypointNet(values=params, dtype=dt)
+            net.fuse_dw_bn = fused
+            tr = Trainer(net, hp, use_graph=False)
+            loss = tr.step({"images": img}, dlab).cpu().numpy().copy()
+            out[fused] = (loss, net.grad.cpu().numpy().copy())
+        np.testing.assert_array_equal(out[True][0], out[False][0])          # the forward pass is untouched
+        ga, gb = out[False][1], out[True][1]
+        denom = np.abs(ga).max()
+        assert np.abs(ga - gb).max() <= (2e-5 if dt == torch.float32 else 2e-2) * denom
+        cos = float((ga * gb).sum() / np.sqrt((ga * ga).sum() * (gb * gb).sum()))
+        assert cos > (0.999999 if dt == torch.float32 else 0.999), cos

@@ -161,3 +161,44 @@ def test_heatmap_head_backward(cuda, dtype, M):
     assert_close(dA.reshape(M, 64), a.grad, dtype, 18)
     assert_close(dwdb[:64 * 18].reshape(64, 18), w.grad, torch.float32, M, scale=float(w.grad.abs().max()))
     assert_close(dwdb[64 * 18:], b.grad, torch.float32, M, scale=float(b.grad.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 64, 2), (1, 12, 20, 128, 1), (1, 32, 32, 512, 2),
+                                            (2, 8, 8, 1024, 1), (1, 48, 40, 256, 2)])
+def test_dwconv_bwd_data_with_fused_bn_reduction(cuda, dtype, N, H, W, C, stride):
+    """mpn_dwconv_bwd_data_bn: the same dx as mpn_dwconv_bwd_data, and partial rows that finalize to the dgamma / dbeta
+    of mpn_bn_bwd_reduce on (dx, x_bn)."""
+    ops = _ops()
+    rs = np.random.RandomState(C + stride + H)
+    OH, OW = ops.dwconv_out_hw(H, W, stride)
+    dy = dev(rnd(rs.randn(N, OH, OW, C), dtype), dtype)
+    w = dev((rs.randn(3, 3, C) / 3).astype(np.float32))
+    xbn = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)
+    def mkbn():
+        one = lambda: torch.tensor((0.5 + rs.rand(C)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), 2)
+        bn.scale.copy_(one()); bn.invstd.copy_(one())
+        bn.shift.copy_(torch.tensor((rs.randn(C) * 0.5).astype(np.float32)).cuda()); bn.mean.copy_(torch.tensor((rs.randn(C) * 0.3).astype(np.float32)).cuda())
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+    st = rs.get_state()
+    bn_a = mkbn(); rs.set_state(st); bn_b = mkbn()
+    rows = ops.dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, dy.dtype)
+    assert rows > 0
+    want = ops.dwconv_bwd_data(dy, w, (H, W), stride)
+    got, r2 = ops.dwconv_bwd_data(dy, w, (H, W), stride, bn=bn_a, x_bn=xbn)
+    assert r2 == rows
+    assert torch.equal(got, want)
+    # reference: separate reduction of the same dA
+    M = N * H * W
+    part = torch.empty(ops._lib.lib().mpn_bn_stats_num_parts(M) * 2 * C, device="cuda")
+    dA_sep = want.clone()
+    ops.bn_backward(bn_b, dA_sep, xbn, part, fused=False)
+    part2 = torch.empty(rows * 2 * C, device="cuda")
+    dA_fused, _ = ops.dwconv_bwd_data(dy, w, (H, W), stride, bn=bn_a, x_bn=xbn, part=part2)
+    ops.bn_backward(bn_a, dA_fused, xbn, part2, fused=False, reduced_parts=rows)
+    scale = float(bn_b.dgamma.abs().max()) + 1e-6
+    assert float((bn_a.dgamma - bn_b.dgamma).abs().max()) <= 2e-5 * scale * max(1.0, M ** 0.5 / 16)
+    assert float((bn_a.dbeta - bn_b.dbeta).abs().max()) <= 2e-5 * (float(bn_b.dbeta.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
+    assert_close(dA_fused, dA_sep.float().cpu(), dtype, 4)
