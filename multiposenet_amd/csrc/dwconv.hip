@@ -45,6 +45,7 @@ struct DwParams {
     const float* bnr_mean;
     const float* bnr_invstd;
     int bnr_act;
+    int xcd_remap;      // sliding-window kernels: XCD-aware block -> strip map
 };
 
 // 4-channel (one LDS float4) accessors of the storage type: the COMPUTE granule. 72 weight registers per thread
@@ -81,6 +82,16 @@ __device__ __forceinline__ void store4x2(bf16_t* p, f32x2_t a, f32x2_t b) {
     q.x = __builtin_bit_cast(unsigned, lo);
     q.y = __builtin_bit_cast(unsigned, hi);
     *reinterpret_cast<uint2*>(p) = q;
+}
+
+// XCD-aware work id: the dispatcher deals consecutive block ids round-robin over the 8 XCDs (each with its own L2), so
+// blocks that share an XCD (same id % 8) get a contiguous range of work ids - neighbouring strips, which share halo
+// columns and rows, then hit in one L2 instead of fetching the halo once per XCD. Bijective for any grid size.
+__device__ __forceinline__ int xcd_work_id(int remap) {
+    const int wid = blockIdx.x;
+    if (!remap) return wid;
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wid >> 3);
 }
 
 // the value a consumer reads back after the store (bf16 storage rounds, f32 does not)
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
     __shared__ float red[kThreads * 8];
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     T* __restrict__ y = reinterpret_cast<T*>(p.y);
-    int b = blockIdx.x;
+    int b = xcd_work_id(p.xcd_remap);
     const int xb = b % xblocks; b /= xblocks;
     const int yb = b % yblocks; b /= yblocks;
     const int cgb = b % p.cblocks;
@@ -546,7 +557,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_wgrad_sw_kernel(const DwParam
     __shared__ __attribute__((aligned(16))) float red[9 * kThreads * 4];   // [tap][thread][4 channels]
     const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
     const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
-    int b = blockIdx.x;
+    int b = xcd_work_id(p.xcd_remap);
     const int cgb = b % p.cblocks; b /= p.cblocks;
     const int unit = b;                                               // partial-slab row
     const int xb = b % xblocks; b /= xblocks;
@@ -847,6 +858,11 @@ int fill_params(DwParams& p, int N, int H, int W, int C, int stride, int dtype) 
     MPN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0, MPN_ERR_BAD_SHAPE,
                 "dwconv: C (%d) must be a multiple of %d", C, ve);
     p.N = N; p.H = H; p.W = W; p.C = C;
+    {
+        static int xr = -1;
+        if (xr < 0) { const char* e = getenv("MPN_DW_XCD"); xr = e ? atoi(e) : 1; }
+        p.xcd_remap = xr;
+    }
     tf_same_pad(H, stride, &p.OH, &p.pad_t);
     tf_same_pad(W, stride, &p.OW, &p.pad_l);
     const int th = stride == 1 ? 8 : 4, tw = stride == 1 ? 16 : 8;
@@ -886,7 +902,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
                                                                       int ncg, int cols, int xblocks, int yblocks, int cblocks,
                                                                       const DwParams p) {
     __shared__ float red[BNR ? kThreads * 8 : 1];
-    int bi = blockIdx.x;
+    int bi = xcd_work_id(p.xcd_remap);
     const int xb = bi % xblocks; bi /= xblocks;
     const int yb = bi % yblocks; bi /= yblocks;
     const int cgb = bi % cblocks;
@@ -1161,8 +1177,10 @@ static int dw_bwd_data_impl(const void* dy, const float* w, void* dx, int N, int
         const long long blocks = (long long)N * g.cblocks * g.yblocks * g.xblocks;
         MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_data: grid too large");
         if (bnr != nullptr) {
+            p.part = bnr->part; p.bnr_x = bnr->bnr_x; p.bnr_scale = bnr->bnr_scale; p.bnr_shift = bnr->bnr_shift;
+            p.bnr_mean = bnr->bnr_mean; p.bnr_invstd = bnr->bnr_invstd; p.bnr_act = bnr->bnr_act;
             MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T, true><<<(unsigned)blocks, kThreads, 0, st>>>(
-                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, *bnr)));
+                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p)));
         } else {
             MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T, false><<<(unsigned)blocks, kThreads, 0, st>>>(
                                           (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p)));
