@@ -1091,12 +1091,19 @@ static int launch_conv_ws(const ConvParams& p, int m_tiles, hipStream_t st) {
     return MPN_OK;
 }
 
+// kernel-variant switches (environment defaults; mpn_debug_set_conv_variant overrides them at run time so that the tests
+// can cover the variants that are off by default): -1 = read the environment
+static int g_ws_min = -1, g_big_min = -1, g_ring = -1;
+extern "C" void mpn_debug_set_conv_variant(int ws_min_units, int big_min_blocks, int ring) {
+    g_ws_min = ws_min_units; g_big_min = big_min_blocks; g_ring = ring;
+}
+
 template <typename T, int TAPS, int BN>
 static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
     // MPN_CONV_WS=<min units>: the warp-specialised persistent kernel for bf16 3x3 layers with at least that many tiles
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
-        static int ws_min = -1;
-        if (ws_min < 0) { const char* e = getenv("MPN_CONV_WS"); ws_min = e ? atoi(e) : 0; }
+        if (g_ws_min < 0) { const char* e = getenv("MPN_CONV_WS"); g_ws_min = e ? atoi(e) : 0; }
+        const int ws_min = g_ws_min;
         if (ws_min > 0 && m_tiles * p.n_tiles >= ws_min && p.row_bytes == 128 && p.up_res == nullptr && p.tail.mode == 0 &&
             p.Cin % 8 == 0) {
             const int rc = launch_conv_ws<BN>(p, m_tiles, st);
@@ -1106,12 +1113,12 @@ static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
     // MPN_CONV_RING=1 selects the 3-blocks-per-CU ring variant for 128-byte chunks. Measured equal to the 2-buffer
     // variant (211 vs 210 us on 3x3 128->128 @ [32,128,128]): occupancy is not what limits this kernel, so the
     // simpler variant stays the default.
-    static int ring = -1;
-    if (ring < 0) { const char* e = getenv("MPN_CONV_RING"); ring = e ? atoi(e) : 0; }
+    if (g_ring < 0) { const char* e = getenv("MPN_CONV_RING"); g_ring = e ? atoi(e) : 0; }
+    const int ring = g_ring;
     // 256-pixel tiles (MPN_CONV_BIG=<min blocks>; off by default - measured equal to the 128-pixel tiles)
     if constexpr (sizeof(T) == 2 && TAPS == 9) {
-        static int big_min = -1;
-        if (big_min < 0) { const char* e = getenv("MPN_CONV_BIG"); big_min = e ? atoi(e) : 0; }
+        if (g_big_min < 0) { const char* e = getenv("MPN_CONV_BIG"); g_big_min = e ? atoi(e) : 0; }
+        const int big_min = g_big_min;
         const int m_big = p.N * ((p.tiles_y + 1) >> 1) * p.tiles_x;
         if (big_min > 0 && m_big * p.n_tiles >= big_min && p.row_bytes == 128 && p.up_res == nullptr && p.tail.mode == 0)
             return launch_conv_rb<T, TAPS, BN, 128, true, 8>(p, m_big, st);

@@ -256,3 +256,22 @@ def test_adam_matches_tf_semantics(cuda):
         np.testing.assert_allclose(float(hyper[1]), lr, rtol=1e-6)
         np.testing.assert_allclose(dp.cpu().numpy(), p64, rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(dv.cpu().numpy(), v64, rtol=1e-4)  # (1-beta2) is rounded in f32, as in TF
+
+
+VARIANT_CASES = [c for c in CONV_CASES if c[5] == 3 and not c[8]]
+
+
+@pytest.mark.parametrize("variant", ["ring", "big", "ws"])
+@pytest.mark.parametrize("case", VARIANT_CASES, ids=[f"{c[3]}to{c[4]}_{c[1]}x{c[2]}" for c in VARIANT_CASES])
+def test_conv3x3_kernel_variants(cuda, variant, case):
+    """The 3x3 kernel variants that are off by default (3-slot weight ring, 256-pixel tiles, the warp-specialised
+    persistent kernel) stay parity-green: same reference, same statistics contract as the default kernel."""
+    import ctypes
+    from multiposenet_amd import _lib
+    setv = _lib.lib().mpn_debug_set_conv_variant
+    setv.argtypes, setv.restype = [ctypes.c_int] * 3, None
+    setv(*{"ring": (0, 0, 1), "big": (0, 1, 0), "ws": (1, 0, 0)}[variant])
+    try:
+        test_conv_fwd(cuda, torch.bfloat16, case)
+    finally:
+        setv(-1, -1, -1)
