@@ -101,47 +101,69 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
 // unbiased variance, TF-1.15 fused batch-norm semantic). 16 channels x 16 part-lanes per block.
 constexpr int kFinThreads = 1024, kFinLanes = 64;   // 64 part-lanes x 16 channels per block
 
-// fixed-order f64 reduction of part[nparts][2][C] for the block's 16 channels; result in (s, q) of lanes pl == 0
-__device__ __forceinline__ void reduce_parts16(const float* __restrict__ part, int nparts, int C, int c, int cl, int pl,
-                                               double (*red)[kFinLanes][16], double& s, double& q) {
-    s = 0.0; q = 0.0;
-    if (c < C) {
-        int p = pl;
-        for (; p + 3 * kFinLanes < nparts; p += 4 * kFinLanes) {   // 8 independent loads in flight
-            const float a0 = part[((long long)p * 2 + 0) * C + c], b0 = part[((long long)p * 2 + 1) * C + c];
-            const float a1 = part[((long long)(p + kFinLanes) * 2 + 0) * C + c], b1 = part[((long long)(p + kFinLanes) * 2 + 1) * C + c];
-            const float a2 = part[((long long)(p + 2 * kFinLanes) * 2 + 0) * C + c], b2 = part[((long long)(p + 2 * kFinLanes) * 2 + 1) * C + c];
-            const float a3 = part[((long long)(p + 3 * kFinLanes) * 2 + 0) * C + c], b3 = part[((long long)(p + 3 * kFinLanes) * 2 + 1) * C + c];
-            s += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-            q += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+// fixed-order f64 reduction of part[nparts][2][C] for the block's 16 channels; result in (s, q) of the threads pl == 0
+// (= threadIdx.x < 16, channel cl). Thread t reads float4 pieces: t & 3 = which 4 of the 16 channels, t >> 2 = one of 256
+// row lanes (a 1x1 conv at 256x256 leaves 16 384 partial rows: with one float per thread and 64 row lanes that finalize
+// took 58 us in 2-8 blocks); the 16 row lanes of a wave combine by shuffles, the 16 waves through LDS.
+// CPB = channels per block: 16, or 4 when there are thousands of partial rows (16 384 after a 1x1 conv at 256x256): the
+// reduction is then bound by how many CUs pull on the slab, and C/16 = 4 blocks took 54 us for 8 MB.
+template <int CPB>
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int C,
+                                             double (*red)[kFinLanes][16], double& s, double& q) {
+    constexpr int G4 = CPB / 4;
+    constexpr int kRowLanes = kFinThreads / G4;
+    const int t = threadIdx.x, g4 = t & (G4 - 1), r = t / G4;
+    const int c4 = blockIdx.x * CPB + g4 * 4;
+    double sa[4] = {0.0, 0.0, 0.0, 0.0}, qa[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c4 < C) {
+        int p = r;
+        for (; p + kRowLanes < nparts; p += 2 * kRowLanes) {   // 4 independent 16-byte loads in flight
+            const float4 a0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 0) * C + c4);
+            const float4 b0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 1) * C + c4);
+            const float4 a1 = *reinterpret_cast<const float4*>(part + ((long long)(p + kRowLanes) * 2 + 0) * C + c4);
+            const float4 b1 = *reinterpret_cast<const float4*>(part + ((long long)(p + kRowLanes) * 2 + 1) * C + c4);
+            sa[0] += (double)a0.x + (double)a1.x; sa[1] += (double)a0.y + (double)a1.y;
+            sa[2] += (double)a0.z + (double)a1.z; sa[3] += (double)a0.w + (double)a1.w;
+            qa[0] += (double)b0.x + (double)b1.x; qa[1] += (double)b0.y + (double)b1.y;
+            qa[2] += (double)b0.z + (double)b1.z; qa[3] += (double)b0.w + (double)b1.w;
         }
-        for (; p < nparts; p += kFinLanes) {
-            s += (double)part[((long long)p * 2 + 0) * C + c];
-            q += (double)part[((long long)p * 2 + 1) * C + c];
+        for (; p < nparts; p += kRowLanes) {
+            const float4 a0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 0) * C + c4);
+            const float4 b0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 1) * C + c4);
+            sa[0] += (double)a0.x; sa[1] += (double)a0.y; sa[2] += (double)a0.z; sa[3] += (double)a0.w;
+            qa[0] += (double)b0.x; qa[1] += (double)b0.y; qa[2] += (double)b0.z; qa[3] += (double)b0.w;
         }
     }
-    red[0][pl][cl] = s;
-    red[1][pl][cl] = q;
+    // the row lanes of a wave (lane bits above the channel-group bits), fixed butterfly order
+#pragma unroll
+    for (int o = G4; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sa[j] += __shfl_xor(sa[j], o, 64); qa[j] += __shfl_xor(qa[j], o, 64); }
+    const int wave = t >> 6, lane = t & 63;
+    if (lane < G4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { red[0][wave][lane * 4 + j] = sa[j]; red[1][wave][lane * 4 + j] = qa[j]; }
+    }
     __syncthreads();
-    if (pl == 0) {
-        s = 0.0; q = 0.0;
-        for (int r = 0; r < kFinLanes; ++r) { s += red[0][r][cl]; q += red[1][r][cl]; }
+    s = 0.0; q = 0.0;
+    if (t < CPB) {
+        for (int w = 0; w < kFinThreads / 64; ++w) { s += red[0][w][t]; q += red[1][w][t]; }
     }
 }
 
 // part [nparts][2][C] -> mean, biased var -> scale/shift (+ moving-average update with the
 // unbiased variance, TF-1.15 fused batch-norm semantic).
+template <int CPB>
 __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(
     const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
     float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
     float* __restrict__ save_invstd) {
     __shared__ double red[2][kFinLanes][16];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = blockIdx.x * CPB + threadIdx.x;
     double s, q;
-    reduce_parts16(part, nparts, C, c, cl, pl, red, s, q);
-    if (pl == 0 && c < C) {
+    reduce_parts<CPB>(part, nparts, C, red, s, q);
+    if ((int)threadIdx.x < CPB && c < C) {
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -254,16 +276,16 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
 }
 
 // part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
+template <int CPB>
 __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
                                                                       double count, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta,
                                                                       float* __restrict__ k1, float* __restrict__ k2) {
     __shared__ double red[2][kFinLanes][16];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    const int c = blockIdx.x * CPB + threadIdx.x;
     double s, q;
-    reduce_parts16(part, nparts, C, c, cl, pl, red, s, q);
-    if (pl == 0 && c < C) {
+    reduce_parts<CPB>(part, nparts, C, red, s, q);
+    if ((int)threadIdx.x < CPB && c < C) {
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         k1[c] = (float)(s / count);
@@ -446,8 +468,13 @@ extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long c
                                mpn_stream_t stream) {
     MPN_REQUIRE(part && gamma && beta && scale && shift, MPN_ERR_BAD_ARG, "bn_finalize: null pointer");
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_finalize: bad sizes");
+    MPN_REQUIRE(C % 4 == 0 && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "bn_finalize: C must be a multiple of 4 and part 16-byte aligned");
     MPN_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), MPN_ERR_BAD_ARG, "bn_finalize: moving stats");
-    bn_finalize_kernel<<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(
+    if (nparts >= 4096)   // many rows, few channels: 4 channels per block so that C/4 CUs pull on the slab
+        bn_finalize_kernel<4><<<(C + 3) / 4, kFinThreads, 0, (hipStream_t)stream>>>(
+            part, nparts, C, (double)count, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    else
+    bn_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(
         part, nparts, C, (double)count, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift, save_mean,
         save_invstd);
     MPN_LAUNCH_CHECK();
@@ -506,7 +533,8 @@ extern "C" int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long lo
                                    float* dbeta, float* k1, float* k2, mpn_stream_t stream) {
     MPN_REQUIRE(part && dgamma && dbeta && k1 && k2, MPN_ERR_BAD_ARG, "bn_bwd_finalize: null pointer");
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_bwd_finalize: bad sizes");
-    bn_bwd_finalize_kernel<<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
+    MPN_REQUIRE(C % 4 == 0 && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "bn_bwd_finalize: C must be a multiple of 4 and part 16-byte aligned");
+    bn_bwd_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
                                                                                dgamma, dbeta, k1, k2);
     MPN_LAUNCH_CHECK();
     return MPN_OK;

@@ -950,12 +950,18 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 // all packing jobs of the network in ONE launch (68 tiny launches per optimizer step otherwise)
 template <typename T>
 __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, int ndesc) {
-    int lo = 0, hi = ndesc - 1;   // binary search of the job that owns this block
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    __shared__ int job;           // the job that owns this block: one parallel read of block_begin + a ballot
+    if (threadIdx.x < 64) {
+        int cnt = 0;
+        for (int base = 0; base < ndesc; base += 64) {
+            const int i = base + (int)threadIdx.x;
+            const bool le = i < ndesc && descs[i].block_begin <= (int)blockIdx.x;
+            cnt += __popcll(__ballot(le));
+        }
+        if (threadIdx.x == 0) job = cnt - 1;
     }
-    const PackDesc d = descs[lo];
+    __syncthreads();
+    const PackDesc d = descs[job];
     const int lb = blockIdx.x - d.block_begin;
     for (long long i = (long long)lb * blockDim.x + threadIdx.x; i < d.total_elems; i += (long long)d.block_count * blockDim.x)
         pack_one<T>(d.w, reinterpret_cast<T*>(d.out), d.Cin_o, d.Cout_o, d.taps, d.transpose, d.BN, d.nchunk, d.row_bytes, i);

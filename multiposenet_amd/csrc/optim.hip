@@ -144,12 +144,20 @@ struct ReduceDesc {
 
 __global__ __launch_bounds__(kThreads) void reduce_partials_batched_kernel(const ReduceDesc* __restrict__ descs, int ndesc) {
     __shared__ float4 red[kThreads];
-    int lo = 0, hi = ndesc - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    __shared__ int job;
+    // the job that owns this block: ONE parallel read of the block_begin column + a ballot (a binary search is ~6 dependent
+    // L2 round trips per block, more than the work of a block that sums 4 rows)
+    if (threadIdx.x < 64) {
+        int cnt = 0;
+        for (int base = 0; base < ndesc; base += 64) {
+            const int i = base + (int)threadIdx.x;
+            const bool le = i < ndesc && descs[i].block_begin <= (int)blockIdx.x;
+            cnt += __popcll(__ballot(le));
+        }
+        if (threadIdx.x == 0) job = cnt - 1;
     }
-    const ReduceDesc d = descs[lo];
+    __syncthreads();
+    const ReduceDesc d = descs[job];
     const int lb = blockIdx.x - d.block_begin;
     const int c = threadIdx.x & (d.cols - 1), sl = threadIdx.x / d.cols, nsl = kThreads / d.cols;
     const long long ncol = d.vec ? (d.n >> 2) : d.n;
