@@ -95,6 +95,9 @@ def main():
         out["label_render"] = render_benchmark(args.batch, args.size, args.size)
         del trainer, net
         torch.cuda.empty_cache()
+        if args.batch == 32 and args.size == 512 and dt == torch.bfloat16:
+            from multiposenet_amd.benchmarks import north_star_kernels
+            out["north_star_kernels"] = north_star_kernels(args.batch)
         out["prn"] = prn_benchmark(128)
     if rank == 0:
         print(json.dumps(out))

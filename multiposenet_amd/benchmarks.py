@@ -47,6 +47,63 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=20):
             "traffic": traffic, "launch_us": round(sec * 1e6, 2)}
 
 
+def north_star_kernels(batch=32, iters=20):
+    """The two kernel families the north star sets targets for, at the bench shape (bs32 @ 512x512, bf16), each launch
+    timed alone with HIP events on the launch stream: the depthwise 3x3 path against the 8 TB/s HBM peak (algorithmic
+    bytes = input read once + output written once) and pointwise 1x1 layers against the 2.5 PFLOP/s bf16 MFMA peak."""
+    dt = torch.bfloat16
+    stream = torch.cuda.current_stream()
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+
+    out = {"depthwise": [], "pointwise": []}
+    for (H, C, s) in [(256, 32, 1), (256, 64, 2), (128, 128, 1), (128, 128, 2), (32, 512, 1)]:
+        x = torch.randn(batch, H, H, C, device="cuda").to(dt)
+        w = torch.randn(3, 3, C, device="cuda") * 0.2
+        aff = ops.Affine(torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1, 2)
+        OH = H // s
+        y = torch.empty(batch, OH, OH, C, device="cuda", dtype=dt)
+        dy = torch.randn(batch, OH, OH, C, device="cuda").to(dt)
+        dx = torch.empty_like(x)
+        dw = torch.empty(3, 3, C, device="cuda")
+        part = torch.empty(ops.dwconv_num_parts(batch, H, H, C, s, dt) * 2 * C, device="cuda")
+        slab = torch.empty(ops.dwconv_wgrad_num_parts(batch, H, H, C, s, dt) * 9 * C, device="cuda")
+        byt = (x.numel() + y.numel()) * 2
+        row = {"layer": f"{C}ch @{H}x{H} stride {s}"}
+        for name, fn in (("fwd", lambda: ops.dwconv_fwd(x, w, s, aff, out=y, stats_part=part)),
+                         ("dgrad", lambda: ops.dwconv_bwd_data(dy, w, (H, H), s, out=dx)),
+                         ("wgrad", lambda: ops.dwconv_bwd_weight(x, dy, s, aff, dw, slab, reduce=False))):
+            sec = timed(fn)
+            row[name + "_GBps"] = round(byt / sec / 1e9, 0)
+            row[name + "_frac_of_8TBps"] = round(byt / sec / 8e12, 3)
+        out["depthwise"].append(row)
+        del x, y, dy, dx
+    for (H, Cin, Cout) in [(128, 128, 128), (64, 256, 256), (32, 512, 512), (16, 1024, 1024)]:
+        x = torch.randn(batch, H, H, Cin, device="cuda").to(dt)
+        pc = ops.PackedConv(torch.randn(1, 1, Cin, Cout, device="cuda") * 0.05, dt)
+        aff = ops.Affine(torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1, 2)
+        y = torch.empty(batch, H, H, Cout, device="cuda", dtype=dt)
+        part = torch.empty(ops.conv_num_parts(batch, H, H, 1) * 2 * Cout, device="cuda")
+        sec = timed(lambda: ops.conv_fwd(x, pc.fwd, Cout, 1, aff, out=y, stats_part=part))
+        fl = 2.0 * batch * H * H * Cin * Cout
+        byt = (x.numel() + y.numel()) * 2
+        out["pointwise"].append({"layer": f"{Cin}->{Cout} @{H}x{H}", "TFLOPs": round(fl / sec / 1e12, 1),
+                                 "frac_of_mfma_peak": round(fl / sec / 1e12 / PEAK_BF16_TFLOPS, 3),
+                                 "GBps": round(byt / sec / 1e9, 0), "frac_of_8TBps": round(byt / sec / 8e12, 3),
+                                 "arithmetic_intensity_flop_per_byte": round(fl / byt, 1)})
+        del x, y
+    return out
+
+
 def cpu_baseline(size, budget_s=20.0):
     """CPU restatement of the reference (oracle/network.py: torch-CPU ops in TF-1.15 semantics, f32), forward + backward
     + Adam on a bounded sample of the same workload, all host cores. Reported next to the GPU number; not the target.

@@ -288,6 +288,10 @@ def dwconv_bwd_data(dy, w, in_hw, stride, out=None, bn=None, x_bn=None, part=Non
     return out
 
 
+def dwconv_wgrad_num_parts(N, H, W, C, stride, dtype):
+    return _lib.lib().mpn_dwconv_wgrad_num_parts(N, H, W, C, stride, _lib.dtype_code(dtype))
+
+
 def dwconv_bwd_weight(x, dy, stride, affine, dw_out, part=None, reduce=True):
     N, H, W, C = x.shape
     dc = _lib.dtype_code(x.dtype)
