@@ -17,10 +17,16 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const T* __restrict_
                                                             int act, int mode, float* __restrict__ out,
                                                             float* __restrict__ out_seg) {
     constexpr int VE = Vec16<T>::N;
-    __shared__ float wl[kMaxCin * kOut];
+    // weight rows padded to 20 floats: the 18 weights of a channel are five 16-byte LDS reads (broadcast) instead of 18
+    // dword reads - one read per FMA made the LDS instruction rate the bound (1152 reads per pixel)
+    constexpr int kWl = 20;
+    __shared__ __attribute__((aligned(16))) float wl[kMaxCin * kWl];
     __shared__ float scl[kMaxCin], shl[kMaxCin];
     __shared__ __attribute__((aligned(16))) float ot[kThreads * kOut];
-    for (int i = threadIdx.x; i < Cin * kOut; i += kThreads) wl[i] = w[i];
+    for (int i = threadIdx.x; i < Cin * kWl; i += kThreads) {
+        const int c = i / kWl, k = i - c * kWl;
+        wl[i] = k < kOut ? w[c * kOut + k] : 0.f;
+    }
     for (int i = threadIdx.x; i < Cin; i += kThreads) { scl[i] = sc ? sc[i] : 1.f; shl[i] = sc ? sh[i] : 0.f; }
     __syncthreads();
     const long long m0 = (long long)blockIdx.x * kThreads;
@@ -39,8 +45,14 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const T* __restrict_
                 float t = f[j] * scl[c0 + j] + shl[c0 + j];
                 if (act != MPN_ACT_NONE) t = fmaxf(t, 0.f);
                 if (act == MPN_ACT_RELU6) t = fminf(t, 6.f);
+                const float4* wr = reinterpret_cast<const float4*>(&wl[(c0 + j) * kWl]);
 #pragma unroll
-                for (int k = 0; k < kOut; ++k) acc[k] += t * wl[(c0 + j) * kOut + k];
+                for (int q = 0; q < 4; ++q) {
+                    const float4 w4 = wr[q];
+                    acc[4 * q] += t * w4.x; acc[4 * q + 1] += t * w4.y; acc[4 * q + 2] += t * w4.z; acc[4 * q + 3] += t * w4.w;
+                }
+                const float4 w5 = wr[4];
+                acc[16] += t * w5.x; acc[17] += t * w5.y;
             }
         }
     }
