@@ -336,7 +336,12 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
             const long long ii = i + u * stride;
             const long long ic = ii < nvec ? ii : i;   // unconditional loads from a valid address (a predicated load waits)
             vd[u].load(dA + ic * VE);
-            vx[u].load(x + ic * VE);
+            {   // x is dead after this pass: a non-temporal load keeps it from displacing dx, which the conv data / weight
+                // gradients read next (256x256x64 layer: 165 -> 131 us, the step -0.85 %)
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(x + ic * VE));
+                __builtin_memcpy(&vx[u].raw, &q, 16);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {

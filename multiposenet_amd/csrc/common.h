@@ -64,6 +64,11 @@ template <> struct Vec16<float> {
     static constexpr int N = 4;
     float4 raw;
     __device__ __forceinline__ void load(const float* p) { raw = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void load_nt(const float* p) {
+        typedef float f32x4n_t __attribute__((ext_vector_type(4)));
+        const f32x4n_t q = __builtin_nontemporal_load(reinterpret_cast<const f32x4n_t*>(p));
+        raw = make_float4(q.x, q.y, q.z, q.w);
+    }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = raw; }
     __device__ __forceinline__ void zero() { raw = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void unpack(float (&f)[4]) const { f[0] = raw.x; f[1] = raw.y; f[2] = raw.z; f[3] = raw.w; }
@@ -73,6 +78,11 @@ template <> struct Vec16<bf16_t> {
     static constexpr int N = 8;
     uint4 raw;
     __device__ __forceinline__ void load(const bf16_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void load_nt(const bf16_t* p) {   // streamed once: do not keep the line
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        raw = make_uint4(q.x, q.y, q.z, q.w);
+    }
     __device__ __forceinline__ void store(bf16_t* p) const { *reinterpret_cast<uint4*>(p) = raw; }
     __device__ __forceinline__ void zero() { raw = make_uint4(0u, 0u, 0u, 0u); }
     __device__ __forceinline__ void unpack(float (&f)[8]) const {

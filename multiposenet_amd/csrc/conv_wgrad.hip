@@ -604,8 +604,10 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
                 for (int r = 0; r < 4; ++r) {
                     const int ci = ci0 + (mt0 + i) * 16 + lq * 4 + r;
                     const int co = co0 + (nt0 + j) * 16 + l15;
-                    if (ci < p.Cin && co < p.Cout)
-                        dst[((long long)t * p.Cin + ci) * p.Cout + co] = acc[t][i][j][r];
+                    if (ci < p.Cin && co < p.Cout) {
+                        // the slab is read once, by the batched reduction at the end of the step: non-temporal
+                        __builtin_nontemporal_store(acc[t][i][j][r], &dst[((long long)t * p.Cin + ci) * p.Cout + co]);
+                    }
                 }
 }
 

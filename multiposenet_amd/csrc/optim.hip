@@ -167,10 +167,12 @@ __global__ __launch_bounds__(kThreads) void reduce_partials_batched_kernel(const
         if (d.vec) {
             int p = sl;
             for (; p + 3 * nsl < d.nparts; p += 4 * nsl) {
-                const float4 v0 = reinterpret_cast<const float4*>(d.part + (long long)p * d.n)[j];
-                const float4 v1 = reinterpret_cast<const float4*>(d.part + (long long)(p + nsl) * d.n)[j];
-                const float4 v2 = reinterpret_cast<const float4*>(d.part + (long long)(p + 2 * nsl) * d.n)[j];
-                const float4 v3 = reinterpret_cast<const float4*>(d.part + (long long)(p + 3 * nsl) * d.n)[j];
+                // (slabs are dead after this read: non-temporal)
+                typedef float f4_t __attribute__((ext_vector_type(4)));
+                const f4_t v0 = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(d.part + (long long)p * d.n) + j);
+                const f4_t v1 = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(d.part + (long long)(p + nsl) * d.n) + j);
+                const f4_t v2 = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(d.part + (long long)(p + 2 * nsl) * d.n) + j);
+                const f4_t v3 = __builtin_nontemporal_load(reinterpret_cast<const f4_t*>(d.part + (long long)(p + 3 * nsl) * d.n) + j);
                 a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
                 b.x += v1.x; b.y += v1.y; b.z += v1.z; b.w += v1.w;
                 a.x += v2.x; a.y += v2.y; a.z += v2.z; a.w += v2.w;
