@@ -302,20 +302,8 @@ __global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma
                 if (more) b_issue(s + 1, (s + 1) & 1);   // buffer (s+1)%2 was last read in stage s-1: all waves are past it
                 load_frags(aP, bP, a_off, b_off);
                 load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
-#if defined(MPN_EXP_SCHED)
-                __builtin_amdgcn_sched_barrier(0);
-#endif
-#if defined(MPN_EXP_PRIO)
-                __builtin_amdgcn_s_setprio(1);
-#endif
                 mma_all(aP, bP);
                 mma_all(aQ, bQ);
-#if defined(MPN_EXP_PRIO)
-                __builtin_amdgcn_s_setprio(0);
-#endif
-#if defined(MPN_EXP_SCHED)
-                __builtin_amdgcn_sched_barrier(0);
-#endif
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
                 __syncthreads();
             } else {
