@@ -129,7 +129,6 @@ __global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma
     constexpr int NPIX = TAPS == 9 ? kHaloW * HALO_H : MT * 32;
     constexpr int NT = BN / 32;                 // 16-channel tiles per wave
     constexpr int KSPS = RING ? 1 : 2;          // k-steps per weight stage
-    constexpr int NBUF = RING ? 3 : 2;
     constexpr int STAGE_BYTES = KSPS * BN * 64;
     constexpr int BVEC = STAGE_BYTES / (kThreads * 16);
     static_assert(BVEC >= 1, "a weight stage is at least one 16-byte vector per thread");
@@ -560,7 +559,6 @@ template <int N> struct WsSet {
 
 constexpr int kWsThreads = 512;
 constexpr int kWsNbuf = 5;
-constexpr int kWsRawSlots = 12;
 
 template <int BN>
 __global__ __launch_bounds__(kWsThreads, 1) void conv_ws_kernel(const ConvParams p, int units_total) {
