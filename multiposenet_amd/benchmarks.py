@@ -16,7 +16,7 @@ def whole_step_mfma_fraction(batch, size, step_seconds):
     return round(flops / step_seconds / (PEAK_BF16_TFLOPS * 1e12), 4)
 
 
-def dominant_kernel_roofline(net, batch, size, dtype, iters=20):
+def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20):
     """The dominant kernel of the step is the dense 3x3 implicit-GEMM conv (conv_mfma_kernel, 128->128 channels
     at stride 4: p2, phi_subnet_2/conv1, conv2 forward and their three data-gradients = 6 launches per step).
     Times that launch with HIP events on the launch stream, on the tensors of the live network."""
@@ -25,7 +25,9 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=20):
     conv = net.phi[2]["conv1"]
     y = torch.empty_like(x)
     stream = torch.cuda.current_stream()
-    for _ in range(3):
+    # (steady state: the chip drops its clock in the host-side gap after the training loop and takes a few
+    #  milliseconds of work to come back - 3 warm-up launches read 177 us where 20 read 144-149 us, tools/roofline_repeat.py)
+    for _ in range(warmup):
         ops.conv_fwd(x, conv.packed.fwd, 128, 3, net.p_bn[2].affine, out=y)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
