@@ -245,7 +245,9 @@ extern "C" int mpn_heatmap_head_fwd(const void* x, const float* w, const float* 
 
 extern "C" int mpn_heatmap_head_bwd_num_parts(long long M) {
     const long long ntiles = (M + kBwdPix - 1) / kBwdPix;
-    return (int)(ntiles < 512 ? ntiles : 512);
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("MPN_HEAD_BWD_BLOCKS"); cap = e ? atoi(e) : 768; }   // three resident blocks per CU (45 KB of LDS each): one more to hide the staging of the others
+    return (int)(ntiles < cap ? ntiles : cap);
 }
 
 /* dA [M][Cin] (storage dtype); part [num_parts][Cin*18 + 18] f32: dW then db partials */
