@@ -48,6 +48,9 @@ __device__ __forceinline__ void stage_patch(const void* images, float* patch, in
 // NHWC tensor: per-thread stores of 16 bytes at the 64-byte pixel stride cost as much as the rest of the kernel.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
+// Two horizontally adjacent output pixels per thread: every 16-byte LDS read of the weights feeds both (the kernel is
+// bound by the LDS instruction rate - 216 broadcast reads per pixel with one pixel per thread - not by HBM).
+constexpr int kFwdTW = 2 * kTile;      // 32 x 16 output pixels per block
 template <typename T, bool U8>
 __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restrict__ images, const float* __restrict__ w,
                                                             T* __restrict__ y, int N, int H, int W, int C0, int OH, int OW,
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restri
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char stem_smem[];
     float* wl = reinterpret_cast<float*>(stem_smem);                        // [27][C0]
-    unsigned char* otile = stem_smem + 27 * kMaxC0 * sizeof(float);         // [256 px][C0 * sizeof(T) + 16]
+    unsigned char* otile = stem_smem + 27 * kMaxC0 * sizeof(float);         // [512 px][C0 * sizeof(T) + 16]
     const int orow = C0 * (int)sizeof(T) + 16;
     int b = blockIdx.x;
     const int tx = b % tiles_x; b /= tiles_x;
@@ -64,66 +67,77 @@ __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restri
     for (int i = threadIdx.x; i < 27 * C0; i += kThreads) wl[i] = w[i];
     __syncthreads();
     const int lx = threadIdx.x % kTile, ly = threadIdx.x / kTile;
-    const int oy = ty * kTile + ly, ox = tx * kTile + lx;
-    if (oy < OH && ox < OW) {
-        float in[27];
-        const int ix0 = 2 * ox - pad_l;
+    const int oy = ty * kTile + ly, ox0 = tx * kFwdTW + lx * 2;
+    if (oy < OH && ox0 < OW) {
+        float in[2][27];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = 2 * oy - pad_t + ky;
-            const bool row_ok = iy >= 0 && iy < H;
-            const long long base = (((long long)img * H + (row_ok ? iy : 0)) * W + ix0) * 3;
-            if (!U8 && row_ok && ix0 >= 0 && ix0 + 2 < W) {
-                const float* src = reinterpret_cast<const float*>(images) + base;
-                const float4 a = *reinterpret_cast<const float4*>(src);
-                const float4 c = *reinterpret_cast<const float4*>(src + 4);
-                const float e = src[8];
-                const float r[9] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, e};
+        for (int q = 0; q < 2; ++q) {
+            const int ox = ox0 + q;
+            const int ix0 = 2 * ox - pad_l;
 #pragma unroll
-                for (int j = 0; j < 9; ++j) in[ky * 9 + j] = 2.0f * r[j] - 1.0f;
-            } else {
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = 2 * oy - pad_t + ky;
+                const bool row_ok = iy >= 0 && iy < H && ox < OW;
+                const long long base = (((long long)img * H + (row_ok ? iy : 0)) * W + (ox < OW ? ix0 : 0)) * 3;
+                if (!U8 && row_ok && ix0 >= 0 && ix0 + 2 < W) {
+                    const float* src = reinterpret_cast<const float*>(images) + base;
+                    const float4 a = *reinterpret_cast<const float4*>(src);   // (global dwordx4 needs dword alignment only)
+                    const float4 c = *reinterpret_cast<const float4*>(src + 4);
+                    const float e = src[8];
+                    const float r[9] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w, e};
 #pragma unroll
-                for (int j = 0; j < 9; ++j) {
-                    const int ix = ix0 + j / 3;
-                    float v = 0.f;   // SAME padding: zeros of the STANDARDISED tensor
-                    if (row_ok && ix >= 0 && ix < W) {
-                        const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[base + j] * (1.0f / 255.0f)
-                                             : reinterpret_cast<const float*>(images)[base + j];
-                        v = 2.0f * raw - 1.0f;
+                    for (int j = 0; j < 9; ++j) in[q][ky * 9 + j] = 2.0f * r[j] - 1.0f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 9; ++j) {
+                        const int ix = ix0 + j / 3;
+                        float v = 0.f;   // SAME padding: zeros of the STANDARDISED tensor
+                        if (row_ok && ix >= 0 && ix < W) {
+                            const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[base + j] * (1.0f / 255.0f)
+                                                 : reinterpret_cast<const float*>(images)[base + j];
+                            v = 2.0f * raw - 1.0f;
+                        }
+                        in[q][ky * 9 + j] = v;
                     }
-                    in[ky * 9 + j] = v;
                 }
             }
         }
+        const int pl = ly * kFwdTW + lx * 2;                     // tile pixel of the first output
         for (int c0 = 0; c0 < C0; c0 += VE) {
-            f32x2_t acc2[VE / 2];
+            f32x2_t acc2[2][VE / 2];
 #pragma unroll
-            for (int j = 0; j < VE / 2; ++j) acc2[j] = (f32x2_t){0.f, 0.f};
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < VE / 2; ++j) acc2[q][j] = (f32x2_t){0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 27; ++t) {
-                const f32x2_t iv = (f32x2_t){in[t], in[t]};
+                const f32x2_t iv0 = (f32x2_t){in[0][t], in[0][t]}, iv1 = (f32x2_t){in[1][t], in[1][t]};
 #pragma unroll
                 for (int j = 0; j < VE; j += 4) {
-                    const float4 q = *reinterpret_cast<const float4*>(&wl[t * C0 + c0 + j]);  // LDS broadcast
-                    acc2[j / 2] += iv * (f32x2_t){q.x, q.y};
-                    acc2[j / 2 + 1] += iv * (f32x2_t){q.z, q.w};
+                    const float4 q4 = *reinterpret_cast<const float4*>(&wl[t * C0 + c0 + j]);  // LDS broadcast
+                    const f32x2_t w01 = (f32x2_t){q4.x, q4.y}, w23 = (f32x2_t){q4.z, q4.w};
+                    acc2[0][j / 2] += iv0 * w01; acc2[0][j / 2 + 1] += iv0 * w23;
+                    acc2[1][j / 2] += iv1 * w01; acc2[1][j / 2 + 1] += iv1 * w23;
                 }
             }
-            float acc[VE];
 #pragma unroll
-            for (int j = 0; j < VE / 2; ++j) { acc[2 * j] = acc2[j].x; acc[2 * j + 1] = acc2[j].y; }
-            Vec16<T> ov;
-            ov.pack(acc);
-            *reinterpret_cast<uint4*>(otile + threadIdx.x * orow + c0 * (int)sizeof(T)) = *reinterpret_cast<const uint4*>(&ov.raw);
+            for (int q = 0; q < 2; ++q) {
+                float acc[VE];
+#pragma unroll
+                for (int j = 0; j < VE / 2; ++j) { acc[2 * j] = acc2[q][j].x; acc[2 * j + 1] = acc2[q][j].y; }
+                Vec16<T> ov;
+                ov.pack(acc);
+                *reinterpret_cast<uint4*>(otile + (pl + q) * orow + c0 * (int)sizeof(T)) = *reinterpret_cast<const uint4*>(&ov.raw);
+            }
         }
     }
     __syncthreads();
-    // copy-out: tile row r = 16 pixels x C0 channels = one contiguous run of the output tensor
+    // copy-out: tile row r = 32 pixels x C0 channels = one contiguous run of the output tensor
     const int ppr = C0 * (int)sizeof(T) / 16;            // 16-byte pieces per pixel
-    for (int i = threadIdx.x; i < kTile * kTile * ppr; i += kThreads) {
+    for (int i = threadIdx.x; i < kTile * kFwdTW * ppr; i += kThreads) {
         const int pxl = i / ppr, piece = i - pxl * ppr;
-        const int r = pxl / kTile, cx = pxl - r * kTile;
-        const int yy = ty * kTile + r, xx = tx * kTile + cx;
+        const int r = pxl / kFwdTW, cx = pxl - r * kFwdTW;
+        const int yy = ty * kTile + r, xx = tx * kFwdTW + cx;
         if (yy < OH && xx < OW)
             *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(y + (((long long)img * OH + yy) * OW + xx) * C0) + piece * 16) =
                 *reinterpret_cast<const uint4*>(otile + pxl * orow + piece * 16);
@@ -296,11 +310,11 @@ extern "C" int mpn_stem_conv_fwd(const void* images, int images_u8, const float*
     int OH, OW, pt, pl;
     same_pad(H, &OH, &pt);
     same_pad(W, &OW, &pl);
-    const int tiles_y = (OH + kTile - 1) / kTile, tiles_x = (OW + kTile - 1) / kTile;
+    const int tiles_y = (OH + kTile - 1) / kTile, tiles_x = (OW + kFwdTW - 1) / kFwdTW;
     const int grid = N * tiles_y * tiles_x;
     hipStream_t st = (hipStream_t)stream;
     MPN_DISPATCH_DTYPE(dtype, {
-        const int sm = 27 * kMaxC0 * (int)sizeof(float) + kThreads * (C0 * (int)sizeof(T) + 16);
+        const int sm = 27 * kMaxC0 * (int)sizeof(float) + 2 * kThreads * (C0 * (int)sizeof(T) + 16);
         if (images_u8) {
             if (sm > 48 * 1024)
                 MPN_HIP(hipFuncSetAttribute((const void*)stem_fwd_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm));
