@@ -331,8 +331,9 @@ __global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams 
 // Lanes run over (column, 4-channel group) with channels fastest, so every wave access is a contiguous run of pixels.
 // output rows per thread: 32 on maps of 64 rows and more (the two primed rows of a strip are 6 % instead of 12 % extra
 // loads; the step -0.8 %), 16 below (strips of 32 would leave the 32x32 and 16x16 maps with too few blocks)
-__host__ __device__ inline int sw_rows(int OH) {
-    return OH >= 64 ? 32 : 16;   // (64-row strips on the 128 / 256-row maps: slightly slower again)
+__host__ __device__ inline int sw_rows(int OH, int stride = 2) {
+    (void)stride;   // (64-row strips for stride 1 on the 128 / 256-row maps: no gain in the forward)
+    return OH >= 64 ? 32 : 16;
 }
 
 template <typename T> struct Raw4;
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
     const float lo = (aff && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
     const float hi = (aff && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
 
-    const int swr = sw_rows(p.OH);
+    const int swr = sw_rows(p.OH, STRIDE);
     const int oy_begin = yb * swr, oy_end = min(oy_begin + swr, p.OH);
     const int ix0 = ox * STRIDE - p.pad_l;                            // leftmost input column of the window
     const T* ximg = x + (long long)img * p.H * p.W * p.C + cc;
@@ -1074,7 +1075,7 @@ static DwSwGeom dw_sw_geom(const DwParams& p) {
     g.cols = kThreads / g.ncg;
     g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
     g.xblocks = (p.OW + g.cols - 1) / g.cols;
-    g.yblocks = (p.OH + sw_rows(p.OH) - 1) / sw_rows(p.OH);
+    g.yblocks = (p.OH + sw_rows(p.OH, p.H == p.OH ? 1 : 2) - 1) / sw_rows(p.OH, p.H == p.OH ? 1 : 2);
     return g;
 }
 
@@ -1258,7 +1259,10 @@ static DwWgSwGeom dw_wg_sw_geom(const DwParams& p) {
     g.ncg = cg_total < 32 ? cg_total : 32;
     g.cols = kThreads / g.ncg;
     g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
-    g.rows = p.OH >= 64 ? 32 : 16;
+    // strip height by map size (measured per layer): stride 1: 64 / 32 / 16 output rows for maps of >= 128 / >= 64 / fewer
+    // rows (128ch @128x128: 74 -> 62 us with 64); stride 2: 32 / 16 / 8
+    const bool s1 = p.H == p.OH;
+    g.rows = s1 ? (p.OH >= 128 ? 64 : (p.OH >= 64 ? 32 : 16)) : (p.OH >= 64 ? 32 : (p.OH >= 32 ? 16 : 8));
     g.xblocks = (p.OW + g.cols - 1) / g.cols;
     g.yblocks = (p.OH + g.rows - 1) / g.rows;
     g.units = p.N * g.yblocks * g.xblocks;
