@@ -911,6 +911,145 @@ __global__ __launch_bounds__(kThreads) void dwconv_wgrad_sw_kernel(const DwParam
     }
 }
 
+// stride-1 weight gradient with TWO output columns per thread (3 x 4 window, as dwconv_fwd_sw2_kernel): the 36
+// accumulators take both columns' products, an input element is activated by 2 threads instead of 3.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void dwconv_wgrad_sw2_kernel(const DwParams p, int ncg, int cols, int xblocks, int yblocks,
+                                                                   int rows) {
+    __shared__ __attribute__((aligned(16))) float red[9 * kThreads * 4];   // [tap][thread][4 channels]
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+    int b = xcd_work_id(p.xcd_remap);
+    const int cgb = b % p.cblocks; b /= p.cblocks;
+    const int unit = b;                                               // partial-slab row
+    const int xb = b % xblocks; b /= xblocks;
+    const int yb = b % yblocks;
+    const int img = b / yblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;       // column PAIR
+    const int c = (cgb * ncg + cgl) * 4;
+    const int ox = (xb * cols + col) * 2;
+    const bool ok0 = c < p.C && ox < p.OW && col < cols;
+    const bool ok1 = ok0 && ox + 1 < p.OW;
+    const int cc = ok0 ? c : 0;
+    const int oxc = ok0 ? ox : 0;
+    float sc[4], sh[4];
+    const bool aff = p.in_scale != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sc[j] = aff ? p.in_scale[cc + j] : 1.f; sh[j] = aff ? p.in_shift[cc + j] : 0.f; }
+    const float lo = (aff && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (aff && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    const int oy_begin = yb * rows, oy_end = min(oy_begin + rows, p.OH);
+    const int ix0 = oxc - p.pad_l;
+    const T* ximg = x + (long long)img * p.H * p.W * p.C + cc;
+    const T* dyimg = dy + ((long long)img * p.OH * p.OW + oxc) * p.C + cc;
+    const int dyoff1 = ok1 ? p.C : 0;
+    bool xok[4];
+    int xoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ix = ix0 + k;
+        xok[k] = ok0 && ix >= 0 && ix < p.W;
+        xoff[k] = (xok[k] ? ix : 0) * p.C;
+    }
+    auto row_load = [&](Raw4<T> (&r)[4], int iy) {
+        const int iyc = min(max(iy, 0), p.H - 1);
+        const T* rowp = ximg + (long long)iyc * p.W * p.C;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) raw_load(r[k], rowp + xoff[k]);
+    };
+    auto dy_load = [&](Raw4<T> (&r)[2], int oy) {
+        const T* q = dyimg + (long long)min(oy, p.OH - 1) * p.OW * p.C;
+        raw_load(r[0], q);
+        raw_load(r[1], q + dyoff1);
+    };
+    auto row_act = [&](const Raw4<T> (&r)[4], int iy, f32x2_t (&a)[4][2]) {
+        if (iy < 0 || iy >= p.H) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[k][0] = (f32x2_t){0.f, 0.f}; a[k][1] = (f32x2_t){0.f, 0.f}; }
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[4];
+            raw_unpack(r[k], f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);
+            if (k != 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = xok[k] ? f[j] : 0.f;
+            }
+            a[k][0] = (f32x2_t){f[0], f[1]};
+            a[k][1] = (f32x2_t){f[2], f[3]};
+        }
+    };
+    f32x2_t a01[9], a23[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { a01[t] = (f32x2_t){0.f, 0.f}; a23[t] = (f32x2_t){0.f, 0.f}; }
+    auto accum = [&](const f32x2_t (&ra_)[4][2], const f32x2_t (&rb_)[4][2], const f32x2_t (&rc_)[4][2], const Raw4<T> (&d)[2]) {
+        float g[4], h[4];
+        raw_unpack(d[0], g);
+        raw_unpack(d[1], h);
+        const float m1 = ok1 ? 1.f : 0.f;                             // the second column may be outside the image
+        const f32x2_t g01 = {g[0], g[1]}, g23 = {g[2], g[3]};
+        const f32x2_t h01 = {h[0] * m1, h[1] * m1}, h23 = {h[2] * m1, h[3] * m1};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a01[k] += ra_[k][0] * g01 + ra_[k + 1][0] * h01;     a23[k] += ra_[k][1] * g23 + ra_[k + 1][1] * h23;
+            a01[3 + k] += rb_[k][0] * g01 + rb_[k + 1][0] * h01; a23[3 + k] += rb_[k][1] * g23 + rb_[k + 1][1] * h23;
+            a01[6 + k] += rc_[k][0] * g01 + rc_[k + 1][0] * h01; a23[6 + k] += rc_[k][1] * g23 + rc_[k + 1][1] * h23;
+        }
+    };
+    f32x2_t r0[4][2], r1[4][2], r2[4][2];
+    Raw4<T> ra[4], rb[4], rc[4], da[2], db[2], dc[2];
+    int iy = oy_begin - p.pad_t;
+    row_load(ra, iy);
+    row_load(rb, iy + 1);
+    row_load(rc, iy + 2);
+    dy_load(da, oy_begin);
+    dy_load(db, oy_begin + 1);
+    dy_load(dc, oy_begin + 2);
+    row_act(ra, iy, r0);
+    row_load(ra, iy + 3);
+    row_act(rb, iy + 1, r1);
+    row_load(rb, iy + 4);
+    iy += 2;
+    for (int oy = oy_begin; oy < oy_end; oy += 3, iy += 3) {
+        row_act(rc, iy, r2);
+        row_load(rc, iy + 3);
+        accum(r0, r1, r2, da);
+        dy_load(da, oy + 3);
+        if (oy + 1 < oy_end) {
+            row_act(ra, iy + 1, r0);
+            row_load(ra, iy + 4);
+            accum(r1, r2, r0, db);
+            dy_load(db, oy + 4);
+        }
+        if (oy + 2 < oy_end) {
+            row_act(rb, iy + 2, r1);
+            row_load(rb, iy + 5);
+            accum(r2, r0, r1, dc);
+            dy_load(dc, oy + 5);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float4 v = make_float4(a01[t].x, a01[t].y, a23[t].x, a23[t].y);
+        if (!ok0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&red[(t * kThreads + threadIdx.x) * 4]) = v;
+    }
+    __syncthreads();
+    const int nch = ncg * 4;
+    float* dst = p.part + (long long)unit * 9 * p.C + cgb * nch;
+    for (int o = threadIdx.x; o < 9 * nch; o += kThreads) {
+        const int t = o / nch, cj = o - t * nch;
+        if (cgb * nch + cj < p.C) {
+            float sum = 0.f;
+            for (int cidx = 0; cidx < cols; ++cidx) sum += red[(t * kThreads + cidx * ncg) * 4 + cj];
+            dst[t * p.C + cj] = sum;
+        }
+    }
+}
+
 // stride-2 data gradient (gather form): dx[iy,ix,c] = sum_{ky,kx} dy[(iy+pt-ky)/2,(ix+pl-kx)/2,c]*w[ky,kx,c]
 // over the taps for which the division is exact. One thread = one input pixel x 16 bytes of channels.
 template <typename T>
@@ -1461,7 +1600,7 @@ extern "C" int mpn_dwconv_bwd_data_bn(const void* dy, const float* w, void* dx, 
 }
 
 // sliding-window weight gradient: blocks of at most 128 channels; strips of 32 output rows on the large maps, 16 below
-struct DwWgSwGeom { int ncg, cols, xblocks, yblocks, cblocks, rows, units; };
+struct DwWgSwGeom { int ncg, cols, xblocks, yblocks, cblocks, rows, units, xt; };
 static DwWgSwGeom dw_wg_sw_geom(const DwParams& p) {
     DwWgSwGeom g;
     const int cg_total = p.C / 4;
@@ -1472,7 +1611,10 @@ static DwWgSwGeom dw_wg_sw_geom(const DwParams& p) {
     // rows (128ch @128x128: 74 -> 62 us with 64); stride 2: 32 / 16 / 8
     const bool s1 = p.H == p.OH;
     g.rows = s1 ? (p.OH >= 128 ? 64 : (p.OH >= 64 ? 32 : 16)) : (p.OH >= 64 ? 32 : (p.OH >= 32 ? 16 : 8));
-    g.xblocks = (p.OW + g.cols - 1) / g.cols;
+    static int wxt = -1;
+    if (wxt < 0) { const char* e = getenv("MPN_DW_WGRAD_XT"); wxt = e ? atoi(e) : 2; }
+    g.xt = (s1 && wxt == 2) ? 2 : 1;
+    g.xblocks = (p.OW + g.cols * g.xt - 1) / (g.cols * g.xt);
     g.yblocks = (p.OH + g.rows - 1) / g.rows;
     g.units = p.N * g.yblocks * g.xblocks;
     return g;
@@ -1515,7 +1657,8 @@ extern "C" int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part,
         const long long blocks = (long long)g.units * g.cblocks;
         MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_weight: grid too large");
         MPN_DISPATCH_DTYPE(dtype, {
-            if (stride == 1) dwconv_wgrad_sw_kernel<T, 1><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+            if (stride == 1 && g.xt == 2) dwconv_wgrad_sw2_kernel<T><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+            else if (stride == 1) dwconv_wgrad_sw_kernel<T, 1><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
             else dwconv_wgrad_sw_kernel<T, 2><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
         });
         MPN_LAUNCH_CHECK();
