@@ -56,7 +56,8 @@ def test_conv_wgrad(cuda, dtype, case):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 64, 2), (1, 12, 20, 128, 1), (1, 14, 10, 256, 2),
-                                            (1, 9, 7, 64, 2), (2, 8, 8, 1024, 1), (1, 32, 32, 512, 2)])
+                                            (1, 9, 7, 64, 2), (2, 8, 8, 1024, 1), (1, 32, 32, 512, 2),
+                                            (1, 9, 7, 64, 1), (2, 5, 13, 32, 1), (1, 70, 33, 128, 1)])   # odd widths, strips of 64 rows
 def test_dwconv_backward(cuda, dtype, N, H, W, C, stride):
     ops = _ops()
     rs = np.random.RandomState(C + stride)
@@ -165,7 +166,7 @@ def test_heatmap_head_backward(cuda, dtype, M):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 64, 2), (1, 12, 20, 128, 1), (1, 32, 32, 512, 2),
-                                            (2, 8, 8, 1024, 1), (1, 48, 40, 256, 2)])
+                                            (2, 8, 8, 1024, 1), (1, 48, 40, 256, 2), (1, 9, 7, 64, 1), (1, 70, 33, 128, 1)])
 def test_dwconv_bwd_data_with_fused_bn_reduction(cuda, dtype, N, H, W, C, stride):
     """mpn_dwconv_bwd_data_bn: the same dx as mpn_dwconv_bwd_data, and partial rows that finalize to the dgamma / dbeta
     of mpn_bn_bwd_reduce on (dx, x_bn)."""

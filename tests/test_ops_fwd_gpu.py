@@ -86,7 +86,8 @@ def test_conv_dgrad_is_transposed_conv(cuda, dtype, k, Cin, Cout):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 64, 2), (1, 12, 20, 128, 1), (1, 14, 10, 256, 2),
-                                            (1, 9, 7, 64, 2), (2, 8, 8, 1024, 1), (1, 32, 32, 512, 2), (1, 6, 6, 8, 1)])
+                                            (1, 9, 7, 64, 2), (2, 8, 8, 1024, 1), (1, 32, 32, 512, 2), (1, 6, 6, 8, 1),
+                                            (1, 9, 7, 64, 1), (2, 5, 13, 32, 1), (1, 70, 33, 128, 1)])   # odd widths: the two-column kernel's tail
 def test_dwconv_fwd(cuda, dtype, N, H, W, C, stride):
     ops = _ops()
     rs = np.random.RandomState(C + stride)
