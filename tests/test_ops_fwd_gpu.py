@@ -28,6 +28,8 @@ CONV_CASES = [
     (2, 16, 16, 256, 128, 1, 2, False, True),    # lateral + upsample-add
     (1, 10, 6, 32, 64, 1, 2, True, False),       # ragged M
     (3, 16, 16, 1024, 1024, 1, 2, True, False),  # pointwise 13 shape
+    (1, 10, 14, 40, 72, 3, 1, True, False),      # channel counts off the tile grid: partial K chunk, partial last n-tile
+    (2, 6, 10, 136, 200, 1, 2, True, False),     # same for 1x1 (XCD-remapped block map, 4 n-tiles of 64)
 ]
 
 
