@@ -46,7 +46,7 @@ def bucket_bounds(numel, bucket_elems, align=4):
 class GradientAllReducer:
     """Sums a flat gradient arena across ranks in a few large buckets (async, waited before the optimizer)."""
 
-    def __init__(self, flat_grad, group=None, bucket_bytes=8 << 20):
+    def __init__(self, flat_grad, group=None, bucket_bytes=16 << 20):
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1

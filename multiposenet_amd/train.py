@@ -10,7 +10,7 @@ from .parallel import GradientAllReducer
 
 
 class Trainer:
-    def __init__(self, net, params, use_graph=True, distributed=False, bucket_bytes=8 << 20):
+    def __init__(self, net, params, use_graph=True, distributed=False, bucket_bytes=16 << 20):
         self.net = net
         self.lr0 = float(params["initial_learning_rate"])
         self.num_steps = int(params["num_steps"])
