@@ -150,6 +150,21 @@ int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const
                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                     mpn_stream_t stream);
 /* is_training=False path: affine from the moving statistics */
+/* Several independent layers' finalizes in ONE launch (the four pyramid levels of the keypoint subnet,
+ * keypoint_subnet.py:64-91, produce their statistics side by side). Descriptor tables as for the batched slab reduction:
+ * mpn_bn_fin_desc_fill / mpn_bn_bwd_fin_desc_fill write one host-side descriptor each (mpn_*_desc_bytes() bytes; return the
+ * number of blocks of the job, -1 on bad arguments; block_begin = running sum); the caller copies the array to the device
+ * once. Same arithmetic, bit for bit, as mpn_bn_finalize / mpn_bn_bwd_finalize per layer. */
+size_t mpn_bn_fin_desc_bytes(void);
+size_t mpn_bn_bwd_fin_desc_bytes(void);
+int mpn_bn_fin_desc_fill(void* desc_host, const float* part, int nparts, int C, long long count, const float* gamma,
+                         const float* beta, float* moving_mean, float* moving_var, float* scale, float* shift,
+                         float* save_mean, float* save_invstd, int block_begin);
+int mpn_bn_bwd_fin_desc_fill(void* desc_host, const float* part, int nparts, int C, long long count, float* dgamma,
+                             float* dbeta, float* k1, float* k2, int block_begin);
+int mpn_bn_finalize_batched(const void* descs_device, int ndesc, int total_blocks, float momentum, float eps,
+                            mpn_stream_t stream);
+int mpn_bn_bwd_finalize_batched(const void* descs_device, int ndesc, int total_blocks, mpn_stream_t stream);
 int mpn_bn_inference_affine(int C, const float* gamma, const float* beta, const float* moving_mean,
                             const float* moving_var, float eps, float* scale, float* shift,
                             mpn_stream_t stream);

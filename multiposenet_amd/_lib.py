@@ -82,6 +82,12 @@ SIGNATURES = {
     "mpn_bias_relu_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "mpn_bias_relu_bwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
     "mpn_prn_loss": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mpn_bn_fin_desc_bytes": (_Z, []),
+    "mpn_bn_bwd_fin_desc_bytes": (_Z, []),
+    "mpn_bn_fin_desc_fill": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I]),
+    "mpn_bn_bwd_fin_desc_fill": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _I]),
+    "mpn_bn_finalize_batched": (_I, [_P, _I, _I, _F, _F, _P]),
+    "mpn_bn_bwd_finalize_batched": (_I, [_P, _I, _I, _P]),
     "mpn_heatmap_minmax": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mpn_prn_crop": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "mpn_prn_decode": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),

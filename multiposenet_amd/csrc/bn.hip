@@ -11,6 +11,7 @@
 // All reductions are deterministic: partial slabs + fixed-order f64 finalisation, no atomics.
 #include "common.h"
 #include "bn_tail.h"
+#include <string.h>
 
 namespace {
 
@@ -108,12 +109,12 @@ constexpr int kFinThreads = 1024, kFinLanes = 64;   // 64 part-lanes x 16 channe
 // CPB = channels per block: 16, or 4 when there are thousands of partial rows (16 384 after a 1x1 conv at 256x256): the
 // reduction is then bound by how many CUs pull on the slab, and C/16 = 4 blocks took 54 us for 8 MB.
 template <int CPB>
-__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int C,
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int C, int cblock,
                                              double (*red)[kFinLanes][16], double& s, double& q) {
     constexpr int G4 = CPB / 4;
     constexpr int kRowLanes = kFinThreads / G4;
     const int t = threadIdx.x, g4 = t & (G4 - 1), r = t / G4;
-    const int c4 = blockIdx.x * CPB + g4 * 4;
+    const int c4 = cblock * CPB + g4 * 4;
     double sa[4] = {0.0, 0.0, 0.0, 0.0}, qa[4] = {0.0, 0.0, 0.0, 0.0};
     if (c4 < C) {
         int p = r;
@@ -154,15 +155,15 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int
 // part [nparts][2][C] -> mean, biased var -> scale/shift (+ moving-average update with the
 // unbiased variance, TF-1.15 fused batch-norm semantic).
 template <int CPB>
-__global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(
+__device__ __forceinline__ void bn_finalize_block(
+    int cblock, double (*red)[kFinLanes][16],
     const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
     float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
     float* __restrict__ save_invstd) {
-    __shared__ double red[2][kFinLanes][16];
-    const int c = blockIdx.x * CPB + threadIdx.x;
+    const int c = cblock * CPB + threadIdx.x;
     double s, q;
-    reduce_parts<CPB>(part, nparts, C, red, s, q);
+    reduce_parts<CPB>(part, nparts, C, cblock, red, s, q);
     if ((int)threadIdx.x < CPB && c < C) {
         const double mean = s / count;
         double var = q / count - mean * mean;
@@ -179,6 +180,54 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(
             mov_var[c] = mov_var[c] * momentum + (float)unbiased * (1.f - momentum);
         }
     }
+}
+
+template <int CPB>
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(
+    const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
+    float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
+    float* __restrict__ save_invstd) {
+    __shared__ double red[2][kFinLanes][16];
+    bn_finalize_block<CPB>(blockIdx.x, red, part, nparts, C, count, gamma, beta, mov_mean, mov_var, momentum, eps, scale, shift,
+                           save_mean, save_invstd);
+}
+
+// ---- several independent layers' finalizes in ONE launch (the four pyramid levels of the subnet produce their
+// statistics side by side; a finalize is ~6 us of launch + memory latency for microseconds of work). The descriptors
+// live in device memory, built once by the host (shapes and pointers are static).
+struct BnFinDesc {
+    const float* part; const float* gamma; const float* beta;
+    float* mov_mean; float* mov_var; float* scale; float* shift; float* save_mean; float* save_invstd;
+    double count;
+    int nparts, C, block_begin, pad_;
+};
+struct BnBwdFinDesc {
+    const float* part; float* dgamma; float* dbeta; float* k1; float* k2;
+    double count;
+    int nparts, C, block_begin, pad_;
+};
+template <typename D>
+__device__ __forceinline__ int fin_job(const D* __restrict__ descs, int ndesc, int* job_s) {
+    if (threadIdx.x < 64) {
+        int cnt = 0;
+        for (int base = 0; base < ndesc; base += 64) {
+            const int i = base + (int)threadIdx.x;
+            const bool le = i < ndesc && descs[i].block_begin <= (int)blockIdx.x;
+            cnt += __popcll(__ballot(le));
+        }
+        if (threadIdx.x == 0) *job_s = cnt - 1;
+    }
+    __syncthreads();
+    return *job_s;
+}
+__global__ __launch_bounds__(kFinThreads) void bn_finalize_batched_kernel(const BnFinDesc* __restrict__ descs, int ndesc,
+                                                                         float momentum, float eps) {
+    __shared__ double red[2][kFinLanes][16];
+    __shared__ int job_s;
+    const BnFinDesc d = descs[fin_job(descs, ndesc, &job_s)];
+    bn_finalize_block<16>(blockIdx.x - d.block_begin, red, d.part, d.nparts, d.C, d.count, d.gamma, d.beta, d.mov_mean, d.mov_var,
+                          momentum, eps, d.scale, d.shift, d.save_mean, d.save_invstd);
 }
 
 __global__ void bn_inference_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -277,20 +326,33 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
 
 // part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
 template <int CPB>
-__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
-                                                                      double count, float* __restrict__ dgamma,
-                                                                      float* __restrict__ dbeta,
-                                                                      float* __restrict__ k1, float* __restrict__ k2) {
-    __shared__ double red[2][kFinLanes][16];
-    const int c = blockIdx.x * CPB + threadIdx.x;
+__device__ __forceinline__ void bn_bwd_finalize_block(int cblock, double (*red)[kFinLanes][16], const float* __restrict__ part,
+                                                      int nparts, int C, double count, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, float* __restrict__ k1,
+                                                      float* __restrict__ k2) {
+    const int c = cblock * CPB + threadIdx.x;
     double s, q;
-    reduce_parts<CPB>(part, nparts, C, red, s, q);
+    reduce_parts<CPB>(part, nparts, C, cblock, red, s, q);
     if ((int)threadIdx.x < CPB && c < C) {
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         k1[c] = (float)(s / count);
         k2[c] = (float)(q / count);
     }
+}
+template <int CPB>
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
+                                                                      double count, float* __restrict__ dgamma,
+                                                                      float* __restrict__ dbeta,
+                                                                      float* __restrict__ k1, float* __restrict__ k2) {
+    __shared__ double red[2][kFinLanes][16];
+    bn_bwd_finalize_block<CPB>(blockIdx.x, red, part, nparts, C, count, dgamma, dbeta, k1, k2);
+}
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_batched_kernel(const BnBwdFinDesc* __restrict__ descs, int ndesc) {
+    __shared__ double red[2][kFinLanes][16];
+    __shared__ int job_s;
+    const BnBwdFinDesc d = descs[fin_job(descs, ndesc, &job_s)];
+    bn_bwd_finalize_block<16>(blockIdx.x - d.block_begin, red, d.part, d.nparts, d.C, d.count, d.dgamma, d.dbeta, d.k1, d.k2);
 }
 
 // dx = scale * (g - k1 - xhat*k2), written over dA (same storage type); optional extra gradient
@@ -482,6 +544,49 @@ extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long c
     bn_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(
         part, nparts, C, (double)count, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift, save_mean,
         save_invstd);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+extern "C" size_t mpn_bn_fin_desc_bytes(void) { return sizeof(BnFinDesc); }
+extern "C" size_t mpn_bn_bwd_fin_desc_bytes(void) { return sizeof(BnBwdFinDesc); }
+
+/* One host-side descriptor of the batched finalize (mpn_bn_fin_desc_bytes() bytes); returns the blocks the job needs,
+ * block_begin = running sum over the jobs; -1 on bad arguments. The caller copies the array to the device once. */
+extern "C" int mpn_bn_fin_desc_fill(void* desc_host, const float* part, int nparts, int C, long long count, const float* gamma,
+                                    const float* beta, float* moving_mean, float* moving_var, float* scale, float* shift,
+                                    float* save_mean, float* save_invstd, int block_begin) {
+    if (!desc_host || !part || !gamma || !beta || !scale || !shift || nparts <= 0 || C <= 0 || C % 4 != 0 || count <= 0 ||
+        !mpn_aligned16(part) || ((moving_mean == nullptr) != (moving_var == nullptr)))
+        return -1;
+    BnFinDesc d;
+    d.part = part; d.gamma = gamma; d.beta = beta; d.mov_mean = moving_mean; d.mov_var = moving_var; d.scale = scale;
+    d.shift = shift; d.save_mean = save_mean; d.save_invstd = save_invstd; d.count = (double)count;
+    d.nparts = nparts; d.C = C; d.block_begin = block_begin; d.pad_ = 0;
+    memcpy(desc_host, &d, sizeof(d));
+    return (C + 15) / 16;
+}
+extern "C" int mpn_bn_bwd_fin_desc_fill(void* desc_host, const float* part, int nparts, int C, long long count, float* dgamma,
+                                        float* dbeta, float* k1, float* k2, int block_begin) {
+    if (!desc_host || !part || !dgamma || !dbeta || !k1 || !k2 || nparts <= 0 || C <= 0 || C % 4 != 0 || count <= 0 ||
+        !mpn_aligned16(part))
+        return -1;
+    BnBwdFinDesc d;
+    d.part = part; d.dgamma = dgamma; d.dbeta = dbeta; d.k1 = k1; d.k2 = k2; d.count = (double)count;
+    d.nparts = nparts; d.C = C; d.block_begin = block_begin; d.pad_ = 0;
+    memcpy(desc_host, &d, sizeof(d));
+    return (C + 15) / 16;
+}
+extern "C" int mpn_bn_finalize_batched(const void* descs_device, int ndesc, int total_blocks, float momentum, float eps,
+                                       mpn_stream_t stream) {
+    MPN_REQUIRE(descs_device && ndesc > 0 && total_blocks > 0, MPN_ERR_BAD_ARG, "bn_finalize_batched: bad arguments");
+    bn_finalize_batched_kernel<<<total_blocks, kFinThreads, 0, (hipStream_t)stream>>>((const BnFinDesc*)descs_device, ndesc, momentum, eps);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+extern "C" int mpn_bn_bwd_finalize_batched(const void* descs_device, int ndesc, int total_blocks, mpn_stream_t stream) {
+    MPN_REQUIRE(descs_device && ndesc > 0 && total_blocks > 0, MPN_ERR_BAD_ARG, "bn_bwd_finalize_batched: bad arguments");
+    bn_bwd_finalize_batched_kernel<<<total_blocks, kFinThreads, 0, (hipStream_t)stream>>>((const BnBwdFinDesc*)descs_device, ndesc);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

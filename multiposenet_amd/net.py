@@ -14,6 +14,7 @@ Layout decisions (MI355X-first):
   * all buffers are allocated once per input shape, so a whole train step is hipGraph-capturable.
 """
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -231,6 +232,7 @@ class KeypointNet:
         # tested, but SLOWER on MI355X (13.1 vs 12.0 ms/step): the fence-free sc1 hand-off costs >= 4 dependent
         # memory round trips (~2 us each) at the tail of every producer, more than the ~5 us launch it replaces
         self.fuse_bn = False
+        self.batch_finalize = os.environ.get("MPN_BATCH_FINALIZE", "1") != "0"   # the four pyramid levels' batch-norm finalizes in one launch per stage
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
         self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
@@ -311,6 +313,10 @@ class KeypointNet:
         for l in lv:
             stat_floats = max(stat_floats, ops.conv_num_parts(N, *lv[l], 3) * 2 * DEPTH, nbn(N * lv[l][0] * lv[l][1]) * 2 * DEPTH)
         b["stat_part"] = torch.empty(stat_floats, dtype=torch.float32, device=dev)
+        # per-level statistics scratch of the subnet (the levels' finalizes run batched, so their partials coexist)
+        b["stat_lv"] = {l: torch.empty(max(ops.conv_num_parts(N, *lv[l], 3), nbn(N * lv[l][0] * lv[l][1])) * 2 * DEPTH,
+                                       dtype=torch.float32, device=dev) for l in lv}
+        b["fin"] = None     # batched finalize tables, built on first use (ops.BnFinalizeBatch / BnBwdFinalizeBatch)
         b["loss_part"] = torch.empty(ops._lib.lib().mpn_keypoint_loss_num_parts(N, *lv[2]) * 8, dtype=torch.float32, device=dev)
         b["losses"] = torch.zeros(8, dtype=torch.float32, device=dev)
         self._bufs[key] = b
@@ -426,6 +432,28 @@ class KeypointNet:
         T = self._tail if is_training else (lambda bn, count: None)
         sep = is_training and not self.fuse_bn     # separate mpn_bn_finalize launches (the unfused reference path)
         prev = None
+        if sep and self.batch_finalize:
+            # stage by stage over the four levels: their statistics go to per-level scratch and ONE launch per stage
+            # finalizes all four (12 finalize launches -> 3)
+            if b["fin"] is None:
+                b["fin"] = self._finalize_tables(b)
+            fin, spl = b["fin"], b["stat_lv"]
+            for l in (5, 4, 3, 2):
+                raw, aff = feats[f"c{l}"]
+                ops.conv_fwd(raw, self.lateral[l].packed.fwd, DEPTH, 1, aff, out=b["x"][l], up_res=prev)    # fpn.py:38,50-51
+                prev = b["x"][l]
+            for l in (2, 3, 4, 5):
+                ops.conv_fwd(b["x"][l], self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=spl[l])   # fpn.py:39,52
+            fin["p"].run()
+            for l in (2, 3, 4, 5):
+                ops.conv_fwd(b["p"][l], self.phi[l]["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=spl[l])
+            fin["bn1"].run()
+            for l in (2, 3, 4, 5):
+                ops.conv_fwd(b["y1"][l], self.phi[l]["conv2"].packed.fwd, DEPTH, 3, self.phi[l]["bn1"].affine, out=b["y2"][l], stats_part=spl[l])
+            fin["bn2"].run()
+            for l in (2, 3, 4, 5):
+                ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, self.phi[l]["bn2"].affine)   # :86 + :37
+            return self._subnet_final(b, N, sp, T, sep, inference_outputs)
         for l in (5, 4, 3, 2):
             raw, aff = feats[f"c{l}"]
             h, w = b["lv"][l]
@@ -448,6 +476,9 @@ class KeypointNet:
             if sep:
                 ops.bn_finalize(ph["bn2"], sp, nparts, cnt)
             ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, ph["bn2"].affine)   # :86 + :37
+        return self._subnet_final(b, N, sp, T, sep, inference_outputs)
+
+    def _subnet_final(self, b, N, sp, T, sep, inference_outputs):
         h, w = b["lv"][2]
         ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, None, out=b["final"], stats_part=sp,
                      tail=T(self.final_bn, N * h * w))                                                     # :38
@@ -456,6 +487,22 @@ class KeypointNet:
         if inference_outputs:
             return ops.heatmap_head_fwd(b["final"], self.heat_w, self.heat_b, self.final_bn.affine, inference=True)
         return ops.heatmap_head_fwd(b["final"], self.heat_w, self.heat_b, self.final_bn.affine, out=b["logits"])
+
+    def _finalize_tables(self, b):
+        """Device tables of the batched finalizes (forward and backward) of the subnet's three stages x four levels."""
+        N = b["shape"][0]
+        nbn = ops._lib.lib().mpn_bn_stats_num_parts
+        fwd = {k: [] for k in ("p", "bn1", "bn2")}
+        bwd = {k: [] for k in ("p", "bn1", "bn2")}
+        for l in (2, 3, 4, 5):
+            h, w = b["lv"][l]
+            cnt = N * h * w
+            for k, bn in (("p", self.p_bn[l]), ("bn1", self.phi[l]["bn1"]), ("bn2", self.phi[l]["bn2"])):
+                fwd[k].append((bn, b["stat_lv"][l], ops.conv_num_parts(N, h, w, 3), cnt))
+                bwd[k].append((bn, b["stat_lv"][l], nbn(cnt), cnt))
+        out = {k: ops.BnFinalizeBatch(v, self.device) for k, v in fwd.items()}
+        out.update({"d" + k: ops.BnBwdFinalizeBatch(v, self.device) for k, v in bwd.items()})
+        return out
 
     def forward(self, images, is_training):
         """images: [N,H,W,3] f32 in [0,1] (or uint8). Returns (logits [N,H/4,W/4,18] f32 NHWC,
@@ -534,16 +581,44 @@ class KeypointNet:
         W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
         ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm
-        for l in (2, 3, 4, 5):
-            ph = self.phi[l]
-            ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
-            ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp, fused=self.fuse_bn)
-            W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
-            ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
-            ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp, fused=self.fuse_bn)
-            W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
-            ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
-            ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l], fused=self.fuse_bn)
+        if self.batch_finalize and not self.fuse_bn:
+            # stage by stage over the four levels (see subnet_forward): reductions into per-level scratch, ONE finalize
+            # launch per stage, then the applies and the convolutions' gradients
+            if b["fin"] is None:
+                b["fin"] = self._finalize_tables(b)
+            fin, spl = b["fin"], b["stat_lv"]
+            LV = (2, 3, 4, 5)
+            for l in LV:
+                ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
+                ops.bn_bwd_reduce(self.phi[l]["bn2"], g["y2"][l], b["y2"][l], spl[l])
+            fin["dbn2"].run()
+            for l in LV:
+                ph = self.phi[l]
+                ops.bn_bwd_apply(ph["bn2"], g["y2"][l], b["y2"][l])
+                W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
+                ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
+                ops.bn_bwd_reduce(ph["bn1"], g["y1"][l], b["y1"][l], spl[l])
+            fin["dbn1"].run()
+            for l in LV:
+                ph = self.phi[l]
+                ops.bn_bwd_apply(ph["bn1"], g["y1"][l], b["y1"][l])
+                W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
+                ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
+                ops.bn_bwd_reduce(self.p_bn[l], g["p"][l], b["p"][l], spl[l])
+            fin["dp"].run()
+            for l in LV:
+                ops.bn_bwd_apply(self.p_bn[l], g["p"][l], b["p"][l], add_ch0=g["daux"][l])
+        else:
+            for l in (2, 3, 4, 5):
+                ph = self.phi[l]
+                ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
+                ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp, fused=self.fuse_bn)
+                W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
+                ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
+                ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp, fused=self.fuse_bn)
+                W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
+                ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
+                ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l], fused=self.fuse_bn)
         # ---- FPN (top-down path reversed)
         for l in (2, 3, 4, 5):
             W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, slab[id(self.pconv[l].dw)], reduce=False))

@@ -201,6 +201,68 @@ def bn_finalize(bn, part, nparts, count, training=True):
          BN_MOMENTUM, BN_EPSILON, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd), stream_ptr())
 
 
+class BnFinalizeBatch:
+    """Forward finalizes of several independent layers in one launch (mpn_bn_finalize_batched).
+    jobs: list of (bn, part tensor, nparts, count); the device table is built once (pointers are static)."""
+
+    def __init__(self, jobs, device):
+        import ctypes
+        lib = _lib.lib()
+        nb = lib.mpn_bn_fin_desc_bytes()
+        host = (ctypes.c_ubyte * (nb * len(jobs)))()
+        begin = 0
+        for j, (bn, part, nparts, count) in enumerate(jobs):
+            blocks = lib.mpn_bn_fin_desc_fill(ctypes.byref(host, j * nb), ptr(part), int(nparts), bn.C, int(count), ptr(bn.gamma),
+                                              ptr(bn.beta), ptr(bn.moving_mean), ptr(bn.moving_var), ptr(bn.scale), ptr(bn.shift),
+                                              ptr(bn.mean), ptr(bn.invstd), begin)
+            if blocks <= 0:
+                raise ValueError("bad batch-norm finalize job")
+            begin += blocks
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+        self.njobs, self.blocks, self._keep = len(jobs), begin, jobs
+
+    def run(self):
+        call("mpn_bn_finalize_batched", ptr(self.table), self.njobs, self.blocks, BN_MOMENTUM, BN_EPSILON, stream_ptr())
+
+
+class BnBwdFinalizeBatch:
+    """Backward finalizes (dgamma, dbeta, k1, k2) of several independent layers in one launch."""
+
+    def __init__(self, jobs, device):
+        import ctypes
+        lib = _lib.lib()
+        nb = lib.mpn_bn_bwd_fin_desc_bytes()
+        host = (ctypes.c_ubyte * (nb * len(jobs)))()
+        begin = 0
+        for j, (bn, part, nparts, count) in enumerate(jobs):
+            blocks = lib.mpn_bn_bwd_fin_desc_fill(ctypes.byref(host, j * nb), ptr(part), int(nparts), bn.C, int(count),
+                                                  ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), begin)
+            if blocks <= 0:
+                raise ValueError("bad batch-norm backward finalize job")
+            begin += blocks
+        self.table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(device)
+        self.njobs, self.blocks, self._keep = len(jobs), begin, jobs
+
+    def run(self):
+        call("mpn_bn_bwd_finalize_batched", ptr(self.table), self.njobs, self.blocks, stream_ptr())
+
+
+def bn_bwd_reduce(bn, dA, x, part):
+    """First pass of bn_backward alone: partial sums of g and g * xhat into `part` (mpn_bn_stats_num_parts(M) rows)."""
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    call("mpn_bn_bwd_reduce", ptr(dA), ptr(x), M, C, _lib.dtype_code(x.dtype), ptr(bn.scale), ptr(bn.shift), ptr(bn.mean),
+         ptr(bn.invstd), int(bn.act), ptr(part), stream_ptr())
+    return _lib.lib().mpn_bn_stats_num_parts(M)
+
+
+def bn_bwd_apply(bn, dA, x, add_ch0=None):
+    """Last pass of bn_backward alone (after a finalize filled bn.k1 / bn.k2)."""
+    M, C = x.numel() // x.shape[-1], x.shape[-1]
+    call("mpn_bn_bwd_apply", ptr(dA), ptr(x), M, C, _lib.dtype_code(x.dtype), ptr(bn.scale), ptr(bn.shift), ptr(bn.mean),
+         ptr(bn.invstd), ptr(bn.k1), ptr(bn.k2), int(bn.act), ptr(add_ch0), stream_ptr())
+    return dA
+
+
 def bn_inference_affine(bn):
     call("mpn_bn_inference_affine", bn.C, ptr(bn.gamma), ptr(bn.beta), ptr(bn.moving_mean), ptr(bn.moving_var),
          BN_EPSILON, ptr(bn.scale), ptr(bn.shift), stream_ptr())

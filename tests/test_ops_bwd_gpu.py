@@ -203,3 +203,34 @@ def test_dwconv_bwd_data_with_fused_bn_reduction(cuda, dtype, N, H, W, C, stride
     assert float((bn_a.dgamma - bn_b.dgamma).abs().max()) <= 2e-5 * scale * max(1.0, M ** 0.5 / 16)
     assert float((bn_a.dbeta - bn_b.dbeta).abs().max()) <= 2e-5 * (float(bn_b.dbeta.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
     assert_close(dA_fused, dA_sep.float().cpu(), dtype, 4)
+
+
+def test_batched_bn_finalizes_equal_per_layer_launches(cuda):
+    """mpn_bn_finalize_batched / mpn_bn_bwd_finalize_batched: several layers in one launch, bit for bit the per-layer results
+    (scale, shift, saved mean / invstd, moving statistics; dgamma, dbeta, k1, k2)."""
+    ops = _ops()
+    rs = np.random.RandomState(31)
+
+    def mk(C):
+        one = lambda: torch.tensor((0.5 + rs.rand(C)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), 2)
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+
+    shapes = [(128, 4096, 524288), (128, 37, 1000), (64, 1024, 8192), (24, 5, 77)]   # (C, nparts, count)
+    parts = [torch.tensor(rs.randn(n, 2, C).astype(np.float32)).cuda() for (C, n, _) in shapes]
+    st = rs.get_state()
+    a = [mk(C) for (C, _, _) in shapes]
+    rs.set_state(st)
+    b = [mk(C) for (C, _, _) in shapes]
+    for bn, part, (C, n, cnt) in zip(a, parts, shapes):
+        ops.bn_finalize(bn, part, n, cnt)
+        call = ops.call
+        call("mpn_bn_bwd_finalize", ops.ptr(part), n, C, cnt, ops.ptr(bn.dgamma), ops.ptr(bn.dbeta), ops.ptr(bn.k1), ops.ptr(bn.k2),
+             ops.stream_ptr())
+    jobs = [(bn, part, n, cnt) for bn, part, (C, n, cnt) in zip(b, parts, shapes)]
+    ops.BnFinalizeBatch(jobs, "cuda:0").run()
+    ops.BnBwdFinalizeBatch(jobs, "cuda:0").run()
+    for x, y in zip(a, b):
+        for f in ("scale", "shift", "mean", "invstd", "moving_mean", "moving_var", "dgamma", "dbeta", "k1", "k2"):
+            assert torch.equal(getattr(x, f), getattr(y, f)), f
