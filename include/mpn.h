@@ -124,6 +124,14 @@ int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, int N, int H,
                      int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,
                      int in_act, float* stats_part, const void* up_res, const mpn_bn_tail_t* tail,
                      mpn_stream_t stream);
+/* Up to four independent 3x3 convolutions of the same channel geometry in ONE grid, largest first (the four pyramid levels
+ * of a keypoint-subnet stage, keypoint_subnet.py:64-91: as launches of their own the small levels are latency-bound tails
+ * of 15-45 us). Per job: x, w_packed, y, H, W, in_scale / in_shift (or NULL), stats_part (or NULL); shared: N, Cin, Cout,
+ * ksize, dtype, in_act. Results are those of mpn_conv_fwd per job, bit for bit; configurations the grouped grid does
+ * not cover (f32, 1x1, more than four jobs) run as the separate launches they replace. */
+int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N, const int* H,
+                         const int* W, int Cin, int Cout, int ksize, int dtype, const float* const* in_scale,
+                         const float* const* in_shift, int in_act, float* const* stats_part, mpn_stream_t stream);
 
 /* Weight gradient of mpn_conv_fwd: dW[tap][ci][co] = sum_pixels act(bn(x))[pixel+tap][ci]*dy[pixel][co].
  * Split-K over pixel tiles: part [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (one HWIO slab

@@ -37,6 +37,7 @@ SIGNATURES = {
     "mpn_conv_num_parts": (_I, [_I, _I, _I, _I]),
     "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "mpn_conv_fwd_fin": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "mpn_conv_fwd_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
     "mpn_bn_tail_workspace_bytes": (_Z, [_I]),
     "mpn_conv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mpn_conv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),

@@ -119,8 +119,11 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
 // the ring only): the weight image - 295 KB per n-tile of a 128 -> 128 layer, re-read from L2 by EVERY block - then
 // serves twice the pixels, and the halo overhead drops from 1.41 to 1.27. Its statistics rows are those of the two
 // 128-pixel tiles it covers (wave row wm = upper / lower half), so mpn_conv_num_parts does not depend on the variant.
+// (the body is a device function so that the plain kernel and the grouped kernel - several independent launches of the
+//  same instance, e.g. the four pyramid levels of one subnet stage, in ONE grid - share it; blk / nwg = this job's block
+//  index and block count)
 template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4>
-__global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int blk, const int nwg_job) {
     static_assert(MT == 4 || (MT == 8 && TAPS == 9 && RING && sizeof(T) == 2), "256-pixel tiles: bf16 3x3 ring variant only");
     constexpr int HALO_H = MT * 2 + 2;
     constexpr int ES = (int)sizeof(T);
@@ -153,9 +156,9 @@ __global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma
     // own L2), so the blocks that share an XCD (same id % 8) get a CONTIGUOUS range of work ids: the n-tiles of one pixel
     // tile (which re-read the same A rows) and neighbouring pixel tiles (which share halo rows) then hit in one L2
     // instead of fetching the rows once per XCD. Bijective for any grid size.
-    int wid = blockIdx.x;
+    int wid = blk;
     if (p.xcd_remap) {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wid & 7;
+        const int nwg = nwg_job, q = nwg >> 3, r = nwg & 7, xcd = wid & 7;
         wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wid >> 3);
     }
     const int ntile = wid % p.n_tiles;
@@ -530,6 +533,29 @@ __global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma
     }
     MPN_STAMP(4);
 #undef MPN_STAMP
+}
+
+template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4>
+__global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {
+    conv_mfma_body<T, TAPS, BN, RB, RING, MT>(p, blockIdx.x, gridDim.x);
+}
+
+// up to four independent jobs of one kernel instance in one grid (largest first): the small pyramid levels are a few
+// dozen to a few hundred tiles each - as launches of their own they are latency-bound tails of 15-45 us, inside the
+// level-2 grid they fill in at its throughput
+constexpr int kMaxGroup = 4;
+struct ConvGroup {
+    ConvParams p[kMaxGroup];
+    int begin[kMaxGroup + 1];   // first block of each job; begin[njobs] = grid size
+    int njobs;
+};
+template <typename T, int TAPS, int BN, int RB, bool RING>
+__global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_grouped_kernel(const ConvGroup g) {
+    int job = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxGroup; ++j)
+        if (j < g.njobs && (int)blockIdx.x >= g.begin[j]) job = j;   // wave-uniform
+    conv_mfma_body<T, TAPS, BN, RB, RING, 4>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
 }
 
 // ------------------------------------------------------------------ warp-specialised 3x3 kernel (bf16)
@@ -1173,4 +1199,76 @@ extern "C" int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, in
     }
     if (ksize == 3) return g.BN == 128 ? launch_conv<bf16_t, 9, 128>(p, m_tiles, st) : launch_conv<bf16_t, 9, 64>(p, m_tiles, st);
     return g.BN == 128 ? launch_conv<bf16_t, 1, 128>(p, m_tiles, st) : launch_conv<bf16_t, 1, 64>(p, m_tiles, st);
+}
+
+/* Several independent 3x3 convolutions of the same channel geometry in ONE grid (the four pyramid levels of a subnet
+ * stage: keypoint_subnet.py:64-91 applies phi_subnet to p2..p5 independently). bf16, no fused residual, at most 4 jobs,
+ * the default 128-pixel kernel; anything else runs as the separate launches it replaces. Results are those of
+ * mpn_conv_fwd per job, bit for bit (same kernel body, same tiles). */
+extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N,
+                                    const int* H, const int* W, int Cin, int Cout, int ksize, int dtype,
+                                    const float* const* in_scale, const float* const* in_shift, int in_act,
+                                    float* const* stats_part, mpn_stream_t stream) {
+    MPN_REQUIRE(njobs > 0 && x && w_packed && y && H && W && in_scale && in_shift && stats_part, MPN_ERR_BAD_ARG,
+                "conv grouped: bad arguments");
+    const int es = dtype == MPN_F32 ? 4 : 2;
+    const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es);
+    if (g_conv_lds_epilogue < 0) { const char* e = getenv("MPN_CONV_LDS_EPILOGUE"); g_conv_lds_epilogue = e ? atoi(e) : 1; }
+    static int grouped = -1;
+    if (grouped < 0) { const char* e = getenv("MPN_CONV_GROUPED"); grouped = e ? atoi(e) : 1; }
+    const bool fast = grouped && dtype == MPN_BF16 && ksize == 3 && njobs <= kMaxGroup && g.row_bytes == 128 &&
+                      g_conv_lds_epilogue != 0 && g_conv_dbg == nullptr && g_ws_min <= 0 && g_big_min <= 0 && g_ring <= 0;
+    if (!fast) {
+        for (int j = 0; j < njobs; ++j)
+            if (int rc = mpn_conv_fwd_fin(x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, ksize, dtype, in_scale[j], in_shift[j],
+                                          in_act, stats_part[j], nullptr, nullptr, stream))
+                return rc;
+        return MPN_OK;
+    }
+    MPN_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, MPN_ERR_BAD_SHAPE, "conv grouped: bad shape");
+    ConvGroup grp = {};
+    int begin = 0;
+    for (int j = 0; j < njobs; ++j) {
+        MPN_REQUIRE(x[j] && w_packed[j] && y[j] && H[j] > 0 && W[j] > 0, MPN_ERR_BAD_ARG, "conv grouped: null pointer / bad size");
+        MPN_REQUIRE(mpn_aligned16(x[j]) && mpn_aligned16(w_packed[j]) && mpn_aligned16(y[j]), MPN_ERR_BAD_ALIGN,
+                    "conv grouped: pointers must be 16-byte aligned");
+        MPN_REQUIRE((in_scale[j] == nullptr) == (in_shift[j] == nullptr), MPN_ERR_BAD_ARG, "conv grouped: scale/shift mismatch");
+        ConvParams& p = grp.p[j];
+        p.x = x[j]; p.wp = w_packed[j]; p.y = y[j];
+        p.in_scale = in_scale[j]; p.in_shift = in_shift[j]; p.in_act = in_act;
+        p.stats_part = stats_part[j]; p.up_res = nullptr; p.dbg = nullptr;
+        p.lds_epilogue = 1; p.xcd_remap = 0;
+        p.N = N; p.H = H[j]; p.W = W[j]; p.Cin = Cin; p.Cout = Cout;
+        p.tiles_x = (W[j] + 15) / 16; p.tiles_y = (H[j] + 7) / 8;
+        p.M = (long long)N * H[j] * W[j];
+        p.row_bytes = g.row_bytes; p.nchunk = g.nchunk; p.n_tiles = g.n_tiles; p.wp_tile_bytes = g.tile_bytes;
+        bn_tail_prepare(nullptr, 0, Cout, &p.tail);
+        grp.begin[j] = begin;
+        begin += mpn_conv_num_parts(N, H[j], W[j], 3) * g.n_tiles;
+    }
+    for (int j = njobs; j <= kMaxGroup; ++j) grp.begin[j] = begin;
+    grp.njobs = njobs;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int NPIX = kHaloW * kHaloH;
+    if (g.BN == 128) {
+        constexpr int smem = NPIX * a_row_stride(128) + 2 * (2 * 128 * 64);
+        static bool attr_set = false;
+        if (!attr_set) {
+            MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
+    } else {
+        constexpr int smem = NPIX * a_row_stride(128) + 2 * (2 * 64 * 64);
+        static bool attr_set = false;
+        if (!attr_set) {
+            MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_set = true;
+        }
+        conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
+    }
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
 }

@@ -442,14 +442,17 @@ class KeypointNet:
                 raw, aff = feats[f"c{l}"]
                 ops.conv_fwd(raw, self.lateral[l].packed.fwd, DEPTH, 1, aff, out=b["x"][l], up_res=prev)    # fpn.py:38,50-51
                 prev = b["x"][l]
-            for l in (2, 3, 4, 5):
-                ops.conv_fwd(b["x"][l], self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=spl[l])   # fpn.py:39,52
+            LV = (2, 3, 4, 5)
+            sps = [spl[l] for l in LV]
+            # (each stage's four convolutions in ONE grid: the small levels fill in at the level-2 kernel's throughput)
+            ops.conv_fwd_grouped([b["x"][l] for l in LV], [self.pconv[l].packed.fwd for l in LV], DEPTH, 3, [None] * 4,
+                                 [b["p"][l] for l in LV], sps)                                               # fpn.py:39,52
             fin["p"].run()
-            for l in (2, 3, 4, 5):
-                ops.conv_fwd(b["p"][l], self.phi[l]["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=spl[l])
+            ops.conv_fwd_grouped([b["p"][l] for l in LV], [self.phi[l]["conv1"].packed.fwd for l in LV], DEPTH, 3,
+                                 [self.p_bn[l].affine for l in LV], [b["y1"][l] for l in LV], sps)
             fin["bn1"].run()
-            for l in (2, 3, 4, 5):
-                ops.conv_fwd(b["y1"][l], self.phi[l]["conv2"].packed.fwd, DEPTH, 3, self.phi[l]["bn1"].affine, out=b["y2"][l], stats_part=spl[l])
+            ops.conv_fwd_grouped([b["y1"][l] for l in LV], [self.phi[l]["conv2"].packed.fwd for l in LV], DEPTH, 3,
+                                 [self.phi[l]["bn1"].affine for l in LV], [b["y2"][l] for l in LV], sps)
             fin["bn2"].run()
             for l in (2, 3, 4, 5):
                 ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, self.phi[l]["bn2"].affine)   # :86 + :37
@@ -592,18 +595,23 @@ class KeypointNet:
                 ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
                 ops.bn_bwd_reduce(self.phi[l]["bn2"], g["y2"][l], b["y2"][l], spl[l])
             fin["dbn2"].run()
+            none4 = [None] * 4
             for l in LV:
                 ph = self.phi[l]
                 ops.bn_bwd_apply(ph["bn2"], g["y2"][l], b["y2"][l])
                 W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
-                ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
-                ops.bn_bwd_reduce(ph["bn1"], g["y1"][l], b["y1"][l], spl[l])
+            ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
+                                 [g["y1"][l] for l in LV], none4)
+            for l in LV:
+                ops.bn_bwd_reduce(self.phi[l]["bn1"], g["y1"][l], b["y1"][l], spl[l])
             fin["dbn1"].run()
             for l in LV:
                 ph = self.phi[l]
                 ops.bn_bwd_apply(ph["bn1"], g["y1"][l], b["y1"][l])
                 W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
-                ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
+            ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
+                                 [g["p"][l] for l in LV], none4)
+            for l in LV:
                 ops.bn_bwd_reduce(self.p_bn[l], g["p"][l], b["p"][l], spl[l])
             fin["dp"].run()
             for l in LV:

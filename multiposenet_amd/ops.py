@@ -76,6 +76,27 @@ def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_
     return out
 
 
+def conv_fwd_grouped(xs, packeds, cout, ksize, affines, outs, stats_parts):
+    """Several independent convolutions of one channel geometry in one grid (mpn_conv_fwd_grouped): lists per job;
+    affines / stats_parts entries may be None. All inputs [N,H_j,W_j,Cin] of one dtype, same activation code."""
+    import ctypes
+    n = len(xs)
+    N, _, _, cin = xs[0].shape
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    sc, sh, act = [], [], ACT_NONE
+    for a in affines:
+        s_, h_, a_ = _aff(a)
+        sc.append(s_); sh.append(h_)
+        if a is not None:
+            act = a_
+    for x in xs:
+        _check_nhwc(x)
+    call("mpn_conv_fwd_grouped", n, PA(*[ptr(x) for x in xs]), PA(*[ptr(p) for p in packeds]), PA(*[ptr(o) for o in outs]), N,
+         IA(*[x.shape[1] for x in xs]), IA(*[x.shape[2] for x in xs]), cin, cout, ksize, _lib.dtype_code(xs[0].dtype),
+         PA(*sc), PA(*sh), int(act), PA(*[ptr(t) for t in stats_parts]), stream_ptr())
+    return outs
+
+
 def conv_wgrad_num_parts(N, H, W, cin, cout, ksize, dtype):
     return _lib.lib().mpn_conv_wgrad_num_parts(N, H, W, cin, cout, ksize, _lib.dtype_code(dtype))
 

@@ -278,3 +278,35 @@ def test_conv3x3_kernel_variants(cuda, variant, case):
         test_conv_fwd(cuda, torch.bfloat16, case)
     finally:
         setv(-1, -1, -1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_conv_fwd_grouped_equals_separate_launches(cuda, dtype):
+    """mpn_conv_fwd_grouped: four independent 3x3 convolutions (pyramid levels) in one grid = the four separate launches,
+    bit for bit, outputs and statistics rows (f32 takes the documented fallback: the separate launches themselves)."""
+    ops = _ops()
+    rs = np.random.RandomState(17)
+    N, C = 2, 128
+    sizes = [(32, 48), (16, 24), (8, 12), (5, 7)]
+    xs, pcs, affs = [], [], []
+    for (h, w) in sizes:
+        xs.append(dev(rnd(rs.randn(N, h, w, C), dtype), dtype))
+        pcs.append(ops.PackedConv(dev((rs.randn(3, 3, C, C) / np.sqrt(9 * C)).astype(np.float32)), dtype))
+        affs.append(ops.Affine(dev(torch.tensor(0.5 + rs.rand(C), dtype=torch.float32)), dev(torch.tensor(rs.randn(C) * 0.5, dtype=torch.float32)), 1))
+    want, wparts = [], []
+    for x, pc, a, (h, w) in zip(xs, pcs, affs, sizes):
+        part = torch.full((ops.conv_num_parts(N, h, w, 3), 2, C), float("nan"), device="cuda")
+        want.append(ops.conv_fwd(x, pc.fwd, C, 3, a, stats_part=part))
+        wparts.append(part)
+    outs = [torch.full_like(t, float("nan")) for t in want]
+    parts = [torch.full_like(t, float("nan")) for t in wparts]
+    ops.conv_fwd_grouped(xs, [pc.fwd for pc in pcs], C, 3, affs, outs, parts)
+    for a, b, pa, pb in zip(want, outs, wparts, parts):
+        assert torch.equal(a, b)
+        assert torch.equal(pa, pb)
+    # without affine / statistics (the data-gradient use)
+    want2 = [ops.conv_fwd(x, pc.bwd, C, 3) for x, pc in zip(xs, pcs)]
+    outs2 = [torch.empty_like(t) for t in want2]
+    ops.conv_fwd_grouped(xs, [pc.bwd for pc in pcs], C, 3, [None] * 4, outs2, [None] * 4)
+    for a, b in zip(want2, outs2):
+        assert torch.equal(a, b)
