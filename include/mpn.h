@@ -158,6 +158,16 @@ int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const
                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                     mpn_stream_t stream);
 /* is_training=False path: affine from the moving statistics */
+/* The two backward passes of up to four independent layers of one channel count in ONE grid each, largest first (the
+ * pyramid levels of a subnet stage). Arrays per job; results are those of mpn_bn_bwd_reduce / mpn_bn_bwd_apply per layer,
+ * bit for bit; part[j] holds mpn_bn_stats_num_parts(M[j]) rows. */
+int mpn_bn_bwd_reduce_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
+                              const float* const* scale, const float* const* shift, const float* const* mean,
+                              const float* const* invstd, int act, float* const* part, mpn_stream_t stream);
+int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
+                             const float* const* scale, const float* const* shift, const float* const* mean,
+                             const float* const* invstd, const float* const* k1, const float* const* k2, int act,
+                             const float* const* add_ch0, mpn_stream_t stream);
 /* Several independent layers' finalizes in ONE launch (the four pyramid levels of the keypoint subnet,
  * keypoint_subnet.py:64-91, produce their statistics side by side). Descriptor tables as for the batched slab reduction:
  * mpn_bn_fin_desc_fill / mpn_bn_bwd_fin_desc_fill write one host-side descriptor each (mpn_*_desc_bytes() bytes; return the

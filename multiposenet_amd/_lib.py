@@ -83,6 +83,8 @@ SIGNATURES = {
     "mpn_bias_relu_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "mpn_bias_relu_bwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
     "mpn_prn_loss": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mpn_bn_bwd_reduce_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "mpn_bn_bwd_apply_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "mpn_bn_fin_desc_bytes": (_Z, []),
     "mpn_bn_bwd_fin_desc_bytes": (_Z, []),
     "mpn_bn_fin_desc_fill": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I]),

@@ -269,10 +269,10 @@ __global__ __launch_bounds__(kThreads) void bn_act_apply_kernel(const T* __restr
 // ---------------------------------------------------------------- backward
 // g = dA * act'(x*scale+shift);  partials of sum(g) and sum(g*xhat), xhat = (x-mean)*invstd
 template <typename T>
-__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
+__device__ __forceinline__ void bn_bwd_reduce_body(
     const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-    float* __restrict__ part, int rows_per_block, const BnTailDev tail) {
+    float* __restrict__ part, int rows_per_block, const BnTailDev& tail, const int blk) {
     constexpr int VE = Vec16<T>::N;
     __shared__ float smem[kThreads * 2 * VE];
     __shared__ int tail_flag;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
         const int c = m.vg * VE + j;
         sc[j] = scale[c]; sh[j] = shift[c]; is[j] = invstd[c]; nmi[j] = -mean[c] * invstd[c];
     }
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r0 = (long long)blk * rows_per_block;
     const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     if (m.active) {
         constexpr int U = 4;  // rows in flight per thread (8 x 16-byte loads)
@@ -320,8 +320,42 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
             }
         }
     }
-    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C, tail.mode != 0);
-    if (tail.mode) bn_tail(tail, part, C, blockIdx.x, 0, C, 0, threadIdx.x, kThreads, &tail_flag);
+    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blk * 2 * C, C, tail.mode != 0);
+    if (tail.mode) bn_tail(tail, part, C, blk, 0, C, 0, threadIdx.x, kThreads, &tail_flag);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
+    const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+    float* __restrict__ part, int rows_per_block, const BnTailDev tail) {
+    bn_bwd_reduce_body<T>(dA, x, M, C, scale, shift, mean, invstd, act, part, rows_per_block, tail, blockIdx.x);
+}
+
+// up to four independent layers (the pyramid levels of a subnet stage) in one grid, largest first
+constexpr int kBnGroup = 4;
+struct BnBwdJob {
+    void* dA; const void* x; long long M;
+    const float *scale, *shift, *mean, *invstd, *k1, *k2, *add_ch0;
+    float* part;
+    int rows_per_block, pad_;
+};
+struct BnBwdGroup { BnBwdJob j[kBnGroup]; int begin[kBnGroup + 1]; int njobs, C, act, pad_; };
+__device__ __forceinline__ int bn_group_job(const BnBwdGroup& g) {
+    int job = 0;
+#pragma unroll
+    for (int k = 1; k < kBnGroup; ++k)
+        if (k < g.njobs && (int)blockIdx.x >= g.begin[k]) job = k;
+    return job;
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_reduce_grouped_kernel(const BnBwdGroup g) {
+    const int job = bn_group_job(g);
+    const BnBwdJob& q = g.j[job];
+    BnTailDev none;
+    none.mode = 0;
+    bn_bwd_reduce_body<T>((const T*)q.dA, (const T*)q.x, q.M, g.C, q.scale, q.shift, q.mean, q.invstd, g.act, q.part,
+                          q.rows_per_block, none, (int)blockIdx.x - g.begin[job]);
 }
 
 // part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
@@ -358,10 +392,11 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_batched_kernel(co
 // dx = scale * (g - k1 - xhat*k2), written over dA (same storage type); optional extra gradient
 // added to channel 0 (the auxiliary segmentation loss on p_l[...,0], keypoints_model.py:59-66).
 template <typename T>
-__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+__device__ __forceinline__ void bn_bwd_apply_body(
     T* __restrict__ dA, const T* __restrict__ x, long long nvec, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ k1, const float* __restrict__ k2, int act, const float* __restrict__ add_ch0) {
+    const float* __restrict__ k1, const float* __restrict__ k2, int act, const float* __restrict__ add_ch0,
+    const int blk, const int nblk) {
     constexpr int VE = Vec16<T>::N;
     constexpr int U = 4;   // 16-byte vectors of each operand in flight per thread
     const int cvec = C / VE;
@@ -369,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     // a thread keeps its channel vector, so the six per-channel parameters fold into registers ONCE:
     //   out = sc*(g - k1 - xhat*k2) = sc*g + cb*x + cc,  cb = -sc*k2*invstd,  cc = -sc*(k1 - mean*invstd*k2)
     // (re-loading them per element was 48 dword loads per 16-byte vector: bound by the texture unit, not by HBM)
-    const long long i0 = (long long)blockIdx.x * kThreads + threadIdx.x;
+    const long long i0 = (long long)blk * kThreads + threadIdx.x;
     const int vg = (int)(i0 % cvec);
     float sc[VE], sh[VE], cb[VE], cc[VE];
 #pragma unroll
@@ -390,7 +425,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
     }
     const float lo = (act != MPN_ACT_NONE) ? 0.f : -INFINITY;
     const float hi = (act == MPN_ACT_RELU6) ? 6.f : INFINITY;
-    const long long stride = (long long)gridDim.x * kThreads;
+    const long long stride = (long long)nblk * kThreads;
     for (long long i = i0; i < nvec; i += U * stride) {
         Vec16<T> vd[U], vx[U];
 #pragma unroll
@@ -422,6 +457,21 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
             if (ii < nvec) vd[u].store(dA + ii * VE);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(
+    T* __restrict__ dA, const T* __restrict__ x, long long nvec, int C, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ k1, const float* __restrict__ k2, int act, const float* __restrict__ add_ch0) {
+    bn_bwd_apply_body<T>(dA, x, nvec, C, scale, shift, mean, invstd, k1, k2, act, add_ch0, blockIdx.x, gridDim.x);
+}
+template <typename T>
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_grouped_kernel(const BnBwdGroup g) {
+    const int job = bn_group_job(g);
+    const BnBwdJob& q = g.j[job];
+    bn_bwd_apply_body<T>((T*)q.dA, (const T*)q.x, q.M * (g.C / Vec16<T>::N), g.C, q.scale, q.shift, q.mean, q.invstd, q.k1, q.k2,
+                         g.act, q.add_ch0, (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
 }
 
 // any C (a channel vector per thread changes from iteration to iteration: parameters re-loaded per element)
@@ -637,6 +687,80 @@ extern "C" int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int
                                  const float* shift, const float* mean, const float* invstd, int act, float* part,
                                  mpn_stream_t stream) {
     return mpn_bn_bwd_reduce_fin(dA, x, M, C, dtype, scale, shift, mean, invstd, act, part, nullptr, stream);
+}
+
+/* The backward passes of up to four independent layers of one channel count (the pyramid levels of a subnet stage) in ONE
+ * grid each, largest first; per job dA, x, M (rows), scale .. invstd, part (reduce) / k1, k2, add_ch0 (apply). Results are
+ * those of the per-layer launches, bit for bit; shapes the grouped grids do not cover run as those launches. */
+static bool bn_group_ok(int njobs, int C, int dtype) {
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("MPN_BN_GROUPED"); on = e ? atoi(e) : 1; }
+    return on && njobs <= kBnGroup && C % ve == 0 && kThreads % (C / ve) == 0;
+}
+extern "C" int mpn_bn_bwd_reduce_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
+                                         const float* const* scale, const float* const* shift, const float* const* mean,
+                                         const float* const* invstd, int act, float* const* part, mpn_stream_t stream) {
+    MPN_REQUIRE(njobs > 0 && dA && x && M && scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "bn_bwd_reduce_grouped: bad arguments");
+    if (!bn_group_ok(njobs, C, dtype)) {
+        for (int j = 0; j < njobs; ++j)
+            if (int rc = mpn_bn_bwd_reduce(dA[j], x[j], M[j], C, dtype, scale[j], shift[j], mean[j], invstd[j], act, part[j], stream)) return rc;
+        return MPN_OK;
+    }
+    BnBwdGroup g = {};
+    int begin = 0;
+    for (int j = 0; j < njobs; ++j) {
+        int ve;
+        if (int rc = check_rows(M[j], C, dtype, &ve)) return rc;
+        MPN_REQUIRE(dA[j] && x[j] && scale[j] && shift[j] && mean[j] && invstd[j] && part[j], MPN_ERR_BAD_ARG, "bn_bwd_reduce_grouped: null pointer");
+        const int nparts = mpn_bn_stats_num_parts(M[j]);
+        BnBwdJob& q = g.j[j];
+        q.dA = dA[j]; q.x = x[j]; q.M = M[j]; q.scale = scale[j]; q.shift = shift[j]; q.mean = mean[j]; q.invstd = invstd[j];
+        q.part = part[j]; q.rows_per_block = (int)rows_per_block_for(M[j], nparts);
+        g.begin[j] = begin;
+        begin += nparts;
+    }
+    for (int j = njobs; j <= kBnGroup; ++j) g.begin[j] = begin;
+    g.njobs = njobs; g.C = C; g.act = act;
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (bn_bwd_reduce_grouped_kernel<T><<<begin, kThreads, 0, st>>>(g)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+extern "C" int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
+                                        const float* const* scale, const float* const* shift, const float* const* mean,
+                                        const float* const* invstd, const float* const* k1, const float* const* k2, int act,
+                                        const float* const* add_ch0, mpn_stream_t stream) {
+    MPN_REQUIRE(njobs > 0 && dA && x && M && scale && shift && mean && invstd && k1 && k2 && add_ch0, MPN_ERR_BAD_ARG,
+                "bn_bwd_apply_grouped: bad arguments");
+    if (!bn_group_ok(njobs, C, dtype)) {
+        for (int j = 0; j < njobs; ++j)
+            if (int rc = mpn_bn_bwd_apply(dA[j], x[j], M[j], C, dtype, scale[j], shift[j], mean[j], invstd[j], k1[j], k2[j], act,
+                                          add_ch0[j], stream)) return rc;
+        return MPN_OK;
+    }
+    const int ve = dtype == MPN_F32 ? 4 : 8;
+    BnBwdGroup g = {};
+    int begin = 0;
+    for (int j = 0; j < njobs; ++j) {
+        int v2;
+        if (int rc = check_rows(M[j], C, dtype, &v2)) return rc;
+        MPN_REQUIRE(dA[j] && x[j] && scale[j] && shift[j] && mean[j] && invstd[j] && k1[j] && k2[j], MPN_ERR_BAD_ARG, "bn_bwd_apply_grouped: null pointer");
+        BnBwdJob& q = g.j[j];
+        q.dA = dA[j]; q.x = x[j]; q.M = M[j]; q.scale = scale[j]; q.shift = shift[j]; q.mean = mean[j]; q.invstd = invstd[j];
+        q.k1 = k1[j]; q.k2 = k2[j]; q.add_ch0 = add_ch0[j];
+        const long long nvec = M[j] * (C / ve);
+        long long blocks = (nvec + 4 * kThreads - 1) / (4 * kThreads);   // as the per-layer launch
+        if (blocks > 2048) blocks = 2048;
+        g.begin[j] = begin;
+        begin += (int)blocks;
+    }
+    for (int j = njobs; j <= kBnGroup; ++j) g.begin[j] = begin;
+    g.njobs = njobs; g.C = C; g.act = act;
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (bn_bwd_apply_grouped_kernel<T><<<begin, kThreads, 0, st>>>(g)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
 }
 
 extern "C" int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,

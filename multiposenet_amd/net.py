@@ -591,31 +591,32 @@ class KeypointNet:
                 b["fin"] = self._finalize_tables(b)
             fin, spl = b["fin"], b["stat_lv"]
             LV = (2, 3, 4, 5)
+            sps = [spl[l] for l in LV]
+            bn2s, bn1s, pbns = [self.phi[l]["bn2"] for l in LV], [self.phi[l]["bn1"] for l in LV], [self.p_bn[l] for l in LV]
+            gy2, gy1, gp = [g["y2"][l] for l in LV], [g["y1"][l] for l in LV], [g["p"][l] for l in LV]
+            by2, by1, bp = [b["y2"][l] for l in LV], [b["y1"][l] for l in LV], [b["p"][l] for l in LV]
             for l in LV:
                 ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
-                ops.bn_bwd_reduce(self.phi[l]["bn2"], g["y2"][l], b["y2"][l], spl[l])
+            ops.bn_bwd_reduce_grouped(bn2s, gy2, by2, sps)
             fin["dbn2"].run()
             none4 = [None] * 4
+            ops.bn_bwd_apply_grouped(bn2s, gy2, by2)
             for l in LV:
                 ph = self.phi[l]
-                ops.bn_bwd_apply(ph["bn2"], g["y2"][l], b["y2"][l])
                 W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
             ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
                                  [g["y1"][l] for l in LV], none4)
-            for l in LV:
-                ops.bn_bwd_reduce(self.phi[l]["bn1"], g["y1"][l], b["y1"][l], spl[l])
+            ops.bn_bwd_reduce_grouped(bn1s, gy1, by1, sps)
             fin["dbn1"].run()
+            ops.bn_bwd_apply_grouped(bn1s, gy1, by1)
             for l in LV:
                 ph = self.phi[l]
-                ops.bn_bwd_apply(ph["bn1"], g["y1"][l], b["y1"][l])
                 W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
             ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
                                  [g["p"][l] for l in LV], none4)
-            for l in LV:
-                ops.bn_bwd_reduce(self.p_bn[l], g["p"][l], b["p"][l], spl[l])
+            ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
             fin["dp"].run()
-            for l in LV:
-                ops.bn_bwd_apply(self.p_bn[l], g["p"][l], b["p"][l], add_ch0=g["daux"][l])
+            ops.bn_bwd_apply_grouped(pbns, gp, bp, [g["daux"][l] for l in LV])
         else:
             for l in (2, 3, 4, 5):
                 ph = self.phi[l]

@@ -284,6 +284,30 @@ def bn_bwd_apply(bn, dA, x, add_ch0=None):
     return dA
 
 
+def _bn_group_args(bns, dAs, xs):
+    import ctypes
+    n = len(bns)
+    PA, LA = ctypes.c_void_p * n, ctypes.c_longlong * n
+    Ms = [x.numel() // x.shape[-1] for x in xs]
+    return n, PA, PA(*[ptr(t) for t in dAs]), PA(*[ptr(t) for t in xs]), LA(*Ms), xs[0].shape[-1], _lib.dtype_code(xs[0].dtype)
+
+
+def bn_bwd_reduce_grouped(bns, dAs, xs, parts):
+    """bn_bwd_reduce of several independent layers (same channel count, dtype, activation) in one grid."""
+    n, PA, pd, px, Ms, C, dc = _bn_group_args(bns, dAs, xs)
+    call("mpn_bn_bwd_reduce_grouped", n, pd, px, Ms, C, dc, PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]),
+         PA(*[ptr(b.mean) for b in bns]), PA(*[ptr(b.invstd) for b in bns]), int(bns[0].act), PA(*[ptr(p) for p in parts]), stream_ptr())
+
+
+def bn_bwd_apply_grouped(bns, dAs, xs, add_ch0s=None):
+    """bn_bwd_apply of several independent layers in one grid (after their finalizes)."""
+    n, PA, pd, px, Ms, C, dc = _bn_group_args(bns, dAs, xs)
+    add = add_ch0s if add_ch0s is not None else [None] * n
+    call("mpn_bn_bwd_apply_grouped", n, pd, px, Ms, C, dc, PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]),
+         PA(*[ptr(b.mean) for b in bns]), PA(*[ptr(b.invstd) for b in bns]), PA(*[ptr(b.k1) for b in bns]),
+         PA(*[ptr(b.k2) for b in bns]), int(bns[0].act), PA(*[ptr(t) for t in add]), stream_ptr())
+
+
 def bn_inference_affine(bn):
     call("mpn_bn_inference_affine", bn.C, ptr(bn.gamma), ptr(bn.beta), ptr(bn.moving_mean), ptr(bn.moving_var),
          BN_EPSILON, ptr(bn.scale), ptr(bn.shift), stream_ptr())

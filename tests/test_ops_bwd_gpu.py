@@ -234,3 +234,44 @@ def test_batched_bn_finalizes_equal_per_layer_launches(cuda):
     for x, y in zip(a, b):
         for f in ("scale", "shift", "mean", "invstd", "moving_mean", "moving_var", "dgamma", "dbeta", "k1", "k2"):
             assert torch.equal(getattr(x, f), getattr(y, f)), f
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+def test_grouped_bn_backward_passes_equal_per_layer_launches(cuda, dtype):
+    """mpn_bn_bwd_reduce_grouped / mpn_bn_bwd_apply_grouped: four layers (pyramid levels) per grid, bit for bit the per-layer
+    partial rows, dgamma / dbeta and dx (with the extra channel-0 gradient on some jobs)."""
+    ops = _ops()
+    rs = np.random.RandomState(23)
+    C = 128
+    Ms = [2 * 32 * 48, 2 * 16 * 24, 2 * 8 * 12, 77]
+
+    def mk():
+        one = lambda: torch.tensor((0.5 + rs.rand(C)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), 1)
+        bn.scale.copy_(one()); bn.invstd.copy_(one())
+        bn.shift.copy_(torch.tensor((rs.randn(C) * 0.5).astype(np.float32)).cuda())
+        bn.mean.copy_(torch.tensor((rs.randn(C) * 0.3).astype(np.float32)).cuda())
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+
+    xs = [dev(rnd(rs.randn(M, C), dtype), dtype) for M in Ms]
+    dAs = [dev(rnd(rs.randn(M, C), dtype), dtype) for M in Ms]
+    add = [torch.tensor(rs.randn(M).astype(np.float32)).cuda() if j % 2 == 0 else None for j, M in enumerate(Ms)]
+    st = rs.get_state()
+    a = [mk() for _ in Ms]
+    rs.set_state(st)
+    b = [mk() for _ in Ms]
+    nparts = [ops._lib.lib().mpn_bn_stats_num_parts(M) for M in Ms]
+    pa = [torch.full((n * 2 * C,), float("nan"), device="cuda") for n in nparts]
+    pb = [torch.full((n * 2 * C,), float("nan"), device="cuda") for n in nparts]
+    da_a = [t.clone() for t in dAs]
+    da_b = [t.clone() for t in dAs]
+    for bn, d, x, p, ad in zip(a, da_a, xs, pa, add):
+        ops.bn_backward(bn, d, x, p, add_ch0=ad, fused=False)
+    ops.bn_bwd_reduce_grouped(b, da_b, xs, pb)
+    ops.BnBwdFinalizeBatch([(bn, p, n, M) for bn, p, n, M in zip(b, pb, nparts, Ms)], "cuda:0").run()
+    ops.bn_bwd_apply_grouped(b, da_b, xs, add)
+    for j in range(len(Ms)):
+        assert torch.equal(pa[j], pb[j]), j
+        assert torch.equal(a[j].dgamma, b[j].dgamma) and torch.equal(a[j].dbeta, b[j].dbeta), j
+        assert torch.equal(da_a[j], da_b[j]), j
