@@ -316,6 +316,10 @@ int mpn_reduce_desc_fill(void* desc_host, const float* part, int nparts, long lo
                          int block_begin);
 int mpn_reduce_partials_batched(const void* descs_device, int ndesc, int total_blocks, mpn_stream_t stream);
 int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream);
+/* acc[0] += scale * sum(w^2)/2 - `weight_decay * tf.nn.l2_loss(k)` of add_weight_decay (keypoints_model.py:129-138), the
+ * term tf.losses.get_total_loss(add_regularization_losses=True) adds to the reported loss (keypoints_model.py:79).
+ * One block, fixed summation order (f64): deterministic. */
+int mpn_l2_loss_accumulate(long long n, const float* w, float scale, float* acc, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * L1  target-heatmap rendering (label producer of the keypoint path).

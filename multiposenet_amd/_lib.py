@@ -95,6 +95,7 @@ SIGNATURES = {
     "mpn_prn_crop": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "mpn_prn_decode": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mpn_axpy": (_I, [_L, _F, _P, _P, _P]),
+    "mpn_l2_loss_accumulate": (_I, [_L, _P, _F, _P, _P]),
 }
 
 _lib = None

@@ -208,6 +208,26 @@ __global__ __launch_bounds__(kThreads) void axpy_kernel(long long n, float a, co
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
         y[i] += a * x[i];
 }
+
+// acc[0] += scale * sum(w^2)/2 : ONE block, every thread a fixed strided share in f64, fixed-order tree -> the same bits
+// on every run (tf.nn.l2_loss = sum(t^2)/2; keypoints_model.py:137). Regularisation is off in the keypoint run, so this
+// is a correctness path, not a hot one.
+__global__ __launch_bounds__(1024) void l2_loss_kernel(long long n, const float* __restrict__ w, double scale,
+                                                        float* __restrict__ acc) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const double v = (double)w[i];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 512; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[0] = (float)((double)acc[0] + scale * 0.5 * red[0]);
+}
 }  // namespace
 
 /* step: device int64 global_step (incremented); hyper: device f32[4] -> {lr_t, lr, -, -} */
@@ -299,6 +319,15 @@ extern "C" int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stre
     long long blocks = (n + kThreads - 1) / kThreads;
     if (blocks > 2048) blocks = 2048;
     axpy_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(n, a, x, y);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* acc[0] += scale * l2_loss(w), l2_loss(t) = sum(t^2)/2 (tf.nn.l2_loss): the regularisation term that
+ * keypoints_model.py:24-27,79 adds to the total loss when weight_decay > 0. Deterministic (one block, fixed order). */
+extern "C" int mpn_l2_loss_accumulate(long long n, const float* w, float scale, float* acc, mpn_stream_t stream) {
+    MPN_REQUIRE(w && acc && n > 0, MPN_ERR_BAD_ARG, "l2_loss_accumulate: bad arguments");
+    l2_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(n, w, (double)scale, acc);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

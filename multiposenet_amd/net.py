@@ -675,6 +675,15 @@ class KeypointNet:
             if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k:
                 ops.axpy(weight_decay, w.view(-1), self.grads[k].view(-1))
 
+    def add_weight_decay_loss(self, weight_decay):
+        """The regularisation term itself: total_loss += sum_k wd * l2_loss(k) over the same variables
+        (tf.losses.get_total_loss(add_regularization_losses=True), keypoints_model.py:24-27,79). Call after
+        compute_losses; the per-term losses stay as they are."""
+        total = self._last[0]["losses"][6:7]
+        for k, w in self.vars.items():
+            if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k:
+                ops.l2_loss_accumulate(w.view(-1), weight_decay, total)
+
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, initial_learning_rate, num_steps, grad_scale=1.0):
         """Cosine LR + clip(+-200) + TF-Adam over the flat arena, then refresh the packed weights."""

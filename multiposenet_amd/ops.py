@@ -544,3 +544,8 @@ def reduce_partials(part, nparts, n, out, accumulate=False, scale=1.0):
 
 def axpy(a, x, y):
     call("mpn_axpy", x.numel(), float(a), ptr(x), ptr(y), stream_ptr())
+
+
+def l2_loss_accumulate(w, scale, acc):
+    """acc[0] += scale * sum(w^2)/2 (acc: f32 device tensor view of one element)."""
+    call("mpn_l2_loss_accumulate", w.numel(), ptr(w), float(scale), ptr(acc), stream_ptr())

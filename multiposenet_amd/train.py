@@ -29,6 +29,8 @@ class Trainer:
         if part in (None, 0):
             self.net.forward(s["images"], True)
             self.net.compute_losses(s["labels"])
+            if self.weight_decay > 0.0:
+                self.net.add_weight_decay_loss(self.weight_decay)
         self.net.backward(part)
         if part in (None, 1) and self.weight_decay > 0.0:
             self.net.add_weight_decay_gradients(self.weight_decay)
@@ -114,4 +116,7 @@ class Trainer:
 
     def eval_step(self, features, labels):
         self.net.forward(features["images"], False)
-        return self.net.compute_losses(labels, with_grad=False)
+        losses = self.net.compute_losses(labels, with_grad=False)
+        if self.weight_decay > 0.0:
+            self.net.add_weight_decay_loss(self.weight_decay)
+        return losses

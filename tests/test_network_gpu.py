@@ -245,6 +245,55 @@ def test_graph_replay_equals_eager_and_bf16_tracks_f32(cuda):
         np.testing.assert_allclose(b[[0, 6]], a[[0, 6]], rtol=0.12)
 
 
+def test_weight_decay_term_matches_oracle(cuda):
+    """weight_decay > 0 (keypoints_model.py:24-27,79,129-138): the reported total loss carries wd * sum l2_loss(kernel)
+    over the non-depthwise kernels, the gradients carry wd * kernel, eager and hipGraph replay agree bit for bit."""
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
+    rs = np.random.RandomState(11)
+    B, H, W = 2, 128, 128
+    params = _params(7)
+    img = rs.rand(B, H, W, 3).astype(np.float32)
+    lab = _labels(rs, B, H // 4, W // 4)
+    wd = 1e-2
+    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": wd, "depth_multiplier": 1.0}
+    ref = {k: v.astype(np.float64) for k, v in params.items()}
+    m = {k: np.zeros_like(v) for k, v in ref.items()}
+    v = {k: np.zeros_like(v) for k, v in ref.items()}
+    total, losses, _ = onet.train_step(ref, m, v, img, lab, 0, hp, dtype=torch.float64)
+    reg = wd * sum(0.5 * float((p.astype(np.float64) ** 2).sum()) for k, p in params.items()
+                   if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k)
+    assert reg > 1e-3 * total          # the term is visible at this wd
+    feats = {"images": torch.tensor(img).cuda()}
+    dlab = {k: torch.tensor(val).cuda() for k, val in lab.items()}
+    outs, grads = {}, {}
+    for name, graph in (("eager", False), ("graph", True)):
+        net = KeypointNet(values=params, dtype=torch.float32)
+        tr = Trainer(net, hp, use_graph=graph)
+        outs[name] = tr.step(feats, dlab).cpu().numpy().copy()
+        grads[name] = {k: g.cpu().numpy().copy() for k, g in net.grads.items()}
+    out = outs["eager"]
+    np.testing.assert_array_equal(out, outs["graph"])
+    np.testing.assert_allclose(out[6], total, rtol=2e-4)
+    np.testing.assert_allclose(out[:6], list(losses.values()), rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(out[6] - out[:6].sum(), reg, rtol=1e-3, atol=1e-5 * total)
+    # gradients: the same step without decay, plus wd * kernel (depthwise kernels, biases and BN variables untouched)
+    net0 = KeypointNet(values=params, dtype=torch.float32)
+    hp0 = dict(hp, weight_decay=0.0)
+    Trainer(net0, hp0, use_graph=False).step(feats, dlab)
+    for k, g in grads["eager"].items():
+        np.testing.assert_array_equal(g, grads["graph"][k])
+        g0 = net0.grads[k].cpu().numpy()
+        decayed = ("weights" in k or "kernel" in k) and "depthwise_weights" not in k
+        want = g0 + np.float32(wd) * params[k].astype(np.float32) if decayed else g0
+        np.testing.assert_allclose(g, want, rtol=1e-5, atol=1e-7 * max(1.0, float(np.abs(want).max())), err_msg=k)
+    # EVAL reports the same total (moving statistics differ from batch statistics, so compare the term only)
+    ev = tr.eval_step(feats, dlab).cpu().numpy()
+    np.testing.assert_allclose(ev[6] - ev[:6].sum(), wd * sum(
+        0.5 * float((p.astype(np.float64) ** 2).sum()) for k, p in net.state_dict().items()
+        if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k), rtol=1e-3)
+
+
 def test_fused_bn_finalize_equals_separate_launches(cuda):
     """The batch-norm finalize fused into the producing launches (last-finishing blocks, two-level f64 reduction) must
     agree with the separate mpn_bn_finalize / mpn_bn_bwd_finalize launches: identical moving statistics and scale/shift up
