@@ -230,6 +230,15 @@ int mpn_dwconv_bwd_data_bn_num_parts(int N, int H, int W, int C, int stride, int
 int mpn_dwconv_bwd_data_bn(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride, int dtype,
                            const void* x_bn, const float* scale, const float* shift, const float* mean,
                            const float* invstd, int act, float* part, mpn_stream_t stream);
+/* dx = data gradient + addend, addend [N,H,W,C] of dx's type and not aliasing it: the gradient an FPN lateral sends into
+ * the same backbone feature map (the sum of the two consumers of c2..c4, mobilenet_v1.py:76-79 / fpn.py:48) - one read
+ * instead of a separate read-modify-write pass and a single rounding of the sum. x_bn != NULL: also the batch-norm
+ * backward reduction of mpn_dwconv_bwd_data_bn, over the SUM (part: mpn_dwconv_bwd_data_bn_num_parts rows); x_bn == NULL:
+ * scale .. part are ignored. Stride-2 layers with even H, W only (mpn_dwconv_bwd_data_add_supported == 1). */
+int mpn_dwconv_bwd_data_add_supported(int N, int H, int W, int C, int stride, int dtype);
+int mpn_dwconv_bwd_data_add(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride, int dtype,
+                            const void* addend, const void* x_bn, const float* scale, const float* shift,
+                            const float* mean, const float* invstd, int act, float* part, mpn_stream_t stream);
 int mpn_dwconv_wgrad_num_parts(int N, int H, int W, int C, int stride, int dtype);
 /* part [mpn_dwconv_wgrad_num_parts()][9][C]; finish with mpn_reduce_partials */
 int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int C,

@@ -45,6 +45,7 @@ struct DwParams {
     const float* bnr_mean;
     const float* bnr_invstd;
     int bnr_act;
+    const void* addend; // stride-2 sliding-window data gradient: a tensor of dx's shape added before the store (and before BNR)
     int xcd_remap;      // sliding-window kernels: XCD-aware block -> strip map
 };
 
@@ -1237,7 +1238,9 @@ namespace {
 // dY rows per thread: 32 on maps of 64 dY rows and more (256x256 input: 81 -> 72 us), 16 at 32, 8 below (16-row maps
 // would otherwise be one strip per column block)
 __host__ __device__ inline int dg_rows(int OH) { return OH >= 64 ? 32 : (OH >= 32 ? 16 : 8); }
-template <typename T, bool BNR>
+// ADD: dx = gradient + addend (the FPN lateral's gradient into a backbone feature map: one read instead of the separate
+// read-modify-write pass, a single rounding of the sum, and the sum is what the fused batch-norm reduction sees)
+template <typename T, bool BNR, bool ADD>
 __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* __restrict__ dy, const float* __restrict__ w,
                                                                       T* __restrict__ dx, int H, int W, int C, int OH, int OW,
                                                                       int ncg, int cols, int xblocks, int yblocks, int cblocks,
@@ -1322,17 +1325,38 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
         s01 += g01; s23 += g23;
         q01 += g01 * (x01 * bis01 + bnm01); q23 += g23 * (x23 * bis23 + bnm23);
     };
+    const T* adp = nullptr;
+    if constexpr (ADD) adp = reinterpret_cast<const T*>(p.addend) + (((long long)img * H + 2 * a_begin) * W + 2 * bc) * C + cc;
+    Raw4<T> aq[4];   // the addend at the 2x2 block of the NEXT emit (requested one step ahead, like yq)
+    auto add_load = [&](int a) {
+        if constexpr (ADD) {
+            const T* q = adp + (long long)(2 * (min(a, OH - 1) - a_begin)) * xrow;
+            raw_load(aq[0], q); raw_load(aq[1], q + C); raw_load(aq[2], q + xrow); raw_load(aq[3], q + xrow + C);
+        }
+    };
+    auto add_acc = [&](const Raw4<T>& r, f32x2_t& o01, f32x2_t& o23) {
+        float f[4];
+        raw_unpack(r, f);
+        o01 += (f32x2_t){f[0], f[1]};
+        o23 += (f32x2_t){f[2], f[3]};
+    };
     int a_cur = a_begin;
     auto emit = [&](const f32x2_t (&pv)[2][2], const f32x2_t (&cv)[2][2]) {   // previous row a-1, current row a
         // taps t = ky*3 + kx
-        const f32x2_t e01 = cv[1][0] * w01[0] + pv[1][0] * w01[6] + cv[0][0] * w01[2] + pv[0][0] * w01[8];
-        const f32x2_t e23 = cv[1][1] * w23[0] + pv[1][1] * w23[6] + cv[0][1] * w23[2] + pv[0][1] * w23[8];
-        const f32x2_t f01 = cv[1][0] * w01[1] + pv[1][0] * w01[7];
-        const f32x2_t f23 = cv[1][1] * w23[1] + pv[1][1] * w23[7];
-        const f32x2_t g01 = cv[1][0] * w01[3] + cv[0][0] * w01[5];
-        const f32x2_t g23 = cv[1][1] * w23[3] + cv[0][1] * w23[5];
-        const f32x2_t h01 = cv[1][0] * w01[4];
-        const f32x2_t h23 = cv[1][1] * w23[4];
+        f32x2_t e01 = cv[1][0] * w01[0] + pv[1][0] * w01[6] + cv[0][0] * w01[2] + pv[0][0] * w01[8];
+        f32x2_t e23 = cv[1][1] * w23[0] + pv[1][1] * w23[6] + cv[0][1] * w23[2] + pv[0][1] * w23[8];
+        f32x2_t f01 = cv[1][0] * w01[1] + pv[1][0] * w01[7];
+        f32x2_t f23 = cv[1][1] * w23[1] + pv[1][1] * w23[7];
+        f32x2_t g01 = cv[1][0] * w01[3] + cv[0][0] * w01[5];
+        f32x2_t g23 = cv[1][1] * w23[3] + cv[0][1] * w23[5];
+        f32x2_t h01 = cv[1][0] * w01[4];
+        f32x2_t h23 = cv[1][1] * w23[4];
+        if constexpr (ADD) {
+            add_acc(aq[0], e01, e23);
+            add_acc(aq[1], f01, f23);
+            add_acc(aq[2], g01, g23);
+            add_acc(aq[3], h01, h23);
+        }
         if (lane_ok) {
             store4x2(xp, e01, e23);
             store4x2(xp + C, f01, f23);
@@ -1348,8 +1372,10 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
         xp += 2 * xrow;
         ++a_cur;
         bnr_load(a_cur);
+        add_load(a_cur);
     };
     bnr_load(a_begin);
+    add_load(a_begin);
     Raw4<T> ra[2], rb[2], rc[2];
     f32x2_t v0[2][2], v1[2][2];
     row_load(ra, a_begin - 1);
@@ -1510,11 +1536,15 @@ static DwDgS2Geom dw_dg_s2_geom(const DwParams& p) {
 
 // bnr: fuse the batch-norm backward reduction of the layer that dx feeds (p.bnr_* and p.part set); needs the sliding-window kernels
 static int dw_bwd_data_impl(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride, int dtype,
-                            const DwParams* bnr, mpn_stream_t stream) {
+                            const DwParams* bnr, mpn_stream_t stream, const void* addend = nullptr) {
     DwParams p = {};
     if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
     MPN_REQUIRE(dy && w && dx, MPN_ERR_BAD_ARG, "dwconv_bwd_data: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    MPN_REQUIRE(addend == nullptr || (stride == 2 && dw_dg_s2_geom(p).ok), MPN_ERR_BAD_SHAPE,
+                "dwconv_bwd_data_add: needs stride 2, even H and W and a power-of-two channel block (mpn_dwconv_bwd_data_add_supported)");
+    MPN_REQUIRE(addend != dx, MPN_ERR_BAD_ARG, "dwconv_bwd_data_add: addend must not alias dx");
+    p.addend = addend;
     if (stride == 1) {   // correlation with the flipped kernel, pad 1
         if (bnr == nullptr)
             return mpn_dwconv_fwd(dy, w, dx, N, H, W, C, 1, dtype, nullptr, nullptr, MPN_ACT_NONE, 1, nullptr, stream);
@@ -1540,11 +1570,19 @@ static int dw_bwd_data_impl(const void* dy, const float* w, void* dx, int N, int
         if (bnr != nullptr) {
             p.part = bnr->part; p.bnr_x = bnr->bnr_x; p.bnr_scale = bnr->bnr_scale; p.bnr_shift = bnr->bnr_shift;
             p.bnr_mean = bnr->bnr_mean; p.bnr_invstd = bnr->bnr_invstd; p.bnr_act = bnr->bnr_act;
-            MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T, true><<<(unsigned)blocks, kThreads, 0, st>>>(
-                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p)));
+            MPN_DISPATCH_DTYPE(dtype, {
+                if (addend) dwconv_dgrad_s2_sw_kernel<T, true, true><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p);
+                else dwconv_dgrad_s2_sw_kernel<T, true, false><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p);
+            });
         } else {
-            MPN_DISPATCH_DTYPE(dtype, (dwconv_dgrad_s2_sw_kernel<T, false><<<(unsigned)blocks, kThreads, 0, st>>>(
-                                          (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p)));
+            MPN_DISPATCH_DTYPE(dtype, {
+                if (addend) dwconv_dgrad_s2_sw_kernel<T, false, true><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p);
+                else dwconv_dgrad_s2_sw_kernel<T, false, false><<<(unsigned)blocks, kThreads, 0, st>>>(
+                                (const T*)dy, w, (T*)dx, H, W, C, p.OH, p.OW, g.ncg, g.cols, g.xblocks, g.yblocks, g.cblocks, p);
+            });
         }
         MPN_LAUNCH_CHECK();
         return MPN_OK;
@@ -1597,6 +1635,31 @@ extern "C" int mpn_dwconv_bwd_data_bn(const void* dy, const float* w, void* dx, 
     b.part = part; b.bnr_x = x_bn; b.bnr_scale = scale; b.bnr_shift = shift; b.bnr_mean = mean; b.bnr_invstd = invstd;
     b.bnr_act = act;
     return dw_bwd_data_impl(dy, w, dx, N, H, W, C, stride, dtype, &b, stream);
+}
+
+/* 1 when mpn_dwconv_bwd_data_add takes this shape (the stride-2 sliding-window kernel: even H and W, C % 4 == 0) */
+extern "C" int mpn_dwconv_bwd_data_add_supported(int N, int H, int W, int C, int stride, int dtype) {
+    DwParams p = {};
+    if (fill_params(p, N, H, W, C, stride, dtype)) return 0;
+    return (stride == 2 && C % 4 == 0 && dw_dg_s2_geom(p).ok) ? 1 : 0;
+}
+
+/* dx = data gradient + addend (addend: a tensor of dx's shape and type, e.g. the gradient an FPN lateral sends into the
+ * same backbone feature map), optionally with the batch-norm backward reduction of mpn_dwconv_bwd_data_bn over that SUM
+ * (x_bn == NULL: no reduction; then scale .. part are ignored). */
+extern "C" int mpn_dwconv_bwd_data_add(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int stride,
+                                       int dtype, const void* addend, const void* x_bn, const float* scale,
+                                       const float* shift, const float* mean, const float* invstd, int act, float* part,
+                                       mpn_stream_t stream) {
+    MPN_REQUIRE(addend, MPN_ERR_BAD_ARG, "dwconv_bwd_data_add: null addend");
+    MPN_REQUIRE(mpn_dwconv_bwd_data_add_supported(N, H, W, C, stride, dtype), MPN_ERR_BAD_SHAPE,
+                "dwconv_bwd_data_add: shape not supported (mpn_dwconv_bwd_data_add_supported == 0)");
+    if (x_bn == nullptr) return dw_bwd_data_impl(dy, w, dx, N, H, W, C, stride, dtype, nullptr, stream, addend);
+    MPN_REQUIRE(scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "dwconv_bwd_data_add: null batch-norm pointer");
+    DwParams b = {};
+    b.part = part; b.bnr_x = x_bn; b.bnr_scale = scale; b.bnr_shift = shift; b.bnr_mean = mean; b.bnr_invstd = invstd;
+    b.bnr_act = act;
+    return dw_bwd_data_impl(dy, w, dx, N, H, W, C, stride, dtype, &b, stream, addend);
 }
 
 // sliding-window weight gradient: blocks of at most 128 channels; strips of 32 output rows on the large maps, 16 below

@@ -234,6 +234,7 @@ class KeypointNet:
         self.fuse_bn = False
         self.batch_finalize = os.environ.get("MPN_BATCH_FINALIZE", "1") != "0"   # the four pyramid levels' batch-norm finalizes in one launch per stage
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
+        self.fuse_lateral_add = True   # ... and add the FPN lateral's gradient into c2..c4 (mpn_dwconv_bwd_data_add)
         self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
             [self.p_bn[l] for l in (2, 3, 4, 5)] + [self.phi[l][k] for l in (2, 3, 4, 5) for k in ("bn1", "bn2")] + [self.final_bn]
@@ -641,9 +642,10 @@ class KeypointNet:
     def _backward_backbone(self, b, g, images, sp, slab, W):
         dA = g["c"]["c5"]
         reduced = 0
+        lateral_added = False
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
-            if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13:
+            if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13 and not lateral_added:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
             ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, fused=self.fuse_bn, reduced_parts=reduced)
             W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
@@ -658,13 +660,21 @@ class KeypointNet:
             prev_bn = self.blocks[i - 1]["pw_bn"] if i > 0 else self.stem_bn
             prev_x = b["pw"][i - 1] if i > 0 else b["stem"]
             prev_feature = i > 0 and self.blocks[i - 1]["i"] in FEATURE_BLOCKS
+            # c2..c4 have two consumers (the next depthwise conv and an FPN lateral, mobilenet_v1.py:76-79): the lateral's
+            # gradient is added inside the data-gradient kernel where it can be (stride-2 layers with even maps - all three
+            # at the reference's input sizes), otherwise by add_inplace at the top of the next iteration
+            addend = g["c"][FEATURE_BLOCKS[self.blocks[i - 1]["i"]]] if prev_feature else None
+            lateral_added = addend is not None and self.fuse_lateral_add and \
+                ops.dwconv_bwd_data_add_supported(dst.shape[0], *b["hw"][i], dst.shape[3], blk["stride"], dst.dtype)
+            if not lateral_added:
+                addend = None
             reduced = 0
-            if self.fuse_dw_bn and not self.fuse_bn and not prev_feature and \
+            if self.fuse_dw_bn and not self.fuse_bn and (not prev_feature or lateral_added) and \
                     ops.dwconv_bwd_data_bn_num_parts(dst.shape[0], *b["hw"][i], dst.shape[3], blk["stride"], dst.dtype) > 0:
                 _, reduced = ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst, bn=prev_bn,
-                                                 x_bn=prev_x, part=sp)
+                                                 x_bn=prev_x, part=sp, addend=addend)
             else:
-                ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst)
+                ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst, addend=addend)
             dA = dst
         ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp, fused=self.fuse_bn, reduced_parts=reduced)
         W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, slab[id(self.stem_dw)], reduce=False))

@@ -372,14 +372,37 @@ def dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, dtype):
     return _lib.lib().mpn_dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, _lib.dtype_code(dtype))
 
 
-def dwconv_bwd_data(dy, w, in_hw, stride, out=None, bn=None, x_bn=None, part=None):
+def dwconv_bwd_data_add_supported(N, H, W, C, stride, dtype):
+    """True when dwconv_bwd_data(addend=...) takes this shape (stride 2, even H and W)."""
+    return _lib.lib().mpn_dwconv_bwd_data_add_supported(N, H, W, C, stride, _lib.dtype_code(dtype)) == 1
+
+
+def dwconv_bwd_data(dy, w, in_hw, stride, out=None, bn=None, x_bn=None, part=None, addend=None):
     """bn / x_bn / part: fuse the batch-norm backward reduction of the layer that the result feeds (x_bn = that layer's raw
-    conv output, same shape as the result); returns (out, rows) then - pass rows to bn_backward(reduced_parts=rows)."""
+    conv output, same shape as the result); returns (out, rows) then - pass rows to bn_backward(reduced_parts=rows).
+    addend: a tensor of the result's shape added to the gradient before the store (and before the reduction)."""
     N, OH, OW, C = dy.shape
     H, W = in_hw
     if out is None:
         out = torch.empty((N, H, W, C), dtype=dy.dtype, device=dy.device)
     dc = _lib.dtype_code(dy.dtype)
+    if addend is not None:
+        if addend.shape != out.shape or addend.dtype != out.dtype or not addend.is_contiguous():
+            raise ValueError("dwconv_bwd_data: addend must have the result's shape and dtype")
+        rows = 0
+        if bn is not None:
+            rows = dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, dy.dtype)
+            if rows <= 0:
+                raise ValueError("dwconv_bwd_data: fused batch-norm reduction not available for this shape")
+            if part is None:
+                part = _f32(rows * 2 * C, dy.device)
+            if part.numel() < rows * 2 * C:
+                raise ValueError("dwconv_bwd_data: partial slab too small")
+        call("mpn_dwconv_bwd_data_add", ptr(dy), ptr(w), ptr(out), N, H, W, C, stride, dc, ptr(addend),
+             ptr(x_bn) if bn is not None else None, *((ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd), int(bn.act),
+                                                      ptr(part)) if bn is not None else (None, None, None, None, 0, None)),
+             stream_ptr())
+        return (out, rows) if bn is not None else out
     if bn is not None:
         rows = dwconv_bwd_data_bn_num_parts(N, H, W, C, stride, dy.dtype)
         if rows <= 0:

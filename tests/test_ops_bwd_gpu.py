@@ -205,6 +205,55 @@ def test_dwconv_bwd_data_with_fused_bn_reduction(cuda, dtype, N, H, W, C, stride
     assert_close(dA_fused, dA_sep.float().cpu(), dtype, 4)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 16, 64), (1, 32, 32, 512), (1, 48, 40, 256), (2, 64, 64, 128), (1, 6, 10, 1024)])
+def test_dwconv_bwd_data_add(cuda, dtype, N, H, W, C):
+    """mpn_dwconv_bwd_data_add (stride 2): dx = round(gradient + addend) - the f32 gradient of mpn_dwconv_bwd_data plus the
+    addend with ONE rounding (within one storage ulp of the two-pass result, which rounds twice); with the batch-norm
+    reduction the partial rows finalize to the dgamma / dbeta of mpn_bn_bwd_reduce on that sum."""
+    ops = _ops()
+    rs = np.random.RandomState(C + H)
+    OH, OW = ops.dwconv_out_hw(H, W, 2)
+    assert ops.dwconv_bwd_data_add_supported(N, H, W, C, 2, dtype)
+    assert not ops.dwconv_bwd_data_add_supported(N, H, W, C, 1, dtype)
+    assert not ops.dwconv_bwd_data_add_supported(N, H + 1, W, C, 2, dtype)
+    dy = dev(rnd(rs.randn(N, OH, OW, C), dtype), dtype)
+    w = dev((rs.randn(3, 3, C) / 3).astype(np.float32))
+    add = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)
+    xbn = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)
+    g32 = ops.dwconv_bwd_data(dy.float(), w, (H, W), 2)            # the f32 kernel on the same (storage-rounded) values
+    want = (g32 + add.float()).cpu()
+    got = ops.dwconv_bwd_data(dy, w, (H, W), 2, addend=add)
+    assert_close(got, want, dtype, 1)
+    two_pass = ops.add_inplace(ops.dwconv_bwd_data(dy, w, (H, W), 2), add)
+    assert_close(got, two_pass.float().cpu(), dtype, 2)
+    with pytest.raises(Exception):
+        ops.dwconv_bwd_data(dy, w, (H, W), 2, out=add, addend=add)   # aliasing is refused
+
+    def mkbn():
+        one = lambda: torch.tensor((0.5 + rs.rand(C)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), 2)
+        bn.scale.copy_(one()); bn.invstd.copy_(one())
+        bn.shift.copy_(torch.tensor((rs.randn(C) * 0.5).astype(np.float32)).cuda()); bn.mean.copy_(torch.tensor((rs.randn(C) * 0.3).astype(np.float32)).cuda())
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+    st = rs.get_state()
+    bn_a = mkbn(); rs.set_state(st); bn_b = mkbn()
+    rows = ops.dwconv_bwd_data_bn_num_parts(N, H, W, C, 2, dy.dtype)
+    part2 = torch.empty(rows * 2 * C, device="cuda")
+    dA_fused, r2 = ops.dwconv_bwd_data(dy, w, (H, W), 2, bn=bn_a, x_bn=xbn, part=part2, addend=add)
+    assert r2 == rows and torch.equal(dA_fused, got)
+    M = N * H * W
+    part = torch.empty(ops._lib.lib().mpn_bn_stats_num_parts(M) * 2 * C, device="cuda")
+    dA_sep = got.clone()
+    ops.bn_backward(bn_b, dA_sep, xbn, part, fused=False)
+    ops.bn_backward(bn_a, dA_fused, xbn, part2, fused=False, reduced_parts=rows)
+    scale = float(bn_b.dgamma.abs().max()) + 1e-6
+    assert float((bn_a.dgamma - bn_b.dgamma).abs().max()) <= 2e-5 * scale * max(1.0, M ** 0.5 / 16)
+    assert float((bn_a.dbeta - bn_b.dbeta).abs().max()) <= 2e-5 * (float(bn_b.dbeta.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
+    assert_close(dA_fused, dA_sep.float().cpu(), dtype, 4)
+
+
 def test_batched_bn_finalizes_equal_per_layer_launches(cuda):
     """mpn_bn_finalize_batched / mpn_bn_bwd_finalize_batched: several layers in one launch, bit for bit the per-layer results
     (scale, shift, saved mean / invstd, moving statistics; dgamma, dbeta, k1, k2)."""
