@@ -27,6 +27,7 @@ namespace {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -69,6 +70,9 @@ struct ConvParams {
     int xcd_remap;            // XCD-aware block -> tile map (default on)
 };
 
+#ifndef MPN_CONV_M32_DEFAULT
+#define MPN_CONV_M32_DEFAULT 0
+#endif
 constexpr int kThreads = 256;
 constexpr int kHaloW = 18, kHaloH = 10;
 
@@ -122,9 +126,14 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
 // (the body is a device function so that the plain kernel and the grouped kernel - several independent launches of the
 //  same instance, e.g. the four pyramid levels of one subnet stage, in ONE grid - share it; blk / nwg = this job's block
 //  index and block count)
-template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4>
+// M32: the same tiles on v_mfma_f32_32x32x16_bf16 - per 64-byte k-step a wave issues 2 x 2 x 2 MFMAs of 8 passes instead
+// of 4 x 4 of 4 passes: the same matrix cycles and the same LDS reads (8 x 16 bytes per lane), half the MFMA instructions
+// on the vector issue port. bf16, 128-pixel tiles, the LDS epilogue only (the launcher guarantees
+// up_res == NULL and lds_epilogue).
+template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4, bool M32 = false>
 __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int blk, const int nwg_job) {
     static_assert(MT == 4 || (MT == 8 && TAPS == 9 && RING && sizeof(T) == 2), "256-pixel tiles: bf16 3x3 ring variant only");
+    static_assert(!M32 || (sizeof(T) == 2 && MT == 4 && !RING), "32x32x16 variant: bf16, 128-pixel tiles, two-buffer weights");
     constexpr int HALO_H = MT * 2 + 2;
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
@@ -192,6 +201,33 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
+    // M32: acc32[m2][n2] holds D^T of a 32 px x 32 ch tile: lane (l31, lh) -> pixel m2*32+l31, channels n2*32 + 8g + 4lh + {0..3}
+    // in registers 4g..4g+3
+    constexpr int M2 = MT / 2, N2 = NT / 2;
+    const int l31 = lane & 31, lh = lane >> 5;
+    f32x16_t acc32[M32 ? M2 : 1][M32 ? N2 : 1];
+    if constexpr (M32) {
+#pragma unroll
+        for (int i = 0; i < M2; ++i)
+#pragma unroll
+            for (int j = 0; j < N2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+    }
+    const unsigned char* abase32[M2];
+    const unsigned char* bbase32[2];
+    if constexpr (M32) {
+#pragma unroll
+        for (int m2 = 0; m2 < M2; ++m2) {
+            const int row = wm * (MT * 16) + m2 * 32 + l31;
+            const int pix = (TAPS == 9) ? ((row >> 4) * kHaloW + (row & 15)) : row;
+            abase32[m2] = As + pix * RS + lh * 16;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            bbase32[kk] = Bs + (wn * (BN / 2) + l31) * 64 + ((((kk << 1) | lh) ^ b_swz(l31)) << 4);
+    }
+
     // per-lane fragment base addresses: everything else is a compile-time or wave-uniform offset
     const unsigned char* abase[MT];
 #pragma unroll
@@ -238,6 +274,28 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(b[nt], a[mt], acc[mt][nt]);   // D^T = W^T x A^T
+    };
+
+    // M32 fragments of one 64-byte k-step: [tile][16-element half of the k-step]
+    bf16x8_t a32P[M2][2], b32P[M32 ? N2 : 1][2], a32Q[M2][2], b32Q[M32 ? N2 : 1][2];
+    auto load_frags32 = [&](auto& a, auto& b, int a_off, int b_off) {
+#pragma unroll
+        for (int m2 = 0; m2 < M2; ++m2)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) a[m2][kk] = *reinterpret_cast<const bf16x8_t*>(abase32[m2] + a_off + kk * 32);
+#pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) b[n2][kk] = *reinterpret_cast<const bf16x8_t*>(bbase32[kk] + b_off + n2 * 2048);
+    };
+    auto mma_all32 = [&](const auto& a, const auto& b) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int m2 = 0; m2 < M2; ++m2)
+#pragma unroll
+                for (int n2 = 0; n2 < N2; ++n2)
+                    acc32[m2][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[n2][kk], a[m2][kk], acc32[m2][n2], 0, 0, 0);
     };
 
     int s = 0;
@@ -302,10 +360,22 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                 const int b_off = (s & 1) * STAGE_BYTES;
                 const bool more = (s + 1 < total_stages);
                 if (more) b_issue(s + 1, (s + 1) & 1);   // buffer (s+1)%2 was last read in stage s-1: all waves are past it
+                if constexpr (M32) {
+                    load_frags32(a32P, b32P, a_off, b_off);
+                    load_frags32(a32Q, b32Q, a_off + 64, b_off + BN * 64);
+                    // without the fence the scheduler sinks every read to its first use (read / lgkmcnt(0) / MFMA, no
+                    // prefetch distance); with it the waits are counted and the second k-step's reads land under the
+                    // first one's MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_all32(a32P, b32P);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_all32(a32Q, b32Q);
+                } else {
                 load_frags(aP, bP, a_off, b_off);
                 load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
                 mma_all(aP, bP);
                 mma_all(aQ, bQ);
+                }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
                 __syncthreads();
             } else {
@@ -338,11 +408,28 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
     // windows; (3) after one barrier, whole 16-byte pieces of pixel rows go to global memory, 256 contiguous bytes per
     // 16 lanes. The statistics are those of the ROUNDED outputs - exactly the tensor the consumer normalises.
     if constexpr (sizeof(T) == 2) {
-        if (MT == 8 || (res == nullptr && p.lds_epilogue)) {
+        if (M32 || MT == 8 || (res == nullptr && p.lds_epilogue)) {
             constexpr int RSO = BN * 2 + 8;
             constexpr int ROWS = MT * 32;
             unsigned char* O = smem;
             float* red = reinterpret_cast<float*>(smem + ROWS * RSO);   // [2 wm][2][BN] (+ the tail's flag word)
+            if constexpr (M32) {
+#pragma unroll
+                for (int m2 = 0; m2 < M2; ++m2) {
+                    const int row = wm * (MT * 16) + m2 * 32 + l31;
+                    bool ok;
+                    if (TAPS == 9) ok = (oy0 + (row >> 4)) < p.H && (ox0 + (row & 15)) < p.W;
+                    else ok = (m0 + row) < p.M;
+#pragma unroll
+                    for (int n2 = 0; n2 < N2; ++n2)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4_t v = {acc32[m2][n2][4 * g], acc32[m2][n2][4 * g + 1], acc32[m2][n2][4 * g + 2], acc32[m2][n2][4 * g + 3]};
+                            if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                            store4(reinterpret_cast<bf16_t*>(O + row * RSO + (wn * (BN / 2) + n2 * 32 + g * 8 + lh * 4) * 2), v);
+                        }
+                }
+            } else
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = wm * (MT * 16) + mt * 16 + l15;
@@ -447,6 +534,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
         }
     }
 
+    if constexpr (M32) return;   // (unreachable: the LDS epilogue above is unconditional for M32)
     // ================= direct epilogue (f32 parity build, and the upsample-add variant): each lane owns 4 consecutive
     // output channels of one pixel per (mt, nt) tile -> one 8-byte (bf16) / 16-byte (f32) store; no LDS round trip.
     const int cbase = n0 + wn * (BN / 2) + lq * 4;   // + nt*16
@@ -535,9 +623,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
 #undef MPN_STAMP
 }
 
-template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4>
+template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4, bool M32 = false>
 __global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {
-    conv_mfma_body<T, TAPS, BN, RB, RING, MT>(p, blockIdx.x, gridDim.x);
+    conv_mfma_body<T, TAPS, BN, RB, RING, MT, M32>(p, blockIdx.x, gridDim.x);
 }
 
 // up to four independent jobs of one kernel instance in one grid (largest first): the small pyramid levels are a few
@@ -549,13 +637,13 @@ struct ConvGroup {
     int begin[kMaxGroup + 1];   // first block of each job; begin[njobs] = grid size
     int njobs;
 };
-template <typename T, int TAPS, int BN, int RB, bool RING>
+template <typename T, int TAPS, int BN, int RB, bool RING, bool M32 = false>
 __global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_grouped_kernel(const ConvGroup g) {
     int job = 0;
 #pragma unroll
     for (int j = 1; j < kMaxGroup; ++j)
         if (j < g.njobs && (int)blockIdx.x >= g.begin[j]) job = j;   // wave-uniform
-    conv_mfma_body<T, TAPS, BN, RB, RING, 4>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
+    conv_mfma_body<T, TAPS, BN, RB, RING, 4, M32>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
 }
 
 // ------------------------------------------------------------------ warp-specialised 3x3 kernel (bf16)
@@ -1080,18 +1168,18 @@ extern "C" int mpn_conv_num_parts(int N, int H, int W, int ksize) {
     return (int)(((long long)N * H * W + 127) / 128);
 }
 
-template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4>
+template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4, bool M32 = false>
 static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
     constexpr int NPIX = TAPS == 9 ? kHaloW * (MT * 2 + 2) : MT * 32;
     constexpr int smem = NPIX * a_row_stride(RB) + (RING ? 3 * (BN * 64) : 2 * (2 * BN * 64));
     static_assert(sizeof(T) != 2 || smem >= MT * 32 * (BN * 2 + 8) + 4 * BN * 4 + 16, "the output image of the epilogue fits");
     static bool attr_set = false;
     if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB, RING, MT>,
+        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB, RING, MT, M32>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_set = true;
     }
-    conv_mfma_kernel<T, TAPS, BN, RB, RING, MT><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
+    conv_mfma_kernel<T, TAPS, BN, RB, RING, MT, M32><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -1118,6 +1206,13 @@ static int g_ws_min = -1, g_big_min = -1, g_ring = -1;
 extern "C" void mpn_debug_set_conv_variant(int ws_min_units, int big_min_blocks, int ring) {
     g_ws_min = ws_min_units; g_big_min = big_min_blocks; g_ring = ring;
 }
+// MPN_CONV_M32: bit 0 = 3x3 layers, bit 1 = 1x1 layers on v_mfma_f32_32x32x16_bf16 (bf16 build, LDS epilogue)
+static int g_m32 = -1;
+static int conv_m32_mask() {
+    if (g_m32 < 0) { const char* e = getenv("MPN_CONV_M32"); g_m32 = e ? atoi(e) : MPN_CONV_M32_DEFAULT; }
+    return g_m32;
+}
+extern "C" void mpn_debug_set_conv_m32(int mask) { g_m32 = mask; }
 
 template <typename T, int TAPS, int BN>
 static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
@@ -1143,6 +1238,12 @@ static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
         const int m_big = p.N * ((p.tiles_y + 1) >> 1) * p.tiles_x;
         if (big_min > 0 && m_big * p.n_tiles >= big_min && p.row_bytes == 128 && p.up_res == nullptr && p.tail.mode == 0)
             return launch_conv_rb<T, TAPS, BN, 128, true, 8>(p, m_big, st);
+    }
+    if constexpr (sizeof(T) == 2) {
+        if ((conv_m32_mask() & (TAPS == 9 ? 1 : 2)) && p.up_res == nullptr && p.lds_epilogue && !(ring && BN == 128 && p.row_bytes == 128)) {
+            if (p.row_bytes == 256) return launch_conv_rb<T, TAPS, BN, 256, false, 4, true>(p, m_tiles, st);
+            return launch_conv_rb<T, TAPS, BN, 128, false, 4, true>(p, m_tiles, st);
+        }
     }
     if (p.row_bytes == 256) return launch_conv_rb<T, TAPS, BN, 256, false>(p, m_tiles, st);
     if (ring && BN == 128) return launch_conv_rb<T, TAPS, BN, 128, true>(p, m_tiles, st);
@@ -1258,6 +1359,15 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
+        if (conv_m32_mask() & 1) {
+            static bool attr32 = false;
+            if (!attr32) {
+                MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr32 = true;
+            }
+            conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false, true><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
+        } else
         conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
     } else {
         constexpr int smem = NPIX * a_row_stride(128) + 2 * (2 * 64 * 64);
@@ -1267,6 +1377,15 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
                                         hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_set = true;
         }
+        if (conv_m32_mask() & 1) {
+            static bool attr32 = false;
+            if (!attr32) {
+                MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+                attr32 = true;
+            }
+            conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false, true><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
+        } else
         conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
     }
     MPN_LAUNCH_CHECK();
