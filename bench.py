@@ -90,6 +90,8 @@ def main():
         out["config"]["step_mfma_frac_of_peak"] = whole_step_mfma_fraction(args.batch, args.size, dt_s / args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from multiposenet_amd.benchmarks import cpu_baseline, decode_benchmark, render_benchmark, prn_benchmark
+        from multiposenet_amd.benchmarks import host_fed_rate
+        out["host_fed"] = host_fed_rate(trainer, feats, labels)     # PCIe-inclusive rate (reported beside `value`, never as it)
         out["cpu_baseline"] = cpu_baseline(args.size)
         out["decode"] = decode_benchmark(32)
         out["label_render"] = render_benchmark(args.batch, args.size, args.size)

@@ -307,3 +307,48 @@ def prn_assign_benchmark(net, images=32, h=128, w=128, iters=20):
     return {"ms_per_batch": round(ms, 3), "persons_per_s": round(B / ms * 1e3, 1), "persons": B, "images": images,
             "alg_MB": round(byt / 1e6, 1), "hbm_GBps": round(byt / ms / 1e6, 1),
             "cpu_port_ms_glue_8_persons": round(cpu_ms, 1)}
+
+
+def host_fed_rate(trainer, features, labels, steps=20, warmup=3):
+    """The PCIe-inclusive rate (never bench.py's `value`): every step's batch starts in pinned HOST memory and travels
+    through HostBatchFeeder (copy of batch i+1 on a side stream beside step i). The pinned slots are filled once - what
+    a loader does in place is not timed - and re-submitted every step. f32 images as the reference's pipeline hands them
+    over, and uint8 images (a quarter of the bytes; the stem kernel standardises them on load)."""
+    import time
+    from .input_feed import HostBatchFeeder
+    B, H, W, _ = features["images"].shape
+    out = {}
+    for name, idt in (("f32_images", torch.float32), ("u8_images", torch.uint8)):
+        feeder = HostBatchFeeder(trainer, B, H, W, depth=2, image_dtype=idt)
+        for _ in range(2):
+            slot = feeder.acquire()
+            arrs = feeder.slot_arrays(slot)
+            img = features["images"]
+            arrs["images"][...] = (img * 255).to(torch.uint8).cpu().numpy() if idt == torch.uint8 else img.cpu().numpy()
+            for k, v in labels.items():
+                arrs[k][...] = v.cpu().numpy()
+            feeder.submit(slot)
+            feeder.train_step()
+        # the copy alone
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            slot = feeder.acquire(); feeder.submit(slot); feeder._ready.pop(); feeder._free.append(slot)
+            feeder._copied[slot].synchronize()
+        copy_s = (time.perf_counter() - t0) / 5
+        slot = feeder.acquire(); feeder.submit(slot)
+        for i in range(warmup + steps):
+            if i == warmup:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+            nxt = feeder.acquire(); feeder.submit(nxt)
+            feeder.train_step()
+        torch.cuda.synchronize()
+        dt_s = (time.perf_counter() - t0) / steps
+        feeder.train_step()
+        torch.cuda.synchronize()
+        out[name] = {"images_per_s": round(B / dt_s, 1), "ms_per_step": round(dt_s * 1e3, 3),
+                     "host_MB_per_batch": round(feeder.bytes_per_batch / 1e6, 1),
+                     "h2d_alone_ms": round(copy_s * 1e3, 3), "h2d_alone_GBps": round(feeder.bytes_per_batch / copy_s / 1e9, 1)}
+        del feeder
+    return out

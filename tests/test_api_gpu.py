@@ -91,3 +91,57 @@ def test_detector_with_prn_assigns_keypoints_to_given_boxes(cuda, tmp_path):
     np.testing.assert_allclose(out["keypoint_scores"], ws, rtol=5e-3)
     assert np.mean(np.all(out["keypoint_positions"] == wp, axis=-1)) >= 0.9
     assert det(img)["keypoint_positions"].shape == (0, 17, 2)                # without boxes: empty, as before
+
+
+@pytest.mark.parametrize("image_dtype", [torch.float32, torch.uint8], ids=["f32", "u8"])
+def test_host_batch_feeder_equals_device_resident_steps(cuda, image_dtype):
+    """HostBatchFeeder (pinned slots, copies on a side stream, the previous step still running): four steps on four
+    different host batches give bit for bit the losses and variables of the same steps fed from device tensors."""
+    from multiposenet_amd.input_feed import HostBatchFeeder
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
+    rs = np.random.RandomState(21)
+    B, H, W = 2, 128, 128
+    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
+
+    def batch():
+        img = rs.rand(B, H, W, 3).astype(np.float32)
+        if image_dtype == torch.uint8:
+            img = (img * 255).astype(np.uint8)
+        heat = (rs.rand(B, H // 4, W // 4, 17) * 0.9).astype(np.float32)
+        heat.reshape(B, -1)[:, rs.randint(0, heat[0].size, 8)] = 1.0
+        lab = {"heatmaps": heat, "loss_masks": (rs.rand(B, H // 4, W // 4) < 0.9).astype(np.float32),
+               "segmentation_masks": (rs.rand(B, H // 4, W // 4) < 0.3).astype(np.float32),
+               "num_boxes": rs.randint(1, 5, size=B).astype(np.int64)}       # int64 as numpy makes it: cast by feed()
+        return {"images": img}, lab
+
+    batches = [batch() for _ in range(4)]
+    a = Trainer(KeypointNet(dtype=torch.bfloat16, seed=3), hp, use_graph=True)
+    b = Trainer(KeypointNet(dtype=torch.bfloat16, seed=3), hp, use_graph=True)
+    want = []
+    for f, l in batches:
+        df = {"images": torch.from_numpy(f["images"]).cuda()}
+        dl = {k: torch.from_numpy(v).cuda().to(torch.int32 if k == "num_boxes" else torch.float32) for k, v in l.items()}
+        want.append(a.step(df, dl).cpu().numpy().copy())
+    feeder = HostBatchFeeder(b, B, H, W, depth=2, image_dtype=image_dtype)
+    got = []
+    feeder.feed(*batches[0])
+    for i in range(4):
+        if i + 1 < 4:
+            feeder.feed(*batches[i + 1])          # copy of batch i+1 runs beside step i
+        assert feeder.pending() >= 1
+        got.append(feeder.train_step().cpu().numpy().copy())
+    with pytest.raises(RuntimeError):
+        feeder.train_step()                        # nothing submitted
+    for w_, g_ in zip(want, got):
+        np.testing.assert_array_equal(w_, g_)
+    sa, sb = a.net.state_dict(), b.net.state_dict()
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)
+    # slots are filled in place too
+    slot = feeder.acquire()
+    arrs = feeder.slot_arrays(slot)
+    assert arrs["images"].shape == (B, H, W, 3) and arrs["num_boxes"].dtype == np.int32
+    feeder.submit(slot)
+    with pytest.raises(RuntimeError):
+        feeder.acquire(); feeder.acquire()         # depth 2: one more is free, the third is not
