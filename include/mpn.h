@@ -252,6 +252,13 @@ int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part, int N, int
  */
 int mpn_stem_conv_fwd(const void* images, int images_u8, const float* w, void* y, int N, int H,
                       int W, int C0, int dtype, mpn_stream_t stream);
+/* The same + the batch-norm statistics of the (rounded) output, fused into the kernel's copy-out: stats_part
+ * [mpn_stem_conv_fwd_num_parts()][2][C0] receives per-tile sum / sum of squares in the layout of mpn_bn_stats (finish with
+ * mpn_bn_finalize; mobilenet_v1.py:56 applies batch-norm to Conv2d_0). num_parts == 0: not available for this C0 - run
+ * mpn_bn_stats on the output instead. stats_part == NULL: plain forward. */
+int mpn_stem_conv_fwd_num_parts(int N, int H, int W, int C0, int dtype);
+int mpn_stem_conv_fwd_stats(const void* images, int images_u8, const float* w, void* y, int N, int H, int W, int C0,
+                            int dtype, float* stats_part, mpn_stream_t stream);
 int mpn_stem_conv_wgrad_num_parts(int N, int H, int W);
 /* part [num_parts][27*C0] */
 int mpn_stem_conv_bwd_weight(const void* images, int images_u8, const void* dy, float* part, int N,

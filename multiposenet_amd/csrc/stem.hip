@@ -54,7 +54,8 @@ constexpr int kFwdTW = 2 * kTile;      // 32 x 16 output pixels per block
 template <typename T, bool U8>
 __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restrict__ images, const float* __restrict__ w,
                                                             T* __restrict__ y, int N, int H, int W, int C0, int OH, int OW,
-                                                            int pad_t, int pad_l, int tiles_x, int tiles_y) {
+                                                            int pad_t, int pad_l, int tiles_x, int tiles_y,
+                                                            float* __restrict__ stats_part) {
     constexpr int VE = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) unsigned char stem_smem[];
     float* wl = reinterpret_cast<float*>(stem_smem);                        // [27][C0]
@@ -134,13 +135,43 @@ __global__ __launch_bounds__(kThreads) void stem_fwd_kernel(const void* __restri
     __syncthreads();
     // copy-out: tile row r = 32 pixels x C0 channels = one contiguous run of the output tensor
     const int ppr = C0 * (int)sizeof(T) / 16;            // 16-byte pieces per pixel
+    // batch-norm statistics of the ROUNDED outputs (the tensor the consumer normalises), fused into the copy-out: with
+    // kThreads % ppr == 0 (the host checks) a thread meets the same 16-byte piece = the same VE channels in every
+    // iteration, so it keeps their sum and sum of squares in registers; one fixed-order LDS reduction per block writes
+    // row blockIdx.x of the partial slab (the layout of mpn_bn_stats: finish with mpn_bn_finalize)
+    float ssum[VE], ssq[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) { ssum[j] = 0.f; ssq[j] = 0.f; }
     for (int i = threadIdx.x; i < kTile * kFwdTW * ppr; i += kThreads) {
         const int pxl = i / ppr, piece = i - pxl * ppr;
         const int r = pxl / kFwdTW, cx = pxl - r * kFwdTW;
         const int yy = ty * kTile + r, xx = tx * kFwdTW + cx;
-        if (yy < OH && xx < OW)
+        if (yy < OH && xx < OW) {
+            Vec16<T> ov;
+            *reinterpret_cast<uint4*>(&ov.raw) = *reinterpret_cast<const uint4*>(otile + pxl * orow + piece * 16);
             *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(y + (((long long)img * OH + yy) * OW + xx) * C0) + piece * 16) =
-                *reinterpret_cast<const uint4*>(otile + pxl * orow + piece * 16);
+                *reinterpret_cast<const uint4*>(&ov.raw);
+            if (stats_part != nullptr) {
+                float f[VE];
+                ov.unpack(f);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) { ssum[j] += f[j]; ssq[j] += f[j] * f[j]; }
+            }
+        }
+    }
+    if (stats_part != nullptr) {   // block-uniform
+        __syncthreads();           // every thread is done with the output tile: reuse it
+        float* red = reinterpret_cast<float*>(otile);          // [kThreads][2 * VE]
+#pragma unroll
+        for (int j = 0; j < VE; ++j) { red[threadIdx.x * 2 * VE + j] = ssum[j]; red[threadIdx.x * 2 * VE + VE + j] = ssq[j]; }
+        __syncthreads();
+        if ((int)threadIdx.x < 2 * C0) {
+            const int which = (int)threadIdx.x / C0, c = (int)threadIdx.x - which * C0;
+            const int piece = c / VE, j = c - piece * VE;
+            float acc = 0.f;
+            for (int t = piece; t < kThreads; t += ppr) acc += red[t * 2 * VE + which * VE + j];
+            stats_part[((long long)blockIdx.x * 2 + which) * C0 + c] = acc;
+        }
     }
 }
 
@@ -303,10 +334,33 @@ int check(int N, int H, int W, int C0, int dtype) {
 
 }  // namespace
 
+/* rows of the statistics slab mpn_stem_conv_fwd_stats writes (one per output tile); 0 = the fused statistics are not
+ * available for this channel count (use mpn_bn_stats on the output instead) */
+extern "C" int mpn_stem_conv_fwd_num_parts(int N, int H, int W, int C0, int dtype) {
+    if (check(N, H, W, C0, dtype)) return 0;
+    const int ppr = C0 * (dtype == MPN_F32 ? 4 : 2) / 16;
+    if (ppr <= 0 || kThreads % ppr != 0 || 2 * C0 > kThreads) return 0;
+    int OH, OW, pt, pl;
+    same_pad(H, &OH, &pt);
+    same_pad(W, &OW, &pl);
+    return N * ((OH + kTile - 1) / kTile) * ((OW + kFwdTW - 1) / kFwdTW);
+}
+
 extern "C" int mpn_stem_conv_fwd(const void* images, int images_u8, const float* w, void* y, int N, int H, int W, int C0,
                                  int dtype, mpn_stream_t stream) {
+    return mpn_stem_conv_fwd_stats(images, images_u8, w, y, N, H, W, C0, dtype, nullptr, stream);
+}
+
+/* mpn_stem_conv_fwd + the batch-norm statistics of its (rounded) output: stats_part [mpn_stem_conv_fwd_num_parts][2][C0]
+ * receives per-tile sum and sum of squares in the layout of mpn_bn_stats (finish with mpn_bn_finalize) - the separate
+ * statistics pass over the largest activation of the network (134 MB at bs32 @ 512x512) is gone. stats_part == NULL:
+ * plain forward. */
+extern "C" int mpn_stem_conv_fwd_stats(const void* images, int images_u8, const float* w, void* y, int N, int H, int W, int C0,
+                                       int dtype, float* stats_part, mpn_stream_t stream) {
     if (int rc = check(N, H, W, C0, dtype)) return rc;
     MPN_REQUIRE(images && w && y, MPN_ERR_BAD_ARG, "stem_fwd: null pointer");
+    MPN_REQUIRE(stats_part == nullptr || mpn_stem_conv_fwd_num_parts(N, H, W, C0, dtype) > 0, MPN_ERR_BAD_SHAPE,
+                "stem_fwd: fused statistics not available for C0 = %d (mpn_stem_conv_fwd_num_parts == 0)", C0);
     int OH, OW, pt, pl;
     same_pad(H, &OH, &pt);
     same_pad(W, &OW, &pl);
@@ -318,11 +372,11 @@ extern "C" int mpn_stem_conv_fwd(const void* images, int images_u8, const float*
         if (images_u8) {
             if (sm > 48 * 1024)
                 MPN_HIP(hipFuncSetAttribute((const void*)stem_fwd_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm));
-            stem_fwd_kernel<T, true><<<grid, kThreads, sm, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+            stem_fwd_kernel<T, true><<<grid, kThreads, sm, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y, stats_part);
         } else {
             if (sm > 48 * 1024)
                 MPN_HIP(hipFuncSetAttribute((const void*)stem_fwd_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm));
-            stem_fwd_kernel<T, false><<<grid, kThreads, sm, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y);
+            stem_fwd_kernel<T, false><<<grid, kThreads, sm, st>>>(images, w, (T*)y, N, H, W, C0, OH, OW, pt, pl, tiles_x, tiles_y, stats_part);
         }
     });
     MPN_LAUNCH_CHECK();

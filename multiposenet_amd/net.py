@@ -234,6 +234,7 @@ class KeypointNet:
         self.fuse_bn = False
         self.batch_finalize = os.environ.get("MPN_BATCH_FINALIZE", "1") != "0"   # the four pyramid levels' batch-norm finalizes in one launch per stage
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
+        self.fuse_stem_stats = True    # the stem kernel writes its own batch-norm partial sums (mpn_stem_conv_fwd_stats)
         self.fuse_lateral_add = True   # ... and add the FPN lateral's gradient into c2..c4 (mpn_dwconv_bwd_data_add)
         self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
@@ -400,13 +401,22 @@ class KeypointNet:
         if not is_training:
             self.prepare_inference()
         sp = b["stat_part"]
-        stem = ops.stem_conv_fwd(images, self.stem_w, self.stem_w.shape[3], self.dtype, out=b["stem"])
+        c0 = self.stem_w.shape[3]
+        # training: the stem kernel writes the batch-norm partial sums of its own output (no separate statistics pass over
+        # the largest activation of the network), unless the fused finalize (fuse_bn) wants mpn_bn_stats' tail
+        stem_rows = ops.stem_conv_fwd_num_parts(N, H, W, c0, self.dtype) if (is_training and not self.fuse_bn and self.fuse_stem_stats) else 0
+        if stem_rows * 2 * c0 > sp.numel():
+            stem_rows = 0
+        stem = ops.stem_conv_fwd(images, self.stem_w, c0, self.dtype, out=b["stem"], stats_part=sp if stem_rows > 0 else None)
         T = self._tail if is_training else (lambda bn, count: None)
         if is_training:
             cnt = stem.numel() // stem.shape[3]
-            _, nparts = ops.bn_stats(stem, sp, tail=T(self.stem_bn, cnt))
-            if not self.fuse_bn:
-                ops.bn_finalize(self.stem_bn, sp, nparts, cnt)
+            if stem_rows > 0:
+                ops.bn_finalize(self.stem_bn, sp, stem_rows, cnt)
+            else:
+                _, nparts = ops.bn_stats(stem, sp, tail=T(self.stem_bn, cnt))
+                if not self.fuse_bn:
+                    ops.bn_finalize(self.stem_bn, sp, nparts, cnt)
         x, aff = stem, self.stem_bn.affine
         feats = {}
         for i, blk in enumerate(self.blocks):

@@ -436,7 +436,14 @@ def dwconv_bwd_weight(x, dy, stride, affine, dw_out, part=None, reduce=True):
 
 
 # ----------------------------------------------------------------------------- stem
-def stem_conv_fwd(images, w, c0, dtype, out=None):
+def stem_conv_fwd_num_parts(N, H, W, c0, dtype):
+    """Rows of the statistics slab stem_conv_fwd(stats_part=...) writes; 0 = fused statistics not available for this c0."""
+    return _lib.lib().mpn_stem_conv_fwd_num_parts(N, H, W, c0, _lib.dtype_code(dtype))
+
+
+def stem_conv_fwd(images, w, c0, dtype, out=None, stats_part=None):
+    """stats_part: f32 slab of stem_conv_fwd_num_parts(...) * 2 * c0 floats - the kernel also writes the batch-norm partial
+    sums of its output there (finish with bn_finalize(bn, stats_part, rows, count))."""
     if images.dim() != 4 or images.shape[3] != 3 or not images.is_contiguous():
         raise ValueError("images must be contiguous [N,H,W,3]")
     u8 = images.dtype == torch.uint8
@@ -445,6 +452,13 @@ def stem_conv_fwd(images, w, c0, dtype, out=None):
     N, H, W, _ = images.shape
     if out is None:
         out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, c0), dtype=dtype, device=images.device)
+    if stats_part is not None:
+        rows = stem_conv_fwd_num_parts(N, H, W, c0, dtype)
+        if rows <= 0 or stats_part.numel() < rows * 2 * c0:
+            raise ValueError("stem_conv_fwd: fused statistics not available for this shape, or slab too small")
+        call("mpn_stem_conv_fwd_stats", ptr(images), int(u8), ptr(w), ptr(out), N, H, W, c0, _lib.dtype_code(dtype),
+             ptr(stats_part), stream_ptr())
+        return out
     call("mpn_stem_conv_fwd", ptr(images), int(u8), ptr(w), ptr(out), N, H, W, c0, _lib.dtype_code(dtype), stream_ptr())
     return out
 

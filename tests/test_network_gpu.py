@@ -320,6 +320,7 @@ def test_fused_bn_finalize_equals_separate_launches(cuda):
                 net = KeypointNet(values=params, dtype=dt)
                 net.fuse_bn = fused
                 net.fuse_dw_bn = False     # (that fusion replaces the reduction launch the fused finalize rides on)
+                net.fuse_stem_stats = False   # (the stem's own partial sums: another summation order, not used with fuse_bn)
                 tr = Trainer(net, hp, use_graph=False)
                 losses = [tr.step({"images": img}, dlab).cpu().numpy().copy() for _ in range(2)]   # 2 steps: tickets reset
                 out[(fused, dt)] = (losses, net.state_dict(), net.grad.cpu().numpy().copy())

@@ -126,6 +126,26 @@ def test_stem_fwd(cuda, dtype, N, H, W, u8):
     want = nhwc(onet.conv2d_tf_same(nchw(2.0 * img - 1.0), torch.tensor(w), 2))
     y = ops.stem_conv_fwd(d_img, dev(w), 32, dtype)
     assert_close(y, want, dtype, 27)
+    # the same launch with its batch-norm partial sums: identical output; the slab finalizes to the mean / variance of the
+    # stored (rounded) output, exactly what mpn_bn_stats on that tensor gives (up to the f32 summation order)
+    rows = ops.stem_conv_fwd_num_parts(N, H, W, 32, dtype)
+    assert rows > 0
+    slab = torch.full((rows * 2 * 32,), float("nan"), device="cuda")
+    y2 = ops.stem_conv_fwd(d_img, dev(w), 32, dtype, stats_part=slab)
+    assert torch.equal(y, y2)
+    M = y.numel() // 32
+    one = lambda: torch.ones(32, device="cuda")
+    bn_a = ops.BNState(one(), torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda"), one(), 2)
+    bn_b = ops.BNState(one(), torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda"), one(), 2)
+    ops.bn_finalize(bn_a, slab, rows, M)
+    part, nparts = ops.bn_stats(y)
+    ops.bn_finalize(bn_b, part, nparts, M)
+    yd = y.double().reshape(M, 32)
+    np.testing.assert_allclose(bn_a.mean.cpu().numpy(), yd.mean(0).cpu().numpy(), atol=1e-5)
+    np.testing.assert_allclose(bn_a.mean.cpu().numpy(), bn_b.mean.cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(bn_a.invstd.cpu().numpy(), bn_b.invstd.cpu().numpy(), rtol=1e-5)
+    np.testing.assert_allclose(bn_a.moving_var.cpu().numpy(), bn_b.moving_var.cpu().numpy(), rtol=1e-5)
+    assert ops.stem_conv_fwd_num_parts(N, H, W, 24, torch.bfloat16) == 0      # 3 pieces per pixel: not fused
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
