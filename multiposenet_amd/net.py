@@ -234,7 +234,10 @@ class KeypointNet:
         self.fuse_bn = False
         self.batch_finalize = os.environ.get("MPN_BATCH_FINALIZE", "1") != "0"   # the four pyramid levels' batch-norm finalizes in one launch per stage
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
-        self.fuse_stem_stats = True    # the stem kernel writes its own batch-norm partial sums (mpn_stem_conv_fwd_stats)
+        # the stem kernel can write its own batch-norm partial sums (mpn_stem_conv_fwd_stats); OFF: measured a wash - the
+        # separate statistics pass (38 us) reads the 134 MB stem output into the memory-side cache, and the first depthwise
+        # layer then runs 52 instead of 83 us
+        self.fuse_stem_stats = False
         self.fuse_lateral_add = True   # ... and add the FPN lateral's gradient into c2..c4 (mpn_dwconv_bwd_data_add)
         self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
