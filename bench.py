@@ -103,7 +103,7 @@ def main():
         out["prn"] = prn_benchmark(128)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():   # (also the 1-rank rehearsal, MPN_DP_FORCE_COLLECTIVE=1)
         torch.distributed.barrier()   # rank 0 runs the roofline leg after the timed region: leave together
         torch.distributed.destroy_process_group()
 
