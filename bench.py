@@ -85,12 +85,12 @@ def main():
                    "final_total_loss": loss},
     }
     if rank == 0 and not args.no_roofline:
-        from multiposenet_amd.benchmarks import dominant_kernel_roofline, whole_step_mfma_fraction
+        from bench_legs import dominant_kernel_roofline, whole_step_mfma_fraction
         out["roofline"] = dominant_kernel_roofline(net, args.batch, args.size, dt)
         out["config"]["step_mfma_frac_of_peak"] = whole_step_mfma_fraction(args.batch, args.size, dt_s / args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from multiposenet_amd.benchmarks import cpu_baseline, decode_benchmark, render_benchmark, prn_benchmark
-        from multiposenet_amd.benchmarks import host_fed_rate
+        from bench_legs import cpu_baseline, decode_benchmark, render_benchmark, prn_benchmark
+        from bench_legs import host_fed_rate
         out["host_fed"] = host_fed_rate(trainer, feats, labels)     # PCIe-inclusive rate (reported beside `value`, never as it)
         out["cpu_baseline"] = cpu_baseline(args.size)
         out["decode"] = decode_benchmark(32)
@@ -98,7 +98,7 @@ def main():
         del trainer, net
         torch.cuda.empty_cache()
         if args.batch == 32 and args.size == 512 and dt == torch.bfloat16:
-            from multiposenet_amd.benchmarks import north_star_kernels
+            from bench_legs import north_star_kernels
             out["north_star_kernels"] = north_star_kernels(args.batch)
         out["prn"] = prn_benchmark(128)
     if rank == 0:

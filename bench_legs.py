@@ -1,10 +1,12 @@
-"""Measurement helpers used by bench.py (roofline of the dominant kernel, CPU baseline leg)."""
+"""Measurement legs of bench.py (roofline of the dominant kernel, CPU baseline, decode / render / PRN / host-fed legs).
+Lives beside bench.py, outside the package: the CPU-baseline legs import oracle/ (as the thing timed beside the GPU path,
+never as part of it), which nothing under multiposenet_amd/ may do."""
 import os
 import time
 
 import torch
 
-from . import ops
+from multiposenet_amd import ops
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
@@ -40,7 +42,7 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20):
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
     achieved = flops / sec / 1e12
     traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-    tj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_dominant_kernel_traffic.json")
+    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_kernel_traffic.json")
     if dtype == torch.bfloat16 and batch == 32 and size == 512 and os.path.exists(tj):
         import json
         traffic = json.load(open(tj))["hbm_bytes_per_launch"]
@@ -143,7 +145,7 @@ def cpu_baseline(size, budget_s=20.0):
 def decode_benchmark(batch=32, h=128, w=128, iters=200):
     """Second half of the BASELINE metric: heatmap peak decode, us/image, B images of [h,w,17] f32 resident in HBM
     (sigmoid of N(-4.6, 1.5^2) logits, threshold 0.2 - SURVEY.md 8(d)). HIP events on the launch stream."""
-    from .inference.utils import KeypointDecoder
+    from multiposenet_amd.inference.utils import KeypointDecoder
     dec = KeypointDecoder(batch)
     hm = torch.sigmoid(torch.randn(batch, h, w, 17, device="cuda") * 1.5 - 4.6)
     box = torch.tensor([[4.0 * h, 4.0 * w]] * batch, dtype=torch.float64, device="cuda")
@@ -185,7 +187,7 @@ def render_benchmark(batch=32, width=512, height=512, downsample=4, persons_per_
     `persons_per_image` persons each (keypoints/boxes resident in HBM). Algorithmic bytes = the [B,h,w,17] f32
     output written once. CPU leg: the numpy oracle (bit-identical to the reference on the goldens), one thread."""
     import numpy as np
-    from .detector.input_pipeline import HeatmapRenderer
+    from multiposenet_amd.detector.input_pipeline import HeatmapRenderer
     rs = np.random.RandomState(11)
     P = batch * persons_per_image
     kp = np.zeros((P, 17, 3), np.int32)
@@ -233,7 +235,7 @@ def prn_benchmark(batch=128, iters=20):
     crops of 56x36x17, bf16 operands / f32 accumulate and masters, replayed from a hipGraph. The step is weight-bandwidth
     bound: algorithmic bytes = the 2 x 35.1 M weights read twice as bf16 operands (fwd, dgrad / as fc1 operand), their f32
     gradients written, 5 f32 Adam streams, 3 operand refreshes (read f32, write bf16)."""
-    from .prn import PoseResidualNet
+    from multiposenet_amd.prn import PoseResidualNet
     net = PoseResidualNet(batch=batch, dtype=torch.bfloat16)
     x = torch.rand(batch, net.h, net.w, net.c, device="cuda")
     y = torch.zeros_like(x)
@@ -267,7 +269,7 @@ def prn_assign_benchmark(net, images=32, h=128, w=128, iters=20):
     crop_and_resize of net.B person boxes to 56x36, PRN forward, softmax / argmax decode - one hipGraph.
     Algorithmic bytes: heatmaps read once for min/max, the crops written + read, the two weight matrices read as bf16
     operands, the logits written + read."""
-    from .prn_inference import KeypointAssigner
+    from multiposenet_amd.prn_inference import KeypointAssigner
     import numpy as np
     rs = np.random.RandomState(0)
     B = net.B
@@ -315,7 +317,7 @@ def host_fed_rate(trainer, features, labels, steps=20, warmup=3):
     a loader does in place is not timed - and re-submitted every step. f32 images as the reference's pipeline hands them
     over, and uint8 images (a quarter of the bytes; the stem kernel standardises them on load)."""
     import time
-    from .input_feed import HostBatchFeeder
+    from multiposenet_amd.input_feed import HostBatchFeeder
     B, H, W, _ = features["images"].shape
     out = {}
     for name, idt in (("f32_images", torch.float32), ("u8_images", torch.uint8)):

@@ -6,8 +6,8 @@ import torch
 
 def run():
     from oracle import network as onet          # checker
-    from .net import KeypointNet
-    from .train import Trainer
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
     rs = np.random.RandomState(0)
     B, H, W = 1, 128, 128
     params = onet.randomize_bn(onet.init_params(0), 1)

@@ -37,3 +37,26 @@ def test_host_side_validation_needs_no_gpu():
     with pytest.raises(ValueError, match="C must be 17"):
         _lib.call("mpn_heatmap_decode", None, 0, 1, 4, 4, 16, None, 0.0, None, None, None, None, 0, None)
     assert _lib.lib().mpn_heatmap_decode_workspace_bytes(32) >= 32 * 17 * 8
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under multiposenet_amd/ may import it (bench.py's CPU-baseline legs and
+    smoke() live at the repository root for that reason)."""
+    import ast
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "multiposenet_amd")
+    bad = []
+    for d, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            tree = ast.parse(open(os.path.join(d, f)).read())
+            for node in ast.walk(tree):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom) and node.level == 0:
+                    names = [node.module or ""]
+                if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad

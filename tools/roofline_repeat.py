@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multiposenet_amd.net import KeypointNet
 from multiposenet_amd.train import Trainer
 from multiposenet_amd.synthetic import synthetic_batch
-from multiposenet_amd.benchmarks import dominant_kernel_roofline
+from bench_legs import dominant_kernel_roofline
 
 net = KeypointNet(dtype=torch.bfloat16, device="cuda:0", seed=0)
 tr = Trainer(net, {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0})
