@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 100
+#define MPN_VERSION 200
 
 enum { MPN_F32 = 0, MPN_BF16 = 1, MPN_F16 = 2 /* decode input only */ };
 
@@ -44,23 +44,6 @@ enum {
 enum { MPN_ACT_NONE = 0, MPN_ACT_RELU = 1, MPN_ACT_RELU6 = 2 };
 
 typedef void* mpn_stream_t; /* hipStream_t */
-
-/* Optional "tail" of a statistics-producing launch (mpn_conv_fwd_fin, mpn_dwconv_fwd_fin, mpn_bn_stats_fin,
- * mpn_bn_bwd_reduce_fin): the last-finishing blocks reduce the partial rows (two levels, f64, fixed order ->
- * deterministic) and do the work of mpn_bn_finalize (mode 1) or mpn_bn_bwd_finalize (mode 2) inside the same launch.
- * Host struct, read at launch time. workspace: mpn_bn_tail_workspace_bytes(C) bytes of device memory, zero-filled ONCE
- * by the caller (the tickets in it reset themselves); it may be shared by launches that do not overlap in time. */
-typedef struct mpn_bn_tail_t {
-    int mode;                 /* 0 = none, 1 = forward statistics -> scale/shift (+ moving stats), 2 = backward sums */
-    long long count;          /* elements per channel (N*H*W) */
-    float momentum, eps;      /* mode 1 */
-    const float* gamma; const float* beta;                                    /* mode 1 */
-    float* moving_mean; float* moving_var;                                    /* mode 1, may be NULL */
-    float* scale; float* shift; float* save_mean; float* save_invstd;         /* mode 1 outputs (save_* may be NULL) */
-    float* dgamma; float* dbeta; float* k1; float* k2;                        /* mode 2 outputs */
-    void* workspace; size_t workspace_bytes;
-} mpn_bn_tail_t;
-size_t mpn_bn_tail_workspace_bytes(int C);
 
 int mpn_version(void);
 /* copies the calling thread's last error message into buf (host), returns its length */
@@ -116,22 +99,22 @@ int mpn_conv_pack_desc_fill(void* desc_host, const float* w_hwio, int Cin, int C
 int mpn_conv_pack_weights_batched(const void* descs_device, int ndesc, int total_blocks, int dtype,
                                   mpn_stream_t stream);
 int mpn_conv_num_parts(int N, int H, int W, int ksize);
+/* x_stride / y_stride: elements between consecutive pixels of x / y; 0 = dense (Cin / Cout). A larger stride reads /
+ * writes a channel slice of a wider NHWC tensor in place - phi_subnet_2's second conv writes straight into the first 128
+ * channels of the 512-channel concat tensor (keypoint_subnet.py:37: tf.concat with upsample factor 1 is a copy). */
 int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin,
-                 int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,
-                 int in_act, float* stats_part, const void* up_res, mpn_stream_t stream);
-/* same + the following batch-norm's finalize inside the launch (tail may be NULL; needs stats_part) */
-int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin,
-                     int Cout, int ksize, int dtype, const float* in_scale, const float* in_shift,
-                     int in_act, float* stats_part, const void* up_res, const mpn_bn_tail_t* tail,
-                     mpn_stream_t stream);
+                 int Cout, int x_stride, int y_stride, int ksize, int dtype, const float* in_scale,
+                 const float* in_shift, int in_act, float* stats_part, const void* up_res,
+                 mpn_stream_t stream);
 /* Up to four independent 3x3 convolutions of the same channel geometry in ONE grid, largest first (the four pyramid levels
  * of a keypoint-subnet stage, keypoint_subnet.py:64-91: as launches of their own the small levels are latency-bound tails
- * of 15-45 us). Per job: x, w_packed, y, H, W, in_scale / in_shift (or NULL), stats_part (or NULL); shared: N, Cin, Cout,
- * ksize, dtype, in_act. Results are those of mpn_conv_fwd per job, bit for bit; configurations the grouped grid does
- * not cover (f32, 1x1, more than four jobs) run as the separate launches they replace. */
+ * of 15-45 us). Per job: x, w_packed, y, H, W, y_stride (array or NULL = dense), in_scale / in_shift (or NULL), stats_part
+ * (or NULL); shared: N, Cin, Cout, ksize, dtype, in_act. Results are those of mpn_conv_fwd per job, bit for bit;
+ * configurations the grouped grid does not cover (f32, 1x1, more than four jobs) run as the separate launches they replace. */
 int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N, const int* H,
-                         const int* W, int Cin, int Cout, int ksize, int dtype, const float* const* in_scale,
-                         const float* const* in_shift, int in_act, float* const* stats_part, mpn_stream_t stream);
+                         const int* W, int Cin, int Cout, const int* y_stride, int ksize, int dtype,
+                         const float* const* in_scale, const float* const* in_shift, int in_act,
+                         float* const* stats_part, mpn_stream_t stream);
 
 /* Weight gradient of mpn_conv_fwd: dW[tap][ci][co] = sum_pixels act(bn(x))[pixel+tap][ci]*dy[pixel][co].
  * Split-K over pixel tiles: part [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (one HWIO slab
@@ -151,8 +134,6 @@ int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H
  */
 int mpn_bn_stats_num_parts(long long M);
 int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream);
-int mpn_bn_stats_fin(const void* x, long long M, int C, int dtype, float* part, const mpn_bn_tail_t* tail,
-                     mpn_stream_t stream);
 int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
                     const float* beta, float* moving_mean, float* moving_var, float momentum,
                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
@@ -193,10 +174,6 @@ int mpn_bn_act_apply(const void* x, void* y, long long M, int C, int dtype, cons
 int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dtype,
                       const float* scale, const float* shift, const float* mean,
                       const float* invstd, int act, float* part, mpn_stream_t stream);
-int mpn_bn_bwd_reduce_fin(const void* dA, const void* x, long long M, int C, int dtype,
-                          const float* scale, const float* shift, const float* mean,
-                          const float* invstd, int act, float* part, const mpn_bn_tail_t* tail,
-                          mpn_stream_t stream);
 int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
                         float* dbeta, float* k1, float* k2, mpn_stream_t stream);
 /* dA <- scale*(g - k1 - xhat*k2) in place; add_ch0 (NULL or [M] f32) is added to channel 0 */
@@ -215,9 +192,6 @@ int mpn_dwconv_num_parts(int N, int H, int W, int C, int stride, int dtype);
 int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
                    int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
                    float* stats_part, mpn_stream_t stream);
-int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
-                       int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
-                       float* stats_part, const mpn_bn_tail_t* tail, mpn_stream_t stream);
 /* dy [N,OH,OW,C] -> dx [N,H,W,C]  (H, W: forward input size) */
 int mpn_dwconv_bwd_data(const void* dy, const float* w, void* dx, int N, int H, int W, int C,
                         int stride, int dtype, mpn_stream_t stream);

@@ -35,26 +35,21 @@ SIGNATURES = {
     "mpn_conv_pack_desc_fill": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I]),
     "mpn_conv_pack_weights_batched": (_I, [_P, _I, _I, _I, _P]),
     "mpn_conv_num_parts": (_I, [_I, _I, _I, _I]),
-    "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
-    "mpn_conv_fwd_fin": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
-    "mpn_conv_fwd_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P, _P]),
-    "mpn_bn_tail_workspace_bytes": (_Z, [_I]),
+    "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "mpn_conv_fwd_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P]),
     "mpn_conv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mpn_conv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_bn_stats_num_parts": (_I, [_L]),
     "mpn_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
-    "mpn_bn_stats_fin": (_I, [_P, _L, _I, _I, _P, _P, _P]),
     "mpn_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
     "mpn_bn_inference_affine": (_I, [_I, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mpn_bn_act_apply": (_I, [_P, _P, _L, _I, _I, _P, _P, _I, _P]),
     "mpn_bn_bwd_reduce": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "mpn_bn_bwd_reduce_fin": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "mpn_bn_bwd_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P]),
     "mpn_bn_bwd_apply": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "mpn_dwconv_out_size": (_I, [_I, _I]),
     "mpn_dwconv_num_parts": (_I, [_I, _I, _I, _I, _I, _I]),
     "mpn_dwconv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P]),
-    "mpn_dwconv_fwd_fin": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "mpn_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mpn_dwconv_bwd_data_bn_num_parts": (_I, [_I, _I, _I, _I, _I, _I]),
     "mpn_dwconv_bwd_data_bn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
@@ -162,6 +157,30 @@ def ptr(t):
 def stream_ptr():
     import torch
     return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def device_guarded(*names):
+    """Class decorator: the named methods run with `self.device` as the CURRENT device. Every launch takes
+    torch.cuda.current_stream() of the current device and HIP function attributes are per device, so an object built
+    for cuda:1 must not launch while cuda:0 is current (kernels would run on device 0's stream against device-1 pointers)."""
+    import functools
+
+    def wrap(fn):
+        @functools.wraps(fn)
+        def inner(self, *a, **k):
+            import torch
+            dev = torch.device(self.device)
+            if dev.type != "cuda" or dev.index is None or dev.index == torch.cuda.current_device():
+                return fn(self, *a, **k)
+            with torch.cuda.device(dev):
+                return fn(self, *a, **k)
+        return inner
+
+    def deco(cls):
+        for n in names:
+            setattr(cls, n, wrap(getattr(cls, n)))
+        return cls
+    return deco
 
 
 def dtype_code(torch_dtype):

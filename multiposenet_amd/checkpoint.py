@@ -28,8 +28,10 @@ def save_npz(path, net, with_optimizer=True, beta1=0.9, beta2=0.999):
             for k, v in views.views(flat).items():
                 out[slot_name(k, slot)] = v.detach().cpu().numpy().copy()
         out["global_step"] = np.int64(step)
-        out["beta1_power"] = np.float32(beta1 ** step) if step else np.float32(beta1)   # TF initialises the powers to beta
-        out["beta2_power"] = np.float32(beta2 ** step) if step else np.float32(beta2)
+        # tf.train.AdamOptimizer creates the powers as beta and multiplies them after every apply: after `step` applies the
+        # checkpoint holds beta^(step+1) (consistent with csrc/optim.hip using t = global_step + 1)
+        out["beta1_power"] = np.float32(beta1 ** (step + 1))
+        out["beta2_power"] = np.float32(beta2 ** (step + 1))
     np.savez(path, **out)
     return sorted(out)
 
@@ -65,7 +67,12 @@ def load_npz(path, net, scopes=None, strict=True, with_optimizer=True):
                     dst.copy_(torch.from_numpy(v))
                     restored.append(name)
         if scopes is None:
-            net.global_step.fill_(int(values["global_step"]))
+            step = int(values["global_step"])
+            for name, beta in (("beta1_power", 0.9), ("beta2_power", 0.999)):
+                if name in values and not np.isclose(float(values[name]), beta ** (step + 1), rtol=1e-3):
+                    raise ValueError(f"{path}: {name} = {float(values[name])} does not belong to global_step {step} "
+                                     f"(expected {beta ** (step + 1)})")
+            net.global_step.fill_(step)
             restored.append("global_step")
     return restored
 

@@ -10,7 +10,6 @@
 // bn_bwd_finalize (dgamma, dbeta, per-channel coefficients), bn_bwd_apply (dx, in place).
 // All reductions are deterministic: partial slabs + fixed-order f64 finalisation, no atomics.
 #include "common.h"
-#include "bn_tail.h"
 #include <string.h>
 
 namespace {
@@ -40,7 +39,7 @@ __device__ __forceinline__ RowMap make_rowmap(int C, int VE) {
 // out (per block) is written by the first `cvec` threads: part[which][c].
 template <int NV, int VE>
 __device__ __forceinline__ void block_reduce_store(const RowMap& m, float (&v)[NV][VE], float* smem,
-                                                   float* __restrict__ dst, long long which_stride, bool sc1 = false) {
+                                                   float* __restrict__ dst, long long which_stride) {
     // smem: [kThreads][NV*VE]
     __syncthreads();
 #pragma unroll
@@ -55,8 +54,7 @@ __device__ __forceinline__ void block_reduce_store(const RowMap& m, float (&v)[N
             for (int j = 0; j < VE; ++j) {
                 float t = 0.f;
                 for (int r = 0; r < m.ppb; ++r) t += smem[(r * m.cvec + m.vg) * (NV * VE) + k * VE + j];
-                if (sc1) st_sc1(&dst[k * which_stride + m.vg * VE + j], t);   // read by other blocks' bn_tail: sc1 hand-off
-                else dst[k * which_stride + m.vg * VE + j] = t;
+                dst[k * which_stride + m.vg * VE + j] = t;
             }
     }
 }
@@ -64,11 +62,9 @@ __device__ __forceinline__ void block_reduce_store(const RowMap& m, float (&v)[N
 // ---------------------------------------------------------------- forward statistics (standalone)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict__ x, long long M, int C,
-                                                            float* __restrict__ part, int rows_per_block,
-                                                            const BnTailDev tail) {
+                                                            float* __restrict__ part, int rows_per_block) {
     constexpr int VE = Vec16<T>::N;
     __shared__ float smem[kThreads * 2 * VE];
-    __shared__ int tail_flag;
     const RowMap m = make_rowmap(C, VE);
     float acc[2][VE];
 #pragma unroll
@@ -93,8 +89,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_kernel(const T* __restrict_
             }
         }
     }
-    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C, tail.mode != 0);
-    if (tail.mode) bn_tail(tail, part, C, blockIdx.x, 0, C, 0, threadIdx.x, kThreads, &tail_flag);
+    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blockIdx.x * 2 * C, C);
 }
 
 // ---------------------------------------------------------------- finalize
@@ -277,10 +272,9 @@ template <typename T>
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-    float* __restrict__ part, int rows_per_block, const BnTailDev& tail, const int blk) {
+    float* __restrict__ part, int rows_per_block, const int blk) {
     constexpr int VE = Vec16<T>::N;
     __shared__ float smem[kThreads * 2 * VE];
-    __shared__ int tail_flag;
     const RowMap m = make_rowmap(C, VE);
     float acc[2][VE];
     float sc[VE], sh[VE], is[VE], nmi[VE];
@@ -325,16 +319,15 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
             }
         }
     }
-    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blk * 2 * C, C, tail.mode != 0);
-    if (tail.mode) bn_tail(tail, part, C, blk, 0, C, 0, threadIdx.x, kThreads, &tail_flag);
+    block_reduce_store<2, VE>(m, acc, smem, part + (long long)blk * 2 * C, C);
 }
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-    float* __restrict__ part, int rows_per_block, const BnTailDev tail) {
-    bn_bwd_reduce_body<T>(dA, x, M, C, scale, shift, mean, invstd, act, part, rows_per_block, tail, blockIdx.x);
+    float* __restrict__ part, int rows_per_block) {
+    bn_bwd_reduce_body<T>(dA, x, M, C, scale, shift, mean, invstd, act, part, rows_per_block, blockIdx.x);
 }
 
 // up to four independent layers (the pyramid levels of a subnet stage) in one grid, largest first
@@ -357,10 +350,8 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_grouped_kernel(const BnBwdGroup g) {
     const int job = bn_group_job(g);
     const BnBwdJob& q = g.j[job];
-    BnTailDev none;
-    none.mode = 0;
     bn_bwd_reduce_body<T>((const T*)q.dA, (const T*)q.x, q.M, g.C, q.scale, q.shift, q.mean, q.invstd, g.act, q.part,
-                          q.rows_per_block, none, (int)blockIdx.x - g.begin[job]);
+                          q.rows_per_block, (int)blockIdx.x - g.begin[job]);
 }
 
 // part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
@@ -548,40 +539,16 @@ extern "C" int mpn_bn_stats_num_parts(long long M) {
 
 static long long rows_per_block_for(long long M, int nparts) { return (M + nparts - 1) / nparts; }
 
-extern "C" size_t mpn_bn_tail_workspace_bytes(int C) { return C > 0 ? bn_tail_workspace_bytes_for(C) : 0; }
-
-int bn_tail_check(const mpn_bn_tail_t* t, int C, const char* who) {
-    if (t == nullptr || t->mode == 0) return MPN_OK;
-    MPN_REQUIRE(t->mode == 1 || t->mode == 2, MPN_ERR_BAD_ARG, "%s: bn tail mode %d", who, t->mode);
-    MPN_REQUIRE(t->count > 0 && t->workspace, MPN_ERR_BAD_ARG, "%s: bn tail needs count and workspace", who);
-    MPN_REQUIRE(t->workspace_bytes >= bn_tail_workspace_bytes_for(C), MPN_ERR_WORKSPACE, "%s: bn tail workspace too small", who);
-    if (t->mode == 1) {
-        MPN_REQUIRE(t->gamma && t->beta && t->scale && t->shift, MPN_ERR_BAD_ARG, "%s: bn tail (forward) null pointer", who);
-        MPN_REQUIRE((t->moving_mean == nullptr) == (t->moving_var == nullptr), MPN_ERR_BAD_ARG, "%s: bn tail moving stats", who);
-    } else {
-        MPN_REQUIRE(t->dgamma && t->dbeta && t->k1 && t->k2, MPN_ERR_BAD_ARG, "%s: bn tail (backward) null pointer", who);
-    }
-    return MPN_OK;
-}
-
-extern "C" int mpn_bn_stats_fin(const void* x, long long M, int C, int dtype, float* part, const mpn_bn_tail_t* tail,
-                                mpn_stream_t stream) {
+extern "C" int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream) {
     int ve;
     if (int rc = check_rows(M, C, dtype, &ve)) return rc;
     MPN_REQUIRE(x && part, MPN_ERR_BAD_ARG, "bn_stats: null pointer");
-    if (int rc = bn_tail_check(tail, C, "bn_stats")) return rc;
     const int nparts = mpn_bn_stats_num_parts(M);
     const int rpb = (int)rows_per_block_for(M, nparts);
-    BnTailDev td;
-    bn_tail_prepare(tail, nparts, C, &td);
     hipStream_t st = (hipStream_t)stream;
-    MPN_DISPATCH_DTYPE(dtype, (bn_stats_kernel<T><<<nparts, kThreads, 0, st>>>((const T*)x, M, C, part, rpb, td)));
+    MPN_DISPATCH_DTYPE(dtype, (bn_stats_kernel<T><<<nparts, kThreads, 0, st>>>((const T*)x, M, C, part, rpb)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
-}
-
-extern "C" int mpn_bn_stats(const void* x, long long M, int C, int dtype, float* part, mpn_stream_t stream) {
-    return mpn_bn_stats_fin(x, M, C, dtype, part, nullptr, stream);
 }
 
 extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
@@ -670,28 +637,19 @@ extern "C" int mpn_bn_act_apply(const void* x, void* y, long long M, int C, int 
     return MPN_OK;
 }
 
-extern "C" int mpn_bn_bwd_reduce_fin(const void* dA, const void* x, long long M, int C, int dtype, const float* scale,
-                                     const float* shift, const float* mean, const float* invstd, int act, float* part,
-                                     const mpn_bn_tail_t* tail, mpn_stream_t stream) {
-    int ve;
-    if (int rc = check_rows(M, C, dtype, &ve)) return rc;
-    MPN_REQUIRE(dA && x && scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "bn_bwd_reduce: null pointer");
-    if (int rc = bn_tail_check(tail, C, "bn_bwd_reduce")) return rc;
-    const int nparts = mpn_bn_stats_num_parts(M);
-    const int rpb = (int)rows_per_block_for(M, nparts);
-    BnTailDev td;
-    bn_tail_prepare(tail, nparts, C, &td);
-    hipStream_t st = (hipStream_t)stream;
-    MPN_DISPATCH_DTYPE(dtype, (bn_bwd_reduce_kernel<T><<<nparts, kThreads, 0, st>>>(
-                                  (const T*)dA, (const T*)x, M, C, scale, shift, mean, invstd, act, part, rpb, td)));
-    MPN_LAUNCH_CHECK();
-    return MPN_OK;
-}
-
 extern "C" int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dtype, const float* scale,
                                  const float* shift, const float* mean, const float* invstd, int act, float* part,
                                  mpn_stream_t stream) {
-    return mpn_bn_bwd_reduce_fin(dA, x, M, C, dtype, scale, shift, mean, invstd, act, part, nullptr, stream);
+    int ve;
+    if (int rc = check_rows(M, C, dtype, &ve)) return rc;
+    MPN_REQUIRE(dA && x && scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "bn_bwd_reduce: null pointer");
+    const int nparts = mpn_bn_stats_num_parts(M);
+    const int rpb = (int)rows_per_block_for(M, nparts);
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, (bn_bwd_reduce_kernel<T><<<nparts, kThreads, 0, st>>>(
+                                  (const T*)dA, (const T*)x, M, C, scale, shift, mean, invstd, act, part, rpb)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
 }
 
 /* The backward passes of up to four independent layers of one channel count (the pyramid levels of a subnet stage) in ONE
@@ -699,9 +657,7 @@ extern "C" int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int
  * those of the per-layer launches, bit for bit; shapes the grouped grids do not cover run as those launches. */
 static bool bn_group_ok(int njobs, int C, int dtype) {
     const int ve = dtype == MPN_F32 ? 4 : 8;
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("MPN_BN_GROUPED"); on = e ? atoi(e) : 1; }
-    return on && njobs <= kBnGroup && C % ve == 0 && kThreads % (C / ve) == 0;
+    return njobs <= kBnGroup && C % ve == 0 && kThreads % (C / ve) == 0;
 }
 extern "C" int mpn_bn_bwd_reduce_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
                                          const float* const* scale, const float* const* shift, const float* const* mean,

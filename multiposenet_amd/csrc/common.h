@@ -35,6 +35,19 @@ void mpn_set_error(const char* fmt, ...);
                      hipGetErrorString(e_));                                      \
     } while (0)
 
+// Dynamic-LDS limit of a kernel above the 64 KB default: HIP function attributes are PER DEVICE, so the "already set"
+// record is a bit per device ordinal (one process may drive several GPUs). `mask` is a static of the calling launcher.
+static inline hipError_t mpn_ensure_dynamic_lds(const void* func, int bytes, unsigned long long* mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*mask & bit) return hipSuccess;
+    e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) *mask |= bit;
+    return e;
+}
+
 static inline bool mpn_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // ---------------------------------------------------------------- storage types

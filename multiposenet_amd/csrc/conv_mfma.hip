@@ -18,8 +18,6 @@
 // Epilogue: accumulators -> LDS -> full 16-byte NHWC stores; optional fused nearest-2x
 // upsample-add (fpn.py:51) and per-tile batch-norm partial sums (sum, sum of squares).
 #include "common.h"
-#include "bn_tail.h"
-#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -58,21 +56,28 @@ struct ConvParams {
     float* stats_part;
     const void* up_res;
     int N, H, W, Cin, Cout;
+    int x_stride, y_stride;   // elements between consecutive pixels of x / y (>= Cin / Cout: channel slices of wider tensors)
     int tiles_x, tiles_y;
     long long M;
     int row_bytes;  // 128 or 256: bytes of K staged per pixel row and channel chunk
     int nchunk;
     int n_tiles;
     long long wp_tile_bytes;  // packed bytes per n-tile
-    BnTailDev tail;           // batch-norm finalize fused into the last-finishing blocks (mode 0: off)
-    unsigned long long* dbg;  // diagnostic builds only (env MPN_CONV_STAMPS): per-block s_memtime stamps, else NULL
-    int lds_epilogue;         // bf16: output tile through LDS + MFMA statistics (default) or the direct epilogue
-    int xcd_remap;            // XCD-aware block -> tile map (default on)
+    int xcd_remap;            // XCD-aware block -> tile map
+#ifdef MPN_DIAG
+    unsigned long long* dbg;  // diagnostic build only (tools/build_variant.sh -DMPN_DIAG): per-block s_memtime stamps, or NULL
+#endif
 };
 
-#ifndef MPN_CONV_M32_DEFAULT
-#define MPN_CONV_M32_DEFAULT 0
+// slots 0-4: s_memtime (shader clock) at the phase boundaries; slots 5, 6: s_memrealtime (100 MHz) at the first and last one
+#ifdef MPN_DIAG
+#define MPN_STAMP(k) do { if (p.dbg && threadIdx.x == 0) { p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    if ((k) == 0) p.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) == 4) p.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define MPN_STAMP(k) do { } while (0)
 #endif
+
 constexpr int kThreads = 256;
 constexpr int kHaloW = 18, kHaloH = 10;
 
@@ -115,32 +120,21 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
     return v;
 }
 
-// RING = false: weight stages of 2 k-steps, 2 LDS buffers, DMA distance 1 (256-byte chunks: 2 blocks per CU).
-// RING = true (128-byte chunks only): stages of 1 k-step in a 3-slot ring, DMA distance 2 behind a COUNTED vmcnt and a
-// raw s_barrier; A image 28.8 KB + 24 KB of weights = 52.8 KB -> THREE blocks per CU, so one block's staging / epilogue
-// always has two others' MFMA phases to hide under.
-// MT = 16-pixel m-tiles per wave: 4 -> a block owns 128 pixels (8 x 16 for 3x3), 8 -> 256 pixels (16 x 16, bf16 3x3 with
-// the ring only): the weight image - 295 KB per n-tile of a 128 -> 128 layer, re-read from L2 by EVERY block - then
-// serves twice the pixels, and the halo overhead drops from 1.41 to 1.27. Its statistics rows are those of the two
-// 128-pixel tiles it covers (wave row wm = upper / lower half), so mpn_conv_num_parts does not depend on the variant.
+// Weight stages of 2 k-steps, 2 LDS buffers, DMA distance 1. A block owns 128 pixels (8 x 16 for 3x3).
 // (the body is a device function so that the plain kernel and the grouped kernel - several independent launches of the
 //  same instance, e.g. the four pyramid levels of one subnet stage, in ONE grid - share it; blk / nwg = this job's block
 //  index and block count)
-// M32: the same tiles on v_mfma_f32_32x32x16_bf16 - per 64-byte k-step a wave issues 2 x 2 x 2 MFMAs of 8 passes instead
-// of 4 x 4 of 4 passes: the same matrix cycles and the same LDS reads (8 x 16 bytes per lane), half the MFMA instructions
-// on the vector issue port. bf16, 128-pixel tiles, the LDS epilogue only (the launcher guarantees
-// up_res == NULL and lds_epilogue).
-template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4, bool M32 = false>
+// Variants that were built, measured and removed again (256-pixel tiles, a 3-slot / 5-slot weight ring, the 32x32x16
+// MFMA shape, a warp-specialised persistent kernel, batch-norm finalizes fused into the last-finishing blocks): DESIGN.md 4c.
+template <typename T, int TAPS, int BN, int RB>
 __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int blk, const int nwg_job) {
-    static_assert(MT == 4 || (MT == 8 && TAPS == 9 && RING && sizeof(T) == 2), "256-pixel tiles: bf16 3x3 ring variant only");
-    static_assert(!M32 || (sizeof(T) == 2 && MT == 4 && !RING), "32x32x16 variant: bf16, 128-pixel tiles, two-buffer weights");
-    constexpr int HALO_H = MT * 2 + 2;
+    constexpr int MT = 4;                       // 16-pixel m-tiles per wave
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
     constexpr int CCE = RB / ES;   // channels per chunk
-    constexpr int NPIX = TAPS == 9 ? kHaloW * HALO_H : MT * 32;
+    constexpr int NPIX = TAPS == 9 ? kHaloW * kHaloH : MT * 32;
     constexpr int NT = BN / 32;                 // 16-channel tiles per wave
-    constexpr int KSPS = RING ? 1 : 2;          // k-steps per weight stage
+    constexpr int KSPS = 2;                     // k-steps per weight stage
     constexpr int STAGE_BYTES = KSPS * BN * 64;
     constexpr int BVEC = STAGE_BYTES / (kThreads * 16);
     static_assert(BVEC >= 1, "a weight stage is at least one 16-byte vector per thread");
@@ -150,7 +144,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
     constexpr int SPT = KSTEPS / KSPS;          // weight stages per tap
     constexpr int AVEC = (NPIX * SLOTS + kThreads - 1) / kThreads;
     using Frag = typename Mma<T>::Frag;
-    static_assert(!RING || RB == 128, "the 3-slot ring is sized for 128-byte chunks");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* As = smem;
@@ -180,9 +173,8 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
     if (TAPS == 9) {
         const int tx = mtile % p.tiles_x;
         const int t2 = mtile / p.tiles_x;
-        const int tiles_y = (MT == 8) ? ((p.tiles_y + 1) >> 1) : p.tiles_y;
-        const int ty = t2 % tiles_y;
-        img = t2 / tiles_y;
+        const int ty = t2 % p.tiles_y;
+        img = t2 / p.tiles_y;
         oy0 = ty * (MT * 2);
         ox0 = tx * 16;
     } else {
@@ -200,33 +192,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    // M32: acc32[m2][n2] holds D^T of a 32 px x 32 ch tile: lane (l31, lh) -> pixel m2*32+l31, channels n2*32 + 8g + 4lh + {0..3}
-    // in registers 4g..4g+3
-    constexpr int M2 = MT / 2, N2 = NT / 2;
-    const int l31 = lane & 31, lh = lane >> 5;
-    f32x16_t acc32[M32 ? M2 : 1][M32 ? N2 : 1];
-    if constexpr (M32) {
-#pragma unroll
-        for (int i = 0; i < M2; ++i)
-#pragma unroll
-            for (int j = 0; j < N2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
-    }
-    const unsigned char* abase32[M2];
-    const unsigned char* bbase32[2];
-    if constexpr (M32) {
-#pragma unroll
-        for (int m2 = 0; m2 < M2; ++m2) {
-            const int row = wm * (MT * 16) + m2 * 32 + l31;
-            const int pix = (TAPS == 9) ? ((row >> 4) * kHaloW + (row & 15)) : row;
-            abase32[m2] = As + pix * RS + lh * 16;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            bbase32[kk] = Bs + (wn * (BN / 2) + l31) * 64 + ((((kk << 1) | lh) ^ b_swz(l31)) << 4);
-    }
 
     // per-lane fragment base addresses: everything else is a compile-time or wave-uniform offset
     const unsigned char* abase[MT];
@@ -250,12 +215,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                                              (__attribute__((address_space(3))) void*)(dst + i * kThreads * 16), 16, 0, 0);
     };
     b_issue(0, 0);
-    if (RING && total_stages > 1) b_issue(1, 1);
 
-// slots 0-4: s_memtime (shader clock) at the phase boundaries; slots 5, 6: s_memrealtime (100 MHz) at the first and last one
-#define MPN_STAMP(k) do { if (p.dbg && tid == 0) { p.dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
-    if ((k) == 0) p.dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime(); \
-    if ((k) == 4) p.dbg[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime(); } } while (0)
     MPN_STAMP(0);
     const bool affine = (p.in_scale != nullptr);
     const float act_lo = (p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
@@ -274,28 +234,6 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) Mma<T>::run(b[nt], a[mt], acc[mt][nt]);   // D^T = W^T x A^T
-    };
-
-    // M32 fragments of one 64-byte k-step: [tile][16-element half of the k-step]
-    bf16x8_t a32P[M2][2], b32P[M32 ? N2 : 1][2], a32Q[M2][2], b32Q[M32 ? N2 : 1][2];
-    auto load_frags32 = [&](auto& a, auto& b, int a_off, int b_off) {
-#pragma unroll
-        for (int m2 = 0; m2 < M2; ++m2)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) a[m2][kk] = *reinterpret_cast<const bf16x8_t*>(abase32[m2] + a_off + kk * 32);
-#pragma unroll
-        for (int n2 = 0; n2 < N2; ++n2)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) b[n2][kk] = *reinterpret_cast<const bf16x8_t*>(bbase32[kk] + b_off + n2 * 2048);
-    };
-    auto mma_all32 = [&](const auto& a, const auto& b) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int m2 = 0; m2 < M2; ++m2)
-#pragma unroll
-                for (int n2 = 0; n2 < N2; ++n2)
-                    acc32[m2][n2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[n2][kk], a[m2][kk], acc32[m2][n2], 0, 0, 0);
     };
 
     int s = 0;
@@ -328,11 +266,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                     const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
                     const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
                     ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    off = (((long long)img * p.H + iy) * p.W + ix) * p.Cin + ce;
+                    off = (((long long)img * p.H + iy) * p.W + ix) * p.x_stride + ce;
                 } else {
                     const long long m = m0 + pix;
                     ok = ok && (m < p.M);
-                    off = m * p.Cin + ce;
+                    off = m * p.x_stride + ce;
                 }
                 inb[i] = ok;
                 if (ok) v[i].load(x + off); else v[i].zero();
@@ -356,39 +294,14 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
             const int tap = sl / SPT, h = sl - tap * SPT;
             const int ky = (tap * 11) >> 5;   // tap / 3 for tap < 9
             const int a_off = ((TAPS == 9) ? (ky * kHaloW + (tap - 3 * ky)) * RS : 0) + h * (KSPS * 64);   // wave-uniform
-            if constexpr (!RING) {
-                const int b_off = (s & 1) * STAGE_BYTES;
-                const bool more = (s + 1 < total_stages);
-                if (more) b_issue(s + 1, (s + 1) & 1);   // buffer (s+1)%2 was last read in stage s-1: all waves are past it
-                if constexpr (M32) {
-                    load_frags32(a32P, b32P, a_off, b_off);
-                    load_frags32(a32Q, b32Q, a_off + 64, b_off + BN * 64);
-                    // without the fence the scheduler sinks every read to its first use (read / lgkmcnt(0) / MFMA, no
-                    // prefetch distance); with it the waits are counted and the second k-step's reads land under the
-                    // first one's MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_all32(a32P, b32P);
-                    __builtin_amdgcn_sched_barrier(0);
-                    mma_all32(a32Q, b32Q);
-                } else {
-                load_frags(aP, bP, a_off, b_off);
-                load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
-                mma_all(aP, bP);
-                mma_all(aQ, bQ);
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
-                __syncthreads();
-            } else {
-                const int b_off = (s % 3) * STAGE_BYTES;
-                const bool more2 = (s + 2 < total_stages);
-                if (more2) b_issue(s + 2, (s + 2) % 3);   // slot (s+2)%3 was last read in stage s-1: all waves are past it
-                load_frags(aP, bP, a_off, b_off);
-                mma_all(aP, bP);
-                // stage s+1 must have landed; the BVEC pieces of stage s+2 just issued may stay in flight
-                if (more2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BVEC) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();   // raw: __syncthreads() would drain the DMA with vmcnt(0)
-            }
+            const int b_off = (s & 1) * STAGE_BYTES;
+            if (s + 1 < total_stages) b_issue(s + 1, (s + 1) & 1);   // buffer (s+1)%2 was last read in stage s-1: all waves are past it
+            load_frags(aP, bP, a_off, b_off);
+            load_frags(aQ, bQ, a_off + 64, b_off + BN * 64);
+            mma_all(aP, bP);
+            mma_all(aQ, bQ);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next stage's weights have landed (this wave's pieces)
+            __syncthreads();
         }
     }
     MPN_STAMP(2);
@@ -408,28 +321,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
     // windows; (3) after one barrier, whole 16-byte pieces of pixel rows go to global memory, 256 contiguous bytes per
     // 16 lanes. The statistics are those of the ROUNDED outputs - exactly the tensor the consumer normalises.
     if constexpr (sizeof(T) == 2) {
-        if (M32 || MT == 8 || (res == nullptr && p.lds_epilogue)) {
+        if (res == nullptr) {
             constexpr int RSO = BN * 2 + 8;
             constexpr int ROWS = MT * 32;
             unsigned char* O = smem;
-            float* red = reinterpret_cast<float*>(smem + ROWS * RSO);   // [2 wm][2][BN] (+ the tail's flag word)
-            if constexpr (M32) {
-#pragma unroll
-                for (int m2 = 0; m2 < M2; ++m2) {
-                    const int row = wm * (MT * 16) + m2 * 32 + l31;
-                    bool ok;
-                    if (TAPS == 9) ok = (oy0 + (row >> 4)) < p.H && (ox0 + (row & 15)) < p.W;
-                    else ok = (m0 + row) < p.M;
-#pragma unroll
-                    for (int n2 = 0; n2 < N2; ++n2)
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4_t v = {acc32[m2][n2][4 * g], acc32[m2][n2][4 * g + 1], acc32[m2][n2][4 * g + 2], acc32[m2][n2][4 * g + 3]};
-                            if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                            store4(reinterpret_cast<bf16_t*>(O + row * RSO + (wn * (BN / 2) + n2 * 32 + g * 8 + lh * 4) * 2), v);
-                        }
-                }
-            } else
+            float* red = reinterpret_cast<float*>(smem + ROWS * RSO);   // [2 wm][2][BN]
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = wm * (MT * 16) + mt * 16 + l15;
@@ -498,43 +394,20 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                     if (ok && cok) {
                         const uint2 a = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16);
                         const uint2 b = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16 + 8);
-                        *reinterpret_cast<uint4*>(y + pixel * p.Cout + n0 + slot * 8) = make_uint4(a.x, a.y, b.x, b.y);
+                        *reinterpret_cast<uint4*>(y + pixel * p.y_stride + n0 + slot * 8) = make_uint4(a.x, a.y, b.x, b.y);
                     }
                 }
             }
-            if (p.stats_part != nullptr) {
-                if constexpr (MT == 8) {
-                    // wave row wm = the 128-pixel tile (ty*2 + wm, tx): one statistics row each, nothing to combine
-                    const int tx = mtile % p.tiles_x;
-                    const int ty8 = (oy0 >> 3);
-                    for (int v = tid; v < 4 * BN; v += kThreads) {
-                        const int half = v / (2 * BN), which = (v / BN) & 1, c = v % BN;
-                        if (ty8 + half < p.tiles_y && n0 + c < p.Cout) {
-                            const long long mt128 = ((long long)img * p.tiles_y + ty8 + half) * p.tiles_x + tx;
-                            p.stats_part[(mt128 * 2 + which) * p.Cout + n0 + c] = red[(half * 2 + which) * BN + c];
-                        }
-                    }
-                } else {
-                    if (tid < 2 * BN) {
-                        const int which = tid / BN, c = tid % BN;
-                        if (n0 + c < p.Cout) {
-                            float* dstp = &p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c];
-                            const float val = red[which * BN + c] + red[(2 + which) * BN + c];
-                            if (p.tail.mode) st_sc1(dstp, val); else *dstp = val;
-                        }
-                    }
-                    if (p.tail.mode) {
-                        int* flag = reinterpret_cast<int*>(red + 4 * BN);
-                        bn_tail(p.tail, p.stats_part, p.Cout, mtile, n0, BN, ntile, tid, kThreads, flag);
-                    }
-                }
+            if (p.stats_part != nullptr && tid < 2 * BN) {
+                const int which = tid / BN, c = tid % BN;
+                if (n0 + c < p.Cout)
+                    p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c] = red[which * BN + c] + red[(2 + which) * BN + c];
             }
             MPN_STAMP(4);
             return;
         }
     }
 
-    if constexpr (M32) return;   // (unreachable: the LDS epilogue above is unconditional for M32)
     // ================= direct epilogue (f32 parity build, and the upsample-add variant): each lane owns 4 consecutive
     // output channels of one pixel per (mt, nt) tile -> one 8-byte (bf16) / 16-byte (f32) store; no LDS round trip.
     const int cbase = n0 + wn * (BN / 2) + lq * 4;   // + nt*16
@@ -571,7 +444,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                 if (res != nullptr) v += load4(res + roff + c);
                 ssum[nt] += v;
                 ssq[nt] += v * v;
-                store4(y + pixel * p.Cout + c, v);
+                store4(y + pixel * p.y_stride + c, v);
             }
         }
     }
@@ -608,24 +481,16 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
         __syncthreads();
         if (tid < 2 * BN) {
             const int which = tid / BN, c = tid % BN;
-            if (n0 + c < p.Cout) {
-                float* dstp = &p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c];
-                const float val = red[which * BN + c] + red[(2 + which) * BN + c];
-                if (p.tail.mode) st_sc1(dstp, val); else *dstp = val;
-            }
-        }
-        if (p.tail.mode) {
-            int* flag = reinterpret_cast<int*>(Bs + 4 * BN * sizeof(float));   // one word behind `red`
-            bn_tail(p.tail, p.stats_part, p.Cout, mtile, n0, BN, ntile, tid, kThreads, flag);
+            if (n0 + c < p.Cout)
+                p.stats_part[((long long)mtile * 2 + which) * p.Cout + n0 + c] = red[which * BN + c] + red[(2 + which) * BN + c];
         }
     }
     MPN_STAMP(4);
-#undef MPN_STAMP
 }
 
-template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4, bool M32 = false>
-__global__ __launch_bounds__(kThreads, (RING && MT == 4) ? 3 : 2) void conv_mfma_kernel(const ConvParams p) {
-    conv_mfma_body<T, TAPS, BN, RB, RING, MT, M32>(p, blockIdx.x, gridDim.x);
+template <typename T, int TAPS, int BN, int RB>
+__global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams p) {
+    conv_mfma_body<T, TAPS, BN, RB>(p, blockIdx.x, gridDim.x);
 }
 
 // up to four independent jobs of one kernel instance in one grid (largest first): the small pyramid levels are a few
@@ -637,365 +502,15 @@ struct ConvGroup {
     int begin[kMaxGroup + 1];   // first block of each job; begin[njobs] = grid size
     int njobs;
 };
-template <typename T, int TAPS, int BN, int RB, bool RING, bool M32 = false>
-__global__ __launch_bounds__(kThreads, RING ? 3 : 2) void conv_mfma_grouped_kernel(const ConvGroup g) {
+template <typename T, int TAPS, int BN, int RB>
+__global__ __launch_bounds__(kThreads, 2) void conv_mfma_grouped_kernel(const ConvGroup g) {
     int job = 0;
 #pragma unroll
     for (int j = 1; j < kMaxGroup; ++j)
         if (j < g.njobs && (int)blockIdx.x >= g.begin[j]) job = j;   // wave-uniform
-    conv_mfma_body<T, TAPS, BN, RB, RING, 4, M32>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
+    conv_mfma_body<T, TAPS, BN, RB>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
 }
 
-// ------------------------------------------------------------------ warp-specialised 3x3 kernel (bf16)
-// ONE persistent 8-wave block per CU. Waves 0-3 ("consumers", 2x2 over 128 pixels x BN channels, one per SIMD) only
-// read LDS and issue MFMAs; waves 4-7 ("producers") move everything: weight stages by LDS-DMA into a 5-deep ring
-// (issued 4 stages ahead: 2 in flight + 2 complete), the NEXT 64-channel chunk's halo by LDS-DMA into a raw ring and,
-// two stages later, through batch-norm affine + activation + zero padding into the other half of a double-buffered A
-// image. One s_barrier per stage (= one tap of one 64-channel chunk, 32 MFMAs per consumer wave) is the only
-// synchronisation: at barrier B(i) weight stage i+2 and every A piece issued two stages earlier are complete, so a
-// consumer reads stage i, prefetches the first fragments of stage i+1 ACROSS the barrier, and never waits for memory.
-// The sequence of (unit, chunk, tap) stages is flat over the block's units, so the first chunk of the next tile is
-// staged during the last chunk of the current one. (The 4-wave kernel above re-reads the 295 KB weight image per
-// 128-pixel tile with 4 LDS-DMA pieces per consumer wave and stage - a third of its main loop)
-// one weight stage's share of a producer lane (2 or 4 x 16 bytes) in NAMED registers (indexed arrays that live across the
-// producer's chunk loop end up in scratch)
-template <int N> struct WsSet {
-    uint4 v0, v1, v2, v3;
-    __device__ __forceinline__ void load(const uint4* src) {
-        v0 = src[0]; v1 = src[64];
-        if constexpr (N > 2) { v2 = src[128]; v3 = src[192]; }
-    }
-    __device__ __forceinline__ void store(uint4* dst) const {
-        dst[0] = v0; dst[64] = v1;
-        if constexpr (N > 2) { dst[128] = v2; dst[192] = v3; }
-    }
-};
-
-constexpr int kWsThreads = 512;
-constexpr int kWsNbuf = 5;
-
-template <int BN>
-__global__ __launch_bounds__(kWsThreads, 1) void conv_ws_kernel(const ConvParams p, int units_total) {
-    using T = bf16_t;
-    using Frag = Mma<T>::Frag;
-    constexpr int RS = 160, NPIX = kHaloW * kHaloH, ABYTES = NPIX * RS;
-    constexpr int STAGE = 2 * BN * 64, NT = BN / 32;
-    constexpr int WPIECES = STAGE / 1024 / 4;            // LDS-DMA pieces per producer wave and stage (4 or 2)
-    constexpr int NRAW = (NPIX + 7) / 8;                  // 23 raw pieces of 8 pixels x 128 bytes per chunk
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* Aimg = smem;                                   // [2][ABYTES]
-    unsigned char* Wring = smem + 2 * ABYTES;                     // [kWsNbuf][STAGE]
-    float* Red = reinterpret_cast<float*>(Wring + kWsNbuf * STAGE);   // [2 wm][2][BN] per-wave-row stats of the last unit
-    float* Aff = Red + 4 * BN;                                    // [Cin] scale, [Cin] shift (producers only)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
-    const int nunits = units_total > (int)blockIdx.x ? (units_total - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
-    const int nchunk = p.nchunk;
-    const int TS = nunits * nchunk * 9;                           // stages of this block
-    if (TS == 0) return;
-    auto unit_coords = [&](int j, int& ntile, int& mtile, int& img, int& oy0, int& ox0) {
-        const int u = (int)blockIdx.x + j * (int)gridDim.x;
-        ntile = u % p.n_tiles;
-        mtile = u / p.n_tiles;
-        const int tx = mtile % p.tiles_x;
-        const int t2 = mtile / p.tiles_x;
-        const int ty = t2 % p.tiles_y;
-        img = t2 / p.tiles_y;
-        oy0 = ty * 8;
-        ox0 = tx * 16;
-    };
-
-    if (wave >= 4) {
-        // =========================================================== producers
-        const int pw = wave - 4;
-        const bool affine = p.in_scale != nullptr;
-        const float act_lo = (affine && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
-        const float act_hi = (affine && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
-        const int nq = nunits * nchunk;                      // flat chunks of this block
-        const unsigned char* wp8 = reinterpret_cast<const unsigned char*>(p.wp);
-        // All global -> LDS traffic goes through REGISTERS (global_load_dwordx4 ... ds_write_b128), three stages in
-        // flight: an LDS-DMA piece blocks the SIMD's issue port for 60-185 cycles, i.e. it is paid by the consumer wave
-        // on the same SIMD (measured: 1060 instead of 512 cycles per stage). Index arithmetic is incremental / scalar: a
-        // producer interval has ~500 cycles, a division by a run-time value costs ~40 instructions.
-        struct UnitPos { int ntile, mtile, img, oy0, ox0; };
-        auto unit_pos = [&](int j) -> UnitPos {
-            UnitPos r;
-            int ntile, mtile, img, oy0, ox0;
-            unit_coords(j, ntile, mtile, img, oy0, ox0);
-            r.ntile = ntile; r.mtile = mtile; r.img = img; r.oy0 = oy0; r.ox0 = ox0;
-            return r;
-        };
-        // source of the next weight stage to load, stages left in its unit, units started
-        const unsigned char* w_src = nullptr;
-        int w_st = 0, w_j = 0, w_left = 0;
-        auto w_next_src = [&]() -> const uint4* {              // per-lane source of the next stage (clamped past the end)
-            if (w_st < TS && w_left == 0) {
-                const int u = (int)blockIdx.x + w_j * (int)gridDim.x;
-                w_src = wp8 + (long long)(u % p.n_tiles) * p.wp_tile_bytes;
-                w_left = nchunk * 9;
-                ++w_j;
-            }
-            const unsigned char* r = w_src + (size_t)(pw * WPIECES) * 1024 + lane * 16;
-            if (w_st < TS) { w_src += STAGE; --w_left; }
-            ++w_st;
-            return reinterpret_cast<const uint4*>(r);
-        };
-        auto a_src = [&](const UnitPos& up, int c, int k) -> const uint4* {   // halo piece k: pixel 8k + lane/8, slot lane%8
-            const int hp = min(8 * k + (lane >> 3), NPIX - 1);
-            const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
-            const int iy = min(max(up.oy0 + hy - 1, 0), p.H - 1), ix = min(max(up.ox0 + hx - 1, 0), p.W - 1);   // clamped: zeroed at commit
-            const int ce = min(c * 64 + (lane & 7) * 8, p.Cin - 8);
-            return reinterpret_cast<const uint4*>(x + (long long)up.img * p.H * p.W * p.Cin + ((iy * p.W + ix) * p.Cin + ce));
-        };
-        // registers -> A image (affine + activation; zero outside the image / beyond Cin). lds_aff: scale / shift from
-        // the LDS table (steady state: a global load here would sit in vmcnt behind the loads just issued) or from
-        // global memory (prologue: the table is complete only after the prologue barrier)
-        auto a_commit = [&](const uint4 raw, const UnitPos& up, int c, int k, unsigned char* abuf, bool lds_aff) {
-            const int hp = 8 * k + (lane >> 3), slot = lane & 7;
-            if (hp >= NPIX) return;
-            const int hy = hp / kHaloW, hx = hp - hy * kHaloW;
-            const int iy = up.oy0 + hy - 1, ix = up.ox0 + hx - 1;
-            const int ce = c * 64 + slot * 8;
-            const bool ok = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && ce < p.Cin;
-            Vec16<T> v;
-            v.raw = raw;
-            if (ok && affine) {
-                float sc[8], sh[8];
-#pragma unroll
-                for (int jj = 0; jj < 8; jj += 4) {
-                    float4 a4, b4;
-                    if (lds_aff) {
-                        a4 = *reinterpret_cast<const float4*>(Aff + ce + jj);
-                        b4 = *reinterpret_cast<const float4*>(Aff + p.Cin + ce + jj);
-                    } else {
-                        a4 = *reinterpret_cast<const float4*>(p.in_scale + ce + jj);
-                        b4 = *reinterpret_cast<const float4*>(p.in_shift + ce + jj);
-                    }
-                    sc[jj] = a4.x; sc[jj + 1] = a4.y; sc[jj + 2] = a4.z; sc[jj + 3] = a4.w;
-                    sh[jj] = b4.x; sh[jj + 1] = b4.y; sh[jj + 2] = b4.z; sh[jj + 3] = b4.w;
-                }
-                apply_affine_act<T>(v, sc, sh, act_lo, act_hi);
-            }
-            if (!ok) v.zero();
-            *reinterpret_cast<uint4*>(abuf + hp * RS + slot * 16) = v.raw;
-        };
-        auto write_stats = [&](const UnitPos& up) {
-            for (int t = lane; t < 2 * BN; t += 64) {
-                const int which = t / BN, c = t - which * BN;
-                if (up.ntile * BN + c < p.Cout)
-                    p.stats_part[((long long)up.mtile * 2 + which) * p.Cout + up.ntile * BN + c] = Red[which * BN + c] + Red[(2 + which) * BN + c];
-            }
-        };
-
-        // weight stage X lives in register set X % 3 (wA, wB, wC) while in flight, halo piece kk of the next chunk in set
-        // kk % 3 (aA, aB, aC). Named sets + a macro per interval with literal set names: indexed arrays end up in scratch.
-        uint4 wA0 = {}, wA1 = {}, wA2 = {}, wA3 = {}, wB0 = {}, wB1 = {}, wB2 = {}, wB3 = {}, wC0 = {}, wC1 = {}, wC2 = {}, wC3 = {};
-#define MPN_WS_WLOAD(S, src)  do { const uint4* s_ = (src); S##0 = s_[0]; S##1 = s_[64]; if (WPIECES > 2) { S##2 = s_[128]; S##3 = s_[192]; } } while (0)
-#define MPN_WS_WSTORE(S, dst) do { uint4* d_ = (dst); d_[0] = S##0; d_[64] = S##1; if (WPIECES > 2) { d_[128] = S##2; d_[192] = S##3; } } while (0)
-        uint4 aA = {}, aB = {}, aC = {};
-        // ---- prologue: scale / shift table; weight stages 0, 1 into the ring, 2..4 into the sets; A image of chunk 0
-        if (affine)
-            for (int c = tid - 256; c < p.Cin; c += 256) { Aff[c] = p.in_scale[c]; Aff[p.Cin + c] = p.in_shift[c]; }
-        UnitPos cur_up = unit_pos(0);                        // unit of the chunk being multiplied
-#pragma unroll
-        for (int st = 0; st < 2; ++st) {
-            const uint4* src = w_next_src();
-            uint4* dst = reinterpret_cast<uint4*>(Wring + st * STAGE + (pw * WPIECES) * 1024) + lane;
-#pragma unroll
-            for (int k = 0; k < WPIECES; ++k) dst[k * 64] = src[k * 64];
-        }
-        for (int k = pw; k < NRAW; k += 4) {
-            const uint4 raw = *a_src(cur_up, 0, k);
-            a_commit(raw, cur_up, 0, k, Aimg, false);
-        }
-        {
-            MPN_WS_WLOAD(wC, w_next_src());   // stage 2
-            MPN_WS_WLOAD(wA, w_next_src());   // stage 3
-            MPN_WS_WLOAD(wB, w_next_src());   // stage 4
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                        // prologue barrier: stages 0, 1, A(0), Aff are complete
-
-        // ---- steady state: interval i = 9q + sl sits between barriers B(i-1) and B(i)
-        UnitPos nxt_up = cur_up;                              // unit / channel chunk of flat chunk q+1
-        int nxt_c = 1;
-        if (nchunk == 1) { nxt_c = 0; if (1 < nunits) nxt_up = unit_pos(1); }
-        bool stats_due = false;                               // the previous interval ended a unit
-        UnitPos done_up = cur_up;
-        int c = 0, wslot = 2;                                 // ring slot of stage i+2
-        unsigned long long t_work = 0, t_bar = 0, t_vm = 0, t0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
-#define MPN_WS_STAMP(accu) do { if (p.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); accu += t_ - t0; t0 = t_; } } while (0)
-        for (int q = 0; q < nq; ++q) {
-            const bool nxt_real = q + 1 < nq;
-            unsigned char* nxt_img = Aimg + ((q + 1) & 1) * ABYTES;
-            // one interval: weight stage i+2 from its set into the ring, the set reloaded with stage i+5; halo piece
-            // SL-2 of the next chunk from its set into the A image, piece SL loaded
-#define MPN_WS_INTERVAL(SL, WSET, ACOMMIT, ALOAD)                                                              \
-            {                                                                                                  \
-                uint4* dst_ = reinterpret_cast<uint4*>(Wring + wslot * STAGE + (pw * WPIECES) * 1024) + lane;  \
-                MPN_WS_WSTORE(WSET, dst_);                                                                     \
-                MPN_WS_WLOAD(WSET, w_next_src());                                                              \
-                wslot = wslot + 1 == kWsNbuf ? 0 : wslot + 1;                                                  \
-                if ((SL) >= 2 && (SL) < 8) {                                                                   \
-                    const int k_ = 4 * ((SL)-2) + pw;                                                          \
-                    if (nxt_real && k_ < NRAW) a_commit(ACOMMIT, nxt_up, nxt_c, k_, nxt_img, true);            \
-                }                                                                                              \
-                if ((SL) < 6) ALOAD = *a_src(nxt_up, nxt_c, min(4 * (SL) + pw, NRAW - 1));                     \
-                if ((SL) == 0) {                                                                               \
-                    if (stats_due && pw == 0 && p.stats_part != nullptr) write_stats(done_up);                 \
-                    stats_due = false;                                                                         \
-                }                                                                                              \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
-                MPN_WS_STAMP(t_work);                                                                          \
-                __builtin_amdgcn_s_barrier();                                                                  \
-                MPN_WS_STAMP(t_bar);                                                                           \
-            }
-            MPN_WS_INTERVAL(0, wC, aA, aA)
-            MPN_WS_INTERVAL(1, wA, aA, aB)
-            MPN_WS_INTERVAL(2, wB, aA, aC)
-            MPN_WS_INTERVAL(3, wC, aB, aA)
-            MPN_WS_INTERVAL(4, wA, aC, aB)
-            MPN_WS_INTERVAL(5, wB, aA, aC)
-            MPN_WS_INTERVAL(6, wC, aB, aA)
-            MPN_WS_INTERVAL(7, wA, aC, aA)
-            MPN_WS_INTERVAL(8, wB, aA, aA)
-#undef MPN_WS_INTERVAL
-#undef MPN_WS_WLOAD
-#undef MPN_WS_WSTORE
-            if (++c == nchunk) { c = 0; stats_due = true; done_up = cur_up; }
-            cur_up = nxt_up;
-            if (++nxt_c == nchunk) nxt_c = 0;
-            if (nxt_c == 0 && q + 2 < nq) nxt_up = unit_pos((q + 2) / nchunk);
-        }
-        if (p.stats_part != nullptr && pw == 0) write_stats(done_up);   // the block's last unit (Red complete at B(TS-1))
-        if (p.dbg && tid == 256) { p.dbg[blockIdx.x * 8 + 3] = t_work; p.dbg[blockIdx.x * 8 + 4] = t_bar; p.dbg[blockIdx.x * 8 + 5] = t_vm; }
-        return;
-    }
-
-    // =============================================================== consumers
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l15 = lane & 15, lq = lane >> 4;
-    f32x4_t acc[4][NT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    int aoff[4];                                                   // per-lane fragment base offsets inside an A image
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int row = wm * 64 + mt * 16 + l15;
-        aoff[mt] = ((row >> 4) * kHaloW + (row & 15)) * RS + lq * 16;
-    }
-    const int boff = (wn * (BN / 2) + l15) * 64 + ((lq ^ b_swz(l15)) << 4);
-    Frag aP[4], bP[NT], aQ[4], bQ[NT];
-    auto load_frags = [&](Frag (&a)[4], Frag (&b)[NT], const unsigned char* Ab, int a_off, const unsigned char* Wb, int b_off) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const Frag*>(Ab + aoff[mt] + a_off);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const Frag*>(Wb + boff + b_off + nt * 1024);
-    };
-    auto mma_all = [&](const Frag (&a)[4], const Frag (&b)[NT]) {
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Mma<T>::run(b[nt], a[mt], acc[mt][nt]);   // D^T = W^T x A^T
-    };
-    auto tap_off = [&](int sl) -> int {
-        const int ky = (sl * 11) >> 5;
-        return (ky * kHaloW + (sl - 3 * ky)) * RS;
-    };
-    T* __restrict__ y = reinterpret_cast<T*>(p.y);
-
-    __builtin_amdgcn_s_barrier();                                  // prologue barrier
-    load_frags(aP, bP, Aimg, tap_off(0), Wring, 0);
-    int q = 0, sl = 0, c = 0, j = 0, wslot = 0;                  // flat chunk, tap, chunk in unit, unit, weight ring slot
-    unsigned long long c_work = 0, c_bar = 0, c_epi = 0, t0 = p.dbg ? __builtin_amdgcn_s_memtime() : 0;
-    for (int i = 0; i < TS; ++i) {
-        const unsigned char* Ab = Aimg + (q & 1) * ABYTES;
-        const unsigned char* Wb = Wring + wslot * STAGE;
-        const int wslot1 = wslot + 1 == kWsNbuf ? 0 : wslot + 1;
-        load_frags(aQ, bQ, Ab, tap_off(sl) + 64, Wb, BN * 64);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_all(aP, bP);
-        __builtin_amdgcn_sched_barrier(0);
-        if (i + 1 < TS) {                                          // first fragments of the next stage, across the barrier
-            const int q1 = sl == 8 ? q + 1 : q, sl1 = sl == 8 ? 0 : sl + 1;
-            load_frags(aP, bP, Aimg + (q1 & 1) * ABYTES, tap_off(sl1), Wring + wslot1 * STAGE, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_all(aQ, bQ);
-        __builtin_amdgcn_sched_barrier(0);
-        const bool unit_end = sl == 8 && c == nchunk - 1;
-        MPN_WS_STAMP(c_work);
-        if (unit_end) {
-            // ---------------- epilogue of unit j: accumulators -> global, per-wave-row statistics -> Red
-            int ntile, mtile, img, oy0, ox0;
-            unit_coords(j, ntile, mtile, img, oy0, ox0);
-            const int cbase = ntile * BN + wn * (BN / 2) + lq * 4;
-            f32x4_t ssum[NT], ssq[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) { ssum[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ssq[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int row = wm * 64 + mt * 16 + l15;
-                const int oy = oy0 + (row >> 4), ox = ox0 + (row & 15);
-                const bool ok = oy < p.H && ox < p.W;
-                const long long pixel = ((long long)img * p.H + oy) * p.W + ox;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int c = cbase + nt * 16;
-                    if (ok && c < p.Cout) {
-                        const f32x4_t v = acc[mt][nt];
-                        ssum[nt] += v;
-                        ssq[nt] += v * v;
-                        store4(y + pixel * p.Cout + c, v);
-                    }
-                    acc[mt][nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                }
-            }
-            if (p.stats_part != nullptr) {
-                auto row_sum16 = [](float v) -> float {
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-                    return v;
-                };
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        ssum[nt][r] = row_sum16(ssum[nt][r]);
-                        ssq[nt][r] = row_sum16(ssq[nt][r]);
-                    }
-                if (l15 == 0) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int cl = wn * (BN / 2) + nt * 16 + lq * 4 + r;
-                            Red[(wm * 2 + 0) * BN + cl] = ssum[nt][r];
-                            Red[(wm * 2 + 1) * BN + cl] = ssq[nt][r];
-                        }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-        }
-        MPN_WS_STAMP(c_epi);
-        __builtin_amdgcn_s_barrier();                              // B(i)
-        MPN_WS_STAMP(c_bar);
-        wslot = wslot1;
-        if (++sl == 9) {
-            sl = 0;
-            ++q;
-            if (++c == nchunk) { c = 0; ++j; }
-        }
-    }
-    if (p.dbg && tid == 0) { p.dbg[blockIdx.x * 8 + 0] = c_work; p.dbg[blockIdx.x * 8 + 1] = c_bar; p.dbg[blockIdx.x * 8 + 2] = c_epi; }
-#undef MPN_WS_STAMP
-}
 
 // ------------------------------------------------------------------ weight packing
 // Packed order (per n-tile of BN output channels): [chunk][tap][stage][kstep(2)][BN][64 bytes].
@@ -1082,8 +597,7 @@ PackGeom pack_geom(int Kin, int Nout, int taps, int es) {
     // 1x1: 256-byte chunks only from 1024 bytes of K on (512 bf16 channels): with 128 / 256 input channels the 128-byte
     // chunks (20 KB A image, three blocks per CU) measured faster - 128->128 @128x128: 57.7 -> 53.1 us, 256->256 @64x64:
     // 42.4 -> 37.2 us - while the 512 / 1024-channel layers on the small maps prefer fewer, longer chunks
-    const char* force = getenv("MPN_CONV_RB");
-    const int pref = force ? atoi(force) : (taps == 9 ? 128 : (kbytes >= 1024 ? 256 : 128));
+    const int pref = taps == 9 ? 128 : (kbytes >= 1024 ? 256 : 128);
     g.row_bytes = (kbytes <= 128 || pref == 128) ? 128 : 256;
     g.nchunk = (kbytes + g.row_bytes - 1) / g.row_bytes;
     const int stages_per_tap = g.row_bytes >> 7;
@@ -1157,109 +671,61 @@ extern "C" int mpn_conv_pack_weights_batched(const void* descs_device, int ndesc
     return MPN_OK;
 }
 
-// diagnostic hook (not part of the public header): device buffer of 8 u64 per block, or NULL
+#ifdef MPN_DIAG
+// diagnostic build only (never in the product library): device buffer of 8 u64 per block, or NULL
 static void* g_conv_dbg = nullptr;
-extern "C" void mpn_debug_set_conv_stamps(void* buf) { g_conv_dbg = buf; }
-static int g_conv_lds_epilogue = -1;   // MPN_CONV_LDS_EPILOGUE=0 / mpn_debug_set_conv_epilogue(0): the direct epilogue
-extern "C" void mpn_debug_set_conv_epilogue(int on) { g_conv_lds_epilogue = on; }
+extern "C" void mpn_diag_set_conv_stamps(void* buf) { g_conv_dbg = buf; }
+#endif
 
 extern "C" int mpn_conv_num_parts(int N, int H, int W, int ksize) {
     if (ksize == 3) return N * ((H + 7) / 8) * ((W + 15) / 16);
     return (int)(((long long)N * H * W + 127) / 128);
 }
 
-template <typename T, int TAPS, int BN, int RB, bool RING, int MT = 4, bool M32 = false>
+template <int TAPS, int BN, int RB> constexpr int conv_smem_bytes() {
+    return (TAPS == 9 ? kHaloW * kHaloH : 128) * a_row_stride(RB) + 2 * (2 * BN * 64);
+}
+
+template <typename T, int TAPS, int BN, int RB>
 static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
-    constexpr int NPIX = TAPS == 9 ? kHaloW * (MT * 2 + 2) : MT * 32;
-    constexpr int smem = NPIX * a_row_stride(RB) + (RING ? 3 * (BN * 64) : 2 * (2 * BN * 64));
-    static_assert(sizeof(T) != 2 || smem >= MT * 32 * (BN * 2 + 8) + 4 * BN * 4 + 16, "the output image of the epilogue fits");
-    static bool attr_set = false;
-    if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_kernel<T, TAPS, BN, RB, RING, MT, M32>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
-    conv_mfma_kernel<T, TAPS, BN, RB, RING, MT, M32><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
+    constexpr int smem = conv_smem_bytes<TAPS, BN, RB>();
+    static_assert(sizeof(T) != 2 || smem >= 128 * (BN * 2 + 8) + 4 * BN * 4, "the output image of the epilogue fits");
+    static unsigned long long attr_mask = 0;
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_kernel<T, TAPS, BN, RB>, smem, &attr_mask));
+    conv_mfma_kernel<T, TAPS, BN, RB><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
-
-template <int BN>
-static int launch_conv_ws(const ConvParams& p, int m_tiles, hipStream_t st) {
-    const int smem = 2 * (kHaloW * kHaloH * 160) + kWsNbuf * (2 * BN * 64) + 16 * BN + 8 * p.Cin;
-    if (smem > 160 * 1024) return -100;   // caller falls back to the 4-wave kernel
-    static int attr_set = 0;
-    if (attr_set < smem) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_ws_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = smem;
-    }
-    const int units = m_tiles * p.n_tiles;
-    const int grid = units < 256 ? units : 256;
-    conv_ws_kernel<BN><<<dim3((unsigned)grid), dim3(kWsThreads), smem, st>>>(p, units);
-    MPN_LAUNCH_CHECK();
-    return MPN_OK;
-}
-
-// kernel-variant switches (environment defaults; mpn_debug_set_conv_variant overrides them at run time so that the tests
-// can cover the variants that are off by default): -1 = read the environment
-static int g_ws_min = -1, g_big_min = -1, g_ring = -1;
-extern "C" void mpn_debug_set_conv_variant(int ws_min_units, int big_min_blocks, int ring) {
-    g_ws_min = ws_min_units; g_big_min = big_min_blocks; g_ring = ring;
-}
-// MPN_CONV_M32: bit 0 = 3x3 layers, bit 1 = 1x1 layers on v_mfma_f32_32x32x16_bf16 (bf16 build, LDS epilogue)
-static int g_m32 = -1;
-static int conv_m32_mask() {
-    if (g_m32 < 0) { const char* e = getenv("MPN_CONV_M32"); g_m32 = e ? atoi(e) : MPN_CONV_M32_DEFAULT; }
-    return g_m32;
-}
-extern "C" void mpn_debug_set_conv_m32(int mask) { g_m32 = mask; }
 
 template <typename T, int TAPS, int BN>
 static int launch_conv(const ConvParams& p, int m_tiles, hipStream_t st) {
-    // MPN_CONV_WS=<min units>: the warp-specialised persistent kernel for bf16 3x3 layers with at least that many tiles
-    if constexpr (sizeof(T) == 2 && TAPS == 9) {
-        if (g_ws_min < 0) { const char* e = getenv("MPN_CONV_WS"); g_ws_min = e ? atoi(e) : 0; }
-        const int ws_min = g_ws_min;
-        if (ws_min > 0 && m_tiles * p.n_tiles >= ws_min && p.row_bytes == 128 && p.up_res == nullptr && p.tail.mode == 0 &&
-            p.Cin % 8 == 0) {
-            const int rc = launch_conv_ws<BN>(p, m_tiles, st);
-            if (rc != -100) return rc;
-        }
-    }
-    // MPN_CONV_RING=1 selects the 3-blocks-per-CU ring variant for 128-byte chunks. Measured equal to the 2-buffer
-    // variant (211 vs 210 us on 3x3 128->128 @ [32,128,128]): occupancy is not what limits this kernel, so the
-    // simpler variant stays the default.
-    if (g_ring < 0) { const char* e = getenv("MPN_CONV_RING"); g_ring = e ? atoi(e) : 0; }
-    const int ring = g_ring;
-    // 256-pixel tiles (MPN_CONV_BIG=<min blocks>; off by default - measured equal to the 128-pixel tiles)
-    if constexpr (sizeof(T) == 2 && TAPS == 9) {
-        if (g_big_min < 0) { const char* e = getenv("MPN_CONV_BIG"); g_big_min = e ? atoi(e) : 0; }
-        const int big_min = g_big_min;
-        const int m_big = p.N * ((p.tiles_y + 1) >> 1) * p.tiles_x;
-        if (big_min > 0 && m_big * p.n_tiles >= big_min && p.row_bytes == 128 && p.up_res == nullptr && p.tail.mode == 0)
-            return launch_conv_rb<T, TAPS, BN, 128, true, 8>(p, m_big, st);
-    }
-    if constexpr (sizeof(T) == 2) {
-        if ((conv_m32_mask() & (TAPS == 9 ? 1 : 2)) && p.up_res == nullptr && p.lds_epilogue && !(ring && BN == 128 && p.row_bytes == 128)) {
-            if (p.row_bytes == 256) return launch_conv_rb<T, TAPS, BN, 256, false, 4, true>(p, m_tiles, st);
-            return launch_conv_rb<T, TAPS, BN, 128, false, 4, true>(p, m_tiles, st);
-        }
-    }
-    if (p.row_bytes == 256) return launch_conv_rb<T, TAPS, BN, 256, false>(p, m_tiles, st);
-    if (ring && BN == 128) return launch_conv_rb<T, TAPS, BN, 128, true>(p, m_tiles, st);
-    return launch_conv_rb<T, TAPS, BN, 128, false>(p, m_tiles, st);
+    if (p.row_bytes == 256) return launch_conv_rb<T, TAPS, BN, 256>(p, m_tiles, st);
+    return launch_conv_rb<T, TAPS, BN, 128>(p, m_tiles, st);
+}
+
+static int conv_fill_params(ConvParams& p, const PackGeom& g, const void* x, const void* w_packed, void* y, int N, int H, int W,
+                            int Cin, int Cout, int x_stride, int y_stride, int ksize, const float* in_scale,
+                            const float* in_shift, int in_act, float* stats_part, const void* up_res) {
+    p.x = x; p.wp = w_packed; p.y = y;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
+    p.stats_part = stats_part; p.up_res = up_res;
+#ifdef MPN_DIAG
+    p.dbg = (unsigned long long*)g_conv_dbg;
+#endif
+    // measured: +10..14 % on 1x1 layers with several n-tiles (A rows re-read from the same L2), -4 % on single-n-tile layers
+    p.xcd_remap = (ksize == 1 && g.n_tiles > 1);
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.x_stride = x_stride > 0 ? x_stride : Cin;
+    p.y_stride = y_stride > 0 ? y_stride : Cout;
+    p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
+    p.M = (long long)N * H * W;
+    p.row_bytes = g.row_bytes; p.nchunk = g.nchunk; p.n_tiles = g.n_tiles; p.wp_tile_bytes = g.tile_bytes;
+    return MPN_OK;
 }
 
 extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
-                            int ksize, int dtype, const float* in_scale, const float* in_shift, int in_act,
-                            float* stats_part, const void* up_res, mpn_stream_t stream) {
-    return mpn_conv_fwd_fin(x, w_packed, y, N, H, W, Cin, Cout, ksize, dtype, in_scale, in_shift, in_act, stats_part, up_res,
-                            nullptr, stream);
-}
-
-extern "C" int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
-                                int ksize, int dtype, const float* in_scale, const float* in_shift, int in_act,
-                                float* stats_part, const void* up_res, const mpn_bn_tail_t* tail, mpn_stream_t stream) {
+                            int x_stride, int y_stride, int ksize, int dtype, const float* in_scale, const float* in_shift,
+                            int in_act, float* stats_part, const void* up_res, mpn_stream_t stream) {
     MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv: ksize must be 1 or 3 (got %d)", ksize);
     MPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, MPN_ERR_BAD_SHAPE, "conv: bad shape");
     MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "conv: dtype %d", dtype);
@@ -1267,6 +733,9 @@ extern "C" int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, in
     const int ve = 16 / es;
     MPN_REQUIRE(Cin % ve == 0 && Cout % ve == 0, MPN_ERR_BAD_SHAPE,
                 "conv: Cin (%d) and Cout (%d) must be multiples of %d", Cin, Cout, ve);
+    MPN_REQUIRE((x_stride == 0 || (x_stride >= Cin && x_stride % ve == 0)) && (y_stride == 0 || (y_stride >= Cout && y_stride % ve == 0)),
+                MPN_ERR_BAD_SHAPE, "conv: pixel strides (%d, %d) must be 0 or multiples of %d not below the channel counts", x_stride,
+                y_stride, ve);
     MPN_REQUIRE(x && w_packed && y, MPN_ERR_BAD_ARG, "conv: null pointer");
     MPN_REQUIRE(mpn_aligned16(x) && mpn_aligned16(w_packed) && mpn_aligned16(y), MPN_ERR_BAD_ALIGN,
                 "conv: pointers must be 16-byte aligned");
@@ -1275,24 +744,8 @@ extern "C" int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, in
                 "conv: upsample-add epilogue needs ksize 1 and even H, W");
     const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es);
     ConvParams p;
-    p.x = x; p.wp = w_packed; p.y = y;
-    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
-    p.stats_part = stats_part; p.up_res = up_res;
-    p.dbg = (unsigned long long*)g_conv_dbg;
-    if (g_conv_lds_epilogue < 0) { const char* e = getenv("MPN_CONV_LDS_EPILOGUE"); g_conv_lds_epilogue = e ? atoi(e) : 1; }
-    p.lds_epilogue = g_conv_lds_epilogue;
-    static int xcd_remap = -1;
-    if (xcd_remap < 0) { const char* e = getenv("MPN_CONV_XCD"); xcd_remap = e ? atoi(e) : 1; }
-    // measured: +10..14 % on 1x1 layers with several n-tiles (A rows re-read from the same L2), -4 % on single-n-tile layers
-    p.xcd_remap = (xcd_remap == 2) || (xcd_remap == 1 && ksize == 1 && g.n_tiles > 1);
-    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-    p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
-    p.M = (long long)N * H * W;
-    p.row_bytes = g.row_bytes; p.nchunk = g.nchunk; p.n_tiles = g.n_tiles; p.wp_tile_bytes = g.tile_bytes;
+    conv_fill_params(p, g, x, w_packed, y, N, H, W, Cin, Cout, x_stride, y_stride, ksize, in_scale, in_shift, in_act, stats_part, up_res);
     const int m_tiles = mpn_conv_num_parts(N, H, W, ksize);
-    MPN_REQUIRE(tail == nullptr || tail->mode == 0 || stats_part != nullptr, MPN_ERR_BAD_ARG, "conv: a bn tail needs stats_part");
-    if (int rc = bn_tail_check(tail, Cout, "conv")) return rc;
-    bn_tail_prepare(tail, m_tiles, Cout, &p.tail);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MPN_F32) {
         if (ksize == 3) return g.BN == 128 ? launch_conv<float, 9, 128>(p, m_tiles, st) : launch_conv<float, 9, 64>(p, m_tiles, st);
@@ -1302,27 +755,33 @@ extern "C" int mpn_conv_fwd_fin(const void* x, const void* w_packed, void* y, in
     return g.BN == 128 ? launch_conv<bf16_t, 1, 128>(p, m_tiles, st) : launch_conv<bf16_t, 1, 64>(p, m_tiles, st);
 }
 
+template <int BN>
+static int launch_conv_grouped(const ConvGroup& grp, int grid, hipStream_t st) {
+    constexpr int smem = conv_smem_bytes<9, BN, 128>();
+    static unsigned long long attr_mask = 0;
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_grouped_kernel<bf16_t, 9, BN, 128>, smem, &attr_mask));
+    conv_mfma_grouped_kernel<bf16_t, 9, BN, 128><<<dim3((unsigned)grid), dim3(kThreads), smem, st>>>(grp);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
 /* Several independent 3x3 convolutions of the same channel geometry in ONE grid (the four pyramid levels of a subnet
- * stage: keypoint_subnet.py:64-91 applies phi_subnet to p2..p5 independently). bf16, no fused residual, at most 4 jobs,
- * the default 128-pixel kernel; anything else runs as the separate launches it replaces. Results are those of
- * mpn_conv_fwd per job, bit for bit (same kernel body, same tiles). */
+ * stage: keypoint_subnet.py:64-91 applies phi_subnet to p2..p5 independently). bf16 3x3 with at most 4 jobs run in one
+ * grid; anything else runs as the separate launches it replaces. Results are those of mpn_conv_fwd per job, bit for bit
+ * (same kernel body, same tiles). y_stride[j] (may be NULL = dense): pixel stride of job j's output. */
 extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N,
-                                    const int* H, const int* W, int Cin, int Cout, int ksize, int dtype,
+                                    const int* H, const int* W, int Cin, int Cout, const int* y_stride, int ksize, int dtype,
                                     const float* const* in_scale, const float* const* in_shift, int in_act,
                                     float* const* stats_part, mpn_stream_t stream) {
     MPN_REQUIRE(njobs > 0 && x && w_packed && y && H && W && in_scale && in_shift && stats_part, MPN_ERR_BAD_ARG,
                 "conv grouped: bad arguments");
     const int es = dtype == MPN_F32 ? 4 : 2;
     const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es);
-    if (g_conv_lds_epilogue < 0) { const char* e = getenv("MPN_CONV_LDS_EPILOGUE"); g_conv_lds_epilogue = e ? atoi(e) : 1; }
-    static int grouped = -1;
-    if (grouped < 0) { const char* e = getenv("MPN_CONV_GROUPED"); grouped = e ? atoi(e) : 1; }
-    const bool fast = grouped && dtype == MPN_BF16 && ksize == 3 && njobs <= kMaxGroup && g.row_bytes == 128 &&
-                      g_conv_lds_epilogue != 0 && g_conv_dbg == nullptr && g_ws_min <= 0 && g_big_min <= 0 && g_ring <= 0;
+    const bool fast = dtype == MPN_BF16 && ksize == 3 && njobs <= kMaxGroup && g.row_bytes == 128;
     if (!fast) {
         for (int j = 0; j < njobs; ++j)
-            if (int rc = mpn_conv_fwd_fin(x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, ksize, dtype, in_scale[j], in_shift[j],
-                                          in_act, stats_part[j], nullptr, nullptr, stream))
+            if (int rc = mpn_conv_fwd(x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, 0, y_stride ? y_stride[j] : 0, ksize, dtype,
+                                      in_scale[j], in_shift[j], in_act, stats_part[j], nullptr, stream))
                 return rc;
         return MPN_OK;
     }
@@ -1334,60 +793,16 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
         MPN_REQUIRE(mpn_aligned16(x[j]) && mpn_aligned16(w_packed[j]) && mpn_aligned16(y[j]), MPN_ERR_BAD_ALIGN,
                     "conv grouped: pointers must be 16-byte aligned");
         MPN_REQUIRE((in_scale[j] == nullptr) == (in_shift[j] == nullptr), MPN_ERR_BAD_ARG, "conv grouped: scale/shift mismatch");
-        ConvParams& p = grp.p[j];
-        p.x = x[j]; p.wp = w_packed[j]; p.y = y[j];
-        p.in_scale = in_scale[j]; p.in_shift = in_shift[j]; p.in_act = in_act;
-        p.stats_part = stats_part[j]; p.up_res = nullptr; p.dbg = nullptr;
-        p.lds_epilogue = 1; p.xcd_remap = 0;
-        p.N = N; p.H = H[j]; p.W = W[j]; p.Cin = Cin; p.Cout = Cout;
-        p.tiles_x = (W[j] + 15) / 16; p.tiles_y = (H[j] + 7) / 8;
-        p.M = (long long)N * H[j] * W[j];
-        p.row_bytes = g.row_bytes; p.nchunk = g.nchunk; p.n_tiles = g.n_tiles; p.wp_tile_bytes = g.tile_bytes;
-        bn_tail_prepare(nullptr, 0, Cout, &p.tail);
+        const int ys = y_stride ? y_stride[j] : 0;
+        MPN_REQUIRE(ys == 0 || (ys >= Cout && ys % 8 == 0), MPN_ERR_BAD_SHAPE, "conv grouped: bad output pixel stride %d", ys);
+        conv_fill_params(grp.p[j], g, x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, 0, ys, 3, in_scale[j], in_shift[j], in_act,
+                         stats_part[j], nullptr);
+        grp.p[j].xcd_remap = 0;
         grp.begin[j] = begin;
         begin += mpn_conv_num_parts(N, H[j], W[j], 3) * g.n_tiles;
     }
     for (int j = njobs; j <= kMaxGroup; ++j) grp.begin[j] = begin;
     grp.njobs = njobs;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int NPIX = kHaloW * kHaloH;
-    if (g.BN == 128) {
-        constexpr int smem = NPIX * a_row_stride(128) + 2 * (2 * 128 * 64);
-        static bool attr_set = false;
-        if (!attr_set) {
-            MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
-        }
-        if (conv_m32_mask() & 1) {
-            static bool attr32 = false;
-            if (!attr32) {
-                MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr32 = true;
-            }
-            conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false, true><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
-        } else
-        conv_mfma_grouped_kernel<bf16_t, 9, 128, 128, false><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
-    } else {
-        constexpr int smem = NPIX * a_row_stride(128) + 2 * (2 * 64 * 64);
-        static bool attr_set = false;
-        if (!attr_set) {
-            MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false>,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-            attr_set = true;
-        }
-        if (conv_m32_mask() & 1) {
-            static bool attr32 = false;
-            if (!attr32) {
-                MPN_HIP(hipFuncSetAttribute((const void*)conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false, true>,
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-                attr32 = true;
-            }
-            conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false, true><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
-        } else
-        conv_mfma_grouped_kernel<bf16_t, 9, 64, 128, false><<<dim3((unsigned)begin), dim3(kThreads), smem, st>>>(grp);
-    }
-    MPN_LAUNCH_CHECK();
-    return MPN_OK;
+    return g.BN == 128 ? launch_conv_grouped<128>(grp, begin, st) : launch_conv_grouped<64>(grp, begin, st);
 }

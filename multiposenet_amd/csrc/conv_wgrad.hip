@@ -15,7 +15,6 @@
 // LDS rows are XOR-swizzled in 32-byte segments so the 8 pixel rows one half-wave touches per
 // transposed read land in 8 different bank groups.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -39,7 +38,9 @@ struct WgradParams {
     int ntiles;   // pixel tiles
     int nsplit;
     int n_cg, n_cb;
-    unsigned long long* dbg;   // diagnostics (mpn_debug_set_wgrad_stamps): per-wave phase times, else NULL
+#ifdef MPN_DIAG
+    unsigned long long* dbg;   // diagnostic build only (mpn_diag_set_wgrad_stamps): per-wave phase times, else NULL
+#endif
 };
 
 __device__ __forceinline__ int fsw256(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
@@ -491,9 +492,13 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
         }
     };
 
+#ifdef MPN_DIAG
     unsigned long long ph[4] = {0, 0, 0, 0}, t_prev = 0;
 #define MPN_WG_STAMP(k) do { if (p.dbg) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                                           ph[k] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define MPN_WG_STAMP(k) do { } while (0)
+#endif
     // Schedule. The 8 waves form two groups (waves 0-3 / 4-7: one wave of each group per SIMD) that run the SAME loop
     //     load(next) ; barrier ; MFMAs(tile i) ; barrier ; commit(next)
     // half a period apart: group 1 executes one barrier more before the loop and group 0 one more after it, so while
@@ -515,7 +520,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
         __syncthreads();
         if (ntl > 1) commit_tile(smem + ABYTES, smem + 2 * ABYTES + DBYTES);
     }
+#ifdef MPN_DIAG
     if (p.dbg) t_prev = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll 1
     for (int it = 0; it < ntl; ++it) {
         const int buf = it & 1;
@@ -587,10 +594,12 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
         MPN_WG_STAMP(0);
     }
     if (STAGGER && grp == 0) __syncthreads();
+#ifdef MPN_DIAG
     if (p.dbg && lane == 0) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) p.dbg[((size_t)blockIdx.x * 8 + wave) * 4 + k] = ph[k];
     }
+#endif
 #undef MPN_WG_STAMP
 
     float* __restrict__ dst = p.part + (long long)split * TAPS * p.Cin * p.Cout;
@@ -647,12 +656,8 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t st) {
     constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int smem = 2 * NPIXA * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * (RBA / 2) * (int)sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_bf16_kernel<TAPS, RBA, RBD, WM, STAGGER>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_bf16_kernel<TAPS, RBA, RBD, WM, STAGGER>, smem, &attr_mask));
     conv_wgrad_bf16_kernel<TAPS, RBA, RBD, WM, STAGGER><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(512), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
@@ -662,12 +667,8 @@ template <typename T, int TAPS, int RBA, int RBD>
 int launch_wgrad_g(const WgradParams& p, hipStream_t st) {
     constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int smem = NPIXA * RBA + 128 * RBD;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MPN_HIP(hipFuncSetAttribute((const void*)conv_wgrad_kernel<T, TAPS, RBA, RBD>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    static unsigned long long attr_mask = 0;
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_kernel<T, TAPS, RBA, RBD>, smem, &attr_mask));
     conv_wgrad_kernel<T, TAPS, RBA, RBD><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
@@ -680,12 +681,16 @@ int launch_wgrad(const WgradParams& p, hipStream_t st) {
     return launch_wgrad_g<T, TAPS, (TAPS == 9 ? 64 : 256), 256>(p, st);
 }
 
+#ifdef MPN_DIAG
 void* g_wgrad_dbg = nullptr;
+#endif
 
 }  // namespace
 
-/* diagnostics only (tools/stamp_wgrad.py): buf = u64 [blocks][8 waves][4 phases] of s_memtime ticks, or NULL */
-extern "C" void mpn_debug_set_wgrad_stamps(void* buf) { g_wgrad_dbg = buf; }
+#ifdef MPN_DIAG
+/* diagnostic build only (tools/stamp_wgrad.py): buf = u64 [blocks][8 waves][4 phases] of s_memtime ticks, or NULL */
+extern "C" void mpn_diag_set_wgrad_stamps(void* buf) { g_wgrad_dbg = buf; }
+#endif
 
 extern "C" int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, int ksize, int dtype) {
     return wgrad_geom(N, H, W, Cin, Cout, ksize, dtype == MPN_F32 ? 4 : 2).nsplit;
@@ -714,13 +719,13 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
     p.M = (long long)N * H * W;
     p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = g.n_cg; p.n_cb = g.n_cb;
+#ifdef MPN_DIAG
     p.dbg = (unsigned long long*)g_wgrad_dbg;
+#endif
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MPN_F32) return ksize == 3 ? launch_wgrad<float, 9>(p, st) : launch_wgrad<float, 1>(p, st);
-    static const int stagger = getenv("MPN_WGRAD_STAGGER") ? atoi(getenv("MPN_WGRAD_STAGGER")) : 6;   // bit per geometry (1x1, narrow 3x3, 3x3): measured best
-    if (ksize == 1)
-        return (stagger & 1) ? launch_wgrad_bf16<1, 256, 256, 4, true>(p, st) : launch_wgrad_bf16<1, 256, 256, 4, false>(p, st);
-    if (Cout <= 64)
-        return (stagger & 2) ? launch_wgrad_bf16<9, 256, 128, 4, true>(p, st) : launch_wgrad_bf16<9, 256, 128, 4, false>(p, st);
-    return (stagger & 4) ? launch_wgrad_bf16<9, 128, 256, 2, true>(p, st) : launch_wgrad_bf16<9, 128, 256, 2, false>(p, st);
+    // the two wave groups run staggered by half a period on the 3x3 geometries, in step on 1x1 (measured best per geometry)
+    if (ksize == 1) return launch_wgrad_bf16<1, 256, 256, 4, false>(p, st);
+    if (Cout <= 64) return launch_wgrad_bf16<9, 256, 128, 4, true>(p, st);
+    return launch_wgrad_bf16<9, 128, 256, 2, true>(p, st);
 }

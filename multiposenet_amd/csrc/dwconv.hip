@@ -9,7 +9,6 @@
 // The following batch-norm's partial statistics come out of the same pass (wave shuffles over
 // the lanes that share a channel vector, then one LDS hop across the 4 waves).
 #include "common.h"
-#include "bn_tail.h"
 #include <stdlib.h>
 
 namespace {
@@ -36,7 +35,6 @@ struct DwParams {
     int tiles_x, tiles_y;
     int nvg;            // channel vectors handled per block (<= 8)
     int cblocks;        // channel blocks
-    BnTailDev tail;     // batch-norm finalize fused into the last-finishing blocks (forward kernel, mode 0: off)
     // data-gradient kernels with the batch-norm backward reduction of the layer they feed fused in (BNR): the output is
     // dA of that layer, bnr_x its raw conv output; part then receives sum(g), sum(g * xhat) instead of the forward statistics
     const void* bnr_x;
@@ -218,109 +216,6 @@ __device__ __forceinline__ void dw_tile_origin(const DwParams& p, int t, int th,
     img = t2 / p.tiles_y;
     oy0 = ty * th;
     ox0 = tx * tw;
-}
-
-// Blocks are persistent over a strided set of tiles of ONE channel block: the 9 x VE weights stay in registers, the
-// batch-norm partial sums accumulate in registers across tiles and are reduced once per block (one partial row per
-// block keeps the finalize kernel short).
-template <typename T, int STRIDE>
-__global__ __launch_bounds__(kThreads, 3) void dwconv_fwd_kernel(const DwParams p, int nsplit) {
-    using TL = DwTile<STRIDE>;
-    constexpr int VE = Vec16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    float* tile = smem_f;                                   // [HH*HW][nvg*VE]
-    float* red = smem_f + TL::HH * TL::HW * p.nvg * VE;         // [4][16][8]
-
-    const int cb = blockIdx.x % p.cblocks;
-    const int split = blockIdx.x / p.cblocks;
-    const int c0 = cb * p.nvg * VE;
-    const int cb_vecs = min(p.nvg, (p.C - c0) / VE);
-    const int cstride = p.nvg * VE;            // channels (floats) per LDS pixel
-    const int ncg = cstride / 4;               // 4-channel compute lanes per pixel (<= 16)
-    const int cg = threadIdx.x % ncg;
-    const int pt = threadIdx.x / ncg;
-    const int npt = kThreads / ncg;
-    const bool cg_ok = cg * 4 < cb_vecs * VE;
-    float wr[9][4];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            wr[t][j] = cg_ok ? p.w[(p.flip ? 8 - t : t) * p.C + c0 + cg * 4 + j] : 0.f;
-
-    f32x2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};   // sum / sum of squares
-    T* __restrict__ y = reinterpret_cast<T*>(p.y);
-
-    const HaloAffine<T> aff = load_halo_affine<T>(p, c0, cb_vecs);
-    const int ntiles = p.N * p.tiles_y * p.tiles_x;
-    HaloRegs<T, STRIDE> hr;
-    int img, oy0, ox0;
-    // loop shape: load(next) ; barrier ; compute(this) ; barrier ; commit(next) - the prefetch registers are written
-    // and read inside ONE iteration (carried across the back edge, hipcc copies them right after the loads and waits)
-    if (split < ntiles) {
-        dw_tile_origin(p, split, TL::TH, TL::TW, img, oy0, ox0);
-        hr.load(p, img, oy0, ox0, c0, cb_vecs);
-        hr.commit(p, aff, tile);
-    }
-    for (int t = split; t < ntiles; t += nsplit) {
-        dw_tile_origin(p, t, TL::TH, TL::TW, img, oy0, ox0);
-        const bool more = t + nsplit < ntiles;
-        if (more) {   // prefetch the next tile: its loads fly while this tile is computed
-            int img2, oy2, ox2;
-            dw_tile_origin(p, t + nsplit, TL::TH, TL::TW, img2, oy2, ox2);
-            hr.load(p, img2, oy2, ox2, c0, cb_vecs);
-        }
-        __syncthreads();  // this tile's halo image is complete
-        // The phase is bound by vector INSTRUCTION ISSUE (~80 instructions per 4-channel output before this rewrite,
-        // 27 of them the 9 LDS reads + 18 packed FMAs): a thread's column (oxl) and its LDS / output offsets are fixed
-        // across its pixels (npt is a multiple of the tile width), rows advance by constant strides, the output address
-        // is a per-tile scalar base + a 32-bit per-thread offset, and interior tiles skip the bounds tests. All 9 LDS
-        // reads of a pixel are issued before its first FMA (fenced: hipcc otherwise emits read / lgkmcnt(0) / FMA nine
-        // times - nine exposed LDS round trips).
-        {
-            const int oxl = pt % TL::TW, oyl0 = pt / TL::TW, dyl = npt / TL::TW;      // npt % TW == 0 (host-checked)
-            const float* lbase = tile + ((oyl0 * STRIDE) * TL::HW + oxl * STRIDE) * cstride + cg * 4;
-            const int lstep = dyl * STRIDE * TL::HW * cstride;
-            T* ytile = y + (((long long)img * p.OH + oy0) * p.OW + ox0) * p.C + c0;   // scalar
-            int yoff = (oyl0 * p.OW + oxl) * p.C + cg * 4;
-            const int ystep = dyl * p.OW * p.C;
-            const bool full = oy0 + TL::TH <= p.OH && ox0 + TL::TW <= p.OW;          // scalar
-            const bool col_ok = cg_ok && ox0 + oxl < p.OW;
-#pragma unroll 1
-            for (int oyl = oyl0; oyl < TL::TH; oyl += dyl, lbase += lstep, yoff += ystep) {
-                float4 q[9];
-#pragma unroll
-                for (int t = 0; t < 9; ++t) q[t] = *reinterpret_cast<const float4*>(lbase + ((t / 3) * TL::HW + (t % 3)) * cstride);
-                __builtin_amdgcn_sched_barrier(0);
-                f32x2_t a01 = {0.f, 0.f}, a23 = {0.f, 0.f};   // packed FP32 FMAs (v_pk_fma_f32): two channels per instruction
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    a01 += (f32x2_t){q[t].x, q[t].y} * (f32x2_t){wr[t][0], wr[t][1]};
-                    a23 += (f32x2_t){q[t].z, q[t].w} * (f32x2_t){wr[t][2], wr[t][3]};
-                }
-                if (full ? cg_ok : (col_ok && oy0 + oyl < p.OH)) {
-                    s01 += a01; s23 += a23;
-                    q01 += a01 * a01; q23 += a23 * a23;
-                    store4x2(ytile + yoff, a01, a23);
-                }
-            }
-        }
-        __syncthreads();  // everybody is done reading this tile
-        if (more) hr.commit(p, aff, tile);
-    }
-    if (p.part != nullptr) {
-        float st[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
-        reduce_same_vg<8>(st, ncg, red);
-        if ((int)threadIdx.x < ncg && cg_ok) {
-            float* dst = p.part + (long long)split * 2 * p.C + c0 + cg * 4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (p.tail.mode) { st_sc1(&dst[j], st[j]); st_sc1(&dst[p.C + j], st[4 + j]); }
-                else { dst[j] = st[j]; dst[p.C + j] = st[4 + j]; }
-            }
-        }
-        if (p.tail.mode) bn_tail(p.tail, p.part, p.C, split, c0, cstride, cb, threadIdx.x, kThreads, reinterpret_cast<int*>(red));
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1198,11 +1093,7 @@ int fill_params(DwParams& p, int N, int H, int W, int C, int stride, int dtype) 
     MPN_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % ve == 0, MPN_ERR_BAD_SHAPE,
                 "dwconv: C (%d) must be a multiple of %d", C, ve);
     p.N = N; p.H = H; p.W = W; p.C = C;
-    {
-        static int xr = -1;
-        if (xr < 0) { const char* e = getenv("MPN_DW_XCD"); xr = e ? atoi(e) : 1; }
-        p.xcd_remap = xr;
-    }
+    p.xcd_remap = 1;
     tf_same_pad(H, stride, &p.OH, &p.pad_t);
     tf_same_pad(W, stride, &p.OW, &p.pad_l);
     const int th = stride == 1 ? 8 : 4, tw = stride == 1 ? 16 : 8;
@@ -1221,8 +1112,8 @@ template <int STRIDE> size_t dw_smem(int ve, int nred, int nvg) {
 }
 
 template <typename K> int set_smem(K kernel, size_t bytes) {
-    if (bytes > 48 * 1024)
-        MPN_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    static unsigned long long attr_mask = 0;   // (one instance per kernel type K; the sizes used are <= the first one's)
+    if (bytes > 48 * 1024) MPN_HIP(mpn_ensure_dynamic_lds((const void*)kernel, (int)bytes, &attr_mask));
     return MPN_OK;
 }
 
@@ -1411,32 +1302,14 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
 }
 }  // namespace
 
-// register sliding-window forward kernel (default) vs the LDS-tile kernel (MPN_DW_SW=0)
-static int g_dw_sw = -1;
-static bool dw_use_sw() {
-    if (g_dw_sw < 0) { const char* e = getenv("MPN_DW_SW"); g_dw_sw = e ? atoi(e) : 1; }
-    return g_dw_sw != 0;
-}
-/* diagnostic hook (not part of the public header): 1 = sliding-window forward kernel, 0 = LDS-tile kernel, -1 = MPN_DW_SW / default.
-   Only call between steps: the stats slab geometry (mpn_dwconv_fwd_num_parts) follows the choice. */
-extern "C" void mpn_debug_set_dw_kernel(int sw) { g_dw_sw = sw; }
-// stride-1 launches use the two-column kernel (MPN_DW_XT=1: the one-column kernel)
-// MPN_DW_XT: bit 0 = forward (with the producer's affine), bit 1 = plain data gradient, bit 2 = data gradient with the
-// fused batch-norm reduction
-static int dw_xt(const DwParams& p) {
-    static int mask = -1;
-    if (mask < 0) { const char* e = getenv("MPN_DW_XT"); mask = e ? atoi(e) : 7; }
-    if (!(p.H == p.OH && p.W == p.OW)) return 1;
-    // (a launch that writes forward statistics counts as "forward" whatever its affine: mpn_dwconv_num_parts must agree)
-    const int kind = p.bnr_x != nullptr ? 4 : ((p.in_scale != nullptr || p.part != nullptr) ? 1 : 2);
-    return (mask & kind) ? 2 : 1;
-}
+// stride-1 launches use the two-column kernel (forward, plain data gradient and data gradient with the fused batch-norm
+// reduction alike), stride 2 the one-column kernel
+static int dw_xt(const DwParams& p) { return (p.H == p.OH && p.W == p.OW) ? 2 : 1; }
 struct DwSwGeom { int ncg, cols, xblocks, yblocks, cblocks; };
 static DwSwGeom dw_sw_geom(const DwParams& p) {
     DwSwGeom g;
     const int cg_total = p.C / 4;
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("MPN_DW_SW_NCG"); cap = e ? atoi(e) : 32; }   // blocks of <= 128 channels: more columns per block, 4x fewer statistics rows on the 512 / 1024-channel maps (21.6 -> 18.8, 15.4 -> 13.0 us)
+    const int cap = 32;   // blocks of <= 128 channels: more columns per block, 4x fewer statistics rows on the 512 / 1024-channel maps (21.6 -> 18.8, 15.4 -> 13.0 us)
     g.ncg = cg_total < cap ? cg_total : cap;
     g.cols = kThreads / g.ncg;
     g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
@@ -1445,14 +1318,7 @@ static DwSwGeom dw_sw_geom(const DwParams& p) {
     return g;
 }
 
-static int dw_fwd_nsplit(const DwParams& p, bool lds_kernel = false) {
-    if (dw_use_sw() && !lds_kernel) { const DwSwGeom g = dw_sw_geom(p); return p.N * g.yblocks * g.xblocks; }
-    const int ntiles = p.N * p.tiles_y * p.tiles_x;
-    int nsplit = 2048 / p.cblocks;   // ~8 blocks per CU
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > ntiles) nsplit = ntiles;
-    return nsplit;
-}
+static int dw_fwd_nsplit(const DwParams& p) { const DwSwGeom g = dw_sw_geom(p); return p.N * g.yblocks * g.xblocks; }
 
 /* rows of the stats partial slab written by mpn_dwconv_fwd */
 extern "C" int mpn_dwconv_num_parts(int N, int H, int W, int C, int stride, int dtype) {
@@ -1466,54 +1332,24 @@ extern "C" int mpn_dwconv_num_parts(int N, int H, int W, int C, int stride, int 
 extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
                               int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
                               float* stats_part, mpn_stream_t stream) {
-    return mpn_dwconv_fwd_fin(x, w, y, N, H, W, C, stride, dtype, in_scale, in_shift, in_act, flip, stats_part, nullptr, stream);
-}
-
-extern "C" int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N, int H, int W, int C, int stride,
-                                  int dtype, const float* in_scale, const float* in_shift, int in_act, int flip,
-                                  float* stats_part, const mpn_bn_tail_t* tail, mpn_stream_t stream) {
     DwParams p = {};
     if (int rc = fill_params(p, N, H, W, C, stride, dtype)) return rc;
-    MPN_REQUIRE(tail == nullptr || tail->mode == 0 || stats_part != nullptr, MPN_ERR_BAD_ARG, "dwconv_fwd: a bn tail needs stats_part");
-    if (int rc = bn_tail_check(tail, C, "dwconv_fwd")) return rc;
     MPN_REQUIRE(x && w && y, MPN_ERR_BAD_ARG, "dwconv_fwd: null pointer");
     MPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), MPN_ERR_BAD_ARG, "dwconv_fwd: scale/shift mismatch");
     p.x = x; p.w = w; p.y = y; p.part = stats_part;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.flip = flip;
-    const int ve = dtype == MPN_F32 ? 4 : 8;
-    const bool want_tail = tail != nullptr && tail->mode != 0;   // the fused finalize lives in the LDS-tile kernel only
-    const int nsplit = dw_fwd_nsplit(p, want_tail);
     hipStream_t st = (hipStream_t)stream;
-    if (dw_use_sw() && !want_tail) {
-        const DwSwGeom g = dw_sw_geom(p);
-        p.cblocks = g.cblocks;
-        const long long blocks = (long long)p.N * g.cblocks * g.yblocks * g.xblocks;
-        MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_fwd: grid too large");
-        MPN_DISPATCH_DTYPE(dtype, {
-            if (stride == 1 && dw_xt(p) == 2 && in_scale == nullptr) dwconv_fwd_sw2_kernel<T, false, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
-            else if (stride == 1 && dw_xt(p) == 2) dwconv_fwd_sw2_kernel<T, false, false><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
-            else if (stride == 1 && in_scale == nullptr) dwconv_fwd_sw_kernel<T, 1, false, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
-            else if (stride == 1) dwconv_fwd_sw_kernel<T, 1><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
-            else dwconv_fwd_sw_kernel<T, 2><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
-        });
-        MPN_LAUNCH_CHECK();
-        return MPN_OK;
-    }
-    const int grid = nsplit * p.cblocks;
-    bn_tail_prepare(tail, nsplit, C, &p.tail);
-    if (stride == 1) {
-        const size_t sm = dw_smem<1>(ve, 8, p.nvg);
-        MPN_DISPATCH_DTYPE(dtype, {
-            if (int rc = set_smem(dwconv_fwd_kernel<T, 1>, sm)) return rc;
-            dwconv_fwd_kernel<T, 1><<<grid, kThreads, sm, st>>>(p, nsplit);
-        });
-    } else {
-        const size_t sm = dw_smem<2>(ve, 8, p.nvg);
-        MPN_DISPATCH_DTYPE(dtype, {
-            if (int rc = set_smem(dwconv_fwd_kernel<T, 2>, sm)) return rc;
-            dwconv_fwd_kernel<T, 2><<<grid, kThreads, sm, st>>>(p, nsplit);
-        });
-    }
+    const DwSwGeom g = dw_sw_geom(p);
+    p.cblocks = g.cblocks;
+    const long long blocks = (long long)p.N * g.cblocks * g.yblocks * g.xblocks;
+    MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_fwd: grid too large");
+    MPN_DISPATCH_DTYPE(dtype, {
+        if (stride == 1 && dw_xt(p) == 2 && in_scale == nullptr) dwconv_fwd_sw2_kernel<T, false, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
+        else if (stride == 1 && dw_xt(p) == 2) dwconv_fwd_sw2_kernel<T, false, false><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
+        else if (stride == 1 && in_scale == nullptr) dwconv_fwd_sw_kernel<T, 1, false, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
+        else if (stride == 1) dwconv_fwd_sw_kernel<T, 1><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
+        else dwconv_fwd_sw_kernel<T, 2><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks);
+    });
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -1521,12 +1357,10 @@ extern "C" int mpn_dwconv_fwd_fin(const void* x, const float* w, void* y, int N,
 // stride-2 sliding-window data gradient: geometry (even H, W only; else the gather kernel)
 struct DwDgS2Geom { bool ok; int ncg, cols, cblocks, xblocks, yblocks; };
 static DwDgS2Geom dw_dg_s2_geom(const DwParams& p) {
-    static int sw = -1;
-    if (sw < 0) { const char* e = getenv("MPN_DW_DGRAD_SW"); sw = e ? atoi(e) : 1; }
     DwDgS2Geom g = {};
     const int cg_total = p.C / 4;
     g.ncg = cg_total < 32 ? cg_total : 32;
-    g.ok = sw && p.pad_t == 0 && p.pad_l == 0 && p.H == 2 * p.OH && p.W == 2 * p.OW && (g.ncg & (g.ncg - 1)) == 0;
+    g.ok = p.pad_t == 0 && p.pad_l == 0 && p.H == 2 * p.OH && p.W == 2 * p.OW && (g.ncg & (g.ncg - 1)) == 0;
     g.cols = kThreads / g.ncg;
     g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
     g.xblocks = (p.OW + g.cols - 1) / g.cols;
@@ -1548,7 +1382,6 @@ static int dw_bwd_data_impl(const void* dy, const float* w, void* dx, int N, int
     if (stride == 1) {   // correlation with the flipped kernel, pad 1
         if (bnr == nullptr)
             return mpn_dwconv_fwd(dy, w, dx, N, H, W, C, 1, dtype, nullptr, nullptr, MPN_ACT_NONE, 1, nullptr, stream);
-        MPN_REQUIRE(dw_use_sw(), MPN_ERR_BAD_ARG, "dwconv_bwd_data_bn: needs the sliding-window kernel");
         p.x = dy; p.w = w; p.y = dx; p.flip = 1; p.in_act = MPN_ACT_NONE;
         p.part = bnr->part; p.bnr_x = bnr->bnr_x; p.bnr_scale = bnr->bnr_scale; p.bnr_shift = bnr->bnr_shift;
         p.bnr_mean = bnr->bnr_mean; p.bnr_invstd = bnr->bnr_invstd; p.bnr_act = bnr->bnr_act;
@@ -1611,7 +1444,6 @@ extern "C" int mpn_dwconv_bwd_data_bn_num_parts(int N, int H, int W, int C, int 
     if (fill_params(p, N, H, W, C, stride, dtype)) return 0;
     if (C % 4 != 0) return 0;
     if (stride == 1) {
-        if (!dw_use_sw()) return 0;
         p.bnr_x = &p;   // geometry of the fused launch
         const DwSwGeom g = dw_sw_geom(p);
         if (kThreads % g.ncg != 0) return 0;
@@ -1674,21 +1506,17 @@ static DwWgSwGeom dw_wg_sw_geom(const DwParams& p) {
     // rows (128ch @128x128: 74 -> 62 us with 64); stride 2: 32 / 16 / 8
     const bool s1 = p.H == p.OH;
     g.rows = s1 ? (p.OH >= 128 ? 64 : (p.OH >= 64 ? 32 : 16)) : (p.OH >= 64 ? 32 : (p.OH >= 32 ? 16 : 8));
-    static int wxt = -1;
-    if (wxt < 0) { const char* e = getenv("MPN_DW_WGRAD_XT"); wxt = e ? atoi(e) : 2; }
-    g.xt = (s1 && wxt == 2) ? 2 : 1;
+    g.xt = s1 ? 2 : 1;
     g.xblocks = (p.OW + g.cols * g.xt - 1) / (g.cols * g.xt);
     g.yblocks = (p.OH + g.rows - 1) / g.rows;
     g.units = p.N * g.yblocks * g.xblocks;
     return g;
 }
 static bool dw_wg_use_sw(const DwParams& p) {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("MPN_DW_WGRAD_SW"); v = e ? atoi(e) : 1; }
     const int cg_total = p.C / 4;
     // (the thread map needs a power-of-two group count per block; other channel counts keep the LDS-tile kernel)
     const int ncg = cg_total < 32 ? cg_total : 32;
-    return v != 0 && (ncg & (ncg - 1)) == 0 && kThreads % ncg == 0;
+    return (ncg & (ncg - 1)) == 0 && kThreads % ncg == 0;
 }
 
 extern "C" int mpn_dwconv_wgrad_num_parts(int N, int H, int W, int C, int stride, int dtype) {

@@ -245,8 +245,7 @@ extern "C" int mpn_heatmap_head_fwd(const void* x, const float* w, const float* 
 
 extern "C" int mpn_heatmap_head_bwd_num_parts(long long M) {
     const long long ntiles = (M + kBwdPix - 1) / kBwdPix;
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("MPN_HEAD_BWD_BLOCKS"); cap = e ? atoi(e) : 768; }   // three resident blocks per CU (45 KB of LDS each): one more to hide the staging of the others
+    const int cap = 768;   // three resident blocks per CU (45 KB of LDS each): one more to hide the staging of the others
     return (int)(ntiles < cap ? ntiles : cap);
 }
 

@@ -7,7 +7,6 @@
 //   and the eval metric per_pixel_reg_loss (:81-90).  tf.nn.l2_loss(t) = sum(t^2)/2.
 // Outputs d(total)/d(logits) and d(total)/d(p_l[...,0]). Deterministic block partials.
 #include "common.h"
-#include <stdlib.h>
 
 namespace {
 constexpr int kThreads = 256;
@@ -174,8 +173,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
 extern "C" int mpn_keypoint_loss_num_parts(int B, int h, int w) {
     const long long npix = (long long)B * h * w;
     const long long b = (npix + kThreads - 1) / kThreads;
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("MPN_LOSS_BLOCKS"); cap = e ? atoi(e) : 768; }   // three resident blocks per CU (155 registers): one balanced round
+    const int cap = 768;   // three resident blocks per CU (155 registers): one balanced round
     return (int)(b < cap ? b : cap);
 }
 

@@ -14,6 +14,7 @@ from ... import _lib
 NUM_KEYPOINTS = 17  # detector/constants.py:10
 
 
+@_lib.device_guarded("__call__")
 class HeatmapRenderer:
     """Owns the output + scratch buffers for (batch, image size, downsample); persons per batch may vary."""
 

@@ -37,6 +37,7 @@ def _box_hw(box):
     return float(ymax - ymin), float(xmax - xmin)
 
 
+@_lib.device_guarded("__call__")
 class KeypointDecoder:
     """Owns the (zero-initialised) decode workspace and output buffers for a batch size."""
 
@@ -99,9 +100,11 @@ def get_keypoints_batch(heatmaps, boxes, threshold, return_scores=False):
     box_hw = torch.from_numpy(hw).to(hm.device)
     dec = _decoder(hm.shape[0], hm.device)
     xyv, score, _ = dec(hm, box_hw, thr)
+    # the decoder (workspace + output buffers) is cached per (batch, device): hand out copies, so that a second call with
+    # the same batch size does not overwrite the first call's result. (KeypointDecoder itself is single-stream.)
     if return_scores:
-        return xyv, score
-    return xyv
+        return xyv.clone(), score.clone()
+    return xyv.clone()
 
 
 def get_keypoints(heatmaps, box, threshold):

@@ -32,13 +32,15 @@ EstimatorSpec = namedtuple("EstimatorSpec", ["mode", "loss", "train_op", "eval_m
 _REGISTRY = {}
 
 
-def _as_device(t, dtype=None):
+def _as_device(t, dtype=None, device=None):
     if not torch.is_tensor(t):
         import numpy as np
         t = torch.from_numpy(np.ascontiguousarray(t))
     if dtype is not None and t.dtype != dtype:
         t = t.to(dtype)
-    if not t.is_cuda:
+    if device is not None and t.device != device:
+        t = t.to(device)
+    elif not t.is_cuda:
         t = t.cuda()
     return t.contiguous()
 
@@ -48,10 +50,18 @@ def get_trainer(params):
     dt = {"bf16": torch.bfloat16, "f32": torch.float32}[params.get("dtype", "bf16")]
     key = (params.get("model_dir"), float(params["depth_multiplier"]), dt, int(params.get("seed", 0)))
     if key not in _REGISTRY:
+        distributed = bool(params.get("distributed", False))
+        device = torch.device("cuda", torch.cuda.current_device())
+        if distributed:
+            # one process per GPU under torch.distributed.run: join the process group and bind this rank's device BEFORE
+            # the network is built (identical replicas from the same seed; gradients averaged by the Trainer's reducer)
+            from .parallel import init_distributed
+            _, local_rank, _ = init_distributed()
+            torch.cuda.set_device(local_rank)
+            device = torch.device("cuda", local_rank)
         net = KeypointNet(values=params.get("initial_values"), depth_multiplier=params["depth_multiplier"], dtype=dt,
-                          seed=int(params.get("seed", 0)))
-        _REGISTRY[key] = Trainer(net, params, use_graph=bool(params.get("use_graph", True)),
-                                 distributed=bool(params.get("distributed", False)))
+                          seed=int(params.get("seed", 0)), device=device)
+        _REGISTRY[key] = Trainer(net, params, use_graph=bool(params.get("use_graph", True)), distributed=distributed)
     return _REGISTRY[key]
 
 
@@ -63,11 +73,12 @@ def model_fn(features, labels, mode, params):
     assert mode != ModeKeys.PREDICT                                    # keypoints_model.py:8
     is_training = mode == ModeKeys.TRAIN
     trainer = get_trainer(params)
-    feats = {"images": _as_device(features["images"])}
-    labs = {"heatmaps": _as_device(labels["heatmaps"], torch.float32),
-            "loss_masks": _as_device(labels["loss_masks"], torch.float32),
-            "segmentation_masks": _as_device(labels["segmentation_masks"], torch.float32),
-            "num_boxes": _as_device(labels["num_boxes"], torch.int32)}
+    dev = trainer.net.device
+    feats = {"images": _as_device(features["images"], device=dev)}
+    labs = {"heatmaps": _as_device(labels["heatmaps"], torch.float32, dev),
+            "loss_masks": _as_device(labels["loss_masks"], torch.float32, dev),
+            "segmentation_masks": _as_device(labels["segmentation_masks"], torch.float32, dev),
+            "num_boxes": _as_device(labels["num_boxes"], torch.int32, dev)}
     if feats["images"].shape[1] % 128 or feats["images"].shape[2] % 128:
         raise ValueError("image height and width must be multiples of 128 (detector/constants.py:4)")
     if is_training:

@@ -130,11 +130,20 @@ class _Conv:
         self.packed = ops.PackedConv(w, dtype)
 
 
+@ops._lib.device_guarded("_init", "load_state_dict", "repack_weights", "prepare_inference", "forward", "predict",
+                         "backbone_forward", "subnet_forward", "compute_losses", "backward", "add_weight_decay_gradients",
+                         "add_weight_decay_loss", "optimizer_step")
 class KeypointNet:
     def __init__(self, values=None, depth_multiplier=1.0, dtype=torch.bfloat16, device="cuda:0", seed=0):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("dtype must be torch.float32 or torch.bfloat16")
-        self.dtype, self.device, self.dm = dtype, torch.device(device), depth_multiplier
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.dtype, self.device, self.dm = dtype, dev, depth_multiplier
+        self._init(values, depth_multiplier, dtype, seed)
+
+    def _init(self, values, depth_multiplier, dtype, seed):
         shapes = variable_shapes(depth_multiplier)
         ve = 8 if dtype == torch.bfloat16 else 4
         for n, s in shapes.items():
@@ -228,11 +237,7 @@ class KeypointNet:
         ob, nb, _ = self._train_arena.offsets["heatmaps/bias"]
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
-        # batch-norm finalizes inside the producing launches (mpn_*_fin, 80 launches fewer per step): implemented and
-        # tested, but SLOWER on MI355X (13.1 vs 12.0 ms/step): the fence-free sc1 hand-off costs >= 4 dependent
-        # memory round trips (~2 us each) at the tail of every producer, more than the ~5 us launch it replaces
-        self.fuse_bn = False
-        self.batch_finalize = os.environ.get("MPN_BATCH_FINALIZE", "1") != "0"   # the four pyramid levels' batch-norm finalizes in one launch per stage
+        self.batch_finalize = True   # the four pyramid levels' batch-norm finalizes in one launch per stage
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
         # the stem kernel can write its own batch-norm partial sums (mpn_stem_conv_fwd_stats); OFF: measured a wash - the
         # separate statistics pass (38 us) reads the 134 MB stem output into the memory-side cache, and the first depthwise
@@ -388,10 +393,6 @@ class KeypointNet:
         if training:
             ops.bn_finalize(bn, b["stat_part"], nparts, count, training=True)
 
-    def _tail(self, bn, count):
-        """Descriptor that makes a statistics-producing launch finalize `bn` itself (None: separate mpn_bn_finalize)."""
-        return ops.bn_tail_fwd(bn, count, training=True) if self.fuse_bn else None
-
     def prepare_inference(self):
         """is_training=False: every batch-norm becomes the affine of its moving statistics."""
         for bn in self.all_bn:
@@ -405,34 +406,30 @@ class KeypointNet:
             self.prepare_inference()
         sp = b["stat_part"]
         c0 = self.stem_w.shape[3]
-        # training: the stem kernel writes the batch-norm partial sums of its own output (no separate statistics pass over
-        # the largest activation of the network), unless the fused finalize (fuse_bn) wants mpn_bn_stats' tail
-        stem_rows = ops.stem_conv_fwd_num_parts(N, H, W, c0, self.dtype) if (is_training and not self.fuse_bn and self.fuse_stem_stats) else 0
+        # training (opt-in, fuse_stem_stats): the stem kernel writes the batch-norm partial sums of its own output
+        stem_rows = ops.stem_conv_fwd_num_parts(N, H, W, c0, self.dtype) if (is_training and self.fuse_stem_stats) else 0
         if stem_rows * 2 * c0 > sp.numel():
             stem_rows = 0
         stem = ops.stem_conv_fwd(images, self.stem_w, c0, self.dtype, out=b["stem"], stats_part=sp if stem_rows > 0 else None)
-        T = self._tail if is_training else (lambda bn, count: None)
         if is_training:
             cnt = stem.numel() // stem.shape[3]
             if stem_rows > 0:
                 ops.bn_finalize(self.stem_bn, sp, stem_rows, cnt)
             else:
-                _, nparts = ops.bn_stats(stem, sp, tail=T(self.stem_bn, cnt))
-                if not self.fuse_bn:
-                    ops.bn_finalize(self.stem_bn, sp, nparts, cnt)
+                _, nparts = ops.bn_stats(stem, sp)
+                ops.bn_finalize(self.stem_bn, sp, nparts, cnt)
         x, aff = stem, self.stem_bn.affine
         feats = {}
         for i, blk in enumerate(self.blocks):
             hin, win = b["hw"][i]
             h, w = b["hw"][i + 1]
-            ydw = ops.dwconv_fwd(x, blk["dw_w"], blk["stride"], aff, out=b["dw"][i], stats_part=sp if is_training else None,
-                                 tail=T(blk["dw_bn"], N * h * w))
-            if is_training and not self.fuse_bn:
+            ydw = ops.dwconv_fwd(x, blk["dw_w"], blk["stride"], aff, out=b["dw"][i], stats_part=sp if is_training else None)
+            if is_training:
                 ops.bn_finalize(blk["dw_bn"], sp, ops.dwconv_num_parts(N, hin, win, ydw.shape[3], blk["stride"], self.dtype),
                                 ydw.numel() // ydw.shape[3])
             ypw = ops.conv_fwd(ydw, blk["pw"].packed.fwd, blk["pw"].cout, 1, blk["dw_bn"].affine, out=b["pw"][i],
-                               stats_part=sp if is_training else None, tail=T(blk["pw_bn"], N * h * w))
-            if is_training and not self.fuse_bn:
+                               stats_part=sp if is_training else None)
+            if is_training:
                 ops.bn_finalize(blk["pw_bn"], sp, ops.conv_num_parts(N, h, w, 1), N * h * w)
             x, aff = ypw, blk["pw_bn"].affine
             if blk["i"] in FEATURE_BLOCKS:
@@ -443,8 +440,7 @@ class KeypointNet:
         """KeypointSubnet (detector/keypoint_subnet.py:11-62) on top of feature_pyramid_network (detector/fpn.py:36-55)."""
         N = b["shape"][0]
         sp = b["stat_part"] if is_training else None
-        T = self._tail if is_training else (lambda bn, count: None)
-        sep = is_training and not self.fuse_bn     # separate mpn_bn_finalize launches (the unfused reference path)
+        sep = is_training
         prev = None
         if sep and self.batch_finalize:
             # stage by stage over the four levels: their statistics go to per-level scratch and ONE launch per stage
@@ -470,35 +466,31 @@ class KeypointNet:
             fin["bn2"].run()
             for l in (2, 3, 4, 5):
                 ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, self.phi[l]["bn2"].affine)   # :86 + :37
-            return self._subnet_final(b, N, sp, T, sep, inference_outputs)
+            return self._subnet_final(b, N, sp, sep, inference_outputs)
         for l in (5, 4, 3, 2):
             raw, aff = feats[f"c{l}"]
             h, w = b["lv"][l]
             ops.conv_fwd(raw, self.lateral[l].packed.fwd, DEPTH, 1, aff, out=b["x"][l], up_res=prev)    # fpn.py:38,50-51
             prev = b["x"][l]
-            ops.conv_fwd(prev, self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=sp,
-                         tail=T(self.p_bn[l], N * h * w))                                                  # fpn.py:39,52
+            ops.conv_fwd(prev, self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=sp)      # fpn.py:39,52
             if sep:
                 ops.bn_finalize(self.p_bn[l], sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
         for l in (2, 3, 4, 5):
             ph = self.phi[l]
             h, w = b["lv"][l]
             nparts, cnt = ops.conv_num_parts(N, h, w, 3), N * h * w
-            ops.conv_fwd(b["p"][l], ph["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=sp,
-                         tail=T(ph["bn1"], cnt))
+            ops.conv_fwd(b["p"][l], ph["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=sp)
             if sep:
                 ops.bn_finalize(ph["bn1"], sp, nparts, cnt)
-            ops.conv_fwd(b["y1"][l], ph["conv2"].packed.fwd, DEPTH, 3, ph["bn1"].affine, out=b["y2"][l], stats_part=sp,
-                         tail=T(ph["bn2"], cnt))
+            ops.conv_fwd(b["y1"][l], ph["conv2"].packed.fwd, DEPTH, 3, ph["bn1"].affine, out=b["y2"][l], stats_part=sp)
             if sep:
                 ops.bn_finalize(ph["bn2"], sp, nparts, cnt)
             ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, ph["bn2"].affine)   # :86 + :37
-        return self._subnet_final(b, N, sp, T, sep, inference_outputs)
+        return self._subnet_final(b, N, sp, sep, inference_outputs)
 
-    def _subnet_final(self, b, N, sp, T, sep, inference_outputs):
+    def _subnet_final(self, b, N, sp, sep, inference_outputs):
         h, w = b["lv"][2]
-        ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, None, out=b["final"], stats_part=sp,
-                     tail=T(self.final_bn, N * h * w))                                                     # :38
+        ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, None, out=b["final"], stats_part=sp)   # :38
         if sep:
             ops.bn_finalize(self.final_bn, sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
         if inference_outputs:
@@ -594,11 +586,11 @@ class KeypointNet:
         # ---- head + final conv
         ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
                              slab[id(self._head_grad)], reduce=False)
-        ops.bn_backward(self.final_bn, g["final"], b["final"], sp, fused=self.fuse_bn)
+        ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
         W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
         ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm
-        if self.batch_finalize and not self.fuse_bn:
+        if self.batch_finalize:
             # stage by stage over the four levels (see subnet_forward): reductions into per-level scratch, ONE finalize
             # launch per stage, then the applies and the convolutions' gradients
             if b["fin"] is None:
@@ -635,13 +627,13 @@ class KeypointNet:
             for l in (2, 3, 4, 5):
                 ph = self.phi[l]
                 ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
-                ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp, fused=self.fuse_bn)
+                ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp)
                 W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
                 ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
-                ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp, fused=self.fuse_bn)
+                ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp)
                 W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
                 ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
-                ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l], fused=self.fuse_bn)
+                ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l])
         # ---- FPN (top-down path reversed)
         for l in (2, 3, 4, 5):
             W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, slab[id(self.pconv[l].dw)], reduce=False))
@@ -660,16 +652,16 @@ class KeypointNet:
             blk = self.blocks[i]
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13 and not lateral_added:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
-            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, fused=self.fuse_bn, reduced_parts=reduced)
+            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced)
             W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
             ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
-            ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, fused=self.fuse_bn)
+            ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
             W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))
             dst = g["pw"][i - 1] if i > 0 else g["stem"]
             # the data gradient also reduces for the batch-norm it feeds (one read of dA and one launch less), unless a
-            # lateral's gradient still has to be added to dA first or the fused finalize (fuse_bn) owns the reduction
+            # lateral's gradient still has to be added to dA first
             prev_bn = self.blocks[i - 1]["pw_bn"] if i > 0 else self.stem_bn
             prev_x = b["pw"][i - 1] if i > 0 else b["stem"]
             prev_feature = i > 0 and self.blocks[i - 1]["i"] in FEATURE_BLOCKS
@@ -682,14 +674,14 @@ class KeypointNet:
             if not lateral_added:
                 addend = None
             reduced = 0
-            if self.fuse_dw_bn and not self.fuse_bn and (not prev_feature or lateral_added) and \
+            if self.fuse_dw_bn and (not prev_feature or lateral_added) and \
                     ops.dwconv_bwd_data_bn_num_parts(dst.shape[0], *b["hw"][i], dst.shape[3], blk["stride"], dst.dtype) > 0:
                 _, reduced = ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst, bn=prev_bn,
                                                  x_bn=prev_x, part=sp, addend=addend)
             else:
                 ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst, addend=addend)
             dA = dst
-        ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp, fused=self.fuse_bn, reduced_parts=reduced)
+        ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp, reduced_parts=reduced)
         W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, slab[id(self.stem_dw)], reduce=False))
 
     def add_weight_decay_gradients(self, weight_decay):

@@ -63,16 +63,29 @@ def conv_num_parts(N, H, W, ksize):
     return _lib.lib().mpn_conv_num_parts(N, H, W, ksize)
 
 
-def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_res=None, tail=None):
-    """y = conv(act(bn(x))) [+ nearest2x(up_res)]; optional per-tile BN partial sums; `tail` (bn_tail_fwd) makes the
-    launch finalize the following batch-norm too."""
-    _check_nhwc(x)
+def _slice_stride(t, channels):
+    """Pixel stride (elements) of an NHWC tensor or of a channel slice `t[..., a:a+channels]` of a wider contiguous one."""
+    if t.dim() != 4 or t.shape[3] != channels or t.stride(3) != 1:
+        raise ValueError(f"expected an NHWC tensor (or channel slice) with {channels} channels, got {tuple(t.shape)}")
+    ps = t.stride(2)
+    if t.stride(1) != t.shape[2] * ps or t.stride(0) != t.shape[1] * t.shape[2] * ps or ps < channels:
+        raise ValueError("only channel slices of contiguous NHWC tensors are supported")
+    return ps
+
+
+def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_res=None):
+    """y = conv(act(bn(x))) [+ nearest2x(up_res)]; optional per-tile BN partial sums. x and out may be channel slices
+    (`t[..., a:b]`) of wider contiguous NHWC tensors: the kernel takes their pixel strides."""
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError(f"x must be an NHWC f32/bf16 tensor, got {tuple(x.shape)} {x.dtype}")
     N, H, W, cin = x.shape
+    xs = _slice_stride(x, cin)
     if out is None:
         out = torch.empty((N, H, W, cout), dtype=x.dtype, device=x.device)
+    ys = _slice_stride(out, cout)
     sc, sh, act = _aff(affine)
-    call("mpn_conv_fwd_fin", ptr(x), ptr(packed), ptr(out), N, H, W, cin, cout, ksize, _lib.dtype_code(x.dtype),
-         sc, sh, act, ptr(stats_part), ptr(up_res), _tail_arg(tail), stream_ptr())
+    call("mpn_conv_fwd", ptr(x), ptr(packed), ptr(out), N, H, W, cin, cout, xs, ys, ksize, _lib.dtype_code(x.dtype),
+         sc, sh, act, ptr(stats_part), ptr(up_res), stream_ptr())
     return out
 
 
@@ -92,8 +105,8 @@ def conv_fwd_grouped(xs, packeds, cout, ksize, affines, outs, stats_parts):
     for x in xs:
         _check_nhwc(x)
     call("mpn_conv_fwd_grouped", n, PA(*[ptr(x) for x in xs]), PA(*[ptr(p) for p in packeds]), PA(*[ptr(o) for o in outs]), N,
-         IA(*[x.shape[1] for x in xs]), IA(*[x.shape[2] for x in xs]), cin, cout, ksize, _lib.dtype_code(xs[0].dtype),
-         PA(*sc), PA(*sh), int(act), PA(*[ptr(t) for t in stats_parts]), stream_ptr())
+         IA(*[x.shape[1] for x in xs]), IA(*[x.shape[2] for x in xs]), cin, cout, IA(*[_slice_stride(o, cout) for o in outs]),
+         ksize, _lib.dtype_code(xs[0].dtype), PA(*sc), PA(*sh), int(act), PA(*[ptr(t) for t in stats_parts]), stream_ptr())
     return outs
 
 
@@ -160,59 +173,12 @@ class BNState:
         return Affine(self.scale, self.shift, self.act)
 
 
-class _BnTailStruct(ctypes.Structure):
-    """mpn_bn_tail_t (include/mpn.h)."""
-    _fields_ = [("mode", ctypes.c_int), ("count", ctypes.c_longlong), ("momentum", ctypes.c_float), ("eps", ctypes.c_float),
-                ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("moving_mean", ctypes.c_void_p),
-                ("moving_var", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p),
-                ("save_mean", ctypes.c_void_p), ("save_invstd", ctypes.c_void_p), ("dgamma", ctypes.c_void_p),
-                ("dbeta", ctypes.c_void_p), ("k1", ctypes.c_void_p), ("k2", ctypes.c_void_p),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
-
-
-_tail_ws = {}
-
-
-def bn_tail_workspace(device, C=1024):
-    """Zero-filled once; shared by every fused finalize on this device (launches on one stream never overlap)."""
-    key = str(device)
-    ws = _tail_ws.get(key)
-    need = _lib.lib().mpn_bn_tail_workspace_bytes(C)
-    if ws is None or ws.numel() < need:
-        ws = torch.zeros(need, dtype=torch.uint8, device=device)
-        _tail_ws[key] = ws
-    return ws
-
-
-def _p(t):
-    return None if t is None else t.data_ptr()
-
-
-def bn_tail_fwd(bn, count, training=True):
-    """Tail descriptor: the statistics-producing launch also does mpn_bn_finalize for `bn` (ops.bn_finalize)."""
-    ws = bn_tail_workspace(bn.gamma.device, max(1024, bn.C))
-    return _BnTailStruct(1, int(count), BN_MOMENTUM, BN_EPSILON, _p(bn.gamma), _p(bn.beta),
-                         _p(bn.moving_mean) if training else None, _p(bn.moving_var) if training else None,
-                         _p(bn.scale), _p(bn.shift), _p(bn.mean), _p(bn.invstd), None, None, None, None,
-                         ws.data_ptr(), ws.numel())
-
-
-def bn_tail_bwd(bn, count):
-    ws = bn_tail_workspace(bn.gamma.device, max(1024, bn.C))
-    return _BnTailStruct(2, int(count), 0.0, 0.0, None, None, None, None, None, None, None, None,
-                         _p(bn.dgamma), _p(bn.dbeta), _p(bn.k1), _p(bn.k2), ws.data_ptr(), ws.numel())
-
-
-def _tail_arg(tail):
-    return None if tail is None else ctypes.addressof(tail)
-
-
-def bn_stats(x, part=None, tail=None):
+def bn_stats(x, part=None):
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     nparts = _lib.lib().mpn_bn_stats_num_parts(M)
     if part is None:
         part = _f32(nparts * 2 * C, x.device)
-    call("mpn_bn_stats_fin", ptr(x), M, C, _lib.dtype_code(x.dtype), ptr(part), _tail_arg(tail), stream_ptr())
+    call("mpn_bn_stats", ptr(x), M, C, _lib.dtype_code(x.dtype), ptr(part), stream_ptr())
     return part, nparts
 
 
@@ -322,20 +288,15 @@ def bn_act_apply(x, affine, out=None):
     return out
 
 
-def bn_backward(bn, dA, x, part, add_ch0=None, fused=True, reduced_parts=0):
+def bn_backward(bn, dA, x, part, add_ch0=None, reduced_parts=0):
     """In place: dA (gradient w.r.t. act(bn(x))) -> gradient w.r.t. the raw conv output x.
     Writes bn.dgamma / bn.dbeta. `part` must hold mpn_bn_stats_num_parts(M)*2*C floats.
-    fused: the reduction launch finalizes too (last-finishing blocks) instead of a separate mpn_bn_bwd_finalize.
     reduced_parts > 0: the producer of dA already wrote that many partial rows into `part` (dwconv_bwd_data(..., bn=...))."""
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     dc = _lib.dtype_code(x.dtype)
     nparts = _lib.lib().mpn_bn_stats_num_parts(M)
     if reduced_parts:
         call("mpn_bn_bwd_finalize", ptr(part), int(reduced_parts), C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), stream_ptr())
-    elif fused:
-        tail = bn_tail_bwd(bn, M)
-        call("mpn_bn_bwd_reduce_fin", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean),
-             ptr(bn.invstd), int(bn.act), ptr(part), _tail_arg(tail), stream_ptr())
     else:
         call("mpn_bn_bwd_reduce", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
              int(bn.act), ptr(part), stream_ptr())
@@ -355,15 +316,15 @@ def dwconv_num_parts(N, H, W, C, stride, dtype):
     return _lib.lib().mpn_dwconv_num_parts(N, H, W, C, stride, _lib.dtype_code(dtype))
 
 
-def dwconv_fwd(x, w, stride, affine=None, out=None, stats_part=None, tail=None):
+def dwconv_fwd(x, w, stride, affine=None, out=None, stats_part=None):
     _check_nhwc(x)
     N, H, W, C = x.shape
     OH, OW = dwconv_out_hw(H, W, stride)
     if out is None:
         out = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
     sc, sh, act = _aff(affine)
-    call("mpn_dwconv_fwd_fin", ptr(x), ptr(w), ptr(out), N, H, W, C, stride, _lib.dtype_code(x.dtype), sc, sh, act, 0,
-         ptr(stats_part), _tail_arg(tail), stream_ptr())
+    call("mpn_dwconv_fwd", ptr(x), ptr(w), ptr(out), N, H, W, C, stride, _lib.dtype_code(x.dtype), sc, sh, act, 0,
+         ptr(stats_part), stream_ptr())
     return out
 
 

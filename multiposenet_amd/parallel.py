@@ -49,6 +49,10 @@ class GradientAllReducer:
     def __init__(self, flat_grad, group=None, bucket_bytes=16 << 20):
         self.flat = flat_grad
         self.group = group
+        if not dist.is_initialized() and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            # never fall back to world = 1 silently: that trains unsynchronised replicas
+            raise RuntimeError("data-parallel training was requested under WORLD_SIZE > 1 but torch.distributed is not "
+                               "initialised: call multiposenet_amd.parallel.init_distributed() first")
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bounds = bucket_bounds(flat_grad.numel(), bucket_bytes // flat_grad.element_size())
         self._handles = []

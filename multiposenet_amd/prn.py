@@ -39,15 +39,21 @@ def initial_values(seed=0, **kw):
     return out
 
 
+@_lib.device_guarded("_init", "load_state_dict", "refresh_operands", "forward", "loss", "predict", "backward",
+                     "optimizer_step", "train_step")
 class PoseResidualNet:
     def __init__(self, values=None, batch=128, h=CROP_SIZE[0], w=CROP_SIZE[1], c=NUM_KEYPOINTS, hidden=HIDDEN,
                  dtype=torch.bfloat16, device="cuda:0", seed=0):
+        self.device = torch.device(device)
+        self._init(values, batch, h, w, c, hidden, dtype, seed)
+
+    def _init(self, values, batch, h, w, c, hidden, dtype, seed):
         _lib.lib()   # fail loudly without the HIP library
         self.B, self.h, self.w, self.c, self.hidden = int(batch), h, w, c, hidden
         self.n = h * w * c
         if self.n % 8 or hidden % 8:
             raise ValueError("h*w*c and hidden must be multiples of 8")
-        self.dtype, self.device = dtype, torch.device(device)
+        self.dtype = dtype
         shapes = variable_shapes(h, w, c, hidden)
         self._arena = _Arena(shapes, self.device)
         self.theta, self.grad = self._arena.new(), self._arena.new()

@@ -12,6 +12,7 @@ from ._lib import call, ptr, stream_ptr
 from .prn import CROP_SIZE, NUM_KEYPOINTS
 
 
+@_lib.device_guarded("crops", "__call__")
 class KeypointAssigner:
     """scores, positions = KeypointAssigner(prn_net)(heatmaps, boxes, num_boxes)
 
@@ -23,6 +24,7 @@ class KeypointAssigner:
 
     def __init__(self, prn_net, threshold=0.2):
         self.net = prn_net
+        self.device = prn_net.device
         self.threshold = float(threshold)
         self._keys = None
 

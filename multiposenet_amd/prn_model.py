@@ -14,11 +14,17 @@ _models = {}
 
 
 def _model(params, batch, shape):
-    key = (id(params), batch, shape)
+    """One PoseResidualNet (+ optimizer state) per model configuration: tf.estimator keys its variables by `model_dir`
+    (train_prn.py: RunConfig(model_dir=...)), so does this registry - never by object identity, which is recycled."""
+    dt = torch.float32 if params.get("dtype", "bf16") == "f32" else torch.bfloat16
+    key = (params.get("model_dir"), dt, int(params.get("seed", 0)), batch, shape)
     if key not in _models:
-        dt = torch.float32 if params.get("dtype", "bf16") == "f32" else torch.bfloat16
         _models[key] = PoseResidualNet(values=params.get("values"), batch=batch, h=shape[0], w=shape[1], c=shape[2], dtype=dt)
     return _models[key]
+
+
+def reset_registry():
+    _models.clear()
 
 
 def _dev(a):

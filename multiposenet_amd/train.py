@@ -5,19 +5,22 @@ one optimizer step (batch-norm moving statistics included, as under UPDATE_OPS).
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 from .parallel import GradientAllReducer
 
 
+@_lib.device_guarded("step", "eval_step", "input_buffers")
 class Trainer:
     def __init__(self, net, params, use_graph=True, distributed=False, bucket_bytes=16 << 20):
         self.net = net
+        self.device = net.device
         self.lr0 = float(params["initial_learning_rate"])
         self.num_steps = int(params["num_steps"])
         self.weight_decay = float(params.get("weight_decay", 0.0))
         self.use_graph = use_graph
         self.reducer = GradientAllReducer(net.grad, bucket_bytes=bucket_bytes) if distributed else None
         self._static = None
+        self._losses = None       # the f32[8] loss tensor of the buffer set the train step runs on
         self._graph_fb = None
         self._graph_bb = None
         self._graph_opt = None
@@ -52,6 +55,10 @@ class Trainer:
         if s is None or s["images"].shape != imgs.shape or s["images"].dtype != imgs.dtype:
             self._static = {"images": imgs.clone(), "labels": {k: v.clone() for k, v in labels.items()}}
             self._graph_fb = self._graph_bb = self._graph_opt = None
+            # the loss tensor of THIS shape's buffer set: a graph replay does not touch net._last, which an eval_step at
+            # another batch size rebinds in between
+            N, H, W, _ = imgs.shape
+            self._losses = self.net._buffers(N, H, W)["losses"]
             return
         if s["images"].data_ptr() != imgs.data_ptr():
             s["images"].copy_(imgs)
@@ -112,7 +119,7 @@ class Trainer:
                 self.reducer.start(0, split if early else None)
                 self.reducer.finish()
                 self._graph_opt.replay()
-        return self.net._last[0]["losses"]
+        return self._losses
 
     def eval_step(self, features, labels):
         self.net.forward(features["images"], False)

@@ -24,9 +24,28 @@ def test_header_symbols_exported_and_bound():
         assert n in names, f"{n} bound in _lib.py but not declared in include/mpn.h"
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """`nm -D` of the built library: every exported mpn_* symbol is declared in include/mpn.h (no hidden tuning or debug
+    entry points; diagnostic stamps exist only in -DMPN_DIAG builds made by tools/build_variant.sh)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("mpn_")})
+    assert exported, "nm found no mpn_* exports"
+    declared = set(_declared())
+    extra = [n for n in exported if n not in declared]
+    assert not extra, f"exported but not declared in include/mpn.h: {extra}"
+
+
+def test_no_environment_switches_in_launch_paths():
+    """The library is stateless: no getenv in any kernel source (tuning constants are compile-time)."""
+    csrc = os.path.join(ROOT, "multiposenet_amd", "csrc")
+    bad = [f for f in os.listdir(csrc) if f.endswith((".hip", ".h")) and "getenv" in open(os.path.join(csrc, f)).read()]
+    assert not bad, bad
+
+
 def test_version_and_error_string():
     l = _lib.lib()
-    assert l.mpn_version() == 100
+    assert l.mpn_version() == 200
     assert isinstance(_lib.last_error(), str)
 
 

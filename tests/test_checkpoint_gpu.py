@@ -32,7 +32,7 @@ def test_resume_is_bit_identical_and_names_are_tensorflows(cuda, tmp_path):
     assert "global_step" in names and "beta1_power" in names
     with np.load(path) as z:
         assert int(z["global_step"]) == 2
-        assert abs(float(z["beta1_power"]) - 0.81) < 1e-6 and z["MobilenetV1/Conv2d_1_depthwise/depthwise_weights"].shape[-1] == 1
+        assert abs(float(z["beta1_power"]) - 0.729) < 1e-6 and z["MobilenetV1/Conv2d_1_depthwise/depthwise_weights"].shape[-1] == 1
     third = tr.step({"images": img}, lab).cpu().numpy().copy()
     want = net.state_dict()
     # a fresh process: different initial values, then restore

@@ -294,51 +294,6 @@ def test_weight_decay_term_matches_oracle(cuda):
         if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k), rtol=1e-3)
 
 
-def test_fused_bn_finalize_equals_separate_launches(cuda):
-    """The batch-norm finalize fused into the producing launches (last-finishing blocks, two-level f64 reduction) must
-    agree with the separate mpn_bn_finalize / mpn_bn_bwd_finalize launches: identical moving statistics and scale/shift up
-    to the f64 summation order, and the same gradients."""
-    from multiposenet_amd.net import KeypointNet
-    from multiposenet_amd.train import Trainer
-    rs = np.random.RandomState(9)
-    B, H, W = 2, 128, 128
-    params = _params(5)
-    img = torch.tensor(rs.rand(B, H, W, 3).astype(np.float32)).cuda()
-    dlab = {k: torch.tensor(val).cuda() for k, val in _labels(rs, B, H // 4, W // 4).items()}
-    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
-    out = {}
-    # the fused tail lives in the LDS-tile depthwise kernel only: run both modes on it, so that the comparison sees the
-    # finalize alone (the sliding-window kernel's FMA order differs in the last bit, which 40 batch-norm layers on a
-    # 2-image batch amplify to ~1e-3 at the loss)
-    from multiposenet_amd import _lib
-    set_dw = _lib.lib().mpn_debug_set_dw_kernel
-    set_dw.argtypes, set_dw.restype = [ctypes.c_int], None
-    set_dw(0)
-    try:
-        for fused in (False, True):
-            for dt in (torch.float32, torch.bfloat16):
-                net = KeypointNet(values=params, dtype=dt)
-                net.fuse_bn = fused
-                net.fuse_dw_bn = False     # (that fusion replaces the reduction launch the fused finalize rides on)
-                net.fuse_stem_stats = False   # (the stem's own partial sums: another summation order, not used with fuse_bn)
-                tr = Trainer(net, hp, use_graph=False)
-                losses = [tr.step({"images": img}, dlab).cpu().numpy().copy() for _ in range(2)]   # 2 steps: tickets reset
-                out[(fused, dt)] = (losses, net.state_dict(), net.grad.cpu().numpy().copy())
-    finally:
-        set_dw(-1)
-    for dt in (torch.float32, torch.bfloat16):
-        la, sa, ga = out[(False, dt)]
-        lb, sb, gb = out[(True, dt)]
-        for x, y in zip(la, lb):
-            np.testing.assert_allclose(x, y, rtol=2e-5, atol=1e-7)
-        for k in sa:
-            if "moving" in k:
-                np.testing.assert_allclose(sa[k], sb[k], rtol=1e-5, atol=1e-6, err_msg=k)
-        # gradients of the second step: same up to rounding of the scale/shift (and, for bf16, of re-quantised activations)
-        denom = np.abs(ga).max()
-        assert np.abs(ga - gb).max() <= (1e-4 if dt == torch.float32 else 2e-2) * denom
-
-
 def test_model_fn_contract(cuda):
     from multiposenet_amd import keypoints_model as km
     from multiposenet_amd.synthetic import synthetic_batch

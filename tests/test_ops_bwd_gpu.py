@@ -195,10 +195,10 @@ def test_dwconv_bwd_data_with_fused_bn_reduction(cuda, dtype, N, H, W, C, stride
     M = N * H * W
     part = torch.empty(ops._lib.lib().mpn_bn_stats_num_parts(M) * 2 * C, device="cuda")
     dA_sep = want.clone()
-    ops.bn_backward(bn_b, dA_sep, xbn, part, fused=False)
+    ops.bn_backward(bn_b, dA_sep, xbn, part)
     part2 = torch.empty(rows * 2 * C, device="cuda")
     dA_fused, _ = ops.dwconv_bwd_data(dy, w, (H, W), stride, bn=bn_a, x_bn=xbn, part=part2)
-    ops.bn_backward(bn_a, dA_fused, xbn, part2, fused=False, reduced_parts=rows)
+    ops.bn_backward(bn_a, dA_fused, xbn, part2, reduced_parts=rows)
     scale = float(bn_b.dgamma.abs().max()) + 1e-6
     assert float((bn_a.dgamma - bn_b.dgamma).abs().max()) <= 2e-5 * scale * max(1.0, M ** 0.5 / 16)
     assert float((bn_a.dbeta - bn_b.dbeta).abs().max()) <= 2e-5 * (float(bn_b.dbeta.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
@@ -246,8 +246,8 @@ def test_dwconv_bwd_data_add(cuda, dtype, N, H, W, C):
     M = N * H * W
     part = torch.empty(ops._lib.lib().mpn_bn_stats_num_parts(M) * 2 * C, device="cuda")
     dA_sep = got.clone()
-    ops.bn_backward(bn_b, dA_sep, xbn, part, fused=False)
-    ops.bn_backward(bn_a, dA_fused, xbn, part2, fused=False, reduced_parts=rows)
+    ops.bn_backward(bn_b, dA_sep, xbn, part)
+    ops.bn_backward(bn_a, dA_fused, xbn, part2, reduced_parts=rows)
     scale = float(bn_b.dgamma.abs().max()) + 1e-6
     assert float((bn_a.dgamma - bn_b.dgamma).abs().max()) <= 2e-5 * scale * max(1.0, M ** 0.5 / 16)
     assert float((bn_a.dbeta - bn_b.dbeta).abs().max()) <= 2e-5 * (float(bn_b.dbeta.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
@@ -316,7 +316,7 @@ def test_grouped_bn_backward_passes_equal_per_layer_launches(cuda, dtype):
     da_a = [t.clone() for t in dAs]
     da_b = [t.clone() for t in dAs]
     for bn, d, x, p, ad in zip(a, da_a, xs, pa, add):
-        ops.bn_backward(bn, d, x, p, add_ch0=ad, fused=False)
+        ops.bn_backward(bn, d, x, p, add_ch0=ad)
     ops.bn_bwd_reduce_grouped(b, da_b, xs, pb)
     ops.BnBwdFinalizeBatch([(bn, p, n, M) for bn, p, n, M in zip(b, pb, nparts, Ms)], "cuda:0").run()
     ops.bn_bwd_apply_grouped(b, da_b, xs, add)

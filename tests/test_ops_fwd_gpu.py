@@ -281,57 +281,6 @@ def test_adam_matches_tf_semantics(cuda):
         np.testing.assert_allclose(dv.cpu().numpy(), v64, rtol=1e-4)  # (1-beta2) is rounded in f32, as in TF
 
 
-VARIANT_CASES = [c for c in CONV_CASES if c[5] == 3 and not c[8]]
-
-
-@pytest.mark.parametrize("variant", ["ring", "big", "ws"])
-@pytest.mark.parametrize("case", VARIANT_CASES, ids=[f"{c[3]}to{c[4]}_{c[1]}x{c[2]}" for c in VARIANT_CASES])
-def test_conv3x3_kernel_variants(cuda, variant, case):
-    """The 3x3 kernel variants that are off by default (3-slot weight ring, 256-pixel tiles, the warp-specialised
-    persistent kernel) stay parity-green: same reference, same statistics contract as the default kernel."""
-    import ctypes
-    from multiposenet_amd import _lib
-    setv = _lib.lib().mpn_debug_set_conv_variant
-    setv.argtypes, setv.restype = [ctypes.c_int] * 3, None
-    setv(*{"ring": (0, 0, 1), "big": (0, 1, 0), "ws": (1, 0, 0)}[variant])
-    try:
-        test_conv_fwd(cuda, torch.bfloat16, case)
-    finally:
-        setv(-1, -1, -1)
-
-
-def _set_m32(mask):
-    import ctypes
-    from multiposenet_amd import _lib
-    f = _lib.lib().mpn_debug_set_conv_m32
-    f.argtypes, f.restype = [ctypes.c_int], None
-    f(mask)
-
-
-M32_CASES = [c for c in CONV_CASES if not c[8]]
-
-
-@pytest.mark.parametrize("m32", [0, 3])
-@pytest.mark.parametrize("case", M32_CASES, ids=[f"k{c[5]}_{c[3]}to{c[4]}_{c[1]}x{c[2]}" for c in M32_CASES])
-def test_conv_mfma_32x32_and_16x16_variants(cuda, m32, case):
-    """Both MFMA shapes of the bf16 kernel (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_16x16x32_bf16; MPN_CONV_M32 picks the
-    default) against the same reference with the same statistics contract, 3x3 and 1x1 layers."""
-    _set_m32(m32)
-    try:
-        test_conv_fwd(cuda, torch.bfloat16, case)
-    finally:
-        _set_m32(-1)
-
-
-@pytest.mark.parametrize("m32", [0, 3])
-def test_conv_fwd_grouped_equals_separate_launches_both_mfma_shapes(cuda, m32):
-    _set_m32(m32)
-    try:
-        test_conv_fwd_grouped_equals_separate_launches(cuda, torch.bfloat16)
-    finally:
-        _set_m32(-1)
-
-
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 def test_conv_fwd_grouped_equals_separate_launches(cuda, dtype):
     """mpn_conv_fwd_grouped: four independent 3x3 convolutions (pyramid levels) in one grid = the four separate launches,

@@ -13,13 +13,13 @@ part = torch.empty(nparts * 2 * Cout, device='cuda')
 nblk = nparts * max(1, Cout // 128)
 dbg = torch.zeros(nblk * 8, dtype=torch.int64, device='cuda')
 lib = _lib.lib()
-lib.mpn_debug_set_conv_stamps.argtypes = [ctypes.c_void_p]
+lib.mpn_diag_set_conv_stamps.argtypes = [ctypes.c_void_p]
 for _ in range(3):
     ops.conv_fwd(x, pc.fwd, Cout, k, ops.Affine(sc, sh, 1), out=y, stats_part=part)
-lib.mpn_debug_set_conv_stamps(ctypes.c_void_p(dbg.data_ptr()))
+lib.mpn_diag_set_conv_stamps(ctypes.c_void_p(dbg.data_ptr()))
 ops.conv_fwd(x, pc.fwd, Cout, k, ops.Affine(sc, sh, 1), out=y, stats_part=part)
 torch.cuda.synchronize()
-lib.mpn_debug_set_conv_stamps(None)
+lib.mpn_diag_set_conv_stamps(None)
 d = dbg.cpu().numpy().reshape(nblk, 8).astype(np.float64)
 d = d[d[:, 0] > 0]   # (the 256-pixel variant launches half the blocks)
 nblk = len(d)

@@ -13,13 +13,13 @@ wp = torch.empty(npart * dw.numel(), device='cuda')
 nblk = 4096
 dbg = torch.zeros(nblk * 8 * 4, dtype=torch.int64, device='cuda')
 lib = _lib.lib()
-lib.mpn_debug_set_wgrad_stamps.argtypes = [ctypes.c_void_p]
+lib.mpn_diag_set_wgrad_stamps.argtypes = [ctypes.c_void_p]
 for _ in range(3):
     ops.conv_bwd_weight(x, dy, k, ops.Affine(sc, sh, 1), dw, wp)
-lib.mpn_debug_set_wgrad_stamps(ctypes.c_void_p(dbg.data_ptr()))
+lib.mpn_diag_set_wgrad_stamps(ctypes.c_void_p(dbg.data_ptr()))
 ops.conv_bwd_weight(x, dy, k, ops.Affine(sc, sh, 1), dw, wp)
 torch.cuda.synchronize()
-lib.mpn_debug_set_wgrad_stamps(None)
+lib.mpn_diag_set_wgrad_stamps(None)
 d = dbg.cpu().numpy().reshape(nblk, 8, 4).astype(np.float64)
 used = d.sum(axis=(1, 2)) > 0
 d = d[used] / 100.0   # us
