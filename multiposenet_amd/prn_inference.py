@@ -24,7 +24,8 @@ class KeypointAssigner:
 
     def __init__(self, prn_net, threshold=0.2):
         self.net = prn_net
-        self.device = prn_net.device
+        # (prn_net may be None when only crops()/decode() are used: launches then go to the current device)
+        self.device = prn_net.device if prn_net is not None else torch.device("cuda", torch.cuda.current_device())
         self.threshold = float(threshold)
         self._keys = None
 

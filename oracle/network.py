@@ -12,7 +12,9 @@ PARITY UNPINNED for this part: the arithmetic lives in tensorflow==1.15 (README.
 which is absent from /root/reference and cannot be installed here, and the reference
 holds no tests/golden vectors for it. Every "TF-1.15 semantic" below is restated from
 TensorFlow's documented op behaviour; `oracle/tf_semantics_np.py` re-derives the
-layout/padding/resize rules independently with plain numpy loops as a cross-check.
+layout/padding/resize rules and - loop by loop, without torch, citing the TF 1.15 source file of each op -
+fused batch-norm (+ moving-average update), Adam, cosine decay, the losses and the mask halving, pinned by
+hand-computed known-answer vectors and compared with this file in tests/test_oracle_network.py.
 (The decode part, oracle/decode.py, IS pinned by goldens from the imported reference.)
 
 Layout: NHWC at the API edge, NCHW inside (detector/constants.py:7), exactly like the
@@ -196,7 +198,10 @@ def nearest_neighbor_upsample(x):
 
 def resize_bilinear_legacy(x, out_h, out_w):
     """tf.image.resize_bilinear, TF-1.15 legacy (align_corners=False, half_pixel_centers=False):
-    src = dst * (in/out); lo = floor(src); hi = min(lo+1, in-1); frac = src - lo. x is NCHW."""
+    src = dst * (in/out); lo = floor(src); hi = min(lo+1, in-1); frac = src - lo. x is NCHW.
+    Order of the two lerps: TF (resize_bilinear_op.cc compute_lerp) interpolates along x first, then y; this restatement
+    does y first, then x. The result is the same bilinear form; the two orders differ by rounding only (<= 1 ulp of the
+    working precision - tests/test_oracle_network.py compares them against oracle/tf_semantics_np.resize_bilinear_tf)."""
     def axis(n_in, n_out):
         scale = n_in / n_out
         src = torch.arange(n_out, dtype=torch.float64) * scale

@@ -1,0 +1,103 @@
+"""GPU: the data-parallel train step (one process per device, RCCL all-reduce) against the single-device step.
+
+`test_two_rank_rccl_step_equals_single_rank_step` needs >= 2 visible devices and skips otherwise (a one-GPU box):
+two ranks train on IDENTICAL batches, so the all-reduced gradient sum is exactly twice each rank's gradient and the
+averaged step must reproduce the single-rank step bit for bit - variables, Adam slots and (per-replica) moving statistics.
+`test_one_rank_rccl_rehearsal...` runs everywhere: the three-graph step + the real RCCL collectives with world size 1.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HP = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_steps(device, distributed, use_graph=True, steps=2):
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.synthetic import synthetic_batch
+    from multiposenet_amd.train import Trainer
+    net = KeypointNet(dtype=torch.bfloat16, device=device, seed=0)
+    tr = Trainer(net, HP, use_graph=use_graph, distributed=distributed)
+    feats, labels = synthetic_batch(2, 128, 128, rank=0, device=device)      # the SAME batch on every rank
+    losses = [tr.step(feats, labels).cpu().numpy().copy() for _ in range(steps)]
+    torch.cuda.synchronize(device)
+    return {"losses": np.stack(losses), "theta": net.theta.cpu().numpy(), "m": net.adam_m.cpu().numpy(),
+            "v": net.adam_v.cpu().numpy(), "moving": net.moving.cpu().numpy(), "grad": net.grad.cpu().numpy()}
+
+
+def _worker_main():
+    """Entry point of a spawned rank (python tests/test_dp_gpu.py <out_prefix>); env: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*."""
+    sys.path.insert(0, ROOT)
+    from multiposenet_amd.parallel import init_distributed
+    rank, local_rank, world = init_distributed("nccl")
+    torch.cuda.set_device(local_rank)
+    out = _run_steps(f"cuda:{local_rank}", distributed=True)
+    np.savez(f"{sys.argv[1]}.rank{rank}.npz", world=world, **out)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _spawn(world, prefix, extra_env=None):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r),
+                   WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), prefix], env=env, cwd=ROOT))
+    rcs = [p.wait(timeout=900) for p in procs]
+    assert rcs == [0] * world, f"rank exit codes {rcs}"
+    return [dict(np.load(f"{prefix}.rank{r}.npz")) for r in range(world)]
+
+
+def test_two_rank_rccl_step_equals_single_rank_step(cuda, tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 visible devices (one process per GPU)")
+    want = _run_steps("cuda:0", distributed=False)
+    got = _spawn(2, str(tmp_path / "dp"))
+    for r, g in enumerate(got):
+        assert int(g["world"]) == 2
+        for k in ("losses", "theta", "m", "v", "moving"):
+            np.testing.assert_array_equal(g[k], want[k], err_msg=f"rank {r}: {k}")
+        # the arena holds the all-reduced SUM (the 1/world average is folded into the Adam kernel): exactly 2 x one rank's
+        np.testing.assert_array_equal(g["grad"], 2.0 * want["grad"], err_msg=f"rank {r}: grad")
+
+
+def test_one_rank_rccl_rehearsal_equals_plain_step(cuda, tmp_path):
+    """World size 1 through init_distributed + the three-graph step + RCCL all-reduce (MPN_DP_FORCE_COLLECTIVE=1): the
+    same bits as the one-graph step without a process group."""
+    want = _run_steps("cuda:0", distributed=False)
+    got = _spawn(1, str(tmp_path / "dp1"), {"MPN_DP_FORCE_COLLECTIVE": "1"})[0]
+    assert int(got["world"]) == 1
+    for k in ("losses", "theta", "m", "v", "moving", "grad"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+
+
+def test_distributed_without_process_group_is_refused(cuda, monkeypatch):
+    """Never a silent world = 1: WORLD_SIZE > 1 without an initialised process group raises."""
+    from multiposenet_amd.parallel import GradientAllReducer
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    if torch.distributed.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    with pytest.raises(RuntimeError, match="not initialised"):
+        GradientAllReducer(torch.zeros(16, device="cuda"))
+
+
+if __name__ == "__main__":
+    _worker_main()

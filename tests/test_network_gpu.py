@@ -340,3 +340,28 @@ def test_dw_dgrad_fused_bn_reduction_equals_separate_reduction(cuda):
         assert np.abs(ga - gb).max() <= (2e-5 if dt == torch.float32 else 2e-2) * denom
         cos = float((ga * gb).sum() / np.sqrt((ga * ga).sum() * (gb * gb).sum()))
         assert cos > (0.999999 if dt == torch.float32 else 0.999), cos
+
+
+def test_train_loss_is_not_stale_after_eval_at_another_batch_size(cuda):
+    """A replayed TRAIN step returns the loss tensor of ITS buffer set, also after an EVAL call at another batch size
+    rebound net._last: train, eval at a different batch, train -> the second train loss equals the eager one."""
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
+    rs = np.random.RandomState(21)
+    params = _params(7)
+    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
+    img2 = torch.tensor(rs.rand(2, 128, 128, 3).astype(np.float32)).cuda()
+    lab2 = {k: torch.tensor(v).cuda() for k, v in _labels(rs, 2, 32, 32).items()}
+    img1 = torch.tensor(rs.rand(1, 128, 128, 3).astype(np.float32)).cuda()
+    lab1 = {k: torch.tensor(v).cuda() for k, v in _labels(rs, 1, 32, 32).items()}
+    out = {}
+    for graph in (False, True):
+        net = KeypointNet(values=params, dtype=torch.float32)
+        tr = Trainer(net, hp, use_graph=graph)
+        a = tr.step({"images": img2}, lab2).cpu().numpy().copy()
+        e = tr.eval_step({"images": img1}, lab1).cpu().numpy().copy()
+        b = tr.step({"images": img2}, lab2).cpu().numpy().copy()
+        out[graph] = (a, e, b)
+    for x, y in zip(out[False], out[True]):
+        np.testing.assert_array_equal(x, y)
+    assert not np.array_equal(out[True][1], out[True][2])      # the eval losses are another batch's
