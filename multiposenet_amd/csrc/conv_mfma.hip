@@ -18,6 +18,7 @@
 // Epilogue: accumulators -> LDS -> full 16-byte NHWC stores; optional fused nearest-2x
 // upsample-add (fpn.py:51) and per-tile batch-norm partial sums (sum, sum of squares).
 #include "common.h"
+#include "pointwise.h"
 #include <string.h>
 
 namespace {
@@ -527,9 +528,14 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
                                          int transpose, int BN, int nchunk, int row_bytes, long long i) {
     constexpr int ES = (int)sizeof(T);
     constexpr int EPK = 64 / ES;   // elements per k-step row
-    const int CCE = row_bytes / ES;   // channels per chunk
     const int Kin = transpose ? Cout_o : Cin_o;     // GEMM K channels
     const int Nout = transpose ? Cin_o : Cout_o;    // GEMM N channels
+    if (row_bytes == 0) {   // plain [N][K]: W^T for the forward, the HWIO matrix itself for the data gradient
+        const int n = (int)(i / Kin), k = (int)(i - (long long)n * Kin);
+        out[i] = from_f32<T>(transpose ? w[(long long)n * Cout_o + k] : w[(long long)k * Cout_o + n]);
+        return;
+    }
+    const int CCE = row_bytes / ES;   // channels per chunk
     const int stages_per_tap = row_bytes >> 7;
     long long r = i;
     const int e = (int)(r % EPK); r /= EPK;
@@ -583,12 +589,17 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, 
 }
 
 struct PackGeom {
-    int BN, n_tiles, nchunk, row_bytes;
+    int BN, n_tiles, nchunk, row_bytes;   // row_bytes == 0: plain [N][K] matrix for the GEMM kernel of pointwise.hip
     long long tile_bytes, total_bytes;
 };
 
 PackGeom pack_geom(int Kin, int Nout, int taps, int es) {
     PackGeom g;
+    if (pw_gemm_eligible(Kin, Nout, taps, es)) {
+        g.BN = 256; g.n_tiles = Nout / 256; g.nchunk = 1; g.row_bytes = 0;
+        g.tile_bytes = 256ll * Kin * es; g.total_bytes = (long long)Nout * Kin * es;
+        return g;
+    }
     g.BN = (Nout % 128 == 0) ? 128 : 64;
     g.n_tiles = (Nout + g.BN - 1) / g.BN;
     const int kbytes = Kin * es;
@@ -743,6 +754,11 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
     MPN_REQUIRE(up_res == nullptr || (ksize == 1 && H % 2 == 0 && W % 2 == 0), MPN_ERR_BAD_ARG,
                 "conv: upsample-add epilogue needs ksize 1 and even H, W");
     const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es);
+    if (g.row_bytes == 0) {   // deep 1x1 layer: the GEMM kernel (weights packed as [Cout][Cin])
+        MPN_REQUIRE(up_res == nullptr, MPN_ERR_BAD_ARG, "conv: the upsample-add epilogue needs Cout < 256 or Cin < 256");
+        return pw_gemm_launch(x, w_packed, y, (long long)N * H * W, Cin, Cout, x_stride > 0 ? x_stride : Cin,
+                              y_stride > 0 ? y_stride : Cout, in_scale, in_shift, in_act, stats_part, (hipStream_t)stream);
+    }
     ConvParams p;
     conv_fill_params(p, g, x, w_packed, y, N, H, W, Cin, Cout, x_stride, y_stride, ksize, in_scale, in_shift, in_act, stats_part, up_res);
     const int m_tiles = mpn_conv_num_parts(N, H, W, ksize);

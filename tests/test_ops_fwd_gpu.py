@@ -30,6 +30,13 @@ CONV_CASES = [
     (3, 16, 16, 1024, 1024, 1, 2, True, False),  # pointwise 13 shape
     (1, 10, 14, 40, 72, 3, 1, True, False),      # channel counts off the tile grid: partial K chunk, partial last n-tile
     (2, 6, 10, 136, 200, 1, 2, True, False),     # same for 1x1 (XCD-remapped block map, 4 n-tiles of 64)
+    # the GEMM kernel of pointwise.hip (bf16, K >= 256, N % 256 == 0; the f32 build stays on the tiled kernel)
+    (2, 16, 16, 512, 512, 1, 2, True, False),    # 128-pixel tiles (few tiles), affine + ReLU6, statistics
+    (1, 13, 11, 256, 256, 1, 1, True, False),    # ragged M (143 pixels): partial tile, partial statistics row
+    (2, 16, 16, 512, 256, 1, 0, False, False),   # no affine: A rows by LDS-DMA (the data-gradient configuration)
+    (1, 9, 15, 320, 512, 1, 0, True, False),     # K = 5 k-steps, ragged M, LDS-DMA path with statistics
+    (8, 96, 96, 256, 512, 1, 2, True, False),    # 256-pixel tiles (73 728 pixels x 2 n-tiles = 576 blocks)
+    (9, 85, 83, 256, 256, 1, 0, True, False),    # 256-pixel tiles, ragged M (63 495 pixels), LDS-DMA path
 ]
 
 
@@ -71,7 +78,7 @@ def test_conv_fwd(cuda, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-@pytest.mark.parametrize("k,Cin,Cout", [(3, 128, 128), (3, 512, 64), (1, 256, 128), (1, 64, 128)])
+@pytest.mark.parametrize("k,Cin,Cout", [(3, 128, 128), (3, 512, 64), (1, 256, 128), (1, 64, 128), (1, 512, 1024), (1, 256, 512)])
 def test_conv_dgrad_is_transposed_conv(cuda, dtype, k, Cin, Cout):
     ops = _ops()
     rs = np.random.RandomState(k + Cin)
@@ -311,3 +318,28 @@ def test_conv_fwd_grouped_equals_separate_launches(cuda, dtype):
     ops.conv_fwd_grouped(xs, [pc.bwd for pc in pcs], C, 3, [None] * 4, outs2, [None] * 4)
     for a, b in zip(want2, outs2):
         assert torch.equal(a, b)
+
+
+def test_conv_fwd_channel_slices_of_wider_tensors(cuda):
+    """x / y pixel strides: a conv reads a channel slice of a wider NHWC tensor and writes into a slice of another one
+    (phi_subnet_2/conv2 -> the first 128 channels of the 512-channel concat tensor), 3x3 tiled kernel and 1x1 GEMM kernel."""
+    ops = _ops()
+    rs = np.random.RandomState(3)
+    dtype = torch.bfloat16
+    for (k, Cin, Cout, wide_in, wide_out, off_in, off_out) in [(3, 128, 128, 128, 512, 0, 128), (1, 256, 256, 384, 512, 128, 256),
+                                                                 (1, 64, 128, 128, 128, 64, 0)]:
+        N, H, W = 2, 16, 24
+        xw = dev(rnd(rs.randn(N, H, W, wide_in), dtype), dtype)
+        w = rs.randn(k, k, Cin, Cout).astype(np.float32) / np.sqrt(k * k * Cin)
+        pc = ops.PackedConv(dev(w), dtype)
+        sc = dev(torch.tensor(0.5 + rs.rand(Cin), dtype=torch.float32)); sh = dev(torch.tensor(rs.randn(Cin) * 0.5, dtype=torch.float32))
+        aff = ops.Affine(sc, sh, 1)
+        xs = xw[..., off_in:off_in + Cin]
+        part_a = torch.zeros((ops.conv_num_parts(N, H, W, k), 2, Cout), device="cuda")
+        part_b = torch.zeros_like(part_a)
+        want = ops.conv_fwd(xs.contiguous(), pc.fwd, Cout, k, aff, stats_part=part_a)
+        yw = torch.full((N, H, W, wide_out), 7.0, device="cuda", dtype=dtype)
+        ops.conv_fwd(xs, pc.fwd, Cout, k, aff, out=yw[..., off_out:off_out + Cout], stats_part=part_b)
+        assert torch.equal(yw[..., off_out:off_out + Cout], want) and torch.equal(part_a, part_b)
+        rest = torch.ones(wide_out, dtype=torch.bool); rest[off_out:off_out + Cout] = False
+        assert bool((yw[..., rest.cuda()] == 7.0).all())      # nothing outside the slice is touched
