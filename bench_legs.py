@@ -18,37 +18,52 @@ def whole_step_mfma_fraction(batch, size, step_seconds):
     return round(flops / step_seconds / (PEAK_BF16_TFLOPS * 1e12), 4)
 
 
-def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20):
+def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20, b=None):
     """The dominant kernel of the step is the dense 3x3 implicit-GEMM conv (conv_mfma_kernel, 128->128 channels
     at stride 4: p2, phi_subnet_2/conv1, conv2 forward and their three data-gradients = 6 launches per step).
-    Times that launch with HIP events on the launch stream, on the tensors of the live network."""
+    Times that launch with HIP events on the launch stream, on the tensors of the live network - in the form the forward
+    runs it (producer's batch-norm affine + ReLU on load, batch-norm partial sums of the output in the epilogue: 3 of the
+    6 launches) and without the statistics epilogue (the data gradients)."""
     h = w = size // 4
-    x = net._bufs[(batch, size, size)]["p"][2]
+    b = b if b is not None else net._bufs[(batch, size, size)]
+    x = b["p"][2]
     conv = net.phi[2]["conv1"]
     y = torch.empty_like(x)
+    part = b["stat_lv"][2]
     stream = torch.cuda.current_stream()
-    # (steady state: the chip drops its clock in the host-side gap after the training loop and takes a few
-    #  milliseconds of work to come back - 3 warm-up launches read 177 us where 20 read 144-149 us, tools/roofline_repeat.py)
-    for _ in range(warmup):
-        ops.conv_fwd(x, conv.packed.fwd, 128, 3, net.p_bn[2].affine, out=y)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        ops.conv_fwd(x, conv.packed.fwd, 128, 3, net.p_bn[2].affine, out=y)
-    e1.record(stream)
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / iters
+
+    def timed(stats):
+        # (steady state: the chip drops its clock in the host-side gap after the training loop and takes a few
+        #  milliseconds of work to come back - 3 warm-up launches read 177 us where 20 read 144-149 us)
+        for _ in range(warmup):
+            ops.conv_fwd(x, conv.packed.fwd, 128, 3, net.p_bn[2].affine, out=y, stats_part=part if stats else None)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            ops.conv_fwd(x, conv.packed.fwd, 128, 3, net.p_bn[2].affine, out=y, stats_part=part if stats else None)
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / iters
+    sec_plain = timed(False)
+    sec = timed(True)
     flops = 2.0 * batch * h * w * 128 * 128 * 9          # algorithmic FLOPs of one launch
     peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
     achieved = flops / sec / 1e12
     traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
-    tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_dominant_kernel_traffic.json")
-    if dtype == torch.bfloat16 and batch == 32 and size == 512 and os.path.exists(tj):
-        import json
-        traffic = json.load(open(tj))["hbm_bytes_per_launch"]
-    return {"kernel": "conv_mfma_kernel<3x3,128->128> @ [%d,%d,%d,128]" % (batch, h, w), "bound": "mfma",
-            "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": traffic, "launch_us": round(sec * 1e6, 2)}
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = None
+    for name in ("r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+        tj = os.path.join(here, "profiles", name)
+        if dtype == torch.bfloat16 and batch == 32 and size == 512 and os.path.exists(tj):
+            import json
+            traffic = json.load(open(tj))["hbm_bytes_per_launch"]
+            src = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/one_conv.py; not re-measured by this run)"
+            break
+    return {"kernel": "conv_mfma_kernel<3x3,128->128> @ [%d,%d,%d,128], affine + ReLU on load, batch-norm statistics epilogue" % (batch, h, w),
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+            "traffic": traffic, "traffic_source": src, "launch_us": round(sec * 1e6, 2),
+            "launch_us_without_statistics": round(sec_plain * 1e6, 2),
+            "frac_without_statistics": round(flops / sec_plain / 1e12 / peak, 4)}
 
 
 def north_star_kernels(batch=32, iters=20):
@@ -354,3 +369,64 @@ def host_fed_rate(trainer, features, labels, steps=20, warmup=3):
                      "h2d_alone_ms": round(copy_s * 1e3, 3), "h2d_alone_GBps": round(feeder.bytes_per_batch / copy_s / 1e9, 1)}
         del feeder
     return out
+
+
+def f32_build_rate(batch, size, steps=6, warmup=2):
+    """The same workload in the f32 build (f32 storage, f32-input MFMA at 1/16 of the bf16 rate): the configuration whose
+    logits meet the north star's 1e-3 bound against the oracle (tests/test_network_gpu.py, tests/test_argmax_parity_gpu.py)."""
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.synthetic import synthetic_batch
+    from multiposenet_amd.train import Trainer
+    net = KeypointNet(dtype=torch.float32, seed=0)
+    tr = Trainer(net, {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0})
+    feats, labels = synthetic_batch(batch, size, size)
+    feats, labels = tr.input_buffers(feats, labels)
+    for _ in range(warmup):
+        tr.step(feats, labels)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(feats, labels)
+    torch.cuda.synchronize()
+    dt_s = (time.perf_counter() - t0) / steps
+    loss = float(tr._losses[6])
+    del tr, net
+    torch.cuda.empty_cache()
+    return {"images_per_s": round(batch / dt_s, 1), "ms_per_step": round(dt_s * 1e3, 2), "dtype": "f32", "steps": steps,
+            "final_total_loss": loss,
+            "step_frac_of_f32_mfma_peak": round(6.0 * GMAC_PER_IMAGE_512 * 1e9 * (size / 512.0) ** 2 * batch / dt_s / (PEAK_F32_TFLOPS * 1e12), 4)}
+
+
+def bf16_vs_f32_argmax_agreement(batch, size, seed=0):
+    """What the bf16 throughput build delivers where the north star asks for 1e-3 / bit-exact arg-max: the same images and
+    variables through the f32 build (the yardstick that meets 1e-3 against the oracle) and the bf16 build, inference mode;
+    per (image, keypoint channel): does the arg-max of the logits agree, and the largest logit difference. The head is
+    given trained-like weights (N(0, 0.35^2), bias -1.5): at the reference's N(0, 1e-4) initialisation every map is a tie."""
+    import numpy as np
+    from multiposenet_amd.net import KeypointNet, initial_values
+    from multiposenet_amd.synthetic import synthetic_batch
+    vals = initial_values(seed)
+    rs = np.random.RandomState(seed)
+    vals["heatmaps/kernel"] = (rs.randn(1, 1, 64, 18) * 0.35).astype(np.float32)
+    vals["heatmaps/bias"] = np.concatenate([np.full(17, -1.5), [0.0]]).astype(np.float32)
+    feats, _ = synthetic_batch(batch, size, size)
+    out = {}
+    for dt in (torch.float32, torch.bfloat16):
+        net = KeypointNet(values=vals, dtype=dt)
+        logits, _ = net.forward(feats["images"], False)
+        out[dt] = logits[..., :17].float().clone()
+        del net
+        torch.cuda.empty_cache()
+    a, b = out[torch.float32].reshape(batch, -1, 17), out[torch.bfloat16].reshape(batch, -1, 17)
+    ia, ib = a.argmax(1), b.argmax(1)
+    err = float((a - b).abs().max())
+    top2 = a.topk(2, dim=1).values
+    gap = top2[:, 0] - top2[:, 1]
+    clear = gap > 2 * err
+    agree = (ia == ib)
+    return {"channels": int(agree.numel()), "argmax_agreement": round(float(agree.float().mean()), 4),
+            "max_abs_logit_diff": round(err, 5), "logit_range": [round(float(a.min()), 2), round(float(a.max()), 2)],
+            "channels_with_top2_gap_above_2x_diff": int(clear.sum()),
+            "agreement_on_those": round(float(agree[clear].float().mean()), 4) if bool(clear.any()) else None,
+            "f32_yardstick": "f32 build: |heatmap - f64 oracle| <= 3e-6 and arg-max indices identical on every decided channel "
+                             "(tests/test_argmax_parity_gpu.py)"}

@@ -19,6 +19,8 @@ class Trainer:
         self.weight_decay = float(params.get("weight_decay", 0.0))
         self.use_graph = use_graph
         self.reducer = GradientAllReducer(net.grad, bucket_bytes=bucket_bytes) if distributed else None
+        self.measure_comm = False   # bench: record (end of backward, exchange complete) event pairs per step
+        self.comm_events = []
         self._static = None
         self._losses = None       # the f32[8] loss tensor of the buffer set the train step runs on
         self._graph_fb = None
@@ -116,10 +118,21 @@ class Trainer:
                 if early:
                     self.reducer.start(split, None)      # head + FPN gradients: overlapped with the backbone's backward
                 self._graph_bb.replay()
+                if self.measure_comm:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self.reducer.start(0, split if early else None)
                 self.reducer.finish()
+                if self.measure_comm:
+                    e1.record()
+                    self.comm_events.append((e0, e1))
                 self._graph_opt.replay()
         return self._losses
+
+    def _static_bufs(self):
+        """The buffer set of the bound (static) input shape."""
+        N, H, W, _ = self._static["images"].shape
+        return self.net._buffers(N, H, W)
 
     def eval_step(self, features, labels):
         self.net.forward(features["images"], False)
