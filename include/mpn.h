@@ -108,11 +108,11 @@ int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int
                  mpn_stream_t stream);
 /* Up to four independent 3x3 convolutions of the same channel geometry in ONE grid, largest first (the four pyramid levels
  * of a keypoint-subnet stage, keypoint_subnet.py:64-91: as launches of their own the small levels are latency-bound tails
- * of 15-45 us). Per job: x, w_packed, y, H, W, y_stride (array or NULL = dense), in_scale / in_shift (or NULL), stats_part
+ * of 15-45 us). Per job: x, w_packed, y, H, W, x_stride / y_stride (arrays or NULL = dense), in_scale / in_shift (or NULL), stats_part
  * (or NULL); shared: N, Cin, Cout, ksize, dtype, in_act. Results are those of mpn_conv_fwd per job, bit for bit;
  * configurations the grouped grid does not cover (f32, 1x1, more than four jobs) run as the separate launches they replace. */
 int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N, const int* H,
-                         const int* W, int Cin, int Cout, const int* y_stride, int ksize, int dtype,
+                         const int* W, int Cin, int Cout, const int* x_stride, const int* y_stride, int ksize, int dtype,
                          const float* const* in_scale, const float* const* in_shift, int in_act,
                          float* const* stats_part, mpn_stream_t stream);
 
@@ -120,8 +120,9 @@ int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_p
  * Split-K over pixel tiles: part [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (one HWIO slab
  * per split), summed in a fixed order by mpn_reduce_partials. */
 int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, int ksize, int dtype);
+/* x_stride / dy_stride: pixel strides in elements, 0 = dense (channel slices of wider tensors, as for mpn_conv_fwd) */
 int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int Cin,
-                        int Cout, int ksize, int dtype, const float* in_scale,
+                        int Cout, int x_stride, int dy_stride, int ksize, int dtype, const float* in_scale,
                         const float* in_shift, int in_act, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
@@ -141,14 +142,18 @@ int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const
 /* is_training=False path: affine from the moving statistics */
 /* The two backward passes of up to four independent layers of one channel count in ONE grid each, largest first (the
  * pyramid levels of a subnet stage). Arrays per job; results are those of mpn_bn_bwd_reduce / mpn_bn_bwd_apply per layer,
- * bit for bit; part[j] holds mpn_bn_stats_num_parts(M[j]) rows. */
+ * bit for bit; part[j] holds mpn_bn_stats_num_parts(M[j]) rows. dA_stride / x_stride (arrays or NULL = dense): elements
+ * between consecutive rows of dA[j] / x[j] - the level-2 tensors of phi_subnet's second batch-norm live in channel slices
+ * of the 512-channel concat tensor and of its gradient (keypoint_subnet.py:37). */
 int mpn_bn_bwd_reduce_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
                               const float* const* scale, const float* const* shift, const float* const* mean,
-                              const float* const* invstd, int act, float* const* part, mpn_stream_t stream);
+                              const float* const* invstd, int act, float* const* part, const int* dA_stride,
+                              const int* x_stride, mpn_stream_t stream);
 int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
                              const float* const* scale, const float* const* shift, const float* const* mean,
                              const float* const* invstd, const float* const* k1, const float* const* k2, int act,
-                             const float* const* add_ch0, mpn_stream_t stream);
+                             const float* const* add_ch0, const int* dA_stride, const int* x_stride,
+                             mpn_stream_t stream);
 /* Several independent layers' finalizes in ONE launch (the four pyramid levels of the keypoint subnet,
  * keypoint_subnet.py:64-91, produce their statistics side by side). Descriptor tables as for the batched slab reduction:
  * mpn_bn_fin_desc_fill / mpn_bn_bwd_fin_desc_fill write one host-side descriptor each (mpn_*_desc_bytes() bytes; return the

@@ -36,9 +36,9 @@ SIGNATURES = {
     "mpn_conv_pack_weights_batched": (_I, [_P, _I, _I, _I, _P]),
     "mpn_conv_num_parts": (_I, [_I, _I, _I, _I]),
     "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
-    "mpn_conv_fwd_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P, _I, _P, _P]),
+    "mpn_conv_fwd_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     "mpn_conv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I, _I]),
-    "mpn_conv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "mpn_conv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_bn_stats_num_parts": (_I, [_L]),
     "mpn_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
     "mpn_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),
@@ -82,8 +82,8 @@ SIGNATURES = {
     "mpn_bias_relu_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "mpn_bias_relu_bwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
     "mpn_prn_loss": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
-    "mpn_bn_bwd_reduce_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
-    "mpn_bn_bwd_apply_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "mpn_bn_bwd_reduce_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "mpn_bn_bwd_apply_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mpn_bn_fin_desc_bytes": (_Z, []),
     "mpn_bn_bwd_fin_desc_bytes": (_Z, []),
     "mpn_bn_fin_desc_fill": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I]),

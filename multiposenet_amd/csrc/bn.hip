@@ -272,7 +272,8 @@ template <typename T>
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-    float* __restrict__ part, int rows_per_block, const int blk) {
+    float* __restrict__ part, int rows_per_block, const int blk, const long long dA_stride, const long long x_stride) {
+    // dA_stride / x_stride: elements between consecutive rows (C for dense tensors; larger for channel slices of wider ones)
     constexpr int VE = Vec16<T>::N;
     __shared__ float smem[kThreads * 2 * VE];
     const RowMap m = make_rowmap(C, VE);
@@ -294,8 +295,8 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
             for (int u = 0; u < U; ++u) {
                 const long long rr = r + (long long)u * m.ppb;
                 if (rr < r1) {
-                    vd[u].load(dA + rr * C + m.vg * VE);
-                    vx[u].load(x + rr * C + m.vg * VE);
+                    vd[u].load(dA + rr * dA_stride + m.vg * VE);
+                    vx[u].load(x + rr * x_stride + m.vg * VE);
                 } else {
                     vd[u].zero();
                     vx[u].zero();
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
     const T* __restrict__ dA, const T* __restrict__ x, long long M, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
     float* __restrict__ part, int rows_per_block) {
-    bn_bwd_reduce_body<T>(dA, x, M, C, scale, shift, mean, invstd, act, part, rows_per_block, blockIdx.x);
+    bn_bwd_reduce_body<T>(dA, x, M, C, scale, shift, mean, invstd, act, part, rows_per_block, blockIdx.x, C, C);
 }
 
 // up to four independent layers (the pyramid levels of a subnet stage) in one grid, largest first
@@ -336,7 +337,7 @@ struct BnBwdJob {
     void* dA; const void* x; long long M;
     const float *scale, *shift, *mean, *invstd, *k1, *k2, *add_ch0;
     float* part;
-    int rows_per_block, pad_;
+    int rows_per_block, dA_stride, x_stride, pad_;   // strides: elements between rows (C = dense)
 };
 struct BnBwdGroup { BnBwdJob j[kBnGroup]; int begin[kBnGroup + 1]; int njobs, C, act, pad_; };
 __device__ __forceinline__ int bn_group_job(const BnBwdGroup& g) {
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_grouped_kernel(const B
     const int job = bn_group_job(g);
     const BnBwdJob& q = g.j[job];
     bn_bwd_reduce_body<T>((const T*)q.dA, (const T*)q.x, q.M, g.C, q.scale, q.shift, q.mean, q.invstd, g.act, q.part,
-                          q.rows_per_block, (int)blockIdx.x - g.begin[job]);
+                          q.rows_per_block, (int)blockIdx.x - g.begin[job], q.dA_stride, q.x_stride);
 }
 
 // part [nparts][2][C] -> dgamma, dbeta and the two per-channel coefficients of bn_bwd_apply
@@ -387,15 +388,20 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_batched_kernel(co
 
 // dx = scale * (g - k1 - xhat*k2), written over dA (same storage type); optional extra gradient
 // added to channel 0 (the auxiliary segmentation loss on p_l[...,0], keypoints_model.py:59-66).
-template <typename T>
+template <typename T, bool STRIDED = false>
 __device__ __forceinline__ void bn_bwd_apply_body(
     T* __restrict__ dA, const T* __restrict__ x, long long nvec, int C, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     const float* __restrict__ k1, const float* __restrict__ k2, int act, const float* __restrict__ add_ch0,
-    const int blk, const int nblk) {
+    const int blk, const int nblk, const long long dA_stride = 0, const long long x_stride = 0) {
+    // STRIDED: dA / x are channel slices of wider tensors - vector ii lives at (ii / cvec) * stride + (ii % cvec) * VE
+    // (cvec is a power of two); dense: at ii * VE
     constexpr int VE = Vec16<T>::N;
     constexpr int U = 4;   // 16-byte vectors of each operand in flight per thread
     const int cvec = C / VE;
+    const int cshift = __builtin_ctz(cvec);
+    auto off_d = [&](long long ii) { return STRIDED ? (ii >> cshift) * dA_stride + (ii & (cvec - 1)) * VE : ii * VE; };
+    auto off_x = [&](long long ii) { return STRIDED ? (ii >> cshift) * x_stride + (ii & (cvec - 1)) * VE : ii * VE; };
     // the grid stride (a multiple of kThreads) is a multiple of cvec (a power of two <= kThreads, checked by the launcher):
     // a thread keeps its channel vector, so the six per-channel parameters fold into registers ONCE:
     //   out = sc*(g - k1 - xhat*k2) = sc*g + cb*x + cc,  cb = -sc*k2*invstd,  cc = -sc*(k1 - mean*invstd*k2)
@@ -428,11 +434,11 @@ __device__ __forceinline__ void bn_bwd_apply_body(
         for (int u = 0; u < U; ++u) {
             const long long ii = i + u * stride;
             const long long ic = ii < nvec ? ii : i;   // unconditional loads from a valid address (a predicated load waits)
-            vd[u].load(dA + ic * VE);
+            vd[u].load(dA + off_d(ic));
             {   // x is dead after this pass: a non-temporal load keeps it from displacing dx, which the conv data / weight
                 // gradients read next (256x256x64 layer: 165 -> 131 us, the step -0.85 %)
                 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-                const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(x + ic * VE));
+                const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(x + off_x(ic)));
                 __builtin_memcpy(&vx[u].raw, &q, 16);
             }
         }
@@ -450,7 +456,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
             }
             if (add_ch0 != nullptr && vg == 0 && ii < nvec) d[0] += add_ch0[ii / cvec];
             vd[u].pack(d);
-            if (ii < nvec) vd[u].store(dA + ii * VE);
+            if (ii < nvec) vd[u].store(dA + off_d(ii));
         }
     }
 }
@@ -466,8 +472,13 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_grouped_kernel(const BnBwdGroup g) {
     const int job = bn_group_job(g);
     const BnBwdJob& q = g.j[job];
-    bn_bwd_apply_body<T>((T*)q.dA, (const T*)q.x, q.M * (g.C / Vec16<T>::N), g.C, q.scale, q.shift, q.mean, q.invstd, q.k1, q.k2,
-                         g.act, q.add_ch0, (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
+    if (q.dA_stride != g.C || q.x_stride != g.C)   // (block-uniform)
+        bn_bwd_apply_body<T, true>((T*)q.dA, (const T*)q.x, q.M * (g.C / Vec16<T>::N), g.C, q.scale, q.shift, q.mean, q.invstd, q.k1,
+                                   q.k2, g.act, q.add_ch0, (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job],
+                                   q.dA_stride, q.x_stride);
+    else
+        bn_bwd_apply_body<T>((T*)q.dA, (const T*)q.x, q.M * (g.C / Vec16<T>::N), g.C, q.scale, q.shift, q.mean, q.invstd, q.k1, q.k2,
+                             g.act, q.add_ch0, (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
 }
 
 // any C (a channel vector per thread changes from iteration to iteration: parameters re-loaded per element)
@@ -661,8 +672,11 @@ static bool bn_group_ok(int njobs, int C, int dtype) {
 }
 extern "C" int mpn_bn_bwd_reduce_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
                                          const float* const* scale, const float* const* shift, const float* const* mean,
-                                         const float* const* invstd, int act, float* const* part, mpn_stream_t stream) {
+                                         const float* const* invstd, int act, float* const* part, const int* dA_stride,
+                                         const int* x_stride, mpn_stream_t stream) {
     MPN_REQUIRE(njobs > 0 && dA && x && M && scale && shift && mean && invstd && part, MPN_ERR_BAD_ARG, "bn_bwd_reduce_grouped: bad arguments");
+    MPN_REQUIRE(bn_group_ok(njobs, C, dtype) || (dA_stride == nullptr && x_stride == nullptr), MPN_ERR_BAD_SHAPE,
+                "bn_bwd_reduce_grouped: row strides need a configuration the grouped grid covers");
     if (!bn_group_ok(njobs, C, dtype)) {
         for (int j = 0; j < njobs; ++j)
             if (int rc = mpn_bn_bwd_reduce(dA[j], x[j], M[j], C, dtype, scale[j], shift[j], mean[j], invstd[j], act, part[j], stream)) return rc;
@@ -678,6 +692,10 @@ extern "C" int mpn_bn_bwd_reduce_grouped(int njobs, void* const* dA, const void*
         BnBwdJob& q = g.j[j];
         q.dA = dA[j]; q.x = x[j]; q.M = M[j]; q.scale = scale[j]; q.shift = shift[j]; q.mean = mean[j]; q.invstd = invstd[j];
         q.part = part[j]; q.rows_per_block = (int)rows_per_block_for(M[j], nparts);
+        q.dA_stride = (dA_stride && dA_stride[j] > 0) ? dA_stride[j] : C;
+        q.x_stride = (x_stride && x_stride[j] > 0) ? x_stride[j] : C;
+        MPN_REQUIRE(q.dA_stride >= C && q.x_stride >= C && q.dA_stride % ve == 0 && q.x_stride % ve == 0, MPN_ERR_BAD_SHAPE,
+                    "bn_bwd_reduce_grouped: bad row stride");
         g.begin[j] = begin;
         begin += nparts;
     }
@@ -691,9 +709,12 @@ extern "C" int mpn_bn_bwd_reduce_grouped(int njobs, void* const* dA, const void*
 extern "C" int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* const* x, const long long* M, int C, int dtype,
                                         const float* const* scale, const float* const* shift, const float* const* mean,
                                         const float* const* invstd, const float* const* k1, const float* const* k2, int act,
-                                        const float* const* add_ch0, mpn_stream_t stream) {
+                                        const float* const* add_ch0, const int* dA_stride, const int* x_stride,
+                                        mpn_stream_t stream) {
     MPN_REQUIRE(njobs > 0 && dA && x && M && scale && shift && mean && invstd && k1 && k2 && add_ch0, MPN_ERR_BAD_ARG,
                 "bn_bwd_apply_grouped: bad arguments");
+    MPN_REQUIRE(bn_group_ok(njobs, C, dtype) || (dA_stride == nullptr && x_stride == nullptr), MPN_ERR_BAD_SHAPE,
+                "bn_bwd_apply_grouped: row strides need a configuration the grouped grid covers");
     if (!bn_group_ok(njobs, C, dtype)) {
         for (int j = 0; j < njobs; ++j)
             if (int rc = mpn_bn_bwd_apply(dA[j], x[j], M[j], C, dtype, scale[j], shift[j], mean[j], invstd[j], k1[j], k2[j], act,
@@ -710,6 +731,10 @@ extern "C" int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* 
         BnBwdJob& q = g.j[j];
         q.dA = dA[j]; q.x = x[j]; q.M = M[j]; q.scale = scale[j]; q.shift = shift[j]; q.mean = mean[j]; q.invstd = invstd[j];
         q.k1 = k1[j]; q.k2 = k2[j]; q.add_ch0 = add_ch0[j];
+        q.dA_stride = (dA_stride && dA_stride[j] > 0) ? dA_stride[j] : C;
+        q.x_stride = (x_stride && x_stride[j] > 0) ? x_stride[j] : C;
+        MPN_REQUIRE(q.dA_stride >= C && q.x_stride >= C && q.dA_stride % ve == 0 && q.x_stride % ve == 0, MPN_ERR_BAD_SHAPE,
+                    "bn_bwd_apply_grouped: bad row stride");
         const long long nvec = M[j] * (C / ve);
         long long blocks = (nvec + 4 * kThreads - 1) / (4 * kThreads);   // as the per-layer launch
         if (blocks > 2048) blocks = 2048;

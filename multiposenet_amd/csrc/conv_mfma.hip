@@ -784,9 +784,10 @@ static int launch_conv_grouped(const ConvGroup& grp, int grid, hipStream_t st) {
 /* Several independent 3x3 convolutions of the same channel geometry in ONE grid (the four pyramid levels of a subnet
  * stage: keypoint_subnet.py:64-91 applies phi_subnet to p2..p5 independently). bf16 3x3 with at most 4 jobs run in one
  * grid; anything else runs as the separate launches it replaces. Results are those of mpn_conv_fwd per job, bit for bit
- * (same kernel body, same tiles). y_stride[j] (may be NULL = dense): pixel stride of job j's output. */
+ * (same kernel body, same tiles). x_stride[j] / y_stride[j] (arrays, may be NULL = dense): pixel strides of job j's input / output. */
 extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N,
-                                    const int* H, const int* W, int Cin, int Cout, const int* y_stride, int ksize, int dtype,
+                                    const int* H, const int* W, int Cin, int Cout, const int* x_stride, const int* y_stride,
+                                    int ksize, int dtype,
                                     const float* const* in_scale, const float* const* in_shift, int in_act,
                                     float* const* stats_part, mpn_stream_t stream) {
     MPN_REQUIRE(njobs > 0 && x && w_packed && y && H && W && in_scale && in_shift && stats_part, MPN_ERR_BAD_ARG,
@@ -796,7 +797,8 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
     const bool fast = dtype == MPN_BF16 && ksize == 3 && njobs <= kMaxGroup && g.row_bytes == 128;
     if (!fast) {
         for (int j = 0; j < njobs; ++j)
-            if (int rc = mpn_conv_fwd(x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, 0, y_stride ? y_stride[j] : 0, ksize, dtype,
+            if (int rc = mpn_conv_fwd(x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, x_stride ? x_stride[j] : 0,
+                                      y_stride ? y_stride[j] : 0, ksize, dtype,
                                       in_scale[j], in_shift[j], in_act, stats_part[j], nullptr, stream))
                 return rc;
         return MPN_OK;
@@ -809,9 +811,10 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
         MPN_REQUIRE(mpn_aligned16(x[j]) && mpn_aligned16(w_packed[j]) && mpn_aligned16(y[j]), MPN_ERR_BAD_ALIGN,
                     "conv grouped: pointers must be 16-byte aligned");
         MPN_REQUIRE((in_scale[j] == nullptr) == (in_shift[j] == nullptr), MPN_ERR_BAD_ARG, "conv grouped: scale/shift mismatch");
-        const int ys = y_stride ? y_stride[j] : 0;
-        MPN_REQUIRE(ys == 0 || (ys >= Cout && ys % 8 == 0), MPN_ERR_BAD_SHAPE, "conv grouped: bad output pixel stride %d", ys);
-        conv_fill_params(grp.p[j], g, x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, 0, ys, 3, in_scale[j], in_shift[j], in_act,
+        const int ys = y_stride ? y_stride[j] : 0, xs = x_stride ? x_stride[j] : 0;
+        MPN_REQUIRE((ys == 0 || (ys >= Cout && ys % 8 == 0)) && (xs == 0 || (xs >= Cin && xs % 8 == 0)), MPN_ERR_BAD_SHAPE,
+                    "conv grouped: bad pixel strides %d, %d", xs, ys);
+        conv_fill_params(grp.p[j], g, x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, xs, ys, 3, in_scale[j], in_shift[j], in_act,
                          stats_part[j], nullptr);
         grp.p[j].xcd_remap = 0;
         grp.begin[j] = begin;

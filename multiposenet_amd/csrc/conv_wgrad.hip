@@ -33,6 +33,7 @@ struct WgradParams {
     const float* in_shift;
     int in_act;
     int N, H, W, Cin, Cout;
+    int xs, dys;      // elements between consecutive pixels of x / dy (Cin / Cout when dense)
     int tiles_x, tiles_y;
     long long M;
     int ntiles;   // pixel tiles
@@ -158,11 +159,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
                     const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
                     const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
                     ok = ok && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    off = (((long long)img * p.H + iy) * p.W + ix) * p.Cin + ace;
+                    off = (((long long)img * p.H + iy) * p.W + ix) * p.xs + ace;
                 } else {
                     const long long m = m0 + pix;
                     ok = ok && m < p.M;
-                    off = m * p.Cin + ace;
+                    off = m * p.xs + ace;
                 }
                 inb[i] = ok;
                 if (ok) v[i].load(x + off); else v[i].zero();
@@ -175,11 +176,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
                 if (TAPS == 9) {
                     const int oy = oy0 + (r >> 4), ox = ox0 + (r & 15);
                     ok = ok && oy < p.H && ox < p.W;
-                    off = (((long long)img * p.H + oy) * p.W + ox) * p.Cout + dce;
+                    off = (((long long)img * p.H + oy) * p.W + ox) * p.dys + dce;
                 } else {
                     const long long m = m0 + r;
                     ok = ok && m < p.M;
-                    off = m * p.Cout + dce;
+                    off = m * p.dys + dce;
                 }
                 if (ok) dv[i].load(dy + off); else dv[i].zero();
             }
@@ -384,17 +385,17 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
             const bool ok = ace < p.Cin && vi < NPIXA * ASLOTS;
             if (TAPS == 9) {
                 const int hy = pix / kHaloW, hx = pix - hy * kHaloW;
-                relA[i] = ((hy - 1) * p.W + (hx - 1)) * p.Cin + ace;
+                relA[i] = ((hy - 1) * p.W + (hx - 1)) * p.xs + ace;
                 hyx[i] = ok ? (hy << 8 | hx) : 0x7fff00;        // hy = 32767: never inside an image
             } else {
-                relA[i] = pix * p.Cin + ace;
+                relA[i] = pix * p.xs + ace;
                 hyx[i] = ok ? pix : 0x7fffffff;
             }
         }
 #pragma unroll
         for (int i = 0; i < DVEC; ++i) {
             const int r = (tid / DSLOTS) + i * (NT / DSLOTS);
-            relD[i] = (TAPS == 9 ? ((r >> 4) * p.W + (r & 15)) : r) * p.Cout + dce;
+            relD[i] = (TAPS == 9 ? ((r >> 4) * p.W + (r & 15)) : r) * p.dys + dce;
         }
     }
     const bool dvalid = co0 + dslot * VE < p.Cout;
@@ -413,11 +414,11 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
             oy0 = ty * 8;
             ox0 = tx * 16;
             const int pix0 = (img * p.H + oy0) * p.W + ox0;
-            baseA = pix0 * p.Cin;
-            baseD = pix0 * p.Cout;
+            baseA = pix0 * p.xs;
+            baseD = pix0 * p.dys;
         } else {
-            baseA = tile * 128 * p.Cin;
-            baseD = tile * 128 * p.Cout;
+            baseA = tile * 128 * p.xs;
+            baseD = tile * 128 * p.dys;
             mleft = (int)(p.M - (long long)tile * 128);      // valid pixels from the tile origin on
         }
         int oa[AVEC], od[DVEC];
@@ -698,8 +699,8 @@ extern "C" int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, 
 
 /* part: [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (HWIO per split); finish with mpn_reduce_partials */
 extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int Cin, int Cout,
-                                   int ksize, int dtype, const float* in_scale, const float* in_shift, int in_act,
-                                   mpn_stream_t stream) {
+                                   int x_stride, int dy_stride, int ksize, int dtype, const float* in_scale,
+                                   const float* in_shift, int in_act, mpn_stream_t stream) {
     MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv wgrad: ksize must be 1 or 3");
     MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "conv wgrad: dtype %d", dtype);
     const int es = dtype == MPN_F32 ? 4 : 2;
@@ -716,6 +717,11 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
     p.x = x; p.dy = dy; p.part = part;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
     p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.xs = x_stride > 0 ? x_stride : Cin; p.dys = dy_stride > 0 ? dy_stride : Cout;
+    MPN_REQUIRE(p.xs >= Cin && p.dys >= Cout && p.xs % ve == 0 && p.dys % ve == 0, MPN_ERR_BAD_SHAPE,
+                "conv wgrad: pixel strides (%d, %d) must be multiples of %d not below the channel counts", x_stride, dy_stride, ve);
+    MPN_REQUIRE((long long)N * H * W * p.xs < (1ll << 31) && (long long)N * H * W * p.dys < (1ll << 31), MPN_ERR_BAD_SHAPE,
+                "conv wgrad: strided tensors must span fewer than 2^31 elements");
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
     p.M = (long long)N * H * W;
     p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = g.n_cg; p.n_cb = g.n_cb;

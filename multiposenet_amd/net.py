@@ -230,6 +230,16 @@ class KeypointNet:
                                conv2=self._conv(s + "/conv2/kernel"), bn2=self._bn(s + "/bn2", ACT_RELU))
         self.final_conv = self._conv("final_conv3x3/kernel")
         self.final_bn = self._bn("final_bn", ACT_RELU)
+        # The concat tensor (keypoint_subnet.py:37) holds level 2 RAW: phi_subnet_2/conv2 writes its output straight into
+        # channels 0..127 (an upsampling factor of 1 is a copy) and the consumers - final_conv3x3 and its weight gradient -
+        # apply bn2's affine + ReLU on load like every other consumer of a raw conv output. Channels 128..511 hold the
+        # ACTIVATED, bilinearly upsampled levels 3..5 (non-negative: scale 1, shift 0 and the ReLU are the identity there).
+        # bn2 of level 2 keeps its scale / shift in the head of the composite vectors, so every finalize updates them in place.
+        self.concat_scale = torch.ones(4 * DEPTH, dtype=torch.float32, device=self.device)
+        self.concat_shift = torch.zeros(4 * DEPTH, dtype=torch.float32, device=self.device)
+        self.phi[2]["bn2"].scale = self.concat_scale[:DEPTH]
+        self.phi[2]["bn2"].shift = self.concat_shift[:DEPTH]
+        self.concat_affine = ops.Affine(self.concat_scale, self.concat_shift, ACT_RELU)
         self.heat_w, self.heat_b = self.vars["heatmaps/kernel"], self.vars["heatmaps/bias"]
         # `heatmaps/kernel` and `heatmaps/bias` are adjacent in the arena, so the head backward (dW then db,
         # contiguous) writes straight into the gradient arena.
@@ -237,7 +247,6 @@ class KeypointNet:
         ob, nb, _ = self._train_arena.offsets["heatmaps/bias"]
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
-        self.batch_finalize = True   # the four pyramid levels' batch-norm finalizes in one launch per stage
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
         # the stem kernel can write its own batch-norm partial sums (mpn_stem_conv_fwd_stats); OFF: measured a wash - the
         # separate statistics pass (38 us) reads the 134 MB stem output into the memory-side cache, and the first depthwise
@@ -301,8 +310,9 @@ class KeypointNet:
         b["x"] = {l: act(*lv[l], DEPTH) for l in lv}
         b["p"] = {l: act(*lv[l], DEPTH) for l in lv}
         b["y1"] = {l: act(*lv[l], DEPTH) for l in lv}
-        b["y2"] = {l: act(*lv[l], DEPTH) for l in lv}
         b["concat"] = act(*lv[2], 4 * DEPTH)
+        b["y2"] = {l: act(*lv[l], DEPTH) for l in lv if l != 2}
+        b["y2"][2] = b["concat"][..., :DEPTH]          # level 2 lives in its slice of the concat tensor (raw)
         b["final"] = act(*lv[2], 64)
         b["logits"] = torch.empty((N, lv[2][0], lv[2][1], NUM_KEYPOINTS + 1), dtype=torch.float32, device=dev)
         # scratch for batch-norm partial sums (forward statistics and backward reductions share it):
@@ -342,8 +352,10 @@ class KeypointNet:
         g["daux"] = {l: torch.empty((N, *b["lv"][l]), dtype=torch.float32, device=dev) for l in b["lv"]}
         g["final"] = torch.empty_like(b["final"])
         g["concat"] = torch.empty_like(b["concat"])
-        for k in ("y2", "y1", "p", "x"):
+        for k in ("y1", "p", "x"):
             g[k] = {l: torch.empty_like(b[k][l]) for l in b["lv"]}
+        g["y2"] = {l: torch.empty_like(b["y2"][l]) for l in b["lv"] if l != 2}
+        g["y2"][2] = g["concat"][..., :DEPTH]          # ... and so does its gradient
         g["c"] = {}   # gradient w.r.t. the activated c_l (from the lateral convs)
         for i, name in FEATURE_BLOCKS.items():
             g["c"][name] = torch.empty_like(b["pw"][i - 1])
@@ -442,55 +454,37 @@ class KeypointNet:
         sp = b["stat_part"] if is_training else None
         sep = is_training
         prev = None
-        if sep and self.batch_finalize:
-            # stage by stage over the four levels: their statistics go to per-level scratch and ONE launch per stage
-            # finalizes all four (12 finalize launches -> 3)
-            if b["fin"] is None:
-                b["fin"] = self._finalize_tables(b)
-            fin, spl = b["fin"], b["stat_lv"]
-            for l in (5, 4, 3, 2):
-                raw, aff = feats[f"c{l}"]
-                ops.conv_fwd(raw, self.lateral[l].packed.fwd, DEPTH, 1, aff, out=b["x"][l], up_res=prev)    # fpn.py:38,50-51
-                prev = b["x"][l]
-            LV = (2, 3, 4, 5)
-            sps = [spl[l] for l in LV]
-            # (each stage's four convolutions in ONE grid: the small levels fill in at the level-2 kernel's throughput)
-            ops.conv_fwd_grouped([b["x"][l] for l in LV], [self.pconv[l].packed.fwd for l in LV], DEPTH, 3, [None] * 4,
-                                 [b["p"][l] for l in LV], sps)                                               # fpn.py:39,52
-            fin["p"].run()
-            ops.conv_fwd_grouped([b["p"][l] for l in LV], [self.phi[l]["conv1"].packed.fwd for l in LV], DEPTH, 3,
-                                 [self.p_bn[l].affine for l in LV], [b["y1"][l] for l in LV], sps)
-            fin["bn1"].run()
-            ops.conv_fwd_grouped([b["y1"][l] for l in LV], [self.phi[l]["conv2"].packed.fwd for l in LV], DEPTH, 3,
-                                 [self.phi[l]["bn1"].affine for l in LV], [b["y2"][l] for l in LV], sps)
-            fin["bn2"].run()
-            for l in (2, 3, 4, 5):
-                ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, self.phi[l]["bn2"].affine)   # :86 + :37
-            return self._subnet_final(b, N, sp, sep, inference_outputs)
+        LV = (2, 3, 4, 5)
         for l in (5, 4, 3, 2):
             raw, aff = feats[f"c{l}"]
-            h, w = b["lv"][l]
             ops.conv_fwd(raw, self.lateral[l].packed.fwd, DEPTH, 1, aff, out=b["x"][l], up_res=prev)    # fpn.py:38,50-51
             prev = b["x"][l]
-            ops.conv_fwd(prev, self.pconv[l].packed.fwd, DEPTH, 3, None, out=b["p"][l], stats_part=sp)      # fpn.py:39,52
-            if sep:
-                ops.bn_finalize(self.p_bn[l], sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
-        for l in (2, 3, 4, 5):
-            ph = self.phi[l]
-            h, w = b["lv"][l]
-            nparts, cnt = ops.conv_num_parts(N, h, w, 3), N * h * w
-            ops.conv_fwd(b["p"][l], ph["conv1"].packed.fwd, DEPTH, 3, self.p_bn[l].affine, out=b["y1"][l], stats_part=sp)
-            if sep:
-                ops.bn_finalize(ph["bn1"], sp, nparts, cnt)
-            ops.conv_fwd(b["y1"][l], ph["conv2"].packed.fwd, DEPTH, 3, ph["bn1"].affine, out=b["y2"][l], stats_part=sp)
-            if sep:
-                ops.bn_finalize(ph["bn2"], sp, nparts, cnt)
-            ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, ph["bn2"].affine)   # :86 + :37
+        # stage by stage over the four independent pyramid levels: each stage's four convolutions in ONE grid (the small
+        # levels fill in at the level-2 kernel's throughput), their statistics in per-level scratch, ONE finalize launch
+        fin, spl = None, [None] * 4
+        if sep:
+            if b["fin"] is None:
+                b["fin"] = self._finalize_tables(b)
+            fin, spl = b["fin"], [b["stat_lv"][l] for l in LV]
+        ops.conv_fwd_grouped([b["x"][l] for l in LV], [self.pconv[l].packed.fwd for l in LV], DEPTH, 3, [None] * 4,
+                             [b["p"][l] for l in LV], spl)                                                # fpn.py:39,52
+        if sep:
+            fin["p"].run()
+        ops.conv_fwd_grouped([b["p"][l] for l in LV], [self.phi[l]["conv1"].packed.fwd for l in LV], DEPTH, 3,
+                             [self.p_bn[l].affine for l in LV], [b["y1"][l] for l in LV], spl)
+        if sep:
+            fin["bn1"].run()
+        ops.conv_fwd_grouped([b["y1"][l] for l in LV], [self.phi[l]["conv2"].packed.fwd for l in LV], DEPTH, 3,
+                             [self.phi[l]["bn1"].affine for l in LV], [b["y2"][l] for l in LV], spl)      # (level 2: into the concat slice)
+        if sep:
+            fin["bn2"].run()
+        for l in (3, 4, 5):
+            ops.bilinear_up_fwd(b["y2"][l], 2 ** (l - 2), b["concat"], (l - 2) * DEPTH, self.phi[l]["bn2"].affine)   # :86 + :37
         return self._subnet_final(b, N, sp, sep, inference_outputs)
 
     def _subnet_final(self, b, N, sp, sep, inference_outputs):
         h, w = b["lv"][2]
-        ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, None, out=b["final"], stats_part=sp)   # :38
+        ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, self.concat_affine, out=b["final"], stats_part=sp)   # :38
         if sep:
             ops.bn_finalize(self.final_bn, sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
         if inference_outputs:
@@ -587,53 +581,40 @@ class KeypointNet:
         ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
                              slab[id(self._head_grad)], reduce=False)
         ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
-        W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, None, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
+        W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, self.concat_affine, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
         ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
-        # ---- phi subnets + p{l}_batch_norm
-        if self.batch_finalize:
-            # stage by stage over the four levels (see subnet_forward): reductions into per-level scratch, ONE finalize
-            # launch per stage, then the applies and the convolutions' gradients
-            if b["fin"] is None:
-                b["fin"] = self._finalize_tables(b)
-            fin, spl = b["fin"], b["stat_lv"]
-            LV = (2, 3, 4, 5)
-            sps = [spl[l] for l in LV]
-            bn2s, bn1s, pbns = [self.phi[l]["bn2"] for l in LV], [self.phi[l]["bn1"] for l in LV], [self.p_bn[l] for l in LV]
-            gy2, gy1, gp = [g["y2"][l] for l in LV], [g["y1"][l] for l in LV], [g["p"][l] for l in LV]
-            by2, by1, bp = [b["y2"][l] for l in LV], [b["y1"][l] for l in LV], [b["p"][l] for l in LV]
-            for l in LV:
-                ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
-            ops.bn_bwd_reduce_grouped(bn2s, gy2, by2, sps)
-            fin["dbn2"].run()
-            none4 = [None] * 4
-            ops.bn_bwd_apply_grouped(bn2s, gy2, by2)
-            for l in LV:
-                ph = self.phi[l]
-                W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
-            ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
-                                 [g["y1"][l] for l in LV], none4)
-            ops.bn_bwd_reduce_grouped(bn1s, gy1, by1, sps)
-            fin["dbn1"].run()
-            ops.bn_bwd_apply_grouped(bn1s, gy1, by1)
-            for l in LV:
-                ph = self.phi[l]
-                W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
-            ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
-                                 [g["p"][l] for l in LV], none4)
-            ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
-            fin["dp"].run()
-            ops.bn_bwd_apply_grouped(pbns, gp, bp, [g["daux"][l] for l in LV])
-        else:
-            for l in (2, 3, 4, 5):
-                ph = self.phi[l]
-                ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
-                ops.bn_backward(ph["bn2"], g["y2"][l], b["y2"][l], sp)
-                W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
-                ops.conv_fwd(g["y2"][l], ph["conv2"].packed.bwd, DEPTH, 3, None, out=g["y1"][l])
-                ops.bn_backward(ph["bn1"], g["y1"][l], b["y1"][l], sp)
-                W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
-                ops.conv_fwd(g["y1"][l], ph["conv1"].packed.bwd, DEPTH, 3, None, out=g["p"][l])
-                ops.bn_backward(self.p_bn[l], g["p"][l], b["p"][l], sp, add_ch0=g["daux"][l])
+        # ---- phi subnets + p{l}_batch_norm, stage by stage over the four levels (see subnet_forward): reductions into
+        # per-level scratch, ONE finalize launch per stage, then the applies and the convolutions' gradients
+        if b["fin"] is None:
+            b["fin"] = self._finalize_tables(b)
+        fin, spl = b["fin"], b["stat_lv"]
+        LV = (2, 3, 4, 5)
+        sps = [spl[l] for l in LV]
+        bn2s, bn1s, pbns = [self.phi[l]["bn2"] for l in LV], [self.phi[l]["bn1"] for l in LV], [self.p_bn[l] for l in LV]
+        gy2, gy1, gp = [g["y2"][l] for l in LV], [g["y1"][l] for l in LV], [g["p"][l] for l in LV]
+        by2, by1, bp = [b["y2"][l] for l in LV], [b["y1"][l] for l in LV], [b["p"][l] for l in LV]
+        for l in (3, 4, 5):   # (level 2's gradient IS the first slice of g["concat"])
+            ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
+        ops.bn_bwd_reduce_grouped(bn2s, gy2, by2, sps)
+        fin["dbn2"].run()
+        none4 = [None] * 4
+        ops.bn_bwd_apply_grouped(bn2s, gy2, by2)
+        for l in LV:
+            ph = self.phi[l]
+            W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
+        ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
+                             [g["y1"][l] for l in LV], none4)
+        ops.bn_bwd_reduce_grouped(bn1s, gy1, by1, sps)
+        fin["dbn1"].run()
+        ops.bn_bwd_apply_grouped(bn1s, gy1, by1)
+        for l in LV:
+            ph = self.phi[l]
+            W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
+        ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
+                             [g["p"][l] for l in LV], none4)
+        ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
+        fin["dp"].run()
+        ops.bn_bwd_apply_grouped(pbns, gp, bp, [g["daux"][l] for l in LV])
         # ---- FPN (top-down path reversed)
         for l in (2, 3, 4, 5):
             W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, slab[id(self.pconv[l].dw)], reduce=False))

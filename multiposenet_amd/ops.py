@@ -73,6 +73,20 @@ def _slice_stride(t, channels):
     return ps
 
 
+def _row_stride(t, channels):
+    """Row stride (elements) of a [..., C] tensor viewed as rows of C channels: dense, or a channel slice of a wider
+    contiguous tensor (every leading dimension must collapse onto one uniform row stride)."""
+    if t.shape[-1] != channels or t.stride(-1) != 1 or t.dim() < 2:
+        raise ValueError(f"expected [..., {channels}] with contiguous channels, got {tuple(t.shape)}")
+    rs = t.stride(-2)
+    for d in range(t.dim() - 2, 0, -1):
+        if t.shape[d - 1] != 1 and t.stride(d - 1) != t.shape[d] * t.stride(d):
+            raise ValueError("only channel slices of contiguous tensors are supported")
+    if rs < channels:
+        raise ValueError("overlapping rows")
+    return rs
+
+
 def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_res=None):
     """y = conv(act(bn(x))) [+ nearest2x(up_res)]; optional per-tile BN partial sums. x and out may be channel slices
     (`t[..., a:b]`) of wider contiguous NHWC tensors: the kernel takes their pixel strides."""
@@ -102,11 +116,9 @@ def conv_fwd_grouped(xs, packeds, cout, ksize, affines, outs, stats_parts):
         sc.append(s_); sh.append(h_)
         if a is not None:
             act = a_
-    for x in xs:
-        _check_nhwc(x)
     call("mpn_conv_fwd_grouped", n, PA(*[ptr(x) for x in xs]), PA(*[ptr(p) for p in packeds]), PA(*[ptr(o) for o in outs]), N,
-         IA(*[x.shape[1] for x in xs]), IA(*[x.shape[2] for x in xs]), cin, cout, IA(*[_slice_stride(o, cout) for o in outs]),
-         ksize, _lib.dtype_code(xs[0].dtype), PA(*sc), PA(*sh), int(act), PA(*[ptr(t) for t in stats_parts]), stream_ptr())
+         IA(*[x.shape[1] for x in xs]), IA(*[x.shape[2] for x in xs]), cin, cout, IA(*[_slice_stride(x, cin) for x in xs]),
+         IA(*[_slice_stride(o, cout) for o in outs]), ksize, _lib.dtype_code(xs[0].dtype), PA(*sc), PA(*sh), int(act), PA(*[ptr(t) for t in stats_parts]), stream_ptr())
     return outs
 
 
@@ -124,8 +136,8 @@ def conv_bwd_weight(x, dy, ksize, affine, dw_out, part=None, reduce=True):
     if part is None:
         part = _f32(nparts * n, x.device)
     sc, sh, act = _aff(affine)
-    call("mpn_conv_bwd_weight", ptr(x), ptr(dy), ptr(part), N, H, W, cin, cout, ksize, _lib.dtype_code(x.dtype),
-         sc, sh, act, stream_ptr())
+    call("mpn_conv_bwd_weight", ptr(x), ptr(dy), ptr(part), N, H, W, cin, cout, _slice_stride(x, cin), _slice_stride(dy, cout),
+         ksize, _lib.dtype_code(x.dtype), sc, sh, act, stream_ptr())
     if reduce:
         call("mpn_reduce_partials", ptr(part), nparts, n, ptr(dw_out), 0, 1.0, stream_ptr())
     return dw_out
@@ -253,25 +265,28 @@ def bn_bwd_apply(bn, dA, x, add_ch0=None):
 def _bn_group_args(bns, dAs, xs):
     import ctypes
     n = len(bns)
-    PA, LA = ctypes.c_void_p * n, ctypes.c_longlong * n
+    PA, LA, IA = ctypes.c_void_p * n, ctypes.c_longlong * n, ctypes.c_int * n
+    C = xs[0].shape[-1]
     Ms = [x.numel() // x.shape[-1] for x in xs]
-    return n, PA, PA(*[ptr(t) for t in dAs]), PA(*[ptr(t) for t in xs]), LA(*Ms), xs[0].shape[-1], _lib.dtype_code(xs[0].dtype)
+    strides = (IA(*[_row_stride(t, C) for t in dAs]), IA(*[_row_stride(t, C) for t in xs]))   # channel slices allowed
+    return n, PA, PA(*[ptr(t) for t in dAs]), PA(*[ptr(t) for t in xs]), LA(*Ms), C, _lib.dtype_code(xs[0].dtype), strides
 
 
 def bn_bwd_reduce_grouped(bns, dAs, xs, parts):
     """bn_bwd_reduce of several independent layers (same channel count, dtype, activation) in one grid."""
-    n, PA, pd, px, Ms, C, dc = _bn_group_args(bns, dAs, xs)
+    n, PA, pd, px, Ms, C, dc, (sd, sx) = _bn_group_args(bns, dAs, xs)
     call("mpn_bn_bwd_reduce_grouped", n, pd, px, Ms, C, dc, PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]),
-         PA(*[ptr(b.mean) for b in bns]), PA(*[ptr(b.invstd) for b in bns]), int(bns[0].act), PA(*[ptr(p) for p in parts]), stream_ptr())
+         PA(*[ptr(b.mean) for b in bns]), PA(*[ptr(b.invstd) for b in bns]), int(bns[0].act), PA(*[ptr(p) for p in parts]),
+         sd, sx, stream_ptr())
 
 
 def bn_bwd_apply_grouped(bns, dAs, xs, add_ch0s=None):
     """bn_bwd_apply of several independent layers in one grid (after their finalizes)."""
-    n, PA, pd, px, Ms, C, dc = _bn_group_args(bns, dAs, xs)
+    n, PA, pd, px, Ms, C, dc, (sd, sx) = _bn_group_args(bns, dAs, xs)
     add = add_ch0s if add_ch0s is not None else [None] * n
     call("mpn_bn_bwd_apply_grouped", n, pd, px, Ms, C, dc, PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]),
          PA(*[ptr(b.mean) for b in bns]), PA(*[ptr(b.invstd) for b in bns]), PA(*[ptr(b.k1) for b in bns]),
-         PA(*[ptr(b.k2) for b in bns]), int(bns[0].act), PA(*[ptr(t) for t in add]), stream_ptr())
+         PA(*[ptr(b.k2) for b in bns]), int(bns[0].act), PA(*[ptr(t) for t in add]), sd, sx, stream_ptr())
 
 
 def bn_inference_affine(bn):

@@ -71,6 +71,8 @@ def test_training_forward_every_layer_f32(cuda):
     bad = []
     for k, t in got.items():
         want = taps[k].permute(0, 2, 3, 1).numpy()
+        if k == "concat":   # channels 0..127 hold level 2 RAW (= phi_subnet_2/y2, checked under that name): compare the rest
+            t, want = t[..., 128:], want[..., 128:]
         err = np.abs(t.cpu().numpy().astype(np.float64) - want).max() / (np.abs(want).max() + 1e-30)
         if err > 2e-4:
             bad.append((k, float(err)))
@@ -123,6 +125,8 @@ def _layer_gradient_errors(seed, smooth=False):
     rep = []
     for k, t in got.items():
         want = taps[k].grad.permute(0, 2, 3, 1).numpy()
+        if k == "concat":   # (its first 128 channels were turned into the gradient w.r.t. the raw level-2 output in place)
+            t, want = t[..., 128:], want[..., 128:]
         a = t.cpu().numpy().astype(np.float64)
         rep.append((k, float(np.linalg.norm(a - want) / (np.linalg.norm(want) + 1e-30))))
     rep.sort(key=lambda kv: -kv[1])

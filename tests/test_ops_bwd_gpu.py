@@ -324,3 +324,47 @@ def test_grouped_bn_backward_passes_equal_per_layer_launches(cuda, dtype):
         assert torch.equal(pa[j], pb[j]), j
         assert torch.equal(a[j].dgamma, b[j].dgamma) and torch.equal(a[j].dbeta, b[j].dbeta), j
         assert torch.equal(da_a[j], da_b[j]), j
+
+
+def test_grouped_bn_backward_and_conv_wgrad_on_channel_slices(cuda):
+    """Row strides: the grouped batch-norm backward passes and the conv weight gradient on tensors that live in channel
+    slices of wider ones (level 2 of the concat tensor and of its gradient) = the same calls on dense copies, bit for bit."""
+    ops = _ops()
+    rs = np.random.RandomState(5)
+    dtype = torch.bfloat16
+    N, H, W, C, WIDE = 2, 16, 24, 128, 512
+    xw = dev(rnd(rs.randn(N, H, W, WIDE), dtype), dtype)
+    dw_ = dev(rnd(rs.randn(N, H, W, WIDE), dtype), dtype)
+    x_s, d_s = xw[..., :C], dw_[..., :C]
+    x_d, d_d = x_s.contiguous(), d_s.contiguous()
+
+    def mk():
+        r2 = np.random.RandomState(9)
+        one = lambda: torch.tensor((0.5 + r2.rand(C)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), 1)
+        bn.scale.copy_(one()); bn.invstd.copy_(one())
+        bn.shift.copy_(torch.tensor((r2.randn(C) * 0.5).astype(np.float32)).cuda())
+        bn.mean.copy_(torch.tensor((r2.randn(C) * 0.3).astype(np.float32)).cuda())
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+    M = N * H * W
+    npart = ops._lib.lib().mpn_bn_stats_num_parts(M)
+    res = []
+    for (d, x) in ((d_d, x_d), (d_s, x_s)):
+        bn = mk()
+        part = torch.zeros(npart * 2 * C, device="cuda")
+        ops.bn_bwd_reduce_grouped([bn], [d], [x], [part])
+        ops.BnBwdFinalizeBatch([(bn, part, npart, M)], "cuda:0").run()
+        ops.bn_bwd_apply_grouped([bn], [d], [x])
+        res.append((part.clone(), bn.dgamma.clone(), bn.dbeta.clone(), d.contiguous().clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # conv weight gradient with a strided dy (the slice holds the gradient w.r.t. the raw conv output now)
+    a_in = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)
+    dW_a, dW_b = torch.zeros(3, 3, C, C, device="cuda"), torch.zeros(3, 3, C, C, device="cuda")
+    ops.conv_bwd_weight(a_in, d_s.contiguous(), 3, None, dW_a)
+    ops.conv_bwd_weight(a_in, d_s, 3, None, dW_b)
+    assert torch.equal(dW_a, dW_b)
+    ops.conv_bwd_weight(x_s.contiguous(), d_d, 1, None, dW_a[0, 0])   # strided x, 1x1
+    ops.conv_bwd_weight(x_s, d_d, 1, None, dW_b[0, 0])
+    assert torch.equal(dW_a, dW_b)
