@@ -122,6 +122,8 @@ def main():
             out["f32_build"] = f32_build_rate(args.batch, args.size)          # the build that meets the 1e-3 parity bound
             out["bf16_vs_f32"] = bf16_vs_f32_argmax_agreement(args.batch, args.size)
         out["prn"] = prn_benchmark(128)
+        from bench_legs import retinanet_benchmark
+        out["retinanet"] = retinanet_benchmark(16)               # BASELINE config 4
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():   # (also the 1-rank rehearsal, MPN_DP_FORCE_COLLECTIVE=1)

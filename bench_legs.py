@@ -430,3 +430,63 @@ def bf16_vs_f32_argmax_agreement(batch, size, seed=0):
             "agreement_on_those": round(float(agree[clear].float().mean()), 4) if bool(clear.any()) else None,
             "f32_yardstick": "f32 build: |heatmap - f64 oracle| <= 3e-6 and arg-max indices identical on every decided channel "
                              "(tests/test_argmax_parity_gpu.py)"}
+
+
+def retinanet_benchmark(batch=16, height=896, width=1408, iters=10):
+    """BASELINE config 4: RetinaNet person-detector head fwd + bwd (+ frozen backbone forward, anchor matching, focal + smooth-L1
+    losses, TF-Adam) at batch 16 on 800 x 1333 images padded to 896 x 1408 (the reference's x128 size rule, constants.py:4),
+    bf16 storage / f32 accumulate, the whole step replayed from a hipGraph. Reported with the head's MFMA fraction: forward
+    MACs of the two towers + FPN counted analytically (6 x MAC for fwd + bwd; the frozen backbone adds forward work only)."""
+    import numpy as np
+    from multiposenet_amd.retinanet import LEVELS, PersonDetectorNet
+    net = PersonDetectorNet(dtype=torch.bfloat16, seed=0)
+    g_ = torch.Generator(device="cuda"); g_.manual_seed(4321)
+    images = torch.rand((batch, height, width, 3), generator=g_, device="cuda")
+    rs = np.random.RandomState(7)
+    maxn = 12
+    boxes = np.zeros((batch, maxn, 4), np.float32)
+    for b in range(batch):
+        for n in range(maxn):
+            cy, cx = rs.rand(2); h, w = 0.08 + 0.5 * rs.rand(2)
+            boxes[b, n] = [max(cy - h / 2, 0), max(cx - w / 2, 0), min(cy + h / 2, 1), min(cx + w / 2, 1)]
+    gt = {"boxes": torch.from_numpy(boxes).cuda(), "num_boxes": torch.from_numpy(rs.randint(1, maxn + 1, batch).astype(np.int32)).cuda()}
+    hp = {"initial_learning_rate": 1e-3, "num_steps": 150000, "weight_decay": 5e-5, "localization_loss_weight": 1.0,
+          "classification_loss_weight": 2.0, "gamma": 2.0, "alpha": 0.25}
+    for _ in range(2):
+        net.train_step(images, gt, hp)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        losses = net.train_step(images, gt, hp)
+    graph.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        graph.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    b = net._last[0]
+    px = {l: b["lv"][l][0] * b["lv"][l][1] for l in LEVELS}
+    tower = sum(px.values()) * 9 * (128 * 64 + 3 * 64 * 64) * 2 + sum(px.values()) * 9 * 64 * (24 + 6)        # two towers + output convs
+    fpn = sum(px[l] for l in (3, 4, 5)) * 9 * 128 * 128 + px[3] * 256 * 128 + px[4] * 512 * 128 + px[5] * 1024 * 128 + \
+        px[6] * 9 * 1024 * 128 + px[7] * 9 * 128 * 128
+    head_gmac = (tower + fpn) * batch / 1e9
+    out = {"ms_per_step": round(ms, 3), "images_per_s": round(batch / ms * 1e3, 1), "batch": batch, "image": [height, width],
+           "anchors_per_image": int(b["A"]), "head_fwd_GMAC_per_batch": round(head_gmac, 1),
+           "head_fwd_bwd_TFLOPs_at_this_rate": round(6 * head_gmac * 1e9 / (ms * 1e-3) / 1e12, 1),
+           "losses": {n: round(float(losses[i]), 4) for i, n in enumerate(("localization_loss", "classification_loss", "regularization_loss", "total_loss"))}}
+    # inference: forward + NMS
+    for _ in range(2):
+        net.predict(images, 0.3, 0.6, 25)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        net.predict(images, 0.3, 0.6, 25)
+    e1.record()
+    torch.cuda.synchronize()
+    out["inference_ms_per_batch"] = round(e0.elapsed_time(e1) / iters, 3)
+    del net
+    torch.cuda.empty_cache()
+    return out

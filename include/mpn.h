@@ -106,11 +106,11 @@ int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int
                  int Cout, int x_stride, int y_stride, int ksize, int dtype, const float* in_scale,
                  const float* in_shift, int in_act, float* stats_part, const void* up_res,
                  mpn_stream_t stream);
-/* Up to four independent 3x3 convolutions of the same channel geometry in ONE grid, largest first (the four pyramid levels
+/* Up to five independent 3x3 convolutions of the same channel geometry in ONE grid, largest first (the four pyramid levels
  * of a keypoint-subnet stage, keypoint_subnet.py:64-91: as launches of their own the small levels are latency-bound tails
  * of 15-45 us). Per job: x, w_packed, y, H, W, x_stride / y_stride (arrays or NULL = dense), in_scale / in_shift (or NULL), stats_part
  * (or NULL); shared: N, Cin, Cout, ksize, dtype, in_act. Results are those of mpn_conv_fwd per job, bit for bit;
- * configurations the grouped grid does not cover (f32, 1x1, more than four jobs) run as the separate launches they replace. */
+ * configurations the grouped grid does not cover (f32, 1x1, more than five jobs) run as the separate launches they replace. */
 int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N, const int* H,
                          const int* W, int Cin, int Cout, const int* x_stride, const int* y_stride, int ksize, int dtype,
                          const float* const* in_scale, const float* const* in_shift, int in_act,
@@ -140,7 +140,7 @@ int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const
                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                     mpn_stream_t stream);
 /* is_training=False path: affine from the moving statistics */
-/* The two backward passes of up to four independent layers of one channel count in ONE grid each, largest first (the
+/* The two backward passes of up to five independent layers of one channel count in ONE grid each, largest first (the
  * pyramid levels of a subnet stage). Arrays per job; results are those of mpn_bn_bwd_reduce / mpn_bn_bwd_apply per layer,
  * bit for bit; part[j] holds mpn_bn_stats_num_parts(M[j]) rows. dA_stride / x_stride (arrays or NULL = dense): elements
  * between consecutive rows of dA[j] / x[j] - the level-2 tensors of phi_subnet's second batch-norm live in channel slices
@@ -375,6 +375,48 @@ int mpn_prn_crop(const float* heatmaps, const void* minmax_keys, const float* bo
                  int h, int w, int C, int crop_h, int crop_w, float threshold, float* crops, mpn_stream_t stream);
 int mpn_prn_decode(const float* logits, int nb, int crop_h, int crop_w, int C, float* scores, float* positions,
                    mpn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------
+ * L3  RetinaNet person-detector head (BASELINE config 4): detector/retinanet.py:13-217,
+ * detector/box_predictor.py:6-142, detector/fpn.py:42-46, detector/training_target_creation.py:5-159,
+ * detector/utils/box_utils.py:14-139, detector/utils/nms.py:6-61. Its convolutions / batch-norms / optimizer are the entry
+ * points above; these are the detector-specific pieces. Level arrays have 5 entries (p3..p7); anchors are ordered like
+ * reshape_and_concatenate (box_predictor.py:55-90): level, then y, x, then the 6 anchors of a location.
+ *
+ *   mpn_patchify3x3s2     x [N,H,W,C] -> patches [N,ceil(H/2),ceil(W/2),9*C] for conv2d_same(k=3, stride=2) (pad 1, VALID):
+ *                         the 3x3 stride-2 convolutions p6 / p7 (fpn.py:43,45) = this gather (producer's affine + act applied
+ *                         on the way, zero padding after it) + a 1x1 convolution over 9*C channels with the HWIO kernel viewed
+ *                         as [1,1,9*C,Cout]. mpn_unpatchify3x3s2 is its transpose: dpatches -> dx [N,H,W,C].
+ *   mpn_retina_match      get_training_targets for a batch: anchors f32 [A,4] (normalised), gt_boxes f32 [B,max_boxes,4],
+ *                         num_boxes int32 [B] -> matches int32 [B,A] (-2 ignore, -1 background, else the box index), targets
+ *                         f32 [B,A,4] (encode(), zeros where unmatched), num_matched int32[1] = count of matches >= 0.
+ *                         float32 arithmetic in the reference's operation order; arg-max ties: first index (tf.argmax).
+ *   mpn_retina_loss       focal loss (gamma, alpha; weights = not ignored) + smooth L1 (matched anchors) over raw tower outputs
+ *                         logits[l] [B,h,w,8] (6 used) / boxes[l] [B,h,w,24] + biases, both normalised by max(num_matched, 1);
+ *                         dlogits / dboxes (same layouts, may be NULL arrays) receive d(loc_w*loc + cls_w*cls); part
+ *                         [mpn_retina_loss_num_parts][32] = partial sums of {cls loss, loc loss, dbias_cls[6], dbias_box[24]}
+ *                         (finish with mpn_reduce_partials; the two losses still need the 1/normaliser).
+ *   mpn_retina_nms        get_predictions: sigmoid, score >= threshold, decode + clip to [0,1], greedy NMS, zero padding:
+ *                         out_boxes f32 [B,max_det,4], out_scores f32 [B,max_det], out_num int32 [B].
+ */
+int mpn_patchify3x3s2(const void* x, void* patches, int N, int H, int W, int C, int dtype, const float* in_scale,
+                      const float* in_shift, int in_act, mpn_stream_t stream);
+int mpn_unpatchify3x3s2(const void* dpatches, void* dx, int N, int H, int W, int C, int dtype, mpn_stream_t stream);
+size_t mpn_retina_match_workspace_bytes(int B, int max_boxes);
+int mpn_retina_match(const float* anchors, const float* gt_boxes, const int* num_boxes, int B, int A, int max_boxes,
+                     float positives_threshold, float negatives_threshold, int* matches, float* targets,
+                     int* num_matched, void* workspace, size_t workspace_bytes, mpn_stream_t stream);
+int mpn_retina_loss_num_parts(int B, int A);
+int mpn_retina_loss(const void* const* logits, const void* const* boxes, void* const* dlogits, void* const* dboxes,
+                    const int* h, const int* w, int dtype, const float* cls_bias, const float* box_bias,
+                    const int* matches, const float* targets, const int* num_matched, int B, float gamma, float alpha,
+                    float localization_loss_weight, float classification_loss_weight, float* part,
+                    mpn_stream_t stream);
+size_t mpn_retina_nms_workspace_bytes(int B, int A);
+int mpn_retina_nms(const void* const* logits, const void* const* boxes, const int* h, const int* w, int dtype,
+                   const float* cls_bias, const float* box_bias, const float* anchors, int B, float score_threshold,
+                   float iou_threshold, int max_detections, float* out_boxes, float* out_scores, int* out_num,
+                   void* workspace, size_t workspace_bytes, mpn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -94,6 +94,14 @@ SIGNATURES = {
     "mpn_prn_crop": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "mpn_prn_decode": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mpn_axpy": (_I, [_L, _F, _P, _P, _P]),
+    "mpn_patchify3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "mpn_unpatchify3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mpn_retina_match_workspace_bytes": (_Z, [_I, _I]),
+    "mpn_retina_match": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _P, _P, _P, _P, _Z, _P]),
+    "mpn_retina_loss_num_parts": (_I, [_I, _I]),
+    "mpn_retina_loss": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
+    "mpn_retina_nms_workspace_bytes": (_Z, [_I, _I]),
+    "mpn_retina_nms": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "mpn_l2_loss_accumulate": (_I, [_L, _P, _F, _P, _P]),
 }
 

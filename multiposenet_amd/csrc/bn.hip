@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_reduce_kernel(
 }
 
 // up to four independent layers (the pyramid levels of a subnet stage) in one grid, largest first
-constexpr int kBnGroup = 4;
+constexpr int kBnGroup = 5;   // (the keypoint subnet has 4 pyramid levels, the RetinaNet head 5)
 struct BnBwdJob {
     void* dA; const void* x; long long M;
     const float *scale, *shift, *mean, *invstd, *k1, *k2, *add_ch0;

@@ -494,10 +494,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams
     conv_mfma_body<T, TAPS, BN, RB>(p, blockIdx.x, gridDim.x);
 }
 
-// up to four independent jobs of one kernel instance in one grid (largest first): the small pyramid levels are a few
+// up to five independent jobs of one kernel instance in one grid (largest first): the small pyramid levels are a few
 // dozen to a few hundred tiles each - as launches of their own they are latency-bound tails of 15-45 us, inside the
 // level-2 grid they fill in at its throughput
-constexpr int kMaxGroup = 4;
+constexpr int kMaxGroup = 5;   // (the keypoint subnet has 4 pyramid levels, the RetinaNet head 5)
 struct ConvGroup {
     ConvParams p[kMaxGroup];
     int begin[kMaxGroup + 1];   // first block of each job; begin[njobs] = grid size
@@ -782,7 +782,7 @@ static int launch_conv_grouped(const ConvGroup& grp, int grid, hipStream_t st) {
 }
 
 /* Several independent 3x3 convolutions of the same channel geometry in ONE grid (the four pyramid levels of a subnet
- * stage: keypoint_subnet.py:64-91 applies phi_subnet to p2..p5 independently). bf16 3x3 with at most 4 jobs run in one
+ * stage: keypoint_subnet.py:64-91 applies phi_subnet to p2..p5 independently). bf16 3x3 with at most 5 jobs run in one
  * grid; anything else runs as the separate launches it replaces. Results are those of mpn_conv_fwd per job, bit for bit
  * (same kernel body, same tiles). x_stride[j] / y_stride[j] (arrays, may be NULL = dense): pixel strides of job j's input / output. */
 extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_packed, void* const* y, int N,

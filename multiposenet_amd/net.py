@@ -281,8 +281,9 @@ class KeypointNet:
                  ops._lib.dtype_code(self.dtype), ops.stream_ptr())
 
     # ------------------------------------------------------------------ buffers (allocated once per input shape)
-    def _buffers(self, N, H, W):
-        key = (N, H, W)
+    def _buffers(self, N, H, W, head=True):
+        """head=False: the backbone's buffers only (the person detector runs the frozen backbone under its own head)."""
+        key = (N, H, W) if head else (N, H, W, "backbone")
         b = self._bufs.get(key)
         if b is not None:
             return b
@@ -293,7 +294,7 @@ class KeypointNet:
         def act(h, w, c):
             return torch.empty((N, h, w, c), dtype=dt, device=dev)
 
-        b = {"shape": key}
+        b = {"shape": (N, H, W)}
         h, w = H // 2, W // 2
         c = self.stem_w.shape[3]
         b["stem"] = act(h, w, c)
@@ -305,6 +306,11 @@ class KeypointNet:
             c = blk["pw"].cout
             b["pw"].append(act(h, w, c))
             b["hw"].append((h, w))
+        if not head:
+            nbn0 = ops._lib.lib().mpn_bn_stats_num_parts
+            b["stat_part"] = torch.empty(nbn0(N * (H // 2) * (W // 2)) * 2 * b["stem"].shape[3], dtype=torch.float32, device=dev)
+            self._bufs[key] = b
+            return b
         lv = {l: (H >> l, W >> l) for l in (2, 3, 4, 5)}
         b["lv"] = lv
         b["x"] = {l: act(*lv[l], DEPTH) for l in lv}

@@ -562,3 +562,24 @@ def axpy(a, x, y):
 def l2_loss_accumulate(w, scale, acc):
     """acc[0] += scale * sum(w^2)/2 (acc: f32 device tensor view of one element)."""
     call("mpn_l2_loss_accumulate", w.numel(), ptr(w), float(scale), ptr(acc), stream_ptr())
+
+
+# ----------------------------------------------------------------------------- RetinaNet head pieces
+def patchify3x3s2(x, out, affine=None):
+    """x [N,H,W,C] -> out [N,ceil(H/2),ceil(W/2),9*C]: the gather behind conv2d_same(k=3, stride=2) (mpn_patchify3x3s2)."""
+    _check_nhwc(x)
+    N, H, W, C = x.shape
+    if tuple(out.shape) != (N, (H + 1) // 2, (W + 1) // 2, 9 * C) or out.dtype != x.dtype or not out.is_contiguous():
+        raise ValueError(f"patchify3x3s2: out must be contiguous {(N, (H + 1) // 2, (W + 1) // 2, 9 * C)} {x.dtype}")
+    sc, sh, act = _aff(affine)
+    call("mpn_patchify3x3s2", ptr(x), ptr(out), N, H, W, C, _lib.dtype_code(x.dtype), sc, sh, act, stream_ptr())
+    return out
+
+
+def unpatchify3x3s2(dpatches, dx):
+    """Transpose of patchify3x3s2: dpatches [N,ceil(H/2),ceil(W/2),9*C] -> dx [N,H,W,C]."""
+    N, H, W, C = dx.shape
+    if tuple(dpatches.shape) != (N, (H + 1) // 2, (W + 1) // 2, 9 * C) or dpatches.dtype != dx.dtype:
+        raise ValueError("unpatchify3x3s2: shape / dtype mismatch")
+    call("mpn_unpatchify3x3s2", ptr(dpatches), ptr(dx), N, H, W, C, _lib.dtype_code(dx.dtype), stream_ptr())
+    return dx

@@ -24,3 +24,23 @@ def set_default_net(net):
 
 def reset_default_nets():
     _DEFAULT.clear()
+
+
+_DETECTORS = {}
+
+
+def get_default_detector(depth_multiplier=1.0, dtype=torch.bfloat16):
+    """The process-wide PersonDetectorNet the functional detector API (detector.RetinaNet) resolves its variables in -
+    the stand-in for the 'fpn' / 'box_net' / 'class_net' variable scopes of detector/retinanet.py."""
+    key = (float(depth_multiplier), dtype)
+    if key not in _DETECTORS:
+        from .retinanet import PersonDetectorNet
+        _DETECTORS[key] = PersonDetectorNet(depth_multiplier=depth_multiplier, dtype=dtype)
+        set_default_net(_DETECTORS[key].backbone)      # mobilenet_v1() then runs THIS detector's frozen backbone
+    return _DETECTORS[key]
+
+
+def set_default_detector(net):
+    _DETECTORS[(float(net.dm), net.dtype)] = net
+    set_default_net(net.backbone)
+    return net

@@ -1,0 +1,113 @@
+"""CPU: the RetinaNet-head oracle (oracle/retinanet.py) - hand-computed known answers for the anchor generator, the box
+utilities, the matching quirks and NMS; the product's host-side anchor generator against it."""
+import math
+
+import numpy as np
+
+from oracle import retinanet as R
+
+
+def test_anchor_known_answers():
+    # 128 x 128 image: strides 8..128 -> grids 16, 8, 4, 2, 1; 6 anchors per location
+    a, shapes = R.generate_anchors(128, 128)
+    assert shapes == [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)] and a.shape == ((256 + 64 + 16 + 4 + 1) * 6, 4)
+    # first anchor: level 3, cell (0,0), multiplier 1, ratio 1: centre (4, 4) [offset = 0.5*(128 - 15*8) = 4], size 32 x 32
+    np.testing.assert_allclose(a[0] * 128, [4 - 16, 4 - 16, 4 + 16, 4 + 16], rtol=0, atol=1e-5)
+    # second: ratio 2 -> height 32/sqrt(2), width 32*sqrt(2)
+    h, w = 32 / math.sqrt(2), 32 * math.sqrt(2)
+    np.testing.assert_allclose(a[1] * 128, [4 - h / 2, 4 - w / 2, 4 + h / 2, 4 + w / 2], rtol=0, atol=1e-4)
+    # fourth: multiplier 1.4142, ratio 1 -> size 45.2544
+    s = 32 * 1.4142
+    np.testing.assert_allclose(a[3] * 128, [4 - s / 2, 4 - s / 2, 4 + s / 2, 4 + s / 2], rtol=0, atol=1e-4)
+    # the single level-7 cell: centre (64, 64), scale 512
+    np.testing.assert_allclose(a[-6] * 128, [64 - 256, 64 - 256, 64 + 256, 64 + 256], rtol=0, atol=1e-3)
+    # BASELINE config 4 padded to 896 x 1408
+    a, shapes = R.generate_anchors(896, 1408)
+    assert shapes == [(112, 176), (56, 88), (28, 44), (14, 22), (7, 11)] and a.shape[0] == 157542
+    # non-divisible sizes: h = ceil(100 / 8) = 13, offset = 0.5 * (100 - 12 * 8) = 2
+    a, shapes = R.generate_anchors(100, 100)
+    assert shapes[0] == (13, 13)
+    np.testing.assert_allclose(a[0] * 100, [2 - 16, 2 - 16, 2 + 16, 2 + 16], atol=1e-5)
+
+
+def test_product_anchor_generator_equals_oracle():
+    from multiposenet_amd.retinanet import generate_anchors
+    for hw in ((128, 128), (256, 384), (896, 1408)):
+        a, s = generate_anchors(*hw)
+        b, t = R.generate_anchors(*hw)
+        assert s == t
+        np.testing.assert_array_equal(a, b)
+
+
+def test_iou_encode_decode_known_answers():
+    f = np.float32
+    b1 = np.array([[0.0, 0.0, 0.5, 0.5]], f)
+    b2 = np.array([[0.0, 0.0, 0.5, 0.5], [0.25, 0.25, 0.75, 0.75], [0.5, 0.5, 1.0, 1.0], [0.6, 0.6, 0.9, 0.9]], f)
+    got = R.iou(b1, b2)[0]
+    # identical: 0.25 / (0.25 + 1e-8); quarter overlap: 0.0625 / (0.4375 + 1e-8); touching corner: 0; disjoint: 0
+    np.testing.assert_allclose(got, [0.25 / (0.25 + 1e-8), 0.0625 / 0.4375, 0.0, 0.0], rtol=1e-6)
+    # encode of a box onto itself is ~0; decode inverts encode
+    an = np.array([[0.1, 0.2, 0.5, 0.8], [0.3, 0.3, 0.4, 0.9]], f)
+    bx = np.array([[0.15, 0.25, 0.45, 0.7], [0.2, 0.1, 0.6, 0.95]], f)
+    np.testing.assert_allclose(R.encode(an, an), 0.0, atol=1e-5)
+    np.testing.assert_allclose(R.decode(R.encode(bx, an), an), bx, atol=1e-5)
+    # ty = 10 * (cy - cy_a) / h_a: box centre 0.3 vs anchor centre 0.3 -> 0; th = 5 * ln(h / h_a) = 5 ln(0.3 / 0.4)
+    e = R.encode(bx[:1], an[:1])[0]
+    assert abs(e[0] - 0.0) < 1e-5 and abs(e[2] - 5 * math.log(0.3 / 0.4)) < 1e-5
+
+
+def test_matching_rules_and_quirks():
+    f = np.float32
+    # five anchors on a line, two groundtruth boxes
+    anchors = np.array([[0.0, 0.0, 0.2, 0.2], [0.0, 0.2, 0.2, 0.4], [0.0, 0.4, 0.2, 0.6], [0.0, 0.6, 0.2, 0.8], [0.5, 0.5, 0.6, 0.6]], f)
+    gt = np.array([[0.0, 0.0, 0.2, 0.2],          # = anchor 0 (iou 1)
+                   [0.0, 0.5, 0.2, 0.7]], f)      # half of anchor 2 and half of anchor 3 (iou 1/3 each): forced match -> anchor 2 (first)
+    m = R.match_boxes(anchors, gt)
+    assert list(m) == [0, -1, 1, -1, -1]
+    t, m2 = R.get_training_targets(anchors, gt)
+    assert list(m2) == list(m) and np.all(t[1] == 0) and np.all(t[3] == 0) and np.allclose(t[0], 0, atol=1e-5)
+    # a box that overlaps nothing by >= 0.05 is NOT force-matched; with thresholds 0.5/0.4 the 0.4..0.5 band is ignored (-2)
+    gt2 = np.array([[0.9, 0.9, 0.95, 0.95]], f)
+    assert list(R.match_boxes(anchors, gt2)) == [-1] * 5
+    gt3 = np.array([[0.0, 0.0, 0.2, 0.45]], f)    # iou with anchor 0: 0.2/0.45 = 0.444 -> ignore band; anchor 1 the same
+    m3 = R.match_boxes(anchors, gt3, positives_threshold=0.5, negatives_threshold=0.4, force_match_groundtruth=False)
+    assert list(m3) == [-2, -2, -1, -1, -1]
+    # two boxes forcing the SAME anchor: it takes the smaller box index, even when only the other one passes the 0.05 test
+    anchors2 = np.array([[0.0, 0.0, 0.4, 0.4], [0.6, 0.6, 1.0, 1.0]], f)
+    gt4 = np.array([[0.38, 0.38, 0.5, 0.5],       # iou with anchor 0 = 0.0004/... < 0.05 (not okay), best anchor 0
+                    [0.0, 0.0, 0.3, 0.3]], f)     # iou with anchor 0 = 0.5625 (okay), best anchor 0
+    m4 = R.match_boxes(anchors2, gt4)
+    assert m4[0] == 0 and m4[1] == -1             # row id = first forcing box (0), mask from the okay one (1): the reference's quirk
+    # no groundtruth at all: everything background, zero targets
+    t0, m0 = R.get_training_targets(anchors, np.zeros((0, 4), f))
+    assert list(m0) == [-1] * 5 and not t0.any()
+
+
+def test_nms_known_answers():
+    f = np.float32
+    boxes = np.array([[0.0, 0.0, 0.5, 0.5], [0.0, 0.0, 0.5, 0.45], [0.5, 0.5, 1.0, 1.0], [0.0, 0.0, 0.5, 0.5]], f)
+    scores = np.array([0.9, 0.8, 0.7, 0.9], f)
+    # box 1 overlaps box 0 by 0.9 -> suppressed; box 3 duplicates box 0 (equal score: the lower index goes first) -> suppressed
+    assert R.non_max_suppression(boxes, scores, 10, 0.5, 0.05) == [0, 2]
+    assert R.non_max_suppression(boxes, scores, 1, 0.5, 0.05) == [0]
+    assert R.non_max_suppression(boxes, scores, 10, 0.95, 0.05) == [0, 1, 2]        # iou 0.9 and 1.0 > 0.95 only for the duplicate
+    assert R.non_max_suppression(boxes, scores, 10, 0.5, 0.9) == []                 # strict: score > threshold
+    # degenerate boxes have IOU 0 with everything
+    assert R._nms_iou(np.array([0.1, 0.1, 0.1, 0.5], f), np.array([0.0, 0.0, 1.0, 1.0], f)) == 0.0
+
+
+def test_loss_known_answers():
+    import torch
+    # one matched anchor with logit 0: focal = 0.25 * (1 - 0.5)^2 * ln 2; one background with logit 0: 0.75 * 0.25 * ln 2; one ignored
+    cls = torch.zeros(1, 3, dtype=torch.float64)
+    enc = torch.tensor([[[0.5, -2.0, 0.0, 1.0], [9.0, 9.0, 9.0, 9.0], [9.0, 9.0, 9.0, 9.0]]], dtype=torch.float64)
+    tgt = torch.zeros(1, 3, 4, dtype=torch.float64)
+    matches = torch.tensor([[0, -1, -2]])
+    ls = R.losses_fn(enc, cls, tgt, matches)
+    ln2 = math.log(2.0)
+    assert abs(float(ls["classification_loss"]) - (0.25 * 0.25 * ln2 + 0.75 * 0.25 * ln2)) < 1e-12
+    # smooth L1 on the matched anchor only: 0.5*0.25 + (2 - 0.5) + 0 + (1 - 0.5) = 2.125; normaliser = 1 match
+    assert abs(float(ls["localization_loss"]) - 2.125) < 1e-12
+    # no match at all: normaliser max(0, 1) = 1
+    ls0 = R.losses_fn(enc, cls, tgt, torch.tensor([[-1, -1, -2]]))
+    assert float(ls0["localization_loss"]) == 0.0 and abs(float(ls0["classification_loss"]) - 2 * 0.75 * 0.25 * ln2) < 1e-12
