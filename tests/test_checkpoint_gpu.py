@@ -1,4 +1,6 @@
 """Variables on disk in the reference's naming (multiposenet_amd/checkpoint.py): save / resume / warm start."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -88,3 +90,47 @@ def test_prn_round_trip(cuda, tmp_path):
     np.testing.assert_array_equal(net2.predict(x).cpu().numpy(), want)
     a = float(net.train_step(x, y, 1e-3, 1000)); b = float(net2.train_step(x, y, 1e-3, 1000))
     assert a == b
+
+
+def test_train_keypoints_loop_checkpoints_and_resumes(cuda, tmp_path):
+    """The estimator-loop replacement (multiposenet_amd.train_keypoints.train): warm start of MobilenetV1/* from an .npz,
+    summaries every N steps, a checkpoint at the end, and a second call that RESUMES from model_dir and continues exactly
+    where an uninterrupted run would be (bit-identical variables)."""
+    import json
+    from multiposenet_amd import keypoints_model as km
+    from multiposenet_amd import checkpoint
+    from multiposenet_amd import train_keypoints as tk
+    from multiposenet_amd.net import KeypointNet
+    pre = str(tmp_path / "pretrained.npz")
+    src = KeypointNet(dtype=torch.bfloat16, seed=5)
+    checkpoint.save_npz(pre, src, with_optimizer=False)
+    base = dict(tk.PARAMS, pretrained_checkpoint=pre, batch_size=2, image_size=(128, 128), dtype="bf16", seed=1)
+    cfg = {"save_summary_steps": 2, "log_step_count_steps": 3}
+
+    def batches():
+        return tk.synthetic_batches(2, 128, 128, distinct=3)
+    logs = []
+    km.reset_registry()
+    a = dict(base, model_dir=str(tmp_path / "a"))
+    assert tk.train(a, batches, run_config=cfg, max_steps=5, log=logs.append) == 5
+    assert any("warm start" in l for l in logs) and os.path.exists(os.path.join(a["model_dir"], "model.ckpt-5.npz"))
+    recs = [json.loads(l) for l in open(os.path.join(a["model_dir"], "summaries.jsonl"))]
+    assert [r["step"] for r in recs] == [2, 4] and "focal_loss" in recs[0]
+    net_a = km.get_trainer(a).net
+    want = {k: v.copy() for k, v in net_a.state_dict().items()}
+    # interrupted run: 3 steps, then a fresh process (registry cleared) resumes from model_dir and does steps 4, 5
+    km.reset_registry()
+    b = dict(base, model_dir=str(tmp_path / "b"))
+    tk.train(b, batches, run_config=cfg, max_steps=3, log=logs.append)
+    km.reset_registry()
+
+    def batches_from_4th():
+        it = batches()
+        for _ in range(3):
+            next(it)
+        return it
+    assert tk.train(b, batches_from_4th, run_config=cfg, max_steps=5, log=logs.append) == 5
+    assert any("restored" in l for l in logs)
+    got = km.get_trainer(b).net.state_dict()
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
