@@ -2,7 +2,7 @@
 forward without affine, and a plain device copy of the same tensors (the read + write ceiling): python tools/bench_dw.py"""
 import sys
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from multiposenet_amd import ops
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30

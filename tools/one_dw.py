@@ -1,7 +1,7 @@
 """Run ONE depthwise forward shape a few times (for rocprofv3 --pmc). usage: python tools/one_dw.py H C stride"""
 import sys
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from multiposenet_amd import ops
 
 H, C, s = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])

@@ -1,12 +1,12 @@
-"""Summarise a rocprofv3 --pmc counter_collection.csv for kernels matching a substring."""
+"""Mean counter values of one kernel from rocprofv3 --pmc CSVs: python tools/pmc_summary.py <substring of kernel name> <dir> [<dir> ...]"""
 import collections, csv, glob, sys
-pat = sys.argv[2] if len(sys.argv) > 2 else ''
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True):
-    for r in csv.DictReader(open(f)):
-        if pat in r['Kernel_Name']:
-            agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
-for k, d in agg.items():
-    print(k)
-    for c, v in sorted(d.items()):
-        print(f"   {c:32s} n={len(v)} mean={sum(v)/len(v):.4g}")
+name = sys.argv[1]
+for d in sys.argv[2:]:
+    for f in glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if name in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for k, v in agg.items():
+            v = v[-4:] if len(v) > 4 else v
+            print(f"{k:36s} {sum(v) / len(v):16.0f}   (n={len(v)})")

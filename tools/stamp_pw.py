@@ -1,7 +1,7 @@
 """Phase times of pw_gemm_kernel from a -DMPN_DIAG build: tools/build_variant.sh diag pointwise.hip -DMPN_DIAG;
 MPN_LIB=multiposenet_amd/libmpn_hip_diag.so python tools/stamp_pw.py H Cin Cout affine(0/1)"""
 import sys, ctypes, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from multiposenet_amd import ops, _lib
 H, Cin, Cout, aff = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 dt = torch.bfloat16; N = 32
