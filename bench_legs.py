@@ -245,13 +245,14 @@ def render_benchmark(batch=32, width=512, height=512, downsample=4, persons_per_
             "hbm_frac_of_8TBps": round(byt / us / 1e3 / 8000.0, 4), "cpu_port_us_per_image": round(cpu_us, 1)}
 
 
-def prn_benchmark(batch=128, iters=20):
+def prn_benchmark(batch=128, iters=20, dtype=torch.float16):
     """BASELINE config 5: pose residual network train step (fwd + loss + bwd + Adam + operand refresh) on `batch` person
-    crops of 56x36x17, bf16 operands / f32 accumulate and masters, replayed from a hipGraph. The step is weight-bandwidth
-    bound: algorithmic bytes = the 2 x 35.1 M weights read twice as bf16 operands (fwd, dgrad / as fc1 operand), their f32
-    gradients written, 5 f32 Adam streams, 3 operand refreshes (read f32, write bf16)."""
+    crops of 56x36x17, fp16 operands (the type config 5 names; same kernels on v_mfma_f32_16x16x32_f16) / f32 accumulate
+    and masters, replayed from a hipGraph. The step is weight-bandwidth bound: algorithmic bytes = the 2 x 35.1 M weights
+    read twice as 16-bit operands (fwd, dgrad / as fc1 operand), their f32 gradients written, 5 f32 Adam streams,
+    3 operand refreshes (read f32, write 16-bit)."""
     from multiposenet_amd.prn import PoseResidualNet
-    net = PoseResidualNet(batch=batch, dtype=torch.bfloat16)
+    net = PoseResidualNet(batch=batch, dtype=dtype)
     x = torch.rand(batch, net.h, net.w, net.c, device="cuda")
     y = torch.zeros_like(x)
     y[:, 10, 10, :] = 1.0
@@ -272,7 +273,8 @@ def prn_benchmark(batch=128, iters=20):
     ms = e0.elapsed_time(e1) / iters
     nw = 2 * net.n * net.hidden
     byt = nw * (2 * 3 + 4 + 5 * 4 + 3 * (4 + 2))      # operand reads, f32 grads, Adam, refreshes
-    out = {"ms_per_step": round(ms, 3), "crops_per_s": round(batch / ms * 1e3, 1), "batch": batch,
+    out = {"dtype": {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "f32"}[dtype],
+           "ms_per_step": round(ms, 3), "crops_per_s": round(batch / ms * 1e3, 1), "batch": batch,
            "alg_GB_per_step": round(byt / 1e9, 3), "hbm_GBps": round(byt / ms / 1e6, 1),
            "hbm_frac_of_8TBps": round(byt / ms / 1e6 / 8000.0, 4), "final_loss": round(float(loss), 5)}
     out["assign"] = prn_assign_benchmark(net, iters=iters)

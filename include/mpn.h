@@ -28,7 +28,7 @@ extern "C" {
 
 #define MPN_VERSION 200
 
-enum { MPN_F32 = 0, MPN_BF16 = 1, MPN_F16 = 2 /* decode input only */ };
+enum { MPN_F32 = 0, MPN_BF16 = 1, MPN_F16 = 2 /* dense 1x1 / 3x3 convolutions (forward, weight gradient, pack), the PRN entry points and the decode input; the BN / depthwise / loss kernels of the keypoint step take F32 and BF16 only */ };
 
 enum {
     MPN_OK = 0,
@@ -356,8 +356,10 @@ int mpn_bias_relu_fwd(const void* pre, int pre_dtype, const float* bias, void* y
                       mpn_stream_t stream);
 int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, void* dpre, int dpre_dtype, float* dbias, int R,
                       int C, mpn_stream_t stream);
+/* grad_scale: dlogits = grad_scale * dloss/dlogits (static loss scale of the fp16 build, 1 otherwise; the caller passes
+ * 1 / grad_scale to mpn_adam_step) */
 int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const float* labels, int B, int P, int C,
-                 float* logits, float* dlogits, float* loss_part, mpn_stream_t stream);
+                 float* logits, float* dlogits, float* loss_part, float grad_scale, mpn_stream_t stream);
 
 /* PRN inference glue (create_pb.py:86-142): what sits between the sigmoid heatmaps / the detector's boxes and the
  * network, and between its logits and the exported `keypoint_scores` / `keypoint_positions`.

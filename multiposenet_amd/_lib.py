@@ -81,7 +81,7 @@ SIGNATURES = {
     "mpn_cast": (_I, [_P, _I, _P, _I, _L, _P]),
     "mpn_bias_relu_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),
     "mpn_bias_relu_bwd": (_I, [_P, _I, _P, _P, _I, _P, _I, _I, _P]),
-    "mpn_prn_loss": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "mpn_prn_loss": (_I, [_P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _F, _P]),
     "mpn_bn_bwd_reduce_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mpn_bn_bwd_apply_grouped": (_I, [_I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "mpn_bn_fin_desc_bytes": (_Z, []),

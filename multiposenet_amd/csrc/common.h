@@ -54,6 +54,7 @@ static inline bool mpn_aligned16(const void* p) { return (((uintptr_t)p) & 15u) 
 // Activations are stored either as f32 (parity build) or bf16 (throughput build);
 // all arithmetic accumulates in f32.
 typedef __bf16 bf16_t;
+typedef _Float16 half_t;   // MPN_F16: fp16 storage (BASELINE config 5 runs the pose residual network in fp16)
 
 template <typename T> struct StoreTraits;
 template <> struct StoreTraits<float> {
@@ -64,12 +65,18 @@ template <> struct StoreTraits<bf16_t> {
     static constexpr int kDtype = MPN_BF16;
     static constexpr int kVec = 8;
 };
+template <> struct StoreTraits<half_t> {
+    static constexpr int kDtype = MPN_F16;
+    static constexpr int kVec = 8;
+};
 
 __device__ __forceinline__ float to_f32(float x) { return x; }
 __device__ __forceinline__ float to_f32(bf16_t x) { return (float)x; }
+__device__ __forceinline__ float to_f32(half_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+template <> __device__ __forceinline__ half_t from_f32<half_t>(float x) { return (half_t)x; }   // v_cvt_f16_f32: round to nearest even
 
 // 16-byte vector of T, unpacked to / packed from f32 registers.
 template <typename T> struct Vec16;
@@ -119,6 +126,65 @@ template <> struct Vec16<bf16_t> {
     }
 };
 
+template <> struct Vec16<half_t> {
+    static constexpr int N = 8;
+    uint4 raw;
+    __device__ __forceinline__ void load(const half_t* p) { raw = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void load_nt(const half_t* p) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        raw = make_uint4(q.x, q.y, q.z, q.w);
+    }
+    __device__ __forceinline__ void store(half_t* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+    __device__ __forceinline__ void zero() { raw = make_uint4(0u, 0u, 0u, 0u); }
+    __device__ __forceinline__ void unpack(float (&f)[8]) const {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const h2_t h = __builtin_bit_cast(h2_t, u[i]);
+            f[2 * i] = (float)h[0];
+            f[2 * i + 1] = (float)h[1];
+        }
+    }
+    __device__ __forceinline__ void pack(const float (&f)[8]) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        unsigned u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const h2_t h = {(_Float16)f[2 * i], (_Float16)f[2 * i + 1]};
+            u[i] = __builtin_bit_cast(unsigned, h);
+        }
+        raw = make_uint4(u[0], u[1], u[2], u[3]);
+    }
+};
+
+// The 16-bit storage types on the MFMA path: fragment vectors, v_mfma_f32_16x16x32_{bf16,f16}, transposing LDS read.
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+    typedef __bf16 x8 __attribute__((ext_vector_type(8)));
+    typedef __bf16 x4 __attribute__((ext_vector_type(4)));
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(const x8& a, const x8& b, const acc_t& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ x4 tr_read(const unsigned char* p) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((x4 __attribute__((address_space(3)))*)(p));
+    }
+};
+template <> struct H16<half_t> {
+    typedef _Float16 x8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 x4 __attribute__((ext_vector_type(4)));
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ acc_t mfma(const x8& a, const x8& b, const acc_t& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ x4 tr_read(const unsigned char* p) {
+        typedef __fp16 fp4_t __attribute__((ext_vector_type(4)));   // (the builtin's element type; same bits as _Float16)
+        return __builtin_bit_cast(x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((fp4_t __attribute__((address_space(3)))*)(p)));
+    }
+};
+
 // ---------------------------------------------------------------- wave helpers (wave = 64)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -127,6 +193,15 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 static inline int mpn_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// the dense-conv / PRN entry points also take fp16 storage
+#define MPN_DISPATCH_DTYPE3(dtype, ...)                                 \
+    do {                                                                \
+        if ((dtype) == MPN_F32) { using T = float; __VA_ARGS__; }       \
+        else if ((dtype) == MPN_BF16) { using T = bf16_t; __VA_ARGS__; }\
+        else if ((dtype) == MPN_F16) { using T = half_t; __VA_ARGS__; } \
+        else MPN_FAIL(MPN_ERR_BAD_DTYPE, "unsupported dtype %d", (int)(dtype)); \
+    } while (0)
 
 #define MPN_DISPATCH_DTYPE(dtype, ...)                                  \
     do {                                                                \

@@ -19,6 +19,7 @@
 // upsample-add (fpn.py:51) and per-tile batch-norm partial sums (sum, sum of squares).
 #include "common.h"
 #include "pointwise.h"
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -34,6 +35,10 @@ template <> struct Mma<bf16_t> {
     static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x4_t& c) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+};
+template <> struct Mma<half_t> {
+    using Frag = H16<half_t>::x8;
+    static __device__ __forceinline__ void run(const Frag& a, const Frag& b, f32x4_t& c) { c = H16<half_t>::mfma(a, b, c); }
 };
 template <> struct Mma<float> {
     using Frag = f32x4_t;
@@ -111,6 +116,16 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) {
     q.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
     q.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
     *reinterpret_cast<uint2*>(p) = q;
+}
+__device__ __forceinline__ void store4(half_t* p, const f32x4_t& v) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    const h4_t h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ f32x4_t load4(const half_t* p) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    const h4_t h = __builtin_bit_cast(h4_t, *reinterpret_cast<const uint2*>(p));
+    return (f32x4_t){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
 }
 __device__ __forceinline__ f32x4_t load4(const float* p) { return *reinterpret_cast<const f32x4_t*>(p); }
 __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
@@ -337,7 +352,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                 for (int nt = 0; nt < NT; ++nt) {
                     f32x4_t v = acc[mt][nt];
                     if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // out-of-image pixels must not count in the statistics
-                    store4(reinterpret_cast<bf16_t*>(O + row * RSO + (wn * (BN / 2) + nt * 16 + lq * 4) * 2), v);
+                    store4(reinterpret_cast<T*>(O + row * RSO + (wn * (BN / 2) + nt * 16 + lq * 4) * 2), v);
                 }
             }
             MPN_STAMP(3);
@@ -345,9 +360,10 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                 f32x4_t sa[NT], ga[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) { sa[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ga[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
-                bf16x8_t ones;
+                using HX = H16<std::conditional_t<sizeof(T) == 2, T, bf16_t>>;   // (this branch is 16-bit storage only)
+                typename HX::x8 ones;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ones[j] = (bf16_t)1.0f;
+                for (int j = 0; j < 8; ++j) ones[j] = 1.0f;
                 // lane 4q+pp of a 16-lane group supplies the address of block row q, channels 4pp..4pp+3
                 const unsigned char* tb = O + (wm * (MT * 16) + (lq >> 1) * 2 + 4 * ((lq & 1) * 4 + (l15 >> 2))) * RSO +
                                           (wn * (BN / 2) + 4 * (l15 & 3)) * 2;
@@ -355,11 +371,11 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                 for (int ks = 0; ks < MT / 2; ++ks)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const bf16x4_t lo = o_tr_read(tb + ks * 32 * RSO + nt * 32);
-                        const bf16x4_t hi = o_tr_read(tb + (ks * 32 + 1) * RSO + nt * 32);
-                        const bf16x8_t f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        sa[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, f, sa[nt], 0, 0, 0);
-                        ga[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, ga[nt], 0, 0, 0);
+                        const typename HX::x4 lo = HX::tr_read(tb + ks * 32 * RSO + nt * 32);
+                        const typename HX::x4 hi = HX::tr_read(tb + (ks * 32 + 1) * RSO + nt * 32);
+                        const typename HX::x8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        sa[nt] = HX::mfma(ones, f, sa[nt]);
+                        ga[nt] = HX::mfma(f, f, ga[nt]);
                     }
                 // D layout: lane (l15 = column, lq) holds rows 4 lq + r. Column sums: every row; Gram diagonal: row == column
                 const int r = l15 & 3;
@@ -593,9 +609,9 @@ struct PackGeom {
     long long tile_bytes, total_bytes;
 };
 
-PackGeom pack_geom(int Kin, int Nout, int taps, int es) {
+PackGeom pack_geom(int Kin, int Nout, int taps, int es, int dtype) {
     PackGeom g;
-    if (pw_gemm_eligible(Kin, Nout, taps, es)) {
+    if (dtype == MPN_BF16 && pw_gemm_eligible(Kin, Nout, taps, es)) {
         g.BN = 256; g.n_tiles = Nout / 256; g.nchunk = 1; g.row_bytes = 0;
         g.tile_bytes = 256ll * Kin * es; g.total_bytes = (long long)Nout * Kin * es;
         return g;
@@ -621,7 +637,7 @@ PackGeom pack_geom(int Kin, int Nout, int taps, int es) {
 
 extern "C" size_t mpn_conv_packed_bytes(int Cin, int Cout, int ksize, int transpose, int dtype) {
     const int es = dtype == MPN_F32 ? 4 : 2;
-    const PackGeom g = pack_geom(transpose ? Cout : Cin, transpose ? Cin : Cout, ksize * ksize, es);
+    const PackGeom g = pack_geom(transpose ? Cout : Cin, transpose ? Cin : Cout, ksize * ksize, es, dtype);
     return (size_t)g.total_bytes;
 }
 
@@ -629,19 +645,15 @@ extern "C" int mpn_conv_pack_weights(const float* w_hwio, int Cin, int Cout, int
                                      int dtype, void* out, mpn_stream_t stream) {
     MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv pack: ksize must be 1 or 3");
     MPN_REQUIRE(w_hwio && out, MPN_ERR_BAD_ARG, "conv pack: null pointer");
-    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "conv pack: dtype");
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16 || dtype == MPN_F16, MPN_ERR_BAD_DTYPE, "conv pack: dtype");
     const int es = dtype == MPN_F32 ? 4 : 2;
     const int taps = ksize * ksize;
-    const PackGeom g = pack_geom(transpose ? Cout : Cin, transpose ? Cin : Cout, taps, es);
+    const PackGeom g = pack_geom(transpose ? Cout : Cin, transpose ? Cin : Cout, taps, es, dtype);
     const long long total = g.total_bytes / es;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MPN_F32)
-        pack_weights_kernel<float><<<blocks, 256, 0, st>>>(w_hwio, (float*)out, Cin, Cout, taps, transpose, g.BN,
-                                                          g.n_tiles, g.nchunk, g.row_bytes, total);
-    else
-        pack_weights_kernel<bf16_t><<<blocks, 256, 0, st>>>(w_hwio, (bf16_t*)out, Cin, Cout, taps, transpose, g.BN,
-                                                           g.n_tiles, g.nchunk, g.row_bytes, total);
+    MPN_DISPATCH_DTYPE3(dtype, (pack_weights_kernel<T><<<blocks, 256, 0, st>>>(w_hwio, (T*)out, Cin, Cout, taps, transpose, g.BN, g.n_tiles,
+                                                                              g.nchunk, g.row_bytes, total)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -655,7 +667,7 @@ extern "C" int mpn_conv_pack_desc_fill(void* desc_host, const float* w_hwio, int
     if (!(ksize == 1 || ksize == 3) || !desc_host || !w_hwio || !out) return -1;
     const int es = dtype == MPN_F32 ? 4 : 2;
     const int taps = ksize * ksize;
-    const PackGeom g = pack_geom(transpose ? Cout : Cin, transpose ? Cin : Cout, taps, es);
+    const PackGeom g = pack_geom(transpose ? Cout : Cin, transpose ? Cin : Cout, taps, es, dtype);
     PackDesc d;
     d.w = w_hwio; d.out = out; d.Cin_o = Cin; d.Cout_o = Cout; d.taps = taps; d.transpose = transpose;
     d.BN = g.BN; d.n_tiles = g.n_tiles; d.nchunk = g.nchunk; d.row_bytes = g.row_bytes;
@@ -672,12 +684,9 @@ extern "C" int mpn_conv_pack_desc_fill(void* desc_host, const float* w_hwio, int
 extern "C" int mpn_conv_pack_weights_batched(const void* descs_device, int ndesc, int total_blocks, int dtype,
                                              mpn_stream_t stream) {
     MPN_REQUIRE(descs_device && ndesc > 0 && total_blocks > 0, MPN_ERR_BAD_ARG, "pack batched: bad arguments");
-    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "pack batched: dtype");
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16 || dtype == MPN_F16, MPN_ERR_BAD_DTYPE, "pack batched: dtype");
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MPN_F32)
-        pack_weights_batched_kernel<float><<<total_blocks, 256, 0, st>>>((const PackDesc*)descs_device, ndesc);
-    else
-        pack_weights_batched_kernel<bf16_t><<<total_blocks, 256, 0, st>>>((const PackDesc*)descs_device, ndesc);
+    MPN_DISPATCH_DTYPE3(dtype, (pack_weights_batched_kernel<T><<<total_blocks, 256, 0, st>>>((const PackDesc*)descs_device, ndesc)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -739,7 +748,7 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
                             int in_act, float* stats_part, const void* up_res, mpn_stream_t stream) {
     MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv: ksize must be 1 or 3 (got %d)", ksize);
     MPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, MPN_ERR_BAD_SHAPE, "conv: bad shape");
-    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "conv: dtype %d", dtype);
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16 || dtype == MPN_F16, MPN_ERR_BAD_DTYPE, "conv: dtype %d", dtype);
     const int es = dtype == MPN_F32 ? 4 : 2;
     const int ve = 16 / es;
     MPN_REQUIRE(Cin % ve == 0 && Cout % ve == 0, MPN_ERR_BAD_SHAPE,
@@ -753,7 +762,7 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
     MPN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), MPN_ERR_BAD_ARG, "conv: scale/shift mismatch");
     MPN_REQUIRE(up_res == nullptr || (ksize == 1 && H % 2 == 0 && W % 2 == 0), MPN_ERR_BAD_ARG,
                 "conv: upsample-add epilogue needs ksize 1 and even H, W");
-    const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es);
+    const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es, dtype);
     if (g.row_bytes == 0) {   // deep 1x1 layer: the GEMM kernel (weights packed as [Cout][Cin])
         MPN_REQUIRE(up_res == nullptr, MPN_ERR_BAD_ARG, "conv: the upsample-add epilogue needs Cout < 256 or Cin < 256");
         return pw_gemm_launch(x, w_packed, y, (long long)N * H * W, Cin, Cout, x_stride > 0 ? x_stride : Cin,
@@ -766,6 +775,10 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
     if (dtype == MPN_F32) {
         if (ksize == 3) return g.BN == 128 ? launch_conv<float, 9, 128>(p, m_tiles, st) : launch_conv<float, 9, 64>(p, m_tiles, st);
         return g.BN == 128 ? launch_conv<float, 1, 128>(p, m_tiles, st) : launch_conv<float, 1, 64>(p, m_tiles, st);
+    }
+    if (dtype == MPN_F16) {
+        if (ksize == 3) return g.BN == 128 ? launch_conv<half_t, 9, 128>(p, m_tiles, st) : launch_conv<half_t, 9, 64>(p, m_tiles, st);
+        return g.BN == 128 ? launch_conv<half_t, 1, 128>(p, m_tiles, st) : launch_conv<half_t, 1, 64>(p, m_tiles, st);
     }
     if (ksize == 3) return g.BN == 128 ? launch_conv<bf16_t, 9, 128>(p, m_tiles, st) : launch_conv<bf16_t, 9, 64>(p, m_tiles, st);
     return g.BN == 128 ? launch_conv<bf16_t, 1, 128>(p, m_tiles, st) : launch_conv<bf16_t, 1, 64>(p, m_tiles, st);
@@ -793,7 +806,7 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
     MPN_REQUIRE(njobs > 0 && x && w_packed && y && H && W && in_scale && in_shift && stats_part, MPN_ERR_BAD_ARG,
                 "conv grouped: bad arguments");
     const int es = dtype == MPN_F32 ? 4 : 2;
-    const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es);
+    const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es, dtype);
     const bool fast = dtype == MPN_BF16 && ksize == 3 && njobs <= kMaxGroup && g.row_bytes == 128;
     if (!fast) {
         for (int j = 0; j < njobs; ++j)

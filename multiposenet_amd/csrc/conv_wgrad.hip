@@ -15,11 +15,12 @@
 // LDS rows are XOR-swizzled in 32-byte segments so the 8 pixel rows one half-wave touches per
 // transposed read land in 8 different bank groups.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+// fragment types / MFMA / transposing read of the 16-bit storage type T (bf16 or fp16; a float T never reaches them)
+template <typename T> using HT = H16<std::conditional_t<sizeof(T) == 2, T, bf16_t>>;
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 constexpr int kThreads = 256;
@@ -57,9 +58,8 @@ template <int RB> __device__ __forceinline__ int lds_off(int row, int seg, int w
     return row * RB + ((seg ^ f) << 5) + within;
 }
 
-__device__ __forceinline__ bf16x4_t tr_read(const unsigned char* base, int off) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        (bf16x4_t __attribute__((address_space(3)))*)(base + off));
+template <typename H> __device__ __forceinline__ typename H::x4 tr_read(const unsigned char* base, int off) {
+    return H::tr_read(base + off);
 }
 
 // RBA / RBD: bytes per pixel row of the A (input-channel) and dY (output-channel) LDS images. Default geometry:
@@ -217,13 +217,16 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
         // ---------------- MFMA over the 128 pixels of the tile
         for (int ks = 0; ks < KSTEPS; ++ks) {
             if constexpr (ES == 2) {
+                using H = HT<T>;
+                using X8 = typename H::x8;
+                using X4 = typename H::x4;
                 const int qq = l15 >> 2, pp = l15 & 3;
                 const int r0 = ks * 32 + 8 * lq + qq;  // this lane's pixel row for the first 4-row block
-                bf16x8_t bfr[NTW];
+                X8 bfr[NTW];
 #pragma unroll
                 for (int j = 0; j < NTW; ++j) {
-                    const bf16x4_t lo = tr_read(Ds, lds_off<RBD>(r0, nt0 + j, pp * 8));
-                    const bf16x4_t hi = tr_read(Ds, lds_off<RBD>(r0 + 4, nt0 + j, pp * 8));
+                    const X4 lo = tr_read<H>(Ds, lds_off<RBD>(r0, nt0 + j, pp * 8));
+                    const X4 hi = tr_read<H>(Ds, lds_off<RBD>(r0 + 4, nt0 + j, pp * 8));
                     bfr[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 }
                 // software-pipelined over (tap, m-tile): the fragment of step n+1 is fetched while the
@@ -236,22 +239,22 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
                     }
                     return r0;
                 };
-                auto a_load = [&](int step) -> bf16x8_t {
+                auto a_load = [&](int step) -> X8 {
                     const int t = step / MTW, i = step % MTW;
                     const int arow = a_row(t);
-                    const bf16x4_t lo = tr_read(As, lds_off<RBA>(arow, mt0 + i, pp * 8));
-                    const bf16x4_t hi = tr_read(As, lds_off<RBA>(arow + 4, mt0 + i, pp * 8));
+                    const X4 lo = tr_read<H>(As, lds_off<RBA>(arow, mt0 + i, pp * 8));
+                    const X4 hi = tr_read<H>(As, lds_off<RBA>(arow + 4, mt0 + i, pp * 8));
                     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 };
-                bf16x8_t a_next = a_load(0);
+                X8 a_next = a_load(0);
 #pragma unroll
                 for (int step = 0; step < TAPS * MTW; ++step) {
-                    const bf16x8_t afr = a_next;
+                    const X8 afr = a_next;
                     if (step + 1 < TAPS * MTW) a_next = a_load(step + 1);
                     const int t = step / MTW, i = step % MTW;
 #pragma unroll
                     for (int j = 0; j < NTW; ++j)
-                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr, bfr[j], acc[t][i][j], 0, 0, 0);
+                        acc[t][i][j] = H::mfma(afr, bfr[j], acc[t][i][j]);
                     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // 2 DS reads (next fragment)
                     __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);  // NTW MFMAs (this fragment)
                 }
@@ -307,9 +310,11 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
 //   3x3:              (128, 256, 2x4) = 64 ci x 9 taps x 128 co, 144 accumulator registers per lane
 //   3x3, Cout <= 64:  (256, 128, 4x2) = 128 ci x 9 taps x 64 co
 //   1x1:              (256, 256, 4x2) = 128 ci x 128 co
-template <int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradParams p) {
-    using T = bf16_t;
+    using H = H16<T>;
+    using X8 = typename H::x8;
+    using X4 = typename H::x4;
     constexpr int NT = 512;
     constexpr int VE = 8;
     constexpr int CG = RBA / 2, BNW = RBD / 2;
@@ -547,22 +552,22 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
         constexpr int RING0 = NTW >= 4 ? 4 : 6;
         constexpr int RING = RING0 < STEPS ? RING0 : STEPS;
         constexpr int KSA = (TAPS == 9 ? 2 * kHaloW : 32) * SA, KSD = 32 * SD;
-        auto a_load = [&](int gs) -> bf16x8_t {
+        auto a_load = [&](int gs) -> X8 {
             const int ks = gs / STEPS, step = gs % STEPS;
             const int t = step / MTW, i = step % MTW;
             const int row = TAPS == 9 ? (t / 3) * kHaloW + (t % 3) : 0;
             const int second = TAPS == 9 ? kHaloW : 16;
-            const bf16x4_t l4 = tr_read(a_lane, ks * KSA + row * SA + i * 32);
-            const bf16x4_t h4 = tr_read(a_lane, ks * KSA + (row + second) * SA + i * 32);
+            const X4 l4 = tr_read<H>(a_lane, ks * KSA + row * SA + i * 32);
+            const X4 h4 = tr_read<H>(a_lane, ks * KSA + (row + second) * SA + i * 32);
             return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-        auto b_load = [&](int ks, int j) -> bf16x8_t {
-            const bf16x4_t l4 = tr_read(d_lane, ks * KSD + j * 32);
-            const bf16x4_t h4 = tr_read(d_lane, ks * KSD + 16 * SD + j * 32);
+        auto b_load = [&](int ks, int j) -> X8 {
+            const X4 l4 = tr_read<H>(d_lane, ks * KSD + j * 32);
+            const X4 h4 = tr_read<H>(d_lane, ks * KSD + 16 * SD + j * 32);
             return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
         };
-        bf16x8_t bfr[2][NTW];
-        bf16x8_t ar[RING];
+        X8 bfr[2][NTW];
+        X8 ar[RING];
 #pragma unroll
         for (int j = 0; j < NTW; ++j) bfr[0][j] = b_load(0, j);
 #pragma unroll
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
             const int t = step / MTW, i = step % MTW;
 #pragma unroll
             for (int j = 0; j < NTW; ++j)
-                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ar[gs % RING], bfr[ks & 1][j], acc[t][i][j], 0, 0, 0);
+                acc[t][i][j] = H::mfma(ar[gs % RING], bfr[ks & 1][j], acc[t][i][j]);
             // full fence per step: without it the scheduler sinks every read down to its use (one register set,
             // lgkmcnt(0) before each MFMA group) and the ring degenerates to distance 0
             __builtin_amdgcn_sched_barrier(0);
@@ -652,14 +657,14 @@ WgradGeom wgrad_geom(int N, int H, int W, int Cin, int Cout, int ksize, int es) 
     return g;
 }
 
-template <int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
 int launch_wgrad_bf16(const WgradParams& p, hipStream_t st) {
     constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int smem = 2 * NPIXA * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * (RBA / 2) * (int)sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS budget");
     static unsigned long long attr_mask = 0;
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_bf16_kernel<TAPS, RBA, RBD, WM, STAGGER>, smem, &attr_mask));
-    conv_wgrad_bf16_kernel<TAPS, RBA, RBD, WM, STAGGER><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(512), smem, st>>>(p);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_bf16_kernel<T, TAPS, RBA, RBD, WM, STAGGER>, smem, &attr_mask));
+    conv_wgrad_bf16_kernel<T, TAPS, RBA, RBD, WM, STAGGER><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(512), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -702,7 +707,7 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
                                    int x_stride, int dy_stride, int ksize, int dtype, const float* in_scale,
                                    const float* in_shift, int in_act, mpn_stream_t stream) {
     MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv wgrad: ksize must be 1 or 3");
-    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "conv wgrad: dtype %d", dtype);
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16 || dtype == MPN_F16, MPN_ERR_BAD_DTYPE, "conv wgrad: dtype %d", dtype);
     const int es = dtype == MPN_F32 ? 4 : 2;
     const int ve = 16 / es;
     MPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cin % ve == 0 && Cout % ve == 0, MPN_ERR_BAD_SHAPE,
@@ -731,7 +736,12 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MPN_F32) return ksize == 3 ? launch_wgrad<float, 9>(p, st) : launch_wgrad<float, 1>(p, st);
     // the two wave groups run staggered by half a period on the 3x3 geometries, in step on 1x1 (measured best per geometry)
-    if (ksize == 1) return launch_wgrad_bf16<1, 256, 256, 4, false>(p, st);
-    if (Cout <= 64) return launch_wgrad_bf16<9, 256, 128, 4, true>(p, st);
-    return launch_wgrad_bf16<9, 128, 256, 2, true>(p, st);
+    if (dtype == MPN_F16) {   // same kernel on v_mfma_f32_16x16x32_f16
+        if (ksize == 1) return launch_wgrad_bf16<half_t, 1, 256, 256, 4, false>(p, st);
+        if (Cout <= 64) return launch_wgrad_bf16<half_t, 9, 256, 128, 4, true>(p, st);
+        return launch_wgrad_bf16<half_t, 9, 128, 256, 2, true>(p, st);
+    }
+    if (ksize == 1) return launch_wgrad_bf16<bf16_t, 1, 256, 256, 4, false>(p, st);
+    if (Cout <= 64) return launch_wgrad_bf16<bf16_t, 9, 256, 128, 4, true>(p, st);
+    return launch_wgrad_bf16<bf16_t, 9, 128, 256, 2, true>(p, st);
 }

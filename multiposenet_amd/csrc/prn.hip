@@ -63,12 +63,12 @@ __global__ __launch_bounds__(kThreads) void bias_relu_bwd_kernel(const TY* __res
 }
 
 // logits[b][p][c] = x[b][p][c] + y2[b][p][c];  prob = softmax over p;  loss = mean(log_loss(labels, prob, eps=1e-7));
-// dlogits = d loss / d logits.  One block per image: thread (c, lane) walks pixels lane, lane+LP, ...
+// dlogits = grad_scale * d loss / d logits (ginv = grad_scale / (B P C)).  One block per image: thread (c, lane) walks pixels lane, lane+LP, ...
 constexpr int kPL = 15;   // pixel lanes per channel: 17 channels x 15 = 255 threads
 template <typename TY>
 __global__ __launch_bounds__(kThreads) void prn_loss_kernel(const float* __restrict__ x, const TY* __restrict__ y2,
                                                            const float* __restrict__ labels, int P, int C, float inv_total,
-                                                           float* __restrict__ logits, float* __restrict__ dlogits,
+                                                           float ginv, float* __restrict__ logits, float* __restrict__ dlogits,
                                                            float* __restrict__ loss_part) {
     __shared__ float red[kThreads];
     __shared__ float stat[2][32];
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void prn_loss_kernel(const float* __restr
             const float pr = expf(logits[i] - m) * inv_se;
             const float yv = labels[i];
             l += -yv * logf(pr + eps) - (1.f - yv) * logf(1.f - pr + eps);
-            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * inv_total;
+            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * ginv;
             gp += g * pr;
         }
     gp = reduce_c(gp, false);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void prn_loss_kernel(const float* __restr
             const long long i = base + (long long)p * C + c;
             const float pr = expf(logits[i] - m) * inv_se;
             const float yv = labels[i];
-            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * inv_total;
+            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * ginv;
             dlogits[i] = pr * (g - gp);
         }
     // block loss partial (fixed order)
@@ -142,17 +142,22 @@ int blocks_for(long long n) {
 }
 }  // namespace
 
-/* out[C][R] = cast(in[R][C]); in_dtype / out_dtype: MPN_F32 or MPN_BF16 */
+/* storage types of the PRN entry points: MPN_F32, MPN_BF16, MPN_F16 (config 5 of BASELINE.json runs the PRN in fp16) */
+#define PRN_DISPATCH_ONE(dtype, NAME, ...)                               \
+    do {                                                                 \
+        if ((dtype) == MPN_F32) { using NAME = float; __VA_ARGS__; }     \
+        else if ((dtype) == MPN_BF16) { using NAME = bf16_t; __VA_ARGS__; } \
+        else if ((dtype) == MPN_F16) { using NAME = half_t; __VA_ARGS__; }  \
+        else MPN_FAIL(MPN_ERR_BAD_DTYPE, "prn: unsupported dtype %d", (int)(dtype)); \
+    } while (0)
+#define PRN_DISPATCH_TWO(dt_in, dt_out, ...) PRN_DISPATCH_ONE(dt_in, TI, PRN_DISPATCH_ONE(dt_out, TO, __VA_ARGS__))
+
+/* out[C][R] = cast(in[R][C]); in_dtype / out_dtype: MPN_F32, MPN_BF16 or MPN_F16 */
 extern "C" int mpn_transpose_cast(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, mpn_stream_t stream) {
     MPN_REQUIRE(in && out && R > 0 && C > 0, MPN_ERR_BAD_ARG, "transpose_cast: bad arguments");
-    MPN_REQUIRE((in_dtype == MPN_F32 || in_dtype == MPN_BF16) && (out_dtype == MPN_F32 || out_dtype == MPN_BF16), MPN_ERR_BAD_DTYPE,
-                "transpose_cast: dtype");
     const dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32));
     hipStream_t st = (hipStream_t)stream;
-    if (in_dtype == MPN_F32 && out_dtype == MPN_F32) transpose_cast_kernel<float, float><<<grid, kThreads, 0, st>>>((const float*)in, (float*)out, R, C);
-    else if (in_dtype == MPN_F32) transpose_cast_kernel<float, bf16_t><<<grid, kThreads, 0, st>>>((const float*)in, (bf16_t*)out, R, C);
-    else if (out_dtype == MPN_F32) transpose_cast_kernel<bf16_t, float><<<grid, kThreads, 0, st>>>((const bf16_t*)in, (float*)out, R, C);
-    else transpose_cast_kernel<bf16_t, bf16_t><<<grid, kThreads, 0, st>>>((const bf16_t*)in, (bf16_t*)out, R, C);
+    PRN_DISPATCH_TWO(in_dtype, out_dtype, (transpose_cast_kernel<TI, TO><<<grid, kThreads, 0, st>>>((const TI*)in, (TO*)out, R, C)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -160,13 +165,9 @@ extern "C" int mpn_transpose_cast(const void* in, int in_dtype, void* out, int o
 /* out[i] = cast(in[i]) */
 extern "C" int mpn_cast(const void* in, int in_dtype, void* out, int out_dtype, long long n, mpn_stream_t stream) {
     MPN_REQUIRE(in && out && n > 0, MPN_ERR_BAD_ARG, "cast: bad arguments");
-    MPN_REQUIRE((in_dtype == MPN_F32 || in_dtype == MPN_BF16) && (out_dtype == MPN_F32 || out_dtype == MPN_BF16), MPN_ERR_BAD_DTYPE, "cast: dtype");
     hipStream_t st = (hipStream_t)stream;
     const int g = blocks_for(n);
-    if (in_dtype == MPN_F32 && out_dtype == MPN_BF16) cast_kernel<float, bf16_t><<<g, kThreads, 0, st>>>((const float*)in, (bf16_t*)out, n);
-    else if (in_dtype == MPN_BF16 && out_dtype == MPN_F32) cast_kernel<bf16_t, float><<<g, kThreads, 0, st>>>((const bf16_t*)in, (float*)out, n);
-    else if (in_dtype == MPN_F32) cast_kernel<float, float><<<g, kThreads, 0, st>>>((const float*)in, (float*)out, n);
-    else cast_kernel<bf16_t, bf16_t><<<g, kThreads, 0, st>>>((const bf16_t*)in, (bf16_t*)out, n);
+    PRN_DISPATCH_TWO(in_dtype, out_dtype, (cast_kernel<TI, TO><<<g, kThreads, 0, st>>>((const TI*)in, (TO*)out, n)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -178,39 +179,36 @@ extern "C" int mpn_bias_relu_fwd(const void* pre, int pre_dtype, const float* bi
     const long long n = (long long)R * C;
     hipStream_t st = (hipStream_t)stream;
     const int g = blocks_for(n);
-    if (pre_dtype == MPN_F32 && out_dtype == MPN_F32) bias_relu_fwd_kernel<float, float><<<g, kThreads, 0, st>>>((const float*)pre, bias, (float*)y, n, C);
-    else if (pre_dtype == MPN_F32 && out_dtype == MPN_BF16) bias_relu_fwd_kernel<float, bf16_t><<<g, kThreads, 0, st>>>((const float*)pre, bias, (bf16_t*)y, n, C);
-    else if (pre_dtype == MPN_BF16 && out_dtype == MPN_BF16) bias_relu_fwd_kernel<bf16_t, bf16_t><<<g, kThreads, 0, st>>>((const bf16_t*)pre, bias, (bf16_t*)y, n, C);
-    else if (pre_dtype == MPN_BF16 && out_dtype == MPN_F32) bias_relu_fwd_kernel<bf16_t, float><<<g, kThreads, 0, st>>>((const bf16_t*)pre, bias, (float*)y, n, C);
-    else MPN_FAIL(MPN_ERR_BAD_DTYPE, "bias_relu_fwd: dtype");
+    PRN_DISPATCH_TWO(pre_dtype, out_dtype, (bias_relu_fwd_kernel<TI, TO><<<g, kThreads, 0, st>>>((const TI*)pre, bias, (TO*)y, n, C)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
 
-/* dpre = (y > 0) * dy (storage dtype of the GEMM operand), dbias[c] = column sums; dy f32 */
+/* dpre = (y > 0) * dy (storage dtype of the GEMM operand), dbias[c] = column sums; dy f32; y and dpre share one dtype */
 extern "C" int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, void* dpre, int dpre_dtype, float* dbias, int R,
                                  int C, mpn_stream_t stream) {
     MPN_REQUIRE(y && dy && dpre && dbias && R > 0 && C > 0, MPN_ERR_BAD_ARG, "bias_relu_bwd: bad arguments");
+    MPN_REQUIRE(y_dtype == dpre_dtype, MPN_ERR_BAD_DTYPE, "bias_relu_bwd: y and dpre must share one dtype");
     hipStream_t st = (hipStream_t)stream;
     const int g = (C + kThreads - 1) / kThreads;
-    if (y_dtype == MPN_F32 && dpre_dtype == MPN_F32) bias_relu_bwd_kernel<float, float><<<g, kThreads, 0, st>>>((const float*)y, dy, (float*)dpre, dbias, R, C);
-    else if (y_dtype == MPN_BF16 && dpre_dtype == MPN_BF16) bias_relu_bwd_kernel<bf16_t, bf16_t><<<g, kThreads, 0, st>>>((const bf16_t*)y, dy, (bf16_t*)dpre, dbias, R, C);
-    else MPN_FAIL(MPN_ERR_BAD_DTYPE, "bias_relu_bwd: dtype");
+    PRN_DISPATCH_ONE(y_dtype, TS, (bias_relu_bwd_kernel<TS, TS><<<g, kThreads, 0, st>>>((const TS*)y, dy, (TS*)dpre, dbias, R, C)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
 
 /* PRN loss (prn_model.py:16-30): logits = x + y2 [B][P][C]; softmax over P; mean log_loss; C <= 17.
- * logits, dlogits (may be NULL): f32 [B][P][C]; loss_part: f32 [B] (sum = loss). */
+ * logits, dlogits (may be NULL): f32 [B][P][C]; loss_part: f32 [B] (sum = loss).
+ * grad_scale: dlogits = grad_scale * dloss/dlogits - the static loss scale of the fp16 build (the unscaled gradient of a
+ * mean over B*P*C ~ 4e6 terms is below fp16's normal range once stored as the GEMM operand dpre2); 1 otherwise. The
+ * caller hands 1 / grad_scale to mpn_adam_step. */
 extern "C" int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const float* labels, int B, int P, int C,
-                            float* logits, float* dlogits, float* loss_part, mpn_stream_t stream) {
+                            float* logits, float* dlogits, float* loss_part, float grad_scale, mpn_stream_t stream) {
     MPN_REQUIRE(x && y2 && labels && logits && loss_part, MPN_ERR_BAD_ARG, "prn_loss: null pointer");
+    MPN_REQUIRE(grad_scale > 0.f, MPN_ERR_BAD_ARG, "prn_loss: grad_scale must be positive");
     MPN_REQUIRE(B > 0 && P > 0 && C > 0 && C * kPL <= kThreads, MPN_ERR_BAD_SHAPE, "prn_loss: C must be <= %d", kThreads / kPL);
     const float inv_total = 1.0f / ((float)B * (float)P * (float)C);
     hipStream_t st = (hipStream_t)stream;
-    if (y2_dtype == MPN_F32) prn_loss_kernel<float><<<B, kThreads, 0, st>>>(x, (const float*)y2, labels, P, C, inv_total, logits, dlogits, loss_part);
-    else if (y2_dtype == MPN_BF16) prn_loss_kernel<bf16_t><<<B, kThreads, 0, st>>>(x, (const bf16_t*)y2, labels, P, C, inv_total, logits, dlogits, loss_part);
-    else MPN_FAIL(MPN_ERR_BAD_DTYPE, "prn_loss: dtype");
+    PRN_DISPATCH_ONE(y2_dtype, TS, (prn_loss_kernel<TS><<<B, kThreads, 0, st>>>(x, (const TS*)y2, labels, P, C, inv_total, inv_total * grad_scale, logits, dlogits, loss_part)));
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

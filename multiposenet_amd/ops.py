@@ -90,8 +90,8 @@ def _row_stride(t, channels):
 def conv_fwd(x, packed, cout, ksize, affine=None, out=None, stats_part=None, up_res=None):
     """y = conv(act(bn(x))) [+ nearest2x(up_res)]; optional per-tile BN partial sums. x and out may be channel slices
     (`t[..., a:b]`) of wider contiguous NHWC tensors: the kernel takes their pixel strides."""
-    if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16):
-        raise ValueError(f"x must be an NHWC f32/bf16 tensor, got {tuple(x.shape)} {x.dtype}")
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        raise ValueError(f"x must be an NHWC f32/bf16/f16 tensor, got {tuple(x.shape)} {x.dtype}")
     N, H, W, cin = x.shape
     xs = _slice_stride(x, cin)
     if out is None:

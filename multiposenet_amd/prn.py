@@ -54,6 +54,10 @@ class PoseResidualNet:
         if self.n % 8 or hidden % 8:
             raise ValueError("h*w*c and hidden must be multiples of 8")
         self.dtype = dtype
+        # static loss scale of the fp16 build: the gradient of a mean over batch*h*w*c (~4.4e6) terms sits below fp16's
+        # normal range once it is stored as a GEMM operand (dpre2, dpre1), so the backward pass carries
+        # loss_scale * gradient (a power of two: exact) and Adam divides it out. bf16 / f32 have the exponent range.
+        self.loss_scale = float(2 ** int(np.floor(np.log2(batch * h * w * c)))) if dtype == torch.float16 else 1.0
         shapes = variable_shapes(h, w, c, hidden)
         self._arena = _Arena(shapes, self.device)
         self.theta, self.grad = self._arena.new(), self._arena.new()
@@ -143,7 +147,7 @@ class PoseResidualNet:
         """labels f32 [b,h,w,c]. Returns the device scalar loss (prn_model.py:29); fills logits (and dlogits)."""
         B = self.B
         call("mpn_prn_loss", ptr(self._x), ptr(self.y2), _lib.dtype_code(self.dtype), ptr(labels), B, self.h * self.w, self.c,
-             ptr(self.logits), ptr(self.dlogits) if with_grad else None, ptr(self.loss_part), stream_ptr())
+             ptr(self.logits), ptr(self.dlogits) if with_grad else None, ptr(self.loss_part), self.loss_scale, stream_ptr())
         return self.loss_part.sum()
 
     def predict(self, x):
@@ -168,7 +172,7 @@ class PoseResidualNet:
 
     def optimizer_step(self, initial_learning_rate, num_steps):
         ops.adam_prepare(self.global_step, self.hyper, initial_learning_rate, num_steps)
-        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, clip=float("inf"))
+        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, grad_scale=1.0 / self.loss_scale, clip=float("inf"))
         self.refresh_operands()
 
     def train_step(self, x, labels, initial_learning_rate, num_steps):

@@ -16,7 +16,9 @@ _models = {}
 def _model(params, batch, shape):
     """One PoseResidualNet (+ optimizer state) per model configuration: tf.estimator keys its variables by `model_dir`
     (train_prn.py: RunConfig(model_dir=...)), so does this registry - never by object identity, which is recycled."""
-    dt = torch.float32 if params.get("dtype", "bf16") == "f32" else torch.bfloat16
+    # storage type of the GEMM operands and activations (masters, accumulators and Adam stay f32); "fp16" is the type
+    # BASELINE.json config 5 names
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16}[params.get("dtype", "bf16")]
     key = (params.get("model_dir"), dt, int(params.get("seed", 0)), batch, shape)
     if key not in _models:
         _models[key] = PoseResidualNet(values=params.get("values"), batch=batch, h=shape[0], w=shape[1], c=shape[2], dtype=dt)
