@@ -1,0 +1,413 @@
+// 3x3 convolution (forward and data gradient), 16-bit storage, on v_mfma_f32_16x16x32_{bf16,f16}: ONE 8-wave block per CU
+// owns a 16 x 16 pixel tile x 128 output channels.
+//
+// Why a second 3x3 kernel: the tiled kernel of conv_mfma.hip (4 waves, 128 pixels x 128 channels, two blocks per CU) streams
+// all 9 x Cin x 128 weights through LDS once per 128 pixels - 36 bytes per CU and clock of L2 -> LDS traffic at full MFMA
+// rate, which is what a CU can ingest - and reads one LDS fragment per two MFMAs, which is what the LDS can deliver. Here
+//   * the weight stream is shared by 256 pixels (20 bytes per clock),
+//   * a stage holds the three taps of one kernel COLUMN (ky = 0..2 at fixed kx): output row r at tap ky reads the same
+//     halo row r + ky as output row r + 1 at tap ky - 1, so a wave loads the 6 halo rows of its 4 output rows ONCE per
+//     stage and uses each fragment for up to three taps: 18 fragment reads per 48 MFMAs instead of 24,
+//   * the 18 x 18 halo image of the next 64-channel chunk is fetched into registers and committed (producer's batch-norm
+//     affine + activation + zero padding) into the other half of a double-buffered LDS image while the current chunk is
+//     multiplied: the only exposed staging is that of a tile's first chunk.
+// LDS: 2 x 51 840 (halo images, 160-byte rows: conflict-free ds_read_b128) + 2 x 24 576 (weight stages, LDS-DMA) = 152 832 B.
+// Epilogue as in the tiled kernel: the tile leaves through a bf16 LDS image (whole 256-byte pixel rows to HBM), the
+// batch-norm partial sums come from the matrix unit (ones x F and F^T x F over transposed reads of that image) and are
+// written as the two 8 x 16-pixel rows of the partial slab that the tiled kernel would have written.
+#include "conv3x3.h"
+
+namespace {
+using namespace mpn_c3;
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+constexpr int kHW = 18;                      // halo width = height
+constexpr int kNPix = kHW * kHW;             // 324
+constexpr int kRS = 160;                     // LDS bytes per halo pixel: 128 bytes of K + 32 of padding
+constexpr int kABytes = kNPix * kRS;         // 51 840
+constexpr int kSmem = 2 * kABytes + 2 * kStageBytes;
+constexpr int kAVec = (kNPix * 8 + kThreads - 1) / kThreads;   // 16-byte pieces of a halo image per thread: 6
+constexpr int kRedBytes = 4 * 2 * 128 * (int)sizeof(float);
+constexpr int kMaxCin = 512;                 // scale / shift table of the producer's batch-norm: [2][kMaxCin] floats
+constexpr int kTabBytes = 2 * kMaxCin * (int)sizeof(float);
+constexpr int kLds = kSmem + kRedBytes + kTabBytes;
+static_assert(8 * 32 * (64 * 2 + 8) <= kABytes, "the wave-private epilogue images fit in one halo buffer");
+static_assert(kLds <= 160 * 1024, "LDS budget");
+
+// diagnostic build (tools/stamp_c3.py): s_memtime of this block's THIRD tile at the loop top (0), after each chunk (1, 2, ...)
+// and after the epilogue (7)
+#ifdef MPN_DIAG
+#define C3_STAMP(k) do { if (g.job[0].dbg && threadIdx.x == 0 && titer == 2) g.job[0].dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define C3_STAMP(k) do { } while (0)
+#endif
+
+template <typename T>
+__device__ __forceinline__ void affine_act(Vec16<T>& v, const float (&sc)[8], const float (&sh)[8], float lo, float hi) {
+    float f[8];
+    v.unpack(f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);
+    v.pack(f);
+}
+
+__device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) {
+    typedef __bf16 b4_t __attribute__((ext_vector_type(4)));
+    const b4_t h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ void store4(half_t* p, const f32x4_t& v) {
+    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+    const h4_t h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
+
+struct Group {
+    Job job[kMaxJobs];
+    int begin[kMaxJobs + 1];   // first tile of each job; begin[njobs] = number of tiles
+    int njobs;
+};
+
+// where a tile lives (wave-uniform)
+struct Tile {
+    int job, ntile, img, oy0, ox0, ty, tx;
+};
+__device__ __forceinline__ Tile tile_of(const Group& g, int w) {
+    Tile t;
+    t.job = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxJobs; ++k)
+        if (k < g.njobs && w >= g.begin[k]) t.job = k;
+    const Job& p = g.job[t.job];
+    int b = w - g.begin[t.job];
+    const int n_tiles = p.Cout >> 7, tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
+    t.ntile = b % n_tiles; b /= n_tiles;
+    t.tx = b % tiles_x; b /= tiles_x;
+    t.ty = b % tiles_y;
+    t.img = b / tiles_y;
+    t.oy0 = t.ty * 16; t.ox0 = t.tx * 16;
+    return t;
+}
+
+// PERSISTENT: block b walks tiles b, b + gridDim.x, ... of the group. Across tiles nothing drains: the weight stream and
+// the halo double buffer run on (running stage / chunk counters pick the buffers), the next tile's first halo image is
+// staged under the current tile's last chunk, and the epilogue is wave-local (no block barrier): each wave converts its
+// 64 pixels x 64 channels, stores them straight from the registers (8 bytes per lane: the four 16-channel pieces of a
+// pixel's 128 bytes come from four consecutive stores of one wave and merge in the L2) and - when statistics are asked for -
+// takes them from a wave-private LDS image of 32 pixels at a time in the halo buffer that has just been released.
+template <typename T, bool AFFINE>
+__global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
+    using H = H16<T>;
+    using X8 = typename H::x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* As = smem;                      // [2][324 halo pixels][160]
+    unsigned char* Bs = smem + 2 * kABytes;        // [2][ky 3][128 co][64]
+    float* red = reinterpret_cast<float*>(smem + kSmem);   // [4 wm][2][128] statistics of the tile that has just finished
+    float* tab = reinterpret_cast<float*>(smem + kSmem + kRedBytes);   // [2][kMaxCin] scale, shift of the job in `tab_job`
+
+    const int total = g.begin[g.njobs];
+    int w = blockIdx.x;
+    if (w >= total) return;
+#ifdef MPN_DIAG
+    if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;       // 4 waves along the tile's rows (4 rows each) x 2 along the channels (64 each)
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int Cin = g.job[0].Cin, Cout = g.job[0].Cout;    // (shared by the jobs of a group)
+    const int nchunk = Cin >> 6;
+    const long long wtile = 9ll * Cin * 128 * 2;
+
+    // per-lane fragment bases; everything added later is a compile-time or wave-uniform offset
+    const unsigned char* abase = As + ((4 * wm) * kHW + l15) * kRS + lq * 16;
+    const unsigned char* bbase = Bs + (wn * 64 + l15) * 64 + ((lq ^ swz(l15)) << 4);
+
+    // ---- weights: LDS-DMA, one stage = 3 pieces of 8 KB (one per ky) = one 16-byte vector per thread and piece
+    auto b_issue = [&](const unsigned char* wsrc, int stage, int buf) {
+        const unsigned char* src = wsrc + (size_t)stage * kStageBytes + (size_t)tid * 16;
+        unsigned char* dst = Bs + buf * kStageBytes + wave * 1024;            // (+ lane * 16 by the hardware)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + j * 8192),
+                                             (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
+    };
+
+    // ---- halo staging: thread -> 16-byte slot tid % 8 of halo pixels tid / 8 + 64 i. Loads are unpredicated from clamped
+    // coordinates (a predicated load is waited for on the spot); pixels outside the image are zeroed at commit time.
+    const int slot = tid & 7, prow = tid >> 3;
+    const float act_lo = (AFFINE && g.job[0].in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;     // (in_act is shared by the jobs)
+    const float act_hi = (AFFINE && g.job[0].in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    int tab_job = -1;
+    // the producer's scale / shift of a job, kept in LDS (16 registers per thread otherwise, live across two stages). Rewritten
+    // only where no commit that reads the old table can follow before the next barrier.
+    auto tab_load = [&](int job) {
+        if constexpr (AFFINE) {
+            if (job != tab_job) {
+                for (int i = tid; i < Cin; i += kThreads) { tab[i] = g.job[job].in_scale[i]; tab[kMaxCin + i] = g.job[job].in_shift[i]; }
+                tab_job = job;
+            }
+        }
+    };
+    // The element offsets are recomputed per load (a few dozen scalar-ish VALU instructions per chunk) rather than kept: six more
+    // long-lived registers per thread spill.
+    unsigned okmask = 0;        // of the tile whose halo was fetched last: pixel i of this thread lies inside the image
+    Vec16<T> av[kAVec];
+    auto a_load = [&](const Tile& t, int chunk) {
+        const Job& p = g.job[t.job];
+        const T* xb = reinterpret_cast<const T*>(p.x) + slot * 8 + chunk * 64;
+        okmask = 0;
+        int pr = prow;
+        asm volatile("" : "+v"(pr));   // opaque: keeps the offset arithmetic here instead of hoisted (and spilled) across the tile loop
+#pragma unroll
+        for (int i = 0; i < kAVec; ++i) {
+            const int pix = pr + i * 64;
+            const int pc = pix < kNPix ? pix : kNPix - 1;
+            const int hy = pc / kHW, hx = pc - hy * kHW;
+            const int iy = t.oy0 + hy - 1, ix = t.ox0 + hx - 1;
+            const bool ok = pix < kNPix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            okmask |= (ok ? 1u : 0u) << i;
+            const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
+            av[i].load(xb + ((t.img * p.H + iyc) * p.W + ixc) * p.xs);      // (launch() checks that the offsets fit 31 bits)
+        }
+    };
+    auto a_commit = [&](int buf, int chunk) {
+        unsigned char* dst = As + buf * kABytes + prow * kRS + slot * 16;
+        float sc[8], sh[8];
+        if constexpr (AFFINE) {
+            const float* ts = tab + chunk * 64 + slot * 8;
+            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(ts), s1 = *reinterpret_cast<const f32x4_t*>(ts + 4);
+            const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin), h1 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sc[4 + j] = s1[j]; sh[j] = h0[j]; sh[4 + j] = h1[j]; }
+        }
+#pragma unroll
+        for (int i = 0; i < kAVec; ++i) {
+            if (prow + i * 64 < kNPix) {
+                if constexpr (AFFINE) affine_act<T>(av[i], sc, sh, act_lo, act_hi);
+                if (!((okmask >> i) & 1u)) av[i].zero();
+                *reinterpret_cast<uint4*>(dst + i * 64 * kRS) = av[i].raw;
+            }
+        }
+    };
+
+    // statistics rows of the tile that finished last, written after the next block barrier (red is complete by then)
+    float* st_dst = nullptr;
+    const int st_half = tid >> 8, st_which = (tid >> 7) & 1, st_c = tid & 127;
+    auto stats_flush = [&]() {
+        if (st_dst != nullptr)
+            *st_dst = red[((2 * st_half) * 2 + st_which) * 128 + st_c] + red[((2 * st_half + 1) * 2 + st_which) * 128 + st_c];
+        st_dst = nullptr;
+    };
+
+    Tile cur = tile_of(g, w);
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
+    int cc = 0, ss = 0;        // running chunk / stage counters: halo buffer cc & 1, weight buffer ss & 1
+    b_issue(wsrc, 0, 0);
+    a_load(cur, 0);
+    tab_load(cur.job);
+    __syncthreads();           // table visible
+    a_commit(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#ifdef MPN_DIAG
+    int titer = 0;
+#endif
+    for (;;) {
+        C3_STAMP(0);
+        const int wnext = w + (int)gridDim.x;
+        const bool has_next = wnext < total;
+        const Tile nxt = tile_of(g, has_next ? wnext : w);
+        const unsigned char* wsrc_next = reinterpret_cast<const unsigned char*>(g.job[nxt.job].wp) + nxt.ntile * wtile;
+
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int chunk = 0; chunk < nchunk; ++chunk, ++cc) {
+            const unsigned char* ab = abase + (cc & 1) * kABytes;
+            const bool last_chunk = chunk + 1 == nchunk;
+            const bool stage_more = !last_chunk || has_next;       // a halo image to prepare under this chunk
+#pragma unroll
+            for (int sl = 0; sl < 6; ++sl, ++ss) {
+                // stage sl = (kx, k-step): taps (ky, kx) for ky = 0..2, input channels chunk * 64 + ks * 32 .. + 31
+                const int a_off = (sl >> 1) * kRS + (sl & 1) * 64;
+                const unsigned char* bb = bbase + (ss & 1) * kStageBytes;
+                // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
+                if (sl < 5 || !last_chunk) b_issue(wsrc, chunk * 6 + sl + 1, (ss + 1) & 1);
+                else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
+                if (sl == 0 && stage_more) {
+                    // (last chunk: this tile's commits are all behind a barrier - the table may change for the next tile's job)
+                    if (last_chunk) { a_load(nxt, 0); tab_load(nxt.job); } else a_load(cur, chunk + 1);
+                }
+                X8 a[6], b0[4], b1[4];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) a[r] = *reinterpret_cast<const X8*>(ab + a_off + r * (kHW * kRS));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b0[nt] = *reinterpret_cast<const X8*>(bb + nt * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b1[nt] = *reinterpret_cast<const X8*>(bb + 8192 + nt * 1024);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = H::mfma(b0[nt], a[mt], acc[mt][nt]);       // D^T = W^T x A^T
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) b0[nt] = *reinterpret_cast<const X8*>(bb + 16384 + nt * 1024);   // (ky = 2 into the ky = 0 registers)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = H::mfma(b1[nt], a[mt + 1], acc[mt][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+                // the halo image prepared under this chunk: its loads have had two stages to land, and the buffer was last read
+                // in the previous chunk (the wave-private epilogue images in it: before the barrier of this chunk's first stage)
+                if (sl == 2 && stage_more) a_commit((cc + 1) & 1, last_chunk ? 0 : chunk + 1);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = H::mfma(b0[nt], a[mt + 2], acc[mt][nt]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next weight stage have landed
+                __syncthreads();
+                if (sl == 0 && chunk == 0) stats_flush();          // (every wave's `red` rows of the previous tile are visible)
+            }
+            C3_STAMP(1 + (chunk < 5 ? chunk : 5));
+        }
+
+        // ================= epilogue of tile `cur`, wave-local. Halo buffer (cc - 1) & 1 is free: every wave is past the last
+        // stage's barrier, and the next halo image to be committed into it comes two barriers from now.
+        {
+            const Job& p = g.job[cur.job];
+            T* __restrict__ y = reinterpret_cast<T*>(p.y);
+            const int n0 = cur.ntile * 128;
+            constexpr int RSW = 64 * 2 + 8;                                   // wave-private image: 32 pixels x (128 + 8) bytes
+            unsigned char* Ow = As + ((cc - 1) & 1) * kABytes + wave * (32 * RSW);
+            const bool stats = p.stats_part != nullptr;
+            f32x4_t sa[4], ga[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) { sa[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ga[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+            X8 ones;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ones[j] = 1.0f;
+            // copy-out lanes: lane j moves 16-byte piece j % 8 of image rows j / 8 + 8 k (8 lanes = the wave's 128 bytes of a pixel)
+            const int cpiece = lane & 7, crow = lane >> 3;
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+                for (int ml = 0; ml < 2; ++ml) {
+                    const int mt = hp * 2 + ml;
+                    const bool ok = (cur.oy0 + 4 * wm + mt) < p.H && (cur.ox0 + l15) < p.W;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        f32x4_t v = acc[mt][nt];
+                        if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};           // pixels outside the image must not count in the statistics
+                        store4(reinterpret_cast<T*>(Ow + (ml * 16 + l15) * RSW + (nt * 16 + lq * 4) * 2), v);
+                    }
+                }
+                if (stats) {
+                    // the 32 pixels x 64 channels just written, read back transposed (ds_read_b64_tr_b16): lane 4q+pp of a 16-lane
+                    // group supplies the address of block row q, channels 4pp..4pp+3; the k order of a sum is free
+                    const unsigned char* tb = Ow + ((lq >> 1) * 2 + 4 * ((lq & 1) * 4 + (l15 >> 2))) * RSW + (4 * (l15 & 3)) * 2;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const typename H::x4 lo = H::tr_read(tb + nt * 32);
+                        const typename H::x4 hi = H::tr_read(tb + RSW + nt * 32);
+                        const X8 f = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        sa[nt] = H::mfma(ones, f, sa[nt]);
+                        ga[nt] = H::mfma(f, f, ga[nt]);
+                    }
+                }
+                // whole 128-byte pieces of pixel rows to HBM (the other 64-channel wave writes the other half of the 256 bytes)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int row = crow + 8 * k;                              // image row = (ml, l15)
+                    const int oy = cur.oy0 + 4 * wm + hp * 2 + (row >> 4), ox = cur.ox0 + (row & 15);
+                    if (oy < p.H && ox < p.W) {
+                        const uint2 a = *reinterpret_cast<const uint2*>(Ow + row * RSW + cpiece * 16);
+                        const uint2 b = *reinterpret_cast<const uint2*>(Ow + row * RSW + cpiece * 16 + 8);
+                        *reinterpret_cast<uint4*>(y + (((long long)cur.img * p.H + oy) * p.W + ox) * p.ys + n0 + wn * 64 + cpiece * 8) =
+                            make_uint4(a.x, a.y, b.x, b.y);
+                    }
+                }
+            }
+            if (stats) {
+                const int r = l15 & 3;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float q = r == 0 ? ga[nt][0] : (r == 1 ? ga[nt][1] : (r == 2 ? ga[nt][2] : ga[nt][3]));
+                    if (lq == (l15 >> 2)) {
+                        const int cl = wn * 64 + nt * 16 + l15;
+                        red[(wm * 2 + 0) * 128 + cl] = sa[nt][0];
+                        red[(wm * 2 + 1) * 128 + cl] = q;
+                    }
+                }
+                // two rows of the 8 x 16-pixel partial slab: the tile's upper half (waves wm 0, 1) and lower half (wm 2, 3)
+                const int tiles_y8 = (p.H + 7) >> 3, tiles_x = (p.W + 15) >> 4, ty8 = cur.ty * 2 + st_half;
+                if (ty8 < tiles_y8) {
+                    const long long prow8 = ((long long)cur.img * tiles_y8 + ty8) * tiles_x + cur.tx;
+                    st_dst = p.stats_part + (prow8 * 2 + st_which) * Cout + n0 + st_c;
+                }
+            }
+        }
+        C3_STAMP(7);
+#ifdef MPN_DIAG
+        ++titer;
+#endif
+        if (!has_next) break;
+        cur = nxt;
+        wsrc = wsrc_next;
+        w = wnext;
+    }
+    __syncthreads();
+    stats_flush();
+#ifdef MPN_DIAG
+    if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+template <typename T, bool AFFINE>
+int launch_t(const Group& g, int blocks, hipStream_t st) {
+    static unsigned long long attr_mask = 0;
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE>, kLds, &attr_mask));
+    conv3x3_kernel<T, AFFINE><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+}  // namespace
+
+namespace mpn_c3 {
+
+int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
+    MPN_REQUIRE(njobs >= 1 && njobs <= kMaxJobs, MPN_ERR_BAD_ARG, "conv3x3: %d jobs", njobs);
+    Group g = {};
+    int begin = 0;
+    const bool affine = jobs[0].in_scale != nullptr;
+    MPN_REQUIRE(jobs[0].Cin <= kMaxCin, MPN_ERR_BAD_SHAPE, "conv3x3: at most %d input channels", kMaxCin);
+    for (int j = 0; j < njobs; ++j) {
+        MPN_REQUIRE((jobs[j].in_scale != nullptr) == affine, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the affine / no affine variant");
+        MPN_REQUIRE((long long)jobs[j].N * jobs[j].H * jobs[j].W * jobs[j].xs < (1ll << 31), MPN_ERR_BAD_SHAPE,
+                    "conv3x3: the input tensor must span fewer than 2^31 elements");
+        g.job[j] = jobs[j];
+        g.begin[j] = begin;
+        begin += blocks_of(jobs[j]);
+    }
+    for (int j = njobs; j <= kMaxJobs; ++j) g.begin[j] = begin;
+    g.njobs = njobs;
+    // one persistent block per CU (LDS allows one); fewer when the group has fewer tiles
+    int dev = 0, cus = 0;
+    MPN_HIP(hipGetDevice(&dev));
+    MPN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (begin > cus) begin = cus;   // `begin` is the grid size from here on
+    if (dtype == MPN_BF16) return affine ? launch_t<bf16_t, true>(g, begin, st) : launch_t<bf16_t, false>(g, begin, st);
+    if (dtype == MPN_F16) return affine ? launch_t<half_t, true>(g, begin, st) : launch_t<half_t, false>(g, begin, st);
+    MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");
+}
+
+}  // namespace mpn_c3

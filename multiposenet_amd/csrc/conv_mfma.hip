@@ -19,6 +19,7 @@
 // upsample-add (fpn.py:51) and per-tile batch-norm partial sums (sum, sum of squares).
 #include "common.h"
 #include "pointwise.h"
+#include "conv3x3.h"
 #include <type_traits>
 #include <string.h>
 
@@ -546,6 +547,20 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
     constexpr int EPK = 64 / ES;   // elements per k-step row
     const int Kin = transpose ? Cout_o : Cin_o;     // GEMM K channels
     const int Nout = transpose ? Cin_o : Cout_o;    // GEMM N channels
+    if (row_bytes < 0) {    // the 256-pixel 3x3 kernel's image (conv3x3.h): [n-tile][chunk 64][kx][k-step][ky][co 128][64 bytes]
+        long long r = i;
+        const int e = (int)(r % 32); r /= 32;
+        const int n = (int)(r % 128); r /= 128;
+        const int ky = (int)(r % 3); r /= 3;
+        const int ks = (int)(r % 2); r /= 2;
+        const int kx = (int)(r % 3); r /= 3;
+        const int chunk = (int)(r % nchunk); r /= nchunk;
+        const int c = chunk * 64 + ks * 32 + e, co = (int)r * 128 + n, tap = ky * 3 + kx;
+        const float v = !transpose ? w[((long long)tap * Cin_o + c) * Cout_o + co] : w[((long long)(8 - tap) * Cin_o + co) * Cout_o + c];
+        const int q = e >> 3, within = e & 7;
+        out[i - e + ((q ^ mpn_c3::swz(n & 15)) * 8 + within)] = from_f32<T>(v);
+        return;
+    }
     if (row_bytes == 0) {   // plain [N][K]: W^T for the forward, the HWIO matrix itself for the data gradient
         const int n = (int)(i / Kin), k = (int)(i - (long long)n * Kin);
         out[i] = from_f32<T>(transpose ? w[(long long)n * Cout_o + k] : w[(long long)k * Cout_o + n]);
@@ -605,7 +620,7 @@ __global__ void pack_weights_batched_kernel(const PackDesc* __restrict__ descs, 
 }
 
 struct PackGeom {
-    int BN, n_tiles, nchunk, row_bytes;   // row_bytes == 0: plain [N][K] matrix for the GEMM kernel of pointwise.hip
+    int BN, n_tiles, nchunk, row_bytes;   // row_bytes == 0: plain [N][K] matrix for the GEMM kernel of pointwise.hip; -1: conv3x3.hip
     long long tile_bytes, total_bytes;
 };
 
@@ -614,6 +629,11 @@ PackGeom pack_geom(int Kin, int Nout, int taps, int es, int dtype) {
     if (dtype == MPN_BF16 && pw_gemm_eligible(Kin, Nout, taps, es)) {
         g.BN = 256; g.n_tiles = Nout / 256; g.nchunk = 1; g.row_bytes = 0;
         g.tile_bytes = 256ll * Kin * es; g.total_bytes = (long long)Nout * Kin * es;
+        return g;
+    }
+    if ((dtype == MPN_BF16 || dtype == MPN_F16) && mpn_c3::eligible(Kin, Nout, taps, es)) {
+        g.BN = 128; g.n_tiles = Nout / 128; g.nchunk = Kin / 64; g.row_bytes = -1;
+        g.tile_bytes = mpn_c3::tile_bytes(Kin); g.total_bytes = mpn_c3::packed_bytes(Kin, Nout);
         return g;
     }
     g.BN = (Nout % 128 == 0) ? 128 : 64;
@@ -743,6 +763,16 @@ static int conv_fill_params(ConvParams& p, const PackGeom& g, const void* x, con
     return MPN_OK;
 }
 
+static void c3_fill_job(mpn_c3::Job& j, const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
+                        int x_stride, int y_stride, const float* in_scale, const float* in_shift, int in_act, float* stats_part) {
+    j.x = x; j.wp = w_packed; j.y = y; j.in_scale = in_scale; j.in_shift = in_shift; j.stats_part = stats_part; j.in_act = in_act;
+    j.N = N; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout;
+    j.xs = x_stride > 0 ? x_stride : Cin; j.ys = y_stride > 0 ? y_stride : Cout;
+#ifdef MPN_DIAG
+    j.dbg = (unsigned long long*)g_conv_dbg;
+#endif
+}
+
 extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N, int H, int W, int Cin, int Cout,
                             int x_stride, int y_stride, int ksize, int dtype, const float* in_scale, const float* in_shift,
                             int in_act, float* stats_part, const void* up_res, mpn_stream_t stream) {
@@ -763,6 +793,11 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
     MPN_REQUIRE(up_res == nullptr || (ksize == 1 && H % 2 == 0 && W % 2 == 0), MPN_ERR_BAD_ARG,
                 "conv: upsample-add epilogue needs ksize 1 and even H, W");
     const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es, dtype);
+    if (g.row_bytes < 0) {    // 3x3, 16-bit storage, Cin % 64 == 0, Cout % 128 == 0: 256-pixel tiles, one 8-wave block per CU
+        mpn_c3::Job job;
+        c3_fill_job(job, x, w_packed, y, N, H, W, Cin, Cout, x_stride, y_stride, in_scale, in_shift, in_act, stats_part);
+        return mpn_c3::launch(&job, 1, dtype, (hipStream_t)stream);
+    }
     if (g.row_bytes == 0) {   // deep 1x1 layer: the GEMM kernel (weights packed as [Cout][Cin])
         MPN_REQUIRE(up_res == nullptr, MPN_ERR_BAD_ARG, "conv: the upsample-add epilogue needs Cout < 256 or Cin < 256");
         return pw_gemm_launch(x, w_packed, y, (long long)N * H * W, Cin, Cout, x_stride > 0 ? x_stride : Cin,
@@ -807,6 +842,23 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
                 "conv grouped: bad arguments");
     const int es = dtype == MPN_F32 ? 4 : 2;
     const PackGeom g = pack_geom(Cin, Cout, ksize * ksize, es, dtype);
+    bool same_variant = true;   // (affine on load or not: one kernel instance per grid)
+    for (int j = 1; j < njobs; ++j) same_variant = same_variant && ((in_scale[j] == nullptr) == (in_scale[0] == nullptr));
+    if (g.row_bytes < 0 && njobs <= mpn_c3::kMaxJobs && same_variant) {
+        MPN_REQUIRE(N > 0, MPN_ERR_BAD_SHAPE, "conv grouped: bad shape");
+        mpn_c3::Job jobs[mpn_c3::kMaxJobs];
+        for (int j = 0; j < njobs; ++j) {
+            MPN_REQUIRE(x[j] && w_packed[j] && y[j] && H[j] > 0 && W[j] > 0, MPN_ERR_BAD_ARG, "conv grouped: null pointer / bad size");
+            MPN_REQUIRE(mpn_aligned16(x[j]) && mpn_aligned16(w_packed[j]) && mpn_aligned16(y[j]), MPN_ERR_BAD_ALIGN,
+                        "conv grouped: pointers must be 16-byte aligned");
+            MPN_REQUIRE((in_scale[j] == nullptr) == (in_shift[j] == nullptr), MPN_ERR_BAD_ARG, "conv grouped: scale/shift mismatch");
+            const int ys = y_stride ? y_stride[j] : 0, xs = x_stride ? x_stride[j] : 0;
+            MPN_REQUIRE((ys == 0 || (ys >= Cout && ys % 8 == 0)) && (xs == 0 || (xs >= Cin && xs % 8 == 0)), MPN_ERR_BAD_SHAPE,
+                        "conv grouped: bad pixel strides %d, %d", xs, ys);
+            c3_fill_job(jobs[j], x[j], w_packed[j], y[j], N, H[j], W[j], Cin, Cout, xs, ys, in_scale[j], in_shift[j], in_act, stats_part[j]);
+        }
+        return mpn_c3::launch(jobs, njobs, dtype, (hipStream_t)stream);
+    }
     const bool fast = dtype == MPN_BF16 && ksize == 3 && njobs <= kMaxGroup && g.row_bytes == 128;
     if (!fast) {
         for (int j = 0; j < njobs; ++j)

@@ -10,7 +10,7 @@ sc = torch.rand(Cin, device='cuda') + 0.5; sh = torch.randn(Cin, device='cuda') 
 y = torch.empty(N, H, H, Cout, device='cuda', dtype=dt)
 nparts = ops.conv_num_parts(N, H, H, k)
 part = torch.empty(nparts * 2 * Cout, device='cuda')
-nblk = nparts * max(1, Cout // 128)
+nblk = nparts * max(1, Cout // 128)   # (upper bound: the 256-pixel 3x3 kernel launches half of it)
 dbg = torch.zeros(nblk * 8, dtype=torch.int64, device='cuda')
 lib = _lib.lib()
 lib.mpn_diag_set_conv_stamps.argtypes = [ctypes.c_void_p]
@@ -30,6 +30,5 @@ print("mean phase ticks: stageA %.0f  main %.0f  epilogue %.0f  stats %.0f  | to
 rt = (d[:, 6] - d[:, 5])
 ok = rt > 0
 clk = np.median((d[ok, 4] - d[ok, 0]) / rt[ok]) * 100e6
-mfma_cycles = 4 * max(1, Cout // 128 and 4 or 2) * (k * k * Cin // 32) * 16   # per wave and tile: (64 px x BN/2 ch) x K
 print("in-kernel clock %.2f GHz (s_memtime / s_memrealtime x 100 MHz, median over blocks); block time %.1f us" % (clk / 1e9, np.median(rt[ok]) / 100.0))
 print("start-time spread of blocks (first/last start):", d[:, 0].min() - t0, d[:, 0].max() - t0)
