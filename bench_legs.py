@@ -59,7 +59,7 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20, b=Non
             traffic = json.load(open(tj))["hbm_bytes_per_launch"]
             src = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/one_conv.py; not re-measured by this run)"
             break
-    return {"kernel": "conv_mfma_kernel<3x3,128->128> @ [%d,%d,%d,128], affine + ReLU on load, batch-norm statistics epilogue" % (batch, h, w),
+    return {"kernel": "conv3x3_kernel<bf16, affine> (3x3 128->128, persistent 8-wave blocks, 16x16-pixel tiles) @ [%d,%d,%d,128], affine + ReLU on load, batch-norm statistics epilogue" % (batch, h, w),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": src, "launch_us": round(sec * 1e6, 2),
             "launch_us_without_statistics": round(sec_plain * 1e6, 2),

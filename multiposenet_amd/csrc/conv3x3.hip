@@ -113,6 +113,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 #ifdef MPN_DIAG
     if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 #endif
+#ifdef MPN_DIAG
+    if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -323,17 +326,21 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         ga[nt] = H::mfma(f, f, ga[nt]);
                     }
                 }
-                // whole 128-byte pieces of pixel rows to HBM (the other 64-channel wave writes the other half of the 256 bytes)
+                // whole 128-byte pieces of pixel rows to HBM (the other 64-channel wave writes the other half of the 256 bytes):
+                // all eight LDS reads first (unconditional), then the predicated stores - one LDS round trip per 32 pixels
+                uint2 ca[4], cb[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ca[k] = *reinterpret_cast<const uint2*>(Ow + (crow + 8 * k) * RSW + cpiece * 16);
+                    cb[k] = *reinterpret_cast<const uint2*>(Ow + (crow + 8 * k) * RSW + cpiece * 16 + 8);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int row = crow + 8 * k;                              // image row = (ml, l15)
                     const int oy = cur.oy0 + 4 * wm + hp * 2 + (row >> 4), ox = cur.ox0 + (row & 15);
-                    if (oy < p.H && ox < p.W) {
-                        const uint2 a = *reinterpret_cast<const uint2*>(Ow + row * RSW + cpiece * 16);
-                        const uint2 b = *reinterpret_cast<const uint2*>(Ow + row * RSW + cpiece * 16 + 8);
+                    if (oy < p.H && ox < p.W)
                         *reinterpret_cast<uint4*>(y + (((long long)cur.img * p.H + oy) * p.W + ox) * p.ys + n0 + wn * 64 + cpiece * 8) =
-                            make_uint4(a.x, a.y, b.x, b.y);
-                    }
+                            make_uint4(ca[k].x, ca[k].y, cb[k].x, cb[k].y);
                 }
             }
             if (stats) {
