@@ -35,6 +35,7 @@ constexpr int kTabBytes = 2 * kMaxCin * (int)sizeof(float);
 constexpr int kLds = kSmem + kRedBytes + kTabBytes;
 static_assert(8 * 32 * (64 * 2 + 8) <= kABytes, "the wave-private epilogue images fit in one halo buffer");
 static_assert(kLds <= 160 * 1024, "LDS budget");
+static_assert(kAVec == 6, "the counted wait of a chunk's first stage assumes six halo loads per thread");
 
 // diagnostic build (tools/stamp_c3.py): s_memtime of this block's THIRD tile at the loop top (0), after each chunk (1, 2, ...)
 // and after the epilogue (7)
@@ -62,6 +63,16 @@ __device__ __forceinline__ void store4(half_t* p, const f32x4_t& v) {
     typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
     const h4_t h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
+}
+
+// A 16-byte LDS store the compiler does not see as one: in front of a C++ LDS store hipcc waits for every LDS-DMA in
+// flight (vmcnt(0): it cannot tell that the weight ring and the halo image do not overlap) - here that exposed the whole
+// latency of the weight stage requested at the top of the same stage, once per chunk.
+__device__ __forceinline__ void lds_store16_raw(unsigned char* p, const uint4& v) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    const u32x4_t d = {v.x, v.y, v.z, v.w};
+    const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)p;
+    asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(d) : "memory");
 }
 
 struct Group {
@@ -192,9 +203,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             if (prow + i * 64 < kNPix) {
                 if constexpr (AFFINE) affine_act<T>(av[i], sc, sh, act_lo, act_hi);
                 if (!((okmask >> i) & 1u)) av[i].zero();
-                *reinterpret_cast<uint4*>(dst + i * 64 * kRS) = av[i].raw;
+                lds_store16_raw(dst + i * 64 * kRS, av[i].raw);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler does not track the raw stores: complete before the barrier)
     };
 
     // statistics rows of the tile that finished last, written after the next block barrier (red is complete by then)
@@ -245,9 +257,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
                 if (sl < 5 || !last_chunk) b_issue(wsrc, chunk * 6 + sl + 1, (ss + 1) & 1);
                 else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
-                if (sl == 0 && stage_more) {
+                if (sl == 0) {
+                    // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
+                    // the six registers become PHIs, hipcc copies them right behind the loads - and waits for the loads there
+                    if (last_chunk) a_load(nxt, 0); else a_load(cur, chunk + 1);
                     // (last chunk: this tile's commits are all behind a barrier - the table may change for the next tile's job)
-                    if (last_chunk) { a_load(nxt, 0); tab_load(nxt.job); } else a_load(cur, chunk + 1);
+                    if (last_chunk && has_next) tab_load(nxt.job);
                 }
                 X8 a[6], b0[4], b1[4];
 #pragma unroll
@@ -276,8 +291,16 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = H::mfma(b0[nt], a[mt + 2], acc[mt][nt]);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next weight stage have landed
-                __syncthreads();
+                // this wave's pieces of the next weight stage have landed. In a chunk's first stage the six halo loads issued BEHIND
+                // them stay in flight (the counter retires in order; they are committed two stages later) - behind a raw barrier:
+                // __syncthreads() would wait for them too
+                if (sl == 0) {
+                    asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                }
                 if (sl == 0 && chunk == 0) stats_flush();          // (every wave's `red` rows of the previous tile are visible)
             }
             C3_STAMP(1 + (chunk < 5 ? chunk : 5));
