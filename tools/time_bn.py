@@ -1,8 +1,10 @@
 """Time the batch-norm backward passes at the bench shapes (bs 32 @ 512x512): python tools/time_bn.py"""
 import sys
 import torch
-sys.path.insert(0, '.')
-sys.path.insert(0, 'tools')
+import os
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, _root)
+sys.path.insert(0, os.path.join(_root, 'tools'))
 from multiposenet_amd import ops, _lib
 from multiposenet_amd.ops import call, ptr, stream_ptr
 from time_misc_util import timeit
@@ -32,4 +34,9 @@ for (H, C) in shapes:
                        ptr(bn.invstd), ptr(bn.k1), ptr(bn.k2), 1, None, stream_ptr())
     ur, ua = timeit(red), timeit(app)
     byt = M * C * 2
-    print(f"{H:4d}x{H:<4d} C={C:5d}  reduce {ur:7.1f} us {2 * byt / ur / 1e3:7.0f} GB/s   apply {ua:7.1f} us {3 * byt / ua / 1e3:7.0f} GB/s")
+    # same-box ceilings of the same traffic shapes: torch.add(a, b, out=a) = 2 reads + 1 write, torch copy = 1 read + 1 write
+    y = torch.empty_like(x)
+    ut = timeit(lambda: torch.add(dA, x, out=dA))
+    uc = timeit(lambda: y.copy_(x))
+    print(f"{H:4d}x{H:<4d} C={C:5d}  reduce {ur:7.1f} us {2 * byt / ur / 1e3:7.0f} GB/s   apply {ua:7.1f} us {3 * byt / ua / 1e3:7.0f} GB/s"
+          f"   | torch add (2r+1w) {ut:7.1f} us {3 * byt / ut / 1e3:7.0f} GB/s   copy {uc:7.1f} us {2 * byt / uc / 1e3:7.0f} GB/s")
