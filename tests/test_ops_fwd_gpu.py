@@ -37,6 +37,10 @@ CONV_CASES = [
     (1, 9, 15, 320, 512, 1, 0, True, False),     # K = 5 k-steps, ragged M, LDS-DMA path with statistics
     (8, 96, 96, 256, 512, 1, 2, True, False),    # 256-pixel tiles (73 728 pixels x 2 n-tiles = 576 blocks)
     (9, 85, 83, 256, 256, 1, 0, True, False),    # 256-pixel tiles, ragged M (63 495 pixels), LDS-DMA path
+    # the persistent 3x3 kernel of conv3x3.hip (16-bit storage, Cin % 64 == 0, Cout % 128 == 0; f32 stays on the tiled kernel)
+    (6, 112, 112, 128, 128, 3, 1, True, False),  # 294 tiles on 256 persistent blocks: some blocks walk two tiles
+    (3, 100, 52, 64, 256, 3, 2, True, False),    # one 64-channel chunk per tile, two n-tiles, ragged tiles (100 = 6 x 16 + 4)
+    (2, 40, 24, 256, 128, 3, 0, False, False),   # four chunks, no affine / statistics (the data-gradient configuration)
 ]
 
 
