@@ -119,7 +119,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     float* tab = reinterpret_cast<float*>(smem + kSmem + kRedBytes);   // [2][kMaxCin] scale, shift of the job in `tab_job`
 
     const int total = g.begin[g.njobs];
+    // XCD-aware walk: the dispatcher deals consecutive block ids round-robin over the 8 XCDs (one L2 each); the blocks of one XCD
+    // take CONSECUTIVE tiles of every round, so that the halo rows and columns neighbouring tiles share are read through one L2
+    // instead of from the memory side (measured: 174 MB fetched per launch for 134 MB of input with the plain walk)
     int w = blockIdx.x;
+    if ((gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (w >= total) return;
 #ifdef MPN_DIAG
     if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();

@@ -1,18 +1,16 @@
 """The dominant kernel's launches of bench.py's roofline leg in a rocprofv3 kernel trace (CSV):
 python tools/dominant_from_trace.py run_kernel_trace.csv [n_timed=50]
-The leg is the longest run of consecutive dispatches of the ungrouped bf16 3x3 128->128 kernel on 4096 blocks; its last
-n_timed launches are the ones bench.py brackets with HIP events."""
+The leg is the longest run of consecutive dispatches of the bf16 3x3 kernel with the producer's affine (conv3x3_kernel<bf16, true>,
+one persistent 512-thread block per CU); its last n_timed launches are the ones bench.py brackets with HIP events."""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 n_timed = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-NAME = 'conv_mfma_kernelIDF16bLi9ELi128ELi128ELb0ELi4ELb0E'
-
-
 def is_dom(r):
-    return NAME in r['Kernel_Name'] and int(r['Grid_Size_X']) == 4096 * 256
+    # (rocprofv3 demangles the affine instance badly: "conv3x3_kernel<bool _Accum, bool, E>"; the other one stays mangled)
+    return 'conv3x3_kernel<' in r['Kernel_Name'] and int(r['Grid_Size_X']) == 256 * 512
 
 
 best, cur = [], []
@@ -28,6 +26,6 @@ if len(cur) > len(best):
 timed = best[-n_timed:]
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in timed]
 span = (int(timed[-1]['End_Timestamp']) - int(timed[0]['Start_Timestamp'])) / 1e3 / len(timed)
-print(f"dominant kernel (conv_mfma_kernel<bf16,3x3,BN128,RB128>), the {len(timed)} timed launches of bench.py's roofline leg "
+print(f"dominant kernel (conv3x3_kernel<bf16, affine>), the {len(timed)} timed launches of bench.py's roofline leg "
       f"(run of {len(best)} consecutive dispatches on [32,128,128,128]): mean {sum(d) / len(d):.1f} us (min {min(d):.1f}, "
       f"max {max(d):.1f}); start-to-end span per launch {span:.1f} us")
