@@ -124,6 +124,18 @@ int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, int ksize, 
 int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int Cin,
                         int Cout, int x_stride, int dy_stride, int ksize, int dtype, const float* in_scale,
                         const float* in_shift, int in_act, mpn_stream_t stream);
+/* The weight gradients of njobs independent layers of one (Cin, Cout, ksize, dtype) in ONE grid - the pyramid levels of a
+ * subnet stage (keypoint_subnet.py:66-79: one phi_subnet per level; fpn.py:38-52: one 3x3 per level). The 256 blocks are
+ * divided among the jobs by their pixel counts, so a stage leaves 128 partial slabs in all instead of 128 per level, and the
+ * small levels stop being latency-bound launches of their own. mpn_conv_wgrad_grouped_num_parts fills nparts[j] (the slab
+ * count of job j in THAT grid; f32 / more than 5 jobs: the counts of the separate launches, which the grouped call then
+ * performs); part[j]: [nparts[j]][ksize*ksize][Cin][Cout] f32. Arrays of njobs entries; x_stride / dy_stride may be NULL. */
+int mpn_conv_wgrad_grouped_num_parts(int njobs, int N, const int* H, const int* W, int Cin, int Cout, int ksize, int dtype,
+                                     int* nparts);
+int mpn_conv_bwd_weight_grouped(int njobs, const void* const* x, const void* const* dy, float* const* part, int N,
+                                const int* H, const int* W, int Cin, int Cout, const int* x_stride, const int* dy_stride,
+                                int ksize, int dtype, const float* const* in_scale, const float* const* in_shift,
+                                int in_act, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K4  batch normalisation (tf.layers.batch_normalization(fused=True, momentum=.95, eps=1e-3):

@@ -39,6 +39,8 @@ SIGNATURES = {
     "mpn_conv_fwd_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     "mpn_conv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mpn_conv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "mpn_conv_wgrad_grouped_num_parts": (_I, [_I, _I, _P, _P, _I, _I, _I, _I, _P]),
+    "mpn_conv_bwd_weight_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P]),
     "mpn_bn_stats_num_parts": (_I, [_L]),
     "mpn_bn_stats": (_I, [_P, _L, _I, _I, _P, _P]),
     "mpn_bn_finalize": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P]),

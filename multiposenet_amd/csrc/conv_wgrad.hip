@@ -40,6 +40,7 @@ struct WgradParams {
     int ntiles;   // pixel tiles
     int nsplit;
     int n_cg, n_cb;
+    int xcd_remap;    // XCD-aware block -> work map inside the job (needs the job's first block on XCD 0)
 #ifdef MPN_DIAG
     unsigned long long* dbg;   // diagnostic build only (mpn_diag_set_wgrad_stamps): per-wave phase times, else NULL
 #endif
@@ -310,8 +311,10 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
 //   3x3:              (128, 256, 2x4) = 64 ci x 9 taps x 128 co, 144 accumulator registers per lane
 //   3x3, Cout <= 64:  (256, 128, 4x2) = 128 ci x 9 taps x 64 co
 //   1x1:              (256, 256, 4x2) = 128 ci x 128 co
+// (a device function: the plain kernel and the grouped kernel - several independent layers of one channel geometry, e.g. the
+//  four pyramid levels of a subnet stage, in ONE grid of one block per CU - share it; blk / nblk = this job's block index and count)
 template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
-__global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradParams p) {
+__device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const int blk, const int nblk) {
     using H = H16<T>;
     using X8 = typename H::x8;
     using X4 = typename H::x4;
@@ -342,9 +345,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
 
-    int b;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    int b = blk;
+    if (p.xcd_remap) {   // (the job's first block sits on XCD 0: see the launchers)
+        const int nwg = nblk, q = nwg >> 3, r = nwg & 7, xcd = blk & 7, k = blk >> 3;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
     const int cg = b % p.n_cg; b /= p.n_cg;
@@ -626,6 +629,29 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
                 }
 }
 
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradParams p) {
+    conv_wgrad_bf16_body<T, TAPS, RBA, RBD, WM, STAGGER>(p, blockIdx.x, gridDim.x);
+}
+
+// up to five independent layers of one (Cin, Cout, ksize) in one grid: as launches of their own the small pyramid levels are
+// latency-bound tails, and every launch splits its pixels over all 256 CUs, i.e. writes (and the slab reduction reads) 128
+// partial copies of the 590 KB gradient per LEVEL; in one grid the CUs are divided among the levels by their pixel counts
+constexpr int kMaxWgradGroup = 5;
+struct WgradGroup {
+    WgradParams p[kMaxWgradGroup];
+    int begin[kMaxWgradGroup + 1];   // first block of each job; begin[njobs] = grid size
+    int njobs;
+};
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+__global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_grouped_kernel(const WgradGroup g) {
+    int job = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxWgradGroup; ++j)
+        if (j < g.njobs && (int)blockIdx.x >= g.begin[j]) job = j;   // wave-uniform
+    conv_wgrad_bf16_body<T, TAPS, RBA, RBD, WM, STAGGER>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
+}
+
 struct WgradGeom {
     int n_cg, n_cb, ntiles, nsplit;
 };
@@ -729,7 +755,7 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
                 "conv wgrad: strided tensors must span fewer than 2^31 elements");
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
     p.M = (long long)N * H * W;
-    p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = g.n_cg; p.n_cb = g.n_cb;
+    p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = g.n_cg; p.n_cb = g.n_cb; p.xcd_remap = 1;
 #ifdef MPN_DIAG
     p.dbg = (unsigned long long*)g_wgrad_dbg;
 #endif
@@ -744,4 +770,126 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
     if (ksize == 1) return launch_wgrad_bf16<bf16_t, 1, 256, 256, 4, false>(p, st);
     if (Cout <= 64) return launch_wgrad_bf16<bf16_t, 9, 256, 128, 4, true>(p, st);
     return launch_wgrad_bf16<bf16_t, 9, 128, 256, 2, true>(p, st);
+}
+
+namespace {
+
+// Splits of the jobs of a group: the block budget (one 8-wave block per CU) divided by pixel tiles, in multiples of `quantum`
+// splits (so that every job starts on XCD 0 and its XCD-aware work map holds), at least one quantum, at least 4 tiles per split.
+void wgrad_group_splits(int njobs, int N, const int* H, const int* W, int Cin, int Cout, int ksize, int* nsplit, WgradGeom* geoms) {
+    long long total_tiles = 0;
+    for (int j = 0; j < njobs; ++j) {
+        geoms[j] = wgrad_geom(N, H[j], W[j], Cin, Cout, ksize, 2);
+        total_tiles += geoms[j].ntiles;
+    }
+    const int units = geoms[0].n_cg * geoms[0].n_cb;          // blocks per split (shared by the jobs: same channel geometry)
+    int quantum = 1;
+    while ((quantum * units) % 8 != 0) ++quantum;              // blocks per job in multiples of 8
+    int budget = 256 / units;                                  // splits in all
+    if (budget < quantum * njobs) budget = quantum * njobs;
+    int used = 0;
+    for (int j = 0; j < njobs; ++j) {
+        long long ns = (long long)budget * geoms[j].ntiles / total_tiles;
+        ns = ns / quantum * quantum;
+        const int cap = geoms[j].ntiles / 4 > 0 ? geoms[j].ntiles / 4 : 1;
+        if (ns > cap) ns = cap / quantum * quantum;
+        if (ns < quantum) ns = quantum;
+        if (ns > geoms[j].ntiles) ns = geoms[j].ntiles;        // (tiny maps: fewer splits than a quantum; the job then runs without the XCD map)
+        nsplit[j] = (int)ns;
+        used += (int)ns;
+    }
+    // what rounding left over goes to the largest job
+    int big = 0;
+    for (int j = 1; j < njobs; ++j) if (geoms[j].ntiles > geoms[big].ntiles) big = j;
+    if (used < budget) {
+        const int extra = (budget - used) / quantum * quantum;
+        const int cap = geoms[big].ntiles / 4;
+        if (nsplit[big] + extra <= cap) nsplit[big] += extra;
+    }
+}
+
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+int launch_wgrad_bf16_grouped(const WgradGroup& g, int blocks, hipStream_t st) {
+    constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
+    constexpr int smem = 2 * NPIXA * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * (RBA / 2) * (int)sizeof(float);
+    static unsigned long long attr_mask = 0;
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_bf16_grouped_kernel<T, TAPS, RBA, RBD, WM, STAGGER>, smem, &attr_mask));
+    conv_wgrad_bf16_grouped_kernel<T, TAPS, RBA, RBD, WM, STAGGER><<<dim3((unsigned)blocks), dim3(512), smem, st>>>(g);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+bool wgrad_groupable(int njobs, int dtype) { return njobs >= 2 && njobs <= kMaxWgradGroup && (dtype == MPN_BF16 || dtype == MPN_F16); }
+
+}  // namespace
+
+/* Partial-slab counts of mpn_conv_bwd_weight_grouped, one per job (jobs that cannot share a grid - f32, more than 5 - get the
+ * counts of their separate launches, which is what the grouped call then does). */
+extern "C" int mpn_conv_wgrad_grouped_num_parts(int njobs, int N, const int* H, const int* W, int Cin, int Cout, int ksize, int dtype,
+                                                int* nparts) {
+    MPN_REQUIRE(njobs > 0 && H && W && nparts, MPN_ERR_BAD_ARG, "conv wgrad grouped: bad arguments");
+    if (!wgrad_groupable(njobs, dtype)) {
+        for (int j = 0; j < njobs; ++j) nparts[j] = mpn_conv_wgrad_num_parts(N, H[j], W[j], Cin, Cout, ksize, dtype);
+        return MPN_OK;
+    }
+    WgradGeom geoms[kMaxWgradGroup];
+    wgrad_group_splits(njobs, N, H, W, Cin, Cout, ksize, nparts, geoms);
+    return MPN_OK;
+}
+
+/* The weight gradients of njobs independent layers of one (Cin, Cout, ksize, dtype) - e.g. the pyramid levels of a subnet stage
+ * (keypoint_subnet.py:66-79: one phi_subnet per level) - in one grid. part[j]: [nparts[j]][ksize*ksize][Cin][Cout] f32. */
+extern "C" int mpn_conv_bwd_weight_grouped(int njobs, const void* const* x, const void* const* dy, float* const* part, int N,
+                                           const int* H, const int* W, int Cin, int Cout, const int* x_stride, const int* dy_stride,
+                                           int ksize, int dtype, const float* const* in_scale, const float* const* in_shift,
+                                           int in_act, mpn_stream_t stream) {
+    MPN_REQUIRE(njobs > 0 && x && dy && part && H && W && in_scale && in_shift, MPN_ERR_BAD_ARG, "conv wgrad grouped: bad arguments");
+    if (!wgrad_groupable(njobs, dtype)) {
+        for (int j = 0; j < njobs; ++j)
+            if (int rc = mpn_conv_bwd_weight(x[j], dy[j], part[j], N, H[j], W[j], Cin, Cout, x_stride ? x_stride[j] : 0,
+                                             dy_stride ? dy_stride[j] : 0, ksize, dtype, in_scale[j], in_shift[j], in_act, stream))
+                return rc;
+        return MPN_OK;
+    }
+    MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv wgrad grouped: ksize must be 1 or 3");
+    MPN_REQUIRE(N > 0 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0, MPN_ERR_BAD_SHAPE, "conv wgrad grouped: bad shape");
+    WgradGeom geoms[kMaxWgradGroup];
+    int nsplit[kMaxWgradGroup];
+    wgrad_group_splits(njobs, N, H, W, Cin, Cout, ksize, nsplit, geoms);
+    WgradGroup grp = {};
+    int begin = 0;
+    for (int j = 0; j < njobs; ++j) {
+        MPN_REQUIRE(x[j] && dy[j] && part[j] && H[j] > 0 && W[j] > 0, MPN_ERR_BAD_ARG, "conv wgrad grouped: null pointer / bad size");
+        MPN_REQUIRE(mpn_aligned16(x[j]) && mpn_aligned16(dy[j]), MPN_ERR_BAD_ALIGN, "conv wgrad grouped: pointers must be 16-byte aligned");
+        MPN_REQUIRE((in_scale[j] == nullptr) == (in_shift[j] == nullptr), MPN_ERR_BAD_ARG, "conv wgrad grouped: scale/shift mismatch");
+        WgradParams& p = grp.p[j];
+        p.x = x[j]; p.dy = dy[j]; p.part = part[j];
+        p.in_scale = in_scale[j]; p.in_shift = in_shift[j]; p.in_act = in_act;
+        p.N = N; p.H = H[j]; p.W = W[j]; p.Cin = Cin; p.Cout = Cout;
+        p.xs = (x_stride && x_stride[j] > 0) ? x_stride[j] : Cin; p.dys = (dy_stride && dy_stride[j] > 0) ? dy_stride[j] : Cout;
+        MPN_REQUIRE(p.xs >= Cin && p.dys >= Cout && p.xs % 8 == 0 && p.dys % 8 == 0, MPN_ERR_BAD_SHAPE, "conv wgrad grouped: bad pixel strides");
+        MPN_REQUIRE((long long)N * H[j] * W[j] * p.xs < (1ll << 31) && (long long)N * H[j] * W[j] * p.dys < (1ll << 31), MPN_ERR_BAD_SHAPE,
+                    "conv wgrad grouped: tensors must span fewer than 2^31 elements");
+        p.tiles_x = (W[j] + 15) / 16; p.tiles_y = (H[j] + 7) / 8;
+        p.M = (long long)N * H[j] * W[j];
+        p.ntiles = geoms[j].ntiles; p.nsplit = nsplit[j]; p.n_cg = geoms[j].n_cg; p.n_cb = geoms[j].n_cb;
+        const int blocks = p.n_cg * p.n_cb * p.nsplit;
+        p.xcd_remap = (begin % 8 == 0 && blocks % 8 == 0) ? 1 : 0;
+#ifdef MPN_DIAG
+        p.dbg = nullptr;
+#endif
+        grp.begin[j] = begin;
+        begin += blocks;
+    }
+    for (int j = njobs; j <= kMaxWgradGroup; ++j) grp.begin[j] = begin;
+    grp.njobs = njobs;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPN_F16) {
+        if (ksize == 1) return launch_wgrad_bf16_grouped<half_t, 1, 256, 256, 4, false>(grp, begin, st);
+        if (Cout <= 64) return launch_wgrad_bf16_grouped<half_t, 9, 256, 128, 4, true>(grp, begin, st);
+        return launch_wgrad_bf16_grouped<half_t, 9, 128, 256, 2, true>(grp, begin, st);
+    }
+    if (ksize == 1) return launch_wgrad_bf16_grouped<bf16_t, 1, 256, 256, 4, false>(grp, begin, st);
+    if (Cout <= 64) return launch_wgrad_bf16_grouped<bf16_t, 9, 256, 128, 4, true>(grp, begin, st);
+    return launch_wgrad_bf16_grouped<bf16_t, 9, 128, 256, 2, true>(grp, begin, st);
 }

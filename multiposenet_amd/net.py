@@ -372,9 +372,19 @@ class KeypointNet:
         # end of backward reduces all of them into the gradient arena (ops.SlabReducer; 46 slabs = 87 launches otherwise)
         lib, dc = ops._lib.lib(), ops._lib.dtype_code(dt)
         sites = []   # (key, nparts, n, out)
+        # the 3x3 convolutions that exist once per pyramid level share a grid per stage (ops.conv_bwd_weight_grouped): their slab
+        # counts are those of that grid
+        grouped_np = {}
+        for group in self._wgrad_groups():
+            hws = [self._conv_hw(b, c) for c in group]
+            for c, np_ in zip(group, ops.conv_wgrad_grouped_num_parts(N, hws, group[0].cin, group[0].cout, group[0].ksize, dt)):
+                grouped_np[id(c.dw)] = np_
         for c in self.convs:
             hw = self._conv_hw(b, c)
-            sites.append((id(c.dw), ops.conv_wgrad_num_parts(N, hw[0], hw[1], c.cin, c.cout, c.ksize, dt), c.w.numel(), c.dw))
+            np_ = grouped_np.get(id(c.dw))
+            if np_ is None:
+                np_ = ops.conv_wgrad_num_parts(N, hw[0], hw[1], c.cin, c.cout, c.ksize, dt)
+            sites.append((id(c.dw), np_, c.w.numel(), c.dw))
         for i, blk in enumerate(self.blocks):
             hh, ww = b["hw"][i]
             cc = b["dw"][i].shape[3]
@@ -395,6 +405,10 @@ class KeypointNet:
         g["reducer"] = (ops.SlabReducer(jobs[0], dev), ops.SlabReducer(jobs[1], dev))
         b["g"] = g
         return g
+
+    def _wgrad_groups(self):
+        LV = (2, 3, 4, 5)
+        return [[self.phi[l]["conv2"] for l in LV], [self.phi[l]["conv1"] for l in LV], [self.pconv[l] for l in LV]]
 
     def _conv_hw(self, b, c):
         n = c.name
@@ -605,26 +619,26 @@ class KeypointNet:
         fin["dbn2"].run()
         none4 = [None] * 4
         ops.bn_bwd_apply_grouped(bn2s, gy2, by2)
-        for l in LV:
-            ph = self.phi[l]
-            W(lambda: ops.conv_bwd_weight(b["y1"][l], g["y2"][l], 3, ph["bn1"].affine, ph["conv2"].dw, slab[id(ph["conv2"].dw)], reduce=False))
+        W(lambda: ops.conv_bwd_weight_grouped(by1, gy2, 3, [self.phi[l]["bn1"].affine for l in LV],
+                                              [slab[id(self.phi[l]["conv2"].dw)] for l in LV]))
         ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
                              [g["y1"][l] for l in LV], none4)
         ops.bn_bwd_reduce_grouped(bn1s, gy1, by1, sps)
         fin["dbn1"].run()
         ops.bn_bwd_apply_grouped(bn1s, gy1, by1)
-        for l in LV:
-            ph = self.phi[l]
-            W(lambda: ops.conv_bwd_weight(b["p"][l], g["y1"][l], 3, self.p_bn[l].affine, ph["conv1"].dw, slab[id(ph["conv1"].dw)], reduce=False))
+        W(lambda: ops.conv_bwd_weight_grouped(bp, gy1, 3, [self.p_bn[l].affine for l in LV],
+                                              [slab[id(self.phi[l]["conv1"].dw)] for l in LV]))
         ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
                              [g["p"][l] for l in LV], none4)
         ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
         fin["dp"].run()
         ops.bn_bwd_apply_grouped(pbns, gp, bp, [g["daux"][l] for l in LV])
         # ---- FPN (top-down path reversed)
+        # the four 3x3 convolutions (fpn.py:39,52) are independent: ONE grid for their weight gradients, one for their data
+        # gradients; the nearest-upsample gradients then chain the levels
+        W(lambda: ops.conv_bwd_weight_grouped([b["x"][l] for l in LV], gp, 3, none4, [slab[id(self.pconv[l].dw)] for l in LV]))
+        ops.conv_fwd_grouped(gp, [self.pconv[l].packed.bwd for l in LV], DEPTH, 3, none4, [g["x"][l] for l in LV], none4)
         for l in (2, 3, 4, 5):
-            W(lambda: ops.conv_bwd_weight(b["x"][l], g["p"][l], 3, None, self.pconv[l].dw, slab[id(self.pconv[l].dw)], reduce=False))
-            ops.conv_fwd(g["p"][l], self.pconv[l].packed.bwd, DEPTH, 3, None, out=g["x"][l])
             if l > 2:
                 ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample
             raw, aff = feats[f"c{l}"]

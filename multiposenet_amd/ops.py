@@ -166,6 +166,32 @@ class SlabReducer:
         call("mpn_reduce_partials_batched", ptr(self.table), self.njobs, self.blocks, stream_ptr())
 
 
+def conv_wgrad_grouped_num_parts(N, hws, cin, cout, ksize, dtype):
+    """Slab counts of conv_bwd_weight_grouped for jobs of sizes hws = [(H, W), ...]."""
+    import ctypes
+    n = len(hws)
+    IA = ctypes.c_int * n
+    out = IA()
+    call("mpn_conv_wgrad_grouped_num_parts", n, N, IA(*[h for h, _ in hws]), IA(*[w for _, w in hws]), cin, cout, ksize,
+         _lib.dtype_code(dtype), out)
+    return list(out)
+
+
+def conv_bwd_weight_grouped(xs, dys, ksize, affines, parts):
+    """conv_bwd_weight of several independent layers of one channel geometry in one grid (the pyramid levels of a subnet
+    stage); the slabs stay in `parts` (sized by conv_wgrad_grouped_num_parts) for the batched reduction."""
+    import ctypes
+    n = len(xs)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    N, cin, cout = xs[0].shape[0], xs[0].shape[3], dys[0].shape[3]
+    sc, sh, act = zip(*[_aff(a) for a in affines])
+    if len(set(act)) != 1:
+        raise ValueError("grouped jobs must share the activation")
+    call("mpn_conv_bwd_weight_grouped", n, PA(*[ptr(t) for t in xs]), PA(*[ptr(t) for t in dys]), PA(*[ptr(t) for t in parts]), N,
+         IA(*[t.shape[1] for t in xs]), IA(*[t.shape[2] for t in xs]), cin, cout, IA(*[_slice_stride(t, cin) for t in xs]),
+         IA(*[_slice_stride(t, cout) for t in dys]), ksize, _lib.dtype_code(xs[0].dtype), PA(*sc), PA(*sh), int(act[0]), stream_ptr())
+
+
 # ----------------------------------------------------------------------------- batch norm
 class BNState:
     """Device state of one batch-norm layer: views into the parameter arenas + per-step buffers."""

@@ -368,3 +368,34 @@ def test_grouped_bn_backward_and_conv_wgrad_on_channel_slices(cuda):
     ops.conv_bwd_weight(x_s.contiguous(), d_d, 1, None, dW_a[0, 0])   # strided x, 1x1
     ops.conv_bwd_weight(x_s, d_d, 1, None, dW_b[0, 0])
     assert torch.equal(dW_a, dW_b)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32], ids=["bf16", "fp16", "f32"])
+@pytest.mark.parametrize("k,Cin,Cout", [(3, 128, 128), (1, 256, 128)])
+def test_conv_wgrad_grouped_equals_separate_launches(cuda, dtype, k, Cin, Cout):
+    """mpn_conv_bwd_weight_grouped: the weight gradients of four independent layers (pyramid levels) from ONE grid = the four
+    separate launches up to the f32 summation order (the grid divides its blocks among the jobs: other split counts)."""
+    ops = _ops()
+    rs = np.random.RandomState(23 + k)
+    N = 4
+    sizes = [(40, 48), (20, 24), (10, 12), (5, 6)]
+    xs = [dev(rnd(rs.randn(N, h, w, Cin), dtype), dtype) for h, w in sizes]
+    dys = [dev(rnd(rs.randn(N, h, w, Cout), dtype), dtype) for h, w in sizes]
+    affs = [ops.Affine(dev(torch.tensor(0.5 + rs.rand(Cin), dtype=torch.float32)), dev(torch.tensor(rs.randn(Cin) * 0.5, dtype=torch.float32)), 1)
+            for _ in sizes]
+    want = []
+    for x, dy, a in zip(xs, dys, affs):
+        dw = torch.full((k, k, Cin, Cout), float("nan"), device="cuda")
+        ops.conv_bwd_weight(x, dy, k, a, dw)
+        want.append(dw)
+    nps = ops.conv_wgrad_grouped_num_parts(N, sizes, Cin, Cout, k, dtype)
+    n = k * k * Cin * Cout
+    parts = [torch.full((np_ * n,), float("nan"), device="cuda") for np_ in nps]
+    ops.conv_bwd_weight_grouped(xs, dys, k, affs, parts)
+    if dtype != torch.float32:
+        assert sum(nps) * max(1, Cin // (64 if k == 3 else 128)) * max(1, Cout // 128) <= 256 + 8 * len(sizes)   # one grid of ~256 blocks
+    for w_, part, np_ in zip(want, parts, nps):
+        got = torch.empty(n, device="cuda")
+        ops.reduce_partials(part, np_, n, got)
+        scale = float(w_.abs().max())
+        assert float((got.view_as(w_) - w_).abs().max()) <= 2e-5 * scale * (N * sizes[0][0] * sizes[0][1]) ** 0.5
