@@ -304,7 +304,9 @@ class PersonDetectorNet:
         for c in self._convs:
             n = c.src.numel()
             if c in self.tower["box_net"] or c in self.tower["class_net"] or c in self.out_conv.values():
-                parts = [((c.name, l), ops.conv_wgrad_num_parts(N, *lv[l], c.cin, c.cout, 3, dt)) for l in LEVELS]
+                # (the five levels' weight gradients come from ONE grid: ops.conv_bwd_weight_grouped)
+                nps = ops.conv_wgrad_grouped_num_parts(N, [lv[l] for l in LEVELS], c.cin, c.cout, 3, dt)
+                parts = [((c.name, l), np_) for l, np_ in zip(LEVELS, nps)]
             else:
                 l = int(c.name.split("/")[1].replace("lateral", "").replace("p", ""))
                 parts = [((c.name, l), ops.conv_wgrad_num_parts(N, *lv[l], c.cin, c.cout, c.ksize, dt))]
@@ -445,8 +447,8 @@ class PersonDetectorNet:
         for net, _, _ in NETS:
             oc = self.out_conv[net]
             bn3 = self.tower_bn[net][3]
-            for l in LEVELS:
-                ops.conv_bwd_weight(b["t"][net][3][l], g["out"][net][l], 3, bn3[l].affine, None, slab[(oc.name, l)], reduce=False)
+            ops.conv_bwd_weight_grouped([b["t"][net][3][l] for l in LEVELS], [g["out"][net][l] for l in LEVELS], 3,
+                                        [bn3[l].affine for l in LEVELS], [slab[(oc.name, l)] for l in LEVELS])
             ops.conv_fwd_grouped([g["out"][net][l] for l in LEVELS], [oc.packed.bwd] * 5, TOWER_DEPTH, 3, none5,
                                  [g["t"][net][3][l] for l in LEVELS], none5)
             for i in (3, 2, 1, 0):
@@ -462,8 +464,7 @@ class PersonDetectorNet:
                 else:
                     xin, ain = [b["p"][l] for l in LEVELS], [self.p_bn[l].affine for l in LEVELS]
                     dst = [g["pn"][net][l] for l in LEVELS]
-                for j, l in enumerate(LEVELS):
-                    ops.conv_bwd_weight(xin[j], dAs[j], 3, ain[j], None, slab[(c.name, l)], reduce=False)
+                ops.conv_bwd_weight_grouped(xin, dAs, 3, ain, [slab[(c.name, l)] for l in LEVELS])
                 ops.conv_fwd_grouped(dAs, [c.packed.bwd] * 5, c.cin, 3, none5, dst, none5)
         # the two towers meet at act(bn(p_l)): sum, then through p{l}_batch_norm
         gp = [g["pn"]["box_net"][l] for l in LEVELS]
