@@ -787,25 +787,22 @@ void wgrad_group_splits(int njobs, int N, const int* H, const int* W, int Cin, i
     while ((quantum * units) % 8 != 0) ++quantum;              // blocks per job in multiples of 8
     int budget = 256 / units;                                  // splits in all
     if (budget < quantum * njobs) budget = quantum * njobs;
-    int used = 0;
+    // large jobs in multiples of the quantum (their XCD map), small ones rounded to the nearest split: a job rounded DOWN to a
+    // quantum is the grid's long pole (level 4 of the subnet: 6 splits wanted, 4 given -> 64 instead of 43 tiles per block)
+    int used = 0, big = 0;
     for (int j = 0; j < njobs; ++j) {
-        long long ns = (long long)budget * geoms[j].ntiles / total_tiles;
-        ns = ns / quantum * quantum;
-        const int cap = geoms[j].ntiles / 4 > 0 ? geoms[j].ntiles / 4 : 1;
-        if (ns > cap) ns = cap / quantum * quantum;
-        if (ns < quantum) ns = quantum;
-        if (ns > geoms[j].ntiles) ns = geoms[j].ntiles;        // (tiny maps: fewer splits than a quantum; the job then runs without the XCD map)
+        const double ideal = (double)budget * geoms[j].ntiles / (double)total_tiles;
+        long long ns = ideal >= 4.0 * quantum ? (long long)ideal / quantum * quantum : (long long)(ideal + 0.5);
+        const int cap = geoms[j].ntiles / 4 > 0 ? geoms[j].ntiles / 4 : 1;   // at least 4 tiles per split
+        if (ns > cap) ns = cap;
+        if (ns < 1) ns = 1;
         nsplit[j] = (int)ns;
         used += (int)ns;
+        if (geoms[j].ntiles > geoms[big].ntiles) big = j;
     }
-    // what rounding left over goes to the largest job
-    int big = 0;
-    for (int j = 1; j < njobs; ++j) if (geoms[j].ntiles > geoms[big].ntiles) big = j;
-    if (used < budget) {
-        const int extra = (budget - used) / quantum * quantum;
-        const int cap = geoms[big].ntiles / 4;
-        if (nsplit[big] + extra <= cap) nsplit[big] += extra;
-    }
+    // the largest job absorbs what rounding left over / took too much (in quanta, so that it keeps its XCD map)
+    while (used > budget && nsplit[big] > quantum) { nsplit[big] -= quantum; used -= quantum; }
+    while (used + quantum <= budget && nsplit[big] + quantum <= geoms[big].ntiles / 4) { nsplit[big] += quantum; used += quantum; }
 }
 
 template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
