@@ -1,14 +1,25 @@
 """Benchmark of the keypoint-training hot path (BASELINE.json metric: images/sec, keypoint fwd+bwd(+Adam) @512x512,
 per-GPU batch 32, bf16 storage / f32 accumulate), one process per GPU.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU over RCCL. Either the caller starts the ranks (`python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or - when
+WORLD_SIZE is unset - this process becomes a LAUNCHER: it never touches the GPU, checks that N devices are visible,
+starts the N ranks as child processes of this same script with the rendezvous variables set (127.0.0.1, a free port),
+relays rank 0's single JSON line and exits with the ranks' exit code (any rank failing ends the others).
 
 A step = forward + losses + backward + gradient all-reduce (N>1) + Adam + weight repack on one synthetic batch
 that is resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+
+`--dry-run-cpu` (tests): the same launcher, rendezvous, two-phase gradient exchange, barrier and max-over-ranks timing
+on CPU tensors over gloo - no kernel runs, the line says "dry_run": true and is not a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,6 +34,122 @@ PEAK_HBM_GBS = 8000.0
 GMAC_PER_IMAGE = 17.946     # forward MACs per 512x512 image (BASELINE.md section 3)
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def rank_commands(n, argv, port, base_env=None):
+    """[(argv, env)] of the N rank processes the launcher starts: this script again with the caller's arguments and the
+    rendezvous variables torch.distributed.run would set."""
+    base_env = dict(os.environ if base_env is None else base_env)
+    out = []
+    for r in range(n):
+        env = dict(base_env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
+    return out
+
+
+def launch_ranks(n, argv, dry_run=False, timeout_s=1500.0):
+    """The launcher (parent of the ranks). Makes no GPU call: counting devices does not initialise the runtime."""
+    if not dry_run:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} needs {n} devices, {have} visible\n")
+            return 2
+    cmds = rank_commands(n, argv, _free_port())
+    procs = []
+    try:
+        for r, (cmd, env) in enumerate(cmds):
+            # rank 0's stdout carries the JSON line; the other ranks print nothing on stdout
+            procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        deadline = time.monotonic() + timeout_s
+        rcs = [None] * n
+        line = None
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    rcs[r] = p.poll()
+            if any(rc not in (None, 0) for rc in rcs):
+                break                     # a rank died: its peers would wait in a collective for ever
+            if time.monotonic() > deadline:
+                sys.stderr.write(f"bench.py: ranks still running after {timeout_s:.0f} s\n")
+                break
+            if all(rc is None for rc in rcs) or rcs[0] is None:
+                time.sleep(0.05)
+        if rcs[0] == 0:
+            line = procs[0].stdout.read().decode()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    rcs = [p.returncode for p in procs]
+    if any(rc != 0 for rc in rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        return next((rc for rc in rcs if rc is not None and rc > 0), 1)   # the failing rank's own code, not a peer's SIGTERM
+    # exactly ONE line on stdout: rank 0's JSON; anything else a library printed there goes to stderr
+    lines = [ln for ln in (line or "").splitlines() if ln.strip()]
+    js = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if not js or ln is not js[-1]:
+            sys.stderr.write(ln + "\n")
+    if not js:
+        sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return 1
+    sys.stdout.write(js[-1] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def dry_run_cpu(args):
+    """One rank of the CPU rehearsal: rendezvous over gloo, the Trainer's two-phase exchange on an arena-sized CPU tensor,
+    the bench's barrier / max-over-ranks timing and JSON line. Nothing here is a measurement of the hot path."""
+    from multiposenet_amd import net as mnet
+    from multiposenet_amd.parallel import GradientAllReducer, init_distributed
+    rank, local_rank, world = init_distributed("gloo")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if os.environ.get("MPN_BENCH_FAIL_RANK") == str(rank):       # tests: a rank that dies before the first collective
+        sys.exit(7)
+    shapes = {k: v for k, v in mnet.variable_shapes(1.0).items() if mnet.is_trainable(k)}
+    arena = mnet._Arena(shapes, "cpu")
+    grad = arena.new()
+    split = mnet.backbone_grad_end_of(arena)
+    red = GradientAllReducer(grad)
+    for _ in range(args.warmup):
+        red.start(split, None), red.start(0, split), red.finish()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        grad.fill_(float(rank + 1))
+        red.start(split, None)       # head end first (overlaps the backbone's backward on the GPU path)
+        red.start(0, split)
+        red.finish()
+    torch.distributed.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    want = world * (world + 1) / 2.0
+    ok = bool((grad == want).all())
+    if rank == 0:
+        print(json.dumps({"metric": "images/sec keypoint fwd+bwd+Adam @512x512 bs32/GPU", "value": None, "unit": "images/s",
+                          "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * float(t) / max(1, args.steps), 3), "scaling": "weak",
+                          "config": {"rccl_ranks": torch.distributed.get_world_size(), "backend": "gloo",
+                                     "gradient_elements": grad.numel(), "allreduce_sum_ok": ok}}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,7 +161,14 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse launcher + exchange on CPU over gloo (tests)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.dry_run_cpu))    # before anything touches the GPU
+    if args.dry_run_cpu:
+        sys.exit(dry_run_cpu(args))
 
     from multiposenet_amd import _lib
     from multiposenet_amd.parallel import init_distributed

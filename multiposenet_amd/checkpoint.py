@@ -7,6 +7,8 @@ into the graph. Reading a TF checkpoint needs TensorFlow, which is not in this i
 one-off converter to run where it is (`tf.train.load_checkpoint` -> `np.savez`, names unchanged); everything here works on
 the resulting `.npz` - HWIO kernels, [3,3,C,1] depthwise kernels, f32 - for KeypointNet and PoseResidualNet alike.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -32,7 +34,12 @@ def save_npz(path, net, with_optimizer=True, beta1=0.9, beta2=0.999):
         # checkpoint holds beta^(step+1) (consistent with csrc/optim.hip using t = global_step + 1)
         out["beta1_power"] = np.float32(beta1 ** (step + 1))
         out["beta2_power"] = np.float32(beta2 ** (step + 1))
-    np.savez(path, **out)
+    # a kill during the write must not leave a truncated file under the final name (it would be the newest checkpoint
+    # of model_dir): write beside it under a name no checkpoint glob matches, then rename atomically
+    d, base = os.path.split(os.path.abspath(path))
+    tmp = os.path.join(d, ".partial-" + (base if base.endswith(".npz") else base + ".npz"))
+    np.savez(tmp, **out)
+    os.replace(tmp, path if path.endswith(".npz") else path + ".npz")
     return sorted(out)
 
 

@@ -32,7 +32,9 @@ class RetinaNet:
 
     def loss(self, groundtruth, params):
         """{'localization_loss', 'classification_loss'}: scalar device tensors (retinanet.py:86-144)."""
-        self._net.create_targets(groundtruth)
+        # THIS object's forward pass: another RetinaNet built on the shared detector in between (another image shape)
+        # must not redirect the loss to its outputs and anchors
+        self._net.create_targets(groundtruth, b=self._b)
         losses = self._net.compute_losses(dict(params, weight_decay=0.0, localization_loss_weight=1.0, classification_loss_weight=1.0),
-                                          with_grad=False)
+                                          with_grad=False, b=self._b)
         return {"localization_loss": losses[0], "classification_loss": losses[1]}

@@ -130,6 +130,15 @@ class _Conv:
         self.packed = ops.PackedConv(w, dtype)
 
 
+def backbone_grad_end_of(arena):
+    """Offset in a flat arena of the trainable variables where the backbone's (`MobilenetV1/*`) end."""
+    end = 0
+    for k, (o, n, _) in arena.offsets.items():
+        if k.startswith("MobilenetV1/"):
+            end = max(end, o + (n + 3) // 4 * 4)
+    return end
+
+
 @ops._lib.device_guarded("_init", "load_state_dict", "repack_weights", "prepare_inference", "forward", "predict",
                          "backbone_forward", "subnet_forward", "compute_losses", "backward", "add_weight_decay_gradients",
                          "add_weight_decay_loss", "optimizer_step")
@@ -567,11 +576,7 @@ class KeypointNet:
     @property
     def backbone_grad_end(self):
         """Offset in the flat gradient arena where the backbone's variables end (the arena is laid out backbone first)."""
-        end = 0
-        for k, (o, n, _) in self._train_arena.offsets.items():
-            if k.startswith("MobilenetV1/"):
-                end = max(end, o + (n + 3) // 4 * 4)
-        return end
+        return backbone_grad_end_of(self._train_arena)
 
     def backward(self, part=None):
         """Gradients of the total loss w.r.t. every trainable variable -> self.grad (call after compute_losses).

@@ -43,11 +43,24 @@ def initial_values(seed=0, **kw):
                      "optimizer_step", "train_step")
 class PoseResidualNet:
     def __init__(self, values=None, batch=128, h=CROP_SIZE[0], w=CROP_SIZE[1], c=NUM_KEYPOINTS, hidden=HIDDEN,
-                 dtype=torch.bfloat16, device="cuda:0", seed=0):
-        self.device = torch.device(device)
-        self._init(values, batch, h, w, c, hidden, dtype, seed)
+                 dtype=torch.bfloat16, device="cuda:0", seed=0, share_variables_of=None):
+        """share_variables_of: another PoseResidualNet of the same geometry and dtype - this instance then runs at ITS OWN
+        batch size on the OTHER's variables, Adam slots, step counter and operand copies (one model, several batch
+        sizes: a partial last batch, EVAL at batch 1 after TRAIN at batch 128)."""
+        self.device = torch.device(device) if share_variables_of is None else share_variables_of.device
+        self._init(values, batch, h, w, c, hidden, dtype, seed, share_variables_of)
 
-    def _init(self, values, batch, h, w, c, hidden, dtype, seed):
+    def for_batch(self, batch):
+        """The instance that runs this model at `batch` crops (activation buffers are per batch size, variables shared)."""
+        if int(batch) == self.B:
+            return self
+        sib = self._siblings.get(int(batch))
+        if sib is None:
+            sib = PoseResidualNet(batch=int(batch), h=self.h, w=self.w, c=self.c, hidden=self.hidden, dtype=self.dtype,
+                                  share_variables_of=self)
+        return sib
+
+    def _init(self, values, batch, h, w, c, hidden, dtype, seed, share=None):
         _lib.lib()   # fail loudly without the HIP library
         self.B, self.h, self.w, self.c, self.hidden = int(batch), h, w, c, hidden
         self.n = h * w * c
@@ -58,20 +71,30 @@ class PoseResidualNet:
         # normal range once it is stored as a GEMM operand (dpre2, dpre1), so the backward pass carries
         # loss_scale * gradient (a power of two: exact) and Adam divides it out. bf16 / f32 have the exponent range.
         self.loss_scale = float(2 ** int(np.floor(np.log2(batch * h * w * c)))) if dtype == torch.float16 else 1.0
-        shapes = variable_shapes(h, w, c, hidden)
-        self._arena = _Arena(shapes, self.device)
-        self.theta, self.grad = self._arena.new(), self._arena.new()
-        self.adam_m, self.adam_v = self._arena.new(), self._arena.new()
-        self.vars, self.grads = self._arena.views(self.theta), self._arena.views(self.grad)
-        self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
-        self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
-        self.load_state_dict(values if values is not None else initial_values(seed, h=h, w=w, c=c, hidden=hidden))
         dev, B, n = self.device, self.B, self.n
-        W1, W2 = self.vars["PRN/fc1/weights"], self.vars["PRN/fc2/weights"]
-        # operand copies in the storage dtype: W1 [n,1024] (K-major as stored), W2^T [n,1024], W2 packed for conv_fwd
-        self.w1_op = W1 if dtype == torch.float32 else torch.empty((n, hidden), dtype=dtype, device=dev)
-        self.w2t_op = torch.empty((n, hidden), dtype=dtype, device=dev)
-        self.w2_conv = ops.PackedConv(W2.view(1, 1, hidden, n), dtype)
+        if share is None:
+            shapes = variable_shapes(h, w, c, hidden)
+            self._arena = _Arena(shapes, self.device)
+            self.theta, self.grad = self._arena.new(), self._arena.new()
+            self.adam_m, self.adam_v = self._arena.new(), self._arena.new()
+            self.vars, self.grads = self._arena.views(self.theta), self._arena.views(self.grad)
+            self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+            self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
+            self.load_state_dict(values if values is not None else initial_values(seed, h=h, w=w, c=c, hidden=hidden))
+            W1, W2 = self.vars["PRN/fc1/weights"], self.vars["PRN/fc2/weights"]
+            # operand copies in the storage dtype: W1 [n,1024] (K-major as stored), W2^T [n,1024], W2 packed for conv_fwd
+            self.w1_op = W1 if dtype == torch.float32 else torch.empty((n, hidden), dtype=dtype, device=dev)
+            self.w2t_op = torch.empty((n, hidden), dtype=dtype, device=dev)
+            self.w2_conv = ops.PackedConv(W2.view(1, 1, hidden, n), dtype)
+            self._siblings = {self.B: self}
+        else:
+            if (share.h, share.w, share.c, share.hidden, share.dtype) != (h, w, c, hidden, dtype):
+                raise ValueError("share_variables_of: geometry / dtype differ")
+            for a in ("_arena", "theta", "grad", "adam_m", "adam_v", "vars", "grads", "global_step", "hyper", "w1_op",
+                      "w2t_op", "w2_conv", "_siblings"):
+                setattr(self, a, getattr(share, a))
+            self._siblings[self.B] = self
+            # the fp16 loss scale is a function of the batch size; Adam divides by the scale of the instance that steps
         f32 = torch.float32
         self.xt = torch.empty((n, B), dtype=dtype, device=dev)            # X^T
         self.x_op = torch.empty((B, n), dtype=dtype, device=dev)          # X in the storage dtype (fc1 wgrad operand)
@@ -92,7 +115,8 @@ class PoseResidualNet:
         for name, cin, cout in (("PRN/fc1/weights", n, hidden), ("PRN/fc2/weights", hidden, n)):
             if ops.conv_wgrad_num_parts(1, 1, B, cin, cout, 1, dtype) != 1:
                 raise RuntimeError("weight-gradient geometry changed: expected one slab for " + name)
-        self.refresh_operands()
+        if share is None:
+            self.refresh_operands()
 
     # ---------------------------------------------------------------- state
     def state_dict(self):

@@ -14,15 +14,18 @@ _models = {}
 
 
 def _model(params, batch, shape):
-    """One PoseResidualNet (+ optimizer state) per model configuration: tf.estimator keys its variables by `model_dir`
-    (train_prn.py: RunConfig(model_dir=...)), so does this registry - never by object identity, which is recycled."""
+    """One set of variables (+ optimizer state) per model configuration: tf.estimator keys its variables by `model_dir`
+    (train_prn.py: RunConfig(model_dir=...)), so does this registry - never by object identity, which is recycled, and
+    never by batch size: the reference's eval pipeline ends on a partial batch (`dataset.repeat(1).batch(b)`), which must
+    score the TRAINED variables. Activation buffers are per batch size (`PoseResidualNet.for_batch`)."""
     # storage type of the GEMM operands and activations (masters, accumulators and Adam stay f32); "fp16" is the type
     # BASELINE.json config 5 names
     dt = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16}[params.get("dtype", "bf16")]
-    key = (params.get("model_dir"), dt, int(params.get("seed", 0)), batch, shape)
+    key = (params.get("model_dir"), dt, int(params.get("seed", 0)), shape)
     if key not in _models:
-        _models[key] = PoseResidualNet(values=params.get("values"), batch=batch, h=shape[0], w=shape[1], c=shape[2], dtype=dt)
-    return _models[key]
+        _models[key] = PoseResidualNet(values=params.get("values"), batch=batch, h=shape[0], w=shape[1], c=shape[2], dtype=dt,
+                                       seed=int(params.get("seed", 0)))
+    return _models[key].for_batch(batch)
 
 
 def reset_registry():

@@ -384,9 +384,10 @@ class PersonDetectorNet:
         PA = ctypes.c_void_p * 5
         return PA(*[ptr(d_cls[l]) for l in LEVELS]), PA(*[ptr(d_box[l]) for l in LEVELS])
 
-    def create_targets(self, groundtruth):
-        """retinanet.py:146-166: groundtruth {'boxes': f32 [N,max,4] normalised, 'num_boxes': int32 [N]} -> matches, targets."""
-        b = self._last[0]
+    def create_targets(self, groundtruth, b=None):
+        """retinanet.py:146-166: groundtruth {'boxes': f32 [N,max,4] normalised, 'num_boxes': int32 [N]} -> matches, targets.
+        b: the buffer set of the forward pass the targets belong to (default: the most recent head_forward)."""
+        b = self._last[0] if b is None else b
         boxes, nb = groundtruth["boxes"], groundtruth["num_boxes"]
         N, maxn = boxes.shape[0], boxes.shape[1]
         if boxes.dtype != torch.float32 or not boxes.is_contiguous() or nb.dtype != torch.int32:
@@ -399,10 +400,11 @@ class PersonDetectorNet:
              ptr(b["matches"]), ptr(b["targets"]), ptr(b["num_matched"]), ptr(ws), ws.numel(), stream_ptr())
         return b["targets"], b["matches"]
 
-    def compute_losses(self, params, with_grad=True):
+    def compute_losses(self, params, with_grad=True, b=None):
         """retinanet.py:86-144 + person_detector_model.py:33-45. Call after forward + create_targets. Returns f32[4]
-        (LOSS_NAMES) on the device; with_grad also fills the gradients of the raw tower outputs and the bias gradients."""
-        b = self._last[0]
+        (LOSS_NAMES) on the device; with_grad also fills the gradients of the raw tower outputs and the bias gradients.
+        b: the buffer set of the forward pass to score (default: the most recent head_forward)."""
+        b = self._last[0] if b is None else b
         N = b["shape"][0]
         g = self._grad_buffers(b) if with_grad else None
         lg, bx = self._level_ptrs(b["out"]["box_net"], b["out"]["class_net"])

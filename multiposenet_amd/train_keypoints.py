@@ -18,6 +18,7 @@ import os
 import re
 import time
 
+import numpy as np
 import torch
 
 from . import checkpoint
@@ -44,13 +45,25 @@ RUN_CONFIG = {'save_summary_steps': 200, 'save_checkpoints_secs': 7200, 'log_ste
               'eval_start_delay_secs': 7200, 'eval_throttle_secs': 7200}                                 # :60
 
 
+def _readable(path):
+    try:
+        with np.load(path) as z:
+            return "global_step" in z.files or len(z.files) > 0
+    except Exception:
+        return False
+
+
 def latest_checkpoint(model_dir):
-    best = None
+    """(step, path) of the newest checkpoint numpy can open; files a killed writer left truncated are skipped."""
+    found = []
     for f in glob.glob(os.path.join(model_dir, "model.ckpt-*.npz")):
         m = re.search(r"model\.ckpt-(\d+)\.npz$", f)
-        if m and (best is None or int(m.group(1)) > best[0]):
-            best = (int(m.group(1)), f)
-    return best
+        if m:
+            found.append((int(m.group(1)), f))
+    for step, f in sorted(found, reverse=True):
+        if _readable(f):
+            return (step, f)
+    return None
 
 
 def train(params, train_batches, val_batches=None, run_config=None, max_steps=None, log=print):

@@ -1,0 +1,65 @@
+"""CPU: `python bench.py --gpus N` launches its own N ranks. The launcher never touches the GPU;
+the `--dry-run-cpu` mode runs rendezvous + the Trainer's two-phase gradient exchange + barrier / max-over-ranks timing
+over gloo through the same launcher, so command construction, env plumbing, JSON relay and failure handling are covered
+without a device."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, env=None, timeout=240):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None), e.pop("RANK", None), e.pop("LOCAL_RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=e, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+
+
+def test_rank_commands_carry_the_rendezvous_variables():
+    import bench
+    cmds = bench.rank_commands(4, ["--gpus", "4", "--steps", "3"], 12345, base_env={"PATH": "/usr/bin"})
+    assert len(cmds) == 4
+    for r, (argv, env) in enumerate(cmds):
+        assert argv[0] == sys.executable and argv[1] == BENCH and argv[2:] == ["--gpus", "4", "--steps", "3"]
+        assert env["RANK"] == str(r) and env["LOCAL_RANK"] == str(r) and env["WORLD_SIZE"] == "4"
+        assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] == "12345"
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/usr/bin"
+
+
+def test_gpus_2_without_two_devices_exits_nonzero_in_seconds():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two devices visible: the launcher would start a real run")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], timeout=120)
+    assert r.returncode != 0
+    assert "needs 2 devices" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_two_rank_gloo_dry_run_through_the_launcher_prints_one_json_line():
+    r = _run(["--gpus", "2", "--dry-run-cpu", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["dry_run"] is True and out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak"
+    assert out["config"]["rccl_ranks"] == 2 and out["config"]["allreduce_sum_ok"] is True
+    assert out["config"]["gradient_elements"] >= 5521490
+
+
+def test_a_dying_rank_ends_the_others_and_the_launcher_returns_its_code():
+    r = _run(["--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "0"], env={"MPN_BENCH_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode == 7
+    assert "rank exit codes" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_ranks_started_by_an_outer_launcher_are_not_relaunched():
+    """WORLD_SIZE in the environment (torch.distributed.run) = this process IS a rank: a mismatch with --gpus asserts."""
+    r = _run(["--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "0"],
+             env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -61,7 +61,25 @@ def _spawn(world, prefix, extra_env=None):
                    WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), prefix], env=env, cwd=ROOT))
-    rcs = [p.wait(timeout=900) for p in procs]
+    # poll all ranks: one that dies leaves its peers blocked in a collective - end them instead of waiting them out
+    import time
+    deadline = time.monotonic() + 300
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs) or time.monotonic() > deadline:
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    rcs = [p.returncode for p in procs]
     assert rcs == [0] * world, f"rank exit codes {rcs}"
     return [dict(np.load(f"{prefix}.rank{r}.npz")) for r in range(world)]
 

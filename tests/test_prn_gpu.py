@@ -115,3 +115,35 @@ def test_prn_shim_signature(cuda):
     p = {k: torch.tensor(v, dtype=torch.float64) for k, v in vals.items()}
     want = oprn.prn(torch.tensor(x, dtype=torch.float64), p).numpy()
     np.testing.assert_allclose(got, want, atol=1e-3, rtol=1e-3)
+
+
+def test_prn_model_fn_eval_at_another_batch_size_scores_the_trained_variables(cuda):
+    """variables are keyed by (model_dir, dtype, seed), not by batch size - the reference's eval pipeline ends on
+    a partial batch (`dataset.repeat(1).batch(b)`), which must see the weights TRAIN produced, and a partial train batch
+    must step the same model."""
+    from multiposenet_amd import prn_model
+    from multiposenet_amd.keypoints_model import ModeKeys
+    from multiposenet_amd.prn import PoseResidualNet
+    from multiposenet_amd.prn_model import model_fn
+    prn_model.reset_registry()
+    rs = np.random.RandomState(21)
+    h, w, hidden = 8, 6, 1024
+    x4, y4 = _data(rs, 4, h, w, 17)
+    x3, y3 = _data(rs, 3, h, w, 17)
+    vals = _values(3, h, w, 17, hidden)
+    hp = {"initial_learning_rate": 1e-2, "num_steps": 1000, "dtype": "f32", "values": vals, "model_dir": "prn-advice"}
+    untrained = float(model_fn(x3, y3, ModeKeys.EVAL, hp).loss)
+    for _ in range(3):
+        model_fn(x4, y4, ModeKeys.TRAIN, hp)
+    got = float(model_fn(x3, y3, ModeKeys.EVAL, hp).loss)
+    assert len(prn_model._models) == 1
+    base = next(iter(prn_model._models.values()))
+    assert int(base.global_step.item()) == 3 and set(base._siblings) == {3, 4}
+    fresh = PoseResidualNet(values=base.state_dict(), batch=3, h=h, w=w, dtype=torch.float32)   # the trained weights, alone
+    fresh.forward(torch.from_numpy(x3).cuda())
+    want = float(fresh.loss(torch.from_numpy(y3).cuda(), with_grad=False))
+    assert got == want
+    assert abs(got - untrained) > 1e-6          # (and NOT the loss of freshly initialised weights)
+    model_fn(x3, y3, ModeKeys.TRAIN, hp)        # a partial train batch steps the SAME model
+    assert int(base.global_step.item()) == 4
+    prn_model.reset_registry()

@@ -263,6 +263,12 @@ def test_reference_surface_shims(cuda):
     gt = {"boxes": torch.tensor(boxes).cuda(), "num_boxes": torch.tensor(num).cuda()}
     ls = rn.loss(gt, {"gamma": 2.0, "alpha": 0.25})
     assert set(ls) == {"localization_loss", "classification_loss"} and all(np.isfinite(float(v)) for v in ls.values())
+    # a second RetinaNet on the shared detector at ANOTHER image shape must not redirect the first object's loss
+    img2 = torch.rand(1, 128, 128, 3, device="cuda")
+    RetinaNet(mobilenet_v1(img2, is_training=False, net=net.backbone), img2.shape, False, {"depth_multiplier": 1.0}, net=net)
+    ls2 = rn.loss(gt, {"gamma": 2.0, "alpha": 0.25})
+    for k in ls:
+        assert float(ls2[k]) == float(ls[k]), k
     t, m = get_training_targets(anchors, boxes[0, :num[0]], positives_threshold=0.5, negatives_threshold=0.5)
     wt, wm = R.get_training_targets(anchors, boxes[0, :num[0]])
     np.testing.assert_array_equal(m.cpu().numpy(), wm)
