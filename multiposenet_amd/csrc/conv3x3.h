@@ -9,14 +9,21 @@ namespace mpn_c3 {
 __host__ __device__ inline bool eligible(int Kin, int Nout, int taps, int es) {
     return taps == 9 && es == 2 && Kin % 64 == 0 && Kin <= 512 && Nout % 128 == 0;
 }
+// the 64-channel-tile variant (the two waves of a row group split K): GEMM N an odd multiple of 64
+__host__ __device__ inline bool eligible64(int Kin, int Nout, int taps, int es) {
+    return taps == 9 && es == 2 && Kin % 64 == 0 && Kin <= 512 && Nout % 128 == 64;
+}
 
 // Packed weights, per n-tile of 128 output channels:  [chunk of 64 input channels][kx 3][k-step 2][ky 3][co 128][64 bytes],
 // i.e. stages of 24 576 bytes = the three taps of one kernel COLUMN for one 32-channel k-step; the four 16-byte slots of a
 // 64-byte row are XOR-swizzled with swz(co) like the tiled kernel's image (the global image is the LDS image).
 constexpr int kStageBytes = 3 * 128 * 64;
 __host__ __device__ constexpr int swz(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+// 64-channel-tile variant, per n-tile of 64:  [chunk of 64][kx 3][ky 3][k-step 2][co 64][64 bytes] - the same stage bytes, LDS
+// row = k-step * 64 + co, slots swizzled with swz(co).
 inline long long packed_bytes(int Kin, int Nout) { return 9ll * Kin * Nout * 2; }
 inline long long tile_bytes(int Kin) { return 9ll * Kin * 128 * 2; }
+inline long long tile_bytes64(int Kin) { return 9ll * Kin * 64 * 2; }
 
 constexpr int kMaxJobs = 5;
 struct Job {
@@ -33,7 +40,9 @@ struct Job {
     unsigned long long* dbg;
 #endif
 };
-inline int blocks_of(const Job& j) { return j.N * ((j.H + 15) / 16) * ((j.W + 15) / 16) * (j.Cout / 128); }
+inline int blocks_of(const Job& j) {
+    return j.N * ((j.H + 15) / 16) * ((j.W + 15) / 16) * ((j.Cout & 127) ? j.Cout / 64 : j.Cout / 128);
+}
 
 // one grid over up to kMaxJobs independent layers of the same (Cin, Cout, dtype) - e.g. the pyramid levels of a subnet stage
 int launch(const Job* jobs, int njobs, int dtype, hipStream_t st);

@@ -15,6 +15,14 @@
 // Epilogue as in the tiled kernel: the tile leaves through a bf16 LDS image (whole 256-byte pixel rows to HBM), the
 // batch-norm partial sums come from the matrix unit (ones x F and F^T x F over transposed reads of that image) and are
 // written as the two 8 x 16-pixel rows of the partial slab that the tiled kernel would have written.
+//
+// N64 variant (64 output channels per tile: final_conv3x3 512 -> 64, keypoint_subnet.py:38, and the detector's tower convolutions,
+// box_predictor.py:101-103): the same 16 x 16 pixel tile, the same stage bytes and the same 48 MFMAs per wave and stage - the two
+// waves of a row group split the K dimension instead of the channels: a stage holds the three taps of a kernel column for ALL 64
+// input channels of the chunk ([ky][k-step 2][co 64][64 bytes] = the [ky][row 128][64 bytes] image of the 128-channel variant
+// with row = k-step * 64 + co), wave (wm, wk) multiplies k-step wk. 3 stages per chunk instead of 6. At the end of a tile the
+// pair adds its two partial accumulators through LDS (each wave hands over the half of the rows it will not finish: 8 KB per
+// wave, one block barrier) and finishes 32 pixels x 64 channels each.
 #include "conv3x3.h"
 
 namespace {
@@ -85,6 +93,7 @@ struct Group {
 struct Tile {
     int job, ntile, img, oy0, ox0, ty, tx;
 };
+template <bool N64>
 __device__ __forceinline__ Tile tile_of(const Group& g, int w) {
     Tile t;
     t.job = 0;
@@ -93,7 +102,7 @@ __device__ __forceinline__ Tile tile_of(const Group& g, int w) {
         if (k < g.njobs && w >= g.begin[k]) t.job = k;
     const Job& p = g.job[t.job];
     int b = w - g.begin[t.job];
-    const int n_tiles = p.Cout >> 7, tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
+    const int n_tiles = N64 ? (p.Cout >> 6) : (p.Cout >> 7), tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
     t.ntile = b % n_tiles; b /= n_tiles;
     t.tx = b % tiles_x; b /= tiles_x;
     t.ty = b % tiles_y;
@@ -108,8 +117,10 @@ __device__ __forceinline__ Tile tile_of(const Group& g, int w) {
 // 64 pixels x 64 channels, stores them straight from the registers (8 bytes per lane: the four 16-channel pieces of a
 // pixel's 128 bytes come from four consecutive stores of one wave and merge in the L2) and - when statistics are asked for -
 // takes them from a wave-private LDS image of 32 pixels at a time in the halo buffer that has just been released.
-template <typename T, bool AFFINE>
+template <typename T, bool AFFINE, bool N64>
 __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
+    constexpr int NS = N64 ? 3 : 6;     // weight stages per 64-channel chunk
+    constexpr int BN = N64 ? 64 : 128;  // output channels per tile
     using H = H16<T>;
     using X8 = typename H::x8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -134,11 +145,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;       // 4 waves along the tile's rows (4 rows each) x 2 along the channels (64 each)
+    const int wm = wave >> 1, wn = wave & 1;       // 4 waves along the tile's rows (4 rows each) x 2 along the channels (64 each;
+                                                   // N64: along the two k-steps of a chunk)
     const int l15 = lane & 15, lq = lane >> 4;
     const int Cin = g.job[0].Cin, Cout = g.job[0].Cout;    // (shared by the jobs of a group)
     const int nchunk = Cin >> 6;
-    const long long wtile = 9ll * Cin * 128 * 2;
+    const long long wtile = 9ll * Cin * BN * 2;
 
     // per-lane fragment bases; everything added later is a compile-time or wave-uniform offset
     const unsigned char* abase = As + ((4 * wm) * kHW + l15) * kRS + lq * 16;
@@ -217,12 +229,18 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     float* st_dst = nullptr;
     const int st_half = tid >> 8, st_which = (tid >> 7) & 1, st_c = tid & 127;
     auto stats_flush = [&]() {
-        if (st_dst != nullptr)
-            *st_dst = red[((2 * st_half) * 2 + st_which) * 128 + st_c] + red[((2 * st_half + 1) * 2 + st_which) * 128 + st_c];
+        if (st_dst != nullptr) {
+            if constexpr (N64) {   // red [8 waves][2][64]: the four waves of a tile half, fixed order
+                const float* r = red + ((4 * st_half) * 2 + st_which) * 64 + st_c;
+                *st_dst = (r[0] + r[128]) + (r[256] + r[384]);
+            } else {
+                *st_dst = red[((2 * st_half) * 2 + st_which) * 128 + st_c] + red[((2 * st_half + 1) * 2 + st_which) * 128 + st_c];
+            }
+        }
         st_dst = nullptr;
     };
 
-    Tile cur = tile_of(g, w);
+    Tile cur = tile_of<N64>(g, w);
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
     int cc = 0, ss = 0;        // running chunk / stage counters: halo buffer cc & 1, weight buffer ss & 1
     b_issue(wsrc, 0, 0);
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         C3_STAMP(0);
         const int wnext = w + (int)gridDim.x;
         const bool has_next = wnext < total;
-        const Tile nxt = tile_of(g, has_next ? wnext : w);
+        const Tile nxt = tile_of<N64>(g, has_next ? wnext : w);
         const unsigned char* wsrc_next = reinterpret_cast<const unsigned char*>(g.job[nxt.job].wp) + nxt.ntile * wtile;
 
         f32x4_t acc[4][4];
@@ -254,12 +272,13 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             const bool last_chunk = chunk + 1 == nchunk;
             const bool stage_more = !last_chunk || has_next;       // a halo image to prepare under this chunk
 #pragma unroll
-            for (int sl = 0; sl < 6; ++sl, ++ss) {
+            for (int sl = 0; sl < NS; ++sl, ++ss) {
                 // stage sl = (kx, k-step): taps (ky, kx) for ky = 0..2, input channels chunk * 64 + ks * 32 .. + 31
-                const int a_off = (sl >> 1) * kRS + (sl & 1) * 64;
+                // (N64: stage sl = kx holds both k-steps, this wave multiplies k-step wn)
+                const int a_off = N64 ? sl * kRS + wn * 64 : (sl >> 1) * kRS + (sl & 1) * 64;
                 const unsigned char* bb = bbase + (ss & 1) * kStageBytes;
                 // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
-                if (sl < 5 || !last_chunk) b_issue(wsrc, chunk * 6 + sl + 1, (ss + 1) & 1);
+                if (sl < NS - 1 || !last_chunk) b_issue(wsrc, chunk * NS + sl + 1, (ss + 1) & 1);
                 else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
                 if (sl == 0) {
                     // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
@@ -290,6 +309,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 __builtin_amdgcn_sched_barrier(0);
                 // the halo image prepared under this chunk: its loads have had two stages to land, and the buffer was last read
                 // in the previous chunk (the wave-private epilogue images in it: before the barrier of this chunk's first stage)
+                // (N64: sl == 2 is the chunk's last stage - the commit still completes in front of its barrier)
                 if (sl == 2 && stage_more) a_commit((cc + 1) & 1, last_chunk ? 0 : chunk + 1);
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -315,9 +335,55 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         {
             const Job& p = g.job[cur.job];
             T* __restrict__ y = reinterpret_cast<T*>(p.y);
-            const int n0 = cur.ntile * 128;
+            const int n0 = cur.ntile * BN;
             constexpr int RSW = 64 * 2 + 8;                                   // wave-private image: 32 pixels x (128 + 8) bytes
             unsigned char* Ow = As + ((cc - 1) & 1) * kABytes + wave * (32 * RSW);
+            if constexpr (N64) {
+                // the pair (wm, 0), (wm, 1) holds two partial sums of the same 64 pixels x 64 channels. Each wave hands over the
+                // two image rows it will NOT finish (wave wn keeps rows 2 wn, 2 wn + 1) as f32: 8 KB per wave, slots 0..5 in the
+                // released halo buffer, 6 and 7 in the released weight buffer ((ss + 1) & 1: the last stage read ss - 1... the
+                // one in flight is ss & 1). One block barrier; afterwards a wave's private image lives in the slot it has read.
+                auto slot_of = [&](int wv) -> unsigned char* {
+                    return wv < 6 ? As + ((cc - 1) & 1) * kABytes + wv * 8192 : Bs + ((ss + 1) & 1) * kStageBytes + (wv - 6) * 8192;
+                };
+                unsigned char* mine = slot_of(wave);
+                // (wave-uniform branches with constant register indices: a select between two accumulator rows becomes a
+                //  dynamically indexed array, i.e. scratch)
+                if (wn == 0) {
+#pragma unroll
+                    for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4_t*>(mine + ((ml * 4 + nt) * 64 + lane) * 16) = acc[2 + ml][nt];
+                } else {
+#pragma unroll
+                    for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4_t*>(mine + ((ml * 4 + nt) * 64 + lane) * 16) = acc[ml][nt];
+                }
+                // (raw barriers: only LDS traffic is ordered here - __syncthreads() would also drain the vector-memory counter)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const unsigned char* theirs = slot_of(wave ^ 1);
+                f32x4_t o[2][4];
+#pragma unroll
+                for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) o[ml][nt] = *reinterpret_cast<const f32x4_t*>(theirs + ((ml * 4 + nt) * 64 + lane) * 16);
+                // (fixed order: k-step 0's partial sum + k-step 1's)
+                if (wn == 0) {
+#pragma unroll
+                    for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[ml][nt] = acc[ml][nt] + o[ml][nt];
+                } else {
+#pragma unroll
+                    for (int ml = 0; ml < 2; ++ml)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) acc[ml][nt] = o[ml][nt] + acc[2 + ml][nt];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                Ow = const_cast<unsigned char*>(theirs);
+            }
             const bool stats = p.stats_part != nullptr;
             f32x4_t sa[4], ga[4];
 #pragma unroll
@@ -328,14 +394,15 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             // copy-out lanes: lane j moves 16-byte piece j % 8 of image rows j / 8 + 8 k (8 lanes = the wave's 128 bytes of a pixel)
             const int cpiece = lane & 7, crow = lane >> 3;
 #pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
+            for (int hpi = 0; hpi < (N64 ? 1 : 2); ++hpi) {
+                const int hp = N64 ? wn : hpi;                                // (N64: the rows this wave finishes; their sums sit in acc[0..1])
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml) {
                     const int mt = hp * 2 + ml;
                     const bool ok = (cur.oy0 + 4 * wm + mt) < p.H && (cur.ox0 + l15) < p.W;
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        f32x4_t v = acc[mt][nt];
+                        f32x4_t v = N64 ? acc[ml][nt] : acc[hpi * 2 + ml][nt];
                         if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};           // pixels outside the image must not count in the statistics
                         store4(reinterpret_cast<T*>(Ow + (ml * 16 + l15) * RSW + (nt * 16 + lq * 4) * 2), v);
                     }
@@ -366,7 +433,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                     const int row = crow + 8 * k;                              // image row = (ml, l15)
                     const int oy = cur.oy0 + 4 * wm + hp * 2 + (row >> 4), ox = cur.ox0 + (row & 15);
                     if (oy < p.H && ox < p.W)
-                        *reinterpret_cast<uint4*>(y + (((long long)cur.img * p.H + oy) * p.W + ox) * p.ys + n0 + wn * 64 + cpiece * 8) =
+                        *reinterpret_cast<uint4*>(y + (((long long)cur.img * p.H + oy) * p.W + ox) * p.ys + n0 + (N64 ? 0 : wn * 64) + cpiece * 8) =
                             make_uint4(ca[k].x, ca[k].y, cb[k].x, cb[k].y);
                 }
             }
@@ -376,16 +443,30 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 for (int nt = 0; nt < 4; ++nt) {
                     const float q = r == 0 ? ga[nt][0] : (r == 1 ? ga[nt][1] : (r == 2 ? ga[nt][2] : ga[nt][3]));
                     if (lq == (l15 >> 2)) {
-                        const int cl = wn * 64 + nt * 16 + l15;
-                        red[(wm * 2 + 0) * 128 + cl] = sa[nt][0];
-                        red[(wm * 2 + 1) * 128 + cl] = q;
+                        if constexpr (N64) {
+                            const int cl = nt * 16 + l15;
+                            red[(wave * 2 + 0) * 64 + cl] = sa[nt][0];
+                            red[(wave * 2 + 1) * 64 + cl] = q;
+                        } else {
+                            const int cl = wn * 64 + nt * 16 + l15;
+                            red[(wm * 2 + 0) * 128 + cl] = sa[nt][0];
+                            red[(wm * 2 + 1) * 128 + cl] = q;
+                        }
                     }
                 }
                 // two rows of the 8 x 16-pixel partial slab: the tile's upper half (waves wm 0, 1) and lower half (wm 2, 3)
                 const int tiles_y8 = (p.H + 7) >> 3, tiles_x = (p.W + 15) >> 4, ty8 = cur.ty * 2 + st_half;
-                if (ty8 < tiles_y8) {
+                if (ty8 < tiles_y8 && (!N64 || st_c < 64)) {
                     const long long prow8 = ((long long)cur.img * tiles_y8 + ty8) * tiles_x + cur.tx;
                     st_dst = p.stats_part + (prow8 * 2 + st_which) * Cout + n0 + st_c;
+                }
+            }
+            // N64: the next tile's first weight stage is requested into the weight buffer that held slots 6 and 7
+            // (a raw barrier: the tile's output stores stay in flight)
+            if constexpr (N64) {
+                if (has_next) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
                 }
             }
         }
@@ -405,13 +486,18 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 #endif
 }
 
-template <typename T, bool AFFINE>
+template <typename T, bool AFFINE, bool N64>
 int launch_t(const Group& g, int blocks, hipStream_t st) {
     static unsigned long long attr_mask = 0;
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE>, kLds, &attr_mask));
-    conv3x3_kernel<T, AFFINE><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE, N64>, kLds, &attr_mask));
+    conv3x3_kernel<T, AFFINE, N64><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
+}
+template <typename T>
+int launch_v(const Group& g, int blocks, bool affine, bool n64, hipStream_t st) {
+    if (n64) return affine ? launch_t<T, true, true>(g, blocks, st) : launch_t<T, false, true>(g, blocks, st);
+    return affine ? launch_t<T, true, false>(g, blocks, st) : launch_t<T, false, false>(g, blocks, st);
 }
 
 }  // namespace
@@ -439,8 +525,9 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
     MPN_HIP(hipGetDevice(&dev));
     MPN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (begin > cus) begin = cus;   // `begin` is the grid size from here on
-    if (dtype == MPN_BF16) return affine ? launch_t<bf16_t, true>(g, begin, st) : launch_t<bf16_t, false>(g, begin, st);
-    if (dtype == MPN_F16) return affine ? launch_t<half_t, true>(g, begin, st) : launch_t<half_t, false>(g, begin, st);
+    const bool n64 = (jobs[0].Cout & 127) != 0;     // (the jobs of a group share Cin and Cout)
+    if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, st);
+    if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, st);
     MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");
 }
 

@@ -547,6 +547,20 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, T* __restr
     constexpr int EPK = 64 / ES;   // elements per k-step row
     const int Kin = transpose ? Cout_o : Cin_o;     // GEMM K channels
     const int Nout = transpose ? Cin_o : Cout_o;    // GEMM N channels
+    if (row_bytes == -2) {  // conv3x3.h, 64-channel tiles: [n-tile][chunk 64][kx][ky][k-step][co 64][64 bytes]
+        long long r = i;
+        const int e = (int)(r % 32); r /= 32;
+        const int n = (int)(r % 64); r /= 64;
+        const int ks = (int)(r % 2); r /= 2;
+        const int ky = (int)(r % 3); r /= 3;
+        const int kx = (int)(r % 3); r /= 3;
+        const int chunk = (int)(r % nchunk); r /= nchunk;
+        const int c = chunk * 64 + ks * 32 + e, co = (int)r * 64 + n, tap = ky * 3 + kx;
+        const float v = !transpose ? w[((long long)tap * Cin_o + c) * Cout_o + co] : w[((long long)(8 - tap) * Cin_o + co) * Cout_o + c];
+        const int q = e >> 3, within = e & 7;
+        out[i - e + ((q ^ mpn_c3::swz(n & 15)) * 8 + within)] = from_f32<T>(v);
+        return;
+    }
     if (row_bytes < 0) {    // the 256-pixel 3x3 kernel's image (conv3x3.h): [n-tile][chunk 64][kx][k-step][ky][co 128][64 bytes]
         long long r = i;
         const int e = (int)(r % 32); r /= 32;
@@ -634,6 +648,11 @@ PackGeom pack_geom(int Kin, int Nout, int taps, int es, int dtype) {
     if ((dtype == MPN_BF16 || dtype == MPN_F16) && mpn_c3::eligible(Kin, Nout, taps, es)) {
         g.BN = 128; g.n_tiles = Nout / 128; g.nchunk = Kin / 64; g.row_bytes = -1;
         g.tile_bytes = mpn_c3::tile_bytes(Kin); g.total_bytes = mpn_c3::packed_bytes(Kin, Nout);
+        return g;
+    }
+    if ((dtype == MPN_BF16 || dtype == MPN_F16) && mpn_c3::eligible64(Kin, Nout, taps, es)) {
+        g.BN = 64; g.n_tiles = Nout / 64; g.nchunk = Kin / 64; g.row_bytes = -2;
+        g.tile_bytes = mpn_c3::tile_bytes64(Kin); g.total_bytes = mpn_c3::packed_bytes(Kin, Nout);
         return g;
     }
     g.BN = (Nout % 128 == 0) ? 128 : 64;

@@ -52,7 +52,7 @@ class PoseResidualNet:
 
     def for_batch(self, batch):
         """The instance that runs this model at `batch` crops (activation buffers are per batch size, variables shared)."""
-        if int(batch) == self.B:
+        if int(batch) == self.valid:
             return self
         sib = self._siblings.get(int(batch))
         if sib is None:
@@ -62,7 +62,10 @@ class PoseResidualNet:
 
     def _init(self, values, batch, h, w, c, hidden, dtype, seed, share=None):
         _lib.lib()   # fail loudly without the HIP library
-        self.B, self.h, self.w, self.c, self.hidden = int(batch), h, w, c, hidden
+        # the crop axis is a GEMM dimension (a multiple of 8 elements): `valid` crops run in buffers of B = valid rounded up,
+        # the padding rows stay zero (inputs, loss gradient) and never enter the loss
+        self.valid = int(batch)
+        self.B, self.h, self.w, self.c, self.hidden = (int(batch) + 7) // 8 * 8, h, w, c, hidden
         self.n = h * w * c
         if self.n % 8 or hidden % 8:
             raise ValueError("h*w*c and hidden must be multiples of 8")
@@ -86,14 +89,14 @@ class PoseResidualNet:
             self.w1_op = W1 if dtype == torch.float32 else torch.empty((n, hidden), dtype=dtype, device=dev)
             self.w2t_op = torch.empty((n, hidden), dtype=dtype, device=dev)
             self.w2_conv = ops.PackedConv(W2.view(1, 1, hidden, n), dtype)
-            self._siblings = {self.B: self}
+            self._siblings = {self.valid: self}
         else:
             if (share.h, share.w, share.c, share.hidden, share.dtype) != (h, w, c, hidden, dtype):
                 raise ValueError("share_variables_of: geometry / dtype differ")
             for a in ("_arena", "theta", "grad", "adam_m", "adam_v", "vars", "grads", "global_step", "hyper", "w1_op",
                       "w2t_op", "w2_conv", "_siblings"):
                 setattr(self, a, getattr(share, a))
-            self._siblings[self.B] = self
+            self._siblings[self.valid] = self
             # the fp16 loss scale is a function of the batch size; Adam divides by the scale of the instance that steps
         f32 = torch.float32
         self.xt = torch.empty((n, B), dtype=dtype, device=dev)            # X^T
@@ -103,12 +106,13 @@ class PoseResidualNet:
         self.pre2 = torch.empty((B, n), dtype=dtype, device=dev)
         self.y2 = torch.empty((B, n), dtype=dtype, device=dev)
         self.logits = torch.empty((B, n), dtype=f32, device=dev)
-        self.dlogits = torch.empty((B, n), dtype=f32, device=dev)
+        self.dlogits = torch.zeros((B, n), dtype=f32, device=dev)     # (rows >= valid are never written: stay zero)
+        self._xpad = torch.zeros((B, h, w, c), dtype=f32, device=dev) if self.valid != B else None
         self.dpre2 = torch.empty((B, n), dtype=dtype, device=dev)
         self.dpre2t = torch.empty((n, B), dtype=dtype, device=dev)
         self.dhid = torch.empty((B, hidden), dtype=f32, device=dev)
         self.dpre1 = torch.empty((B, hidden), dtype=dtype, device=dev)
-        self.loss_part = torch.empty(B, dtype=f32, device=dev)
+        self.loss_part = torch.zeros(B, dtype=f32, device=dev)
         nparts = ops.conv_wgrad_num_parts(1, 1, n, B, hidden, 1, dtype)   # the two K = n contractions
         self.kslab = torch.empty(nparts * B * hidden, dtype=f32, device=dev)
         self._kparts = nparts
@@ -155,8 +159,11 @@ class PoseResidualNet:
         """x: f32 [b,h,w,c] device tensor (b == batch). Returns y2 = relu(fc2(relu(fc1(x)))) [b, n] (storage dtype);
         logits = x + y2 are formed by `loss` / `predict`."""
         B, n, dc = self.B, self.n, _lib.dtype_code(self.dtype)
-        if tuple(x.shape) != (B, self.h, self.w, self.c) or x.dtype != torch.float32 or not x.is_contiguous():
-            raise ValueError(f"x must be contiguous float32 [{B},{self.h},{self.w},{self.c}]")
+        if tuple(x.shape) != (self.valid, self.h, self.w, self.c) or x.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError(f"x must be contiguous float32 [{self.valid},{self.h},{self.w},{self.c}]")
+        if self._xpad is not None:
+            self._xpad[:self.valid].copy_(x)
+            x = self._xpad
         f32c = _lib.dtype_code(torch.float32)
         call("mpn_transpose_cast", ptr(x), f32c, ptr(self.xt), dc, B, n, stream_ptr())
         call("mpn_cast", ptr(x), f32c, ptr(self.x_op), dc, B * n, stream_ptr())
@@ -169,7 +176,9 @@ class PoseResidualNet:
 
     def loss(self, labels, with_grad=True):
         """labels f32 [b,h,w,c]. Returns the device scalar loss (prn_model.py:29); fills logits (and dlogits)."""
-        B = self.B
+        B = self.valid      # one block per crop; the mean runs over the valid crops only
+        if tuple(labels.shape) != (B, self.h, self.w, self.c) or labels.dtype != torch.float32 or not labels.is_contiguous():
+            raise ValueError(f"labels must be contiguous float32 [{B},{self.h},{self.w},{self.c}]")
         call("mpn_prn_loss", ptr(self._x), ptr(self.y2), _lib.dtype_code(self.dtype), ptr(labels), B, self.h * self.w, self.c,
              ptr(self.logits), ptr(self.dlogits) if with_grad else None, ptr(self.loss_part), self.loss_scale, stream_ptr())
         return self.loss_part.sum()
@@ -177,7 +186,8 @@ class PoseResidualNet:
     def predict(self, x):
         """Inference: logits [b,h,w,c] f32 (create_pb.py:112)."""
         self.forward(x)
-        return (x.reshape(self.B, self.n) + self.y2.float()).view(self.B, self.h, self.w, self.c)
+        v = self.valid
+        return (x.reshape(v, self.n) + self.y2[:v].float()).view(v, self.h, self.w, self.c)
 
     def backward(self):
         B, n, hidden, dc = self.B, self.n, self.hidden, _lib.dtype_code(self.dtype)

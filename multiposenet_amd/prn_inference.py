@@ -61,7 +61,7 @@ class KeypointAssigner:
         img = torch.arange(b, device=dev, dtype=torch.int32).view(b, 1).expand(b, max_boxes)
         box_ind = torch.where(slot < nb, img, torch.full_like(img, -1)).reshape(-1).contiguous()
         flat = boxes.reshape(-1, 4).to(torch.float32).contiguous()
-        n, B = flat.shape[0], self.net.B
+        n, B = flat.shape[0], self.net.valid
         scores, positions = [], []
         for s in range(0, n, B):   # the network is built for a fixed batch: pad the last chunk with zero crops
             fb, fi = flat[s:s + B], box_ind[s:s + B]

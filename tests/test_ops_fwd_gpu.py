@@ -41,6 +41,11 @@ CONV_CASES = [
     (6, 112, 112, 128, 128, 3, 1, True, False),  # 294 tiles on 256 persistent blocks: some blocks walk two tiles
     (3, 100, 52, 64, 256, 3, 2, True, False),    # one 64-channel chunk per tile, two n-tiles, ragged tiles (100 = 6 x 16 + 4)
     (2, 40, 24, 256, 128, 3, 0, False, False),   # four chunks, no affine / statistics (the data-gradient configuration)
+    # its 64-channel-tile variant (Cout % 128 == 64: the two waves of a row group split K and add their sums through LDS)
+    (5, 128, 128, 512, 64, 3, 1, True, False),   # final_conv3x3 at its full map: 320 tiles on 256 blocks, 8 chunks, affine + statistics
+    (2, 50, 38, 64, 64, 3, 1, True, False),      # the detector's tower shape, one chunk, ragged tiles
+    (3, 24, 40, 128, 192, 3, 2, True, False),    # three n-tiles of 64
+    (2, 33, 17, 256, 64, 3, 0, False, False),    # no affine / statistics (a tower's data gradient)
 ]
 
 
@@ -82,7 +87,7 @@ def test_conv_fwd(cuda, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-@pytest.mark.parametrize("k,Cin,Cout", [(3, 128, 128), (3, 512, 64), (1, 256, 128), (1, 64, 128), (1, 512, 1024), (1, 256, 512)])
+@pytest.mark.parametrize("k,Cin,Cout", [(3, 128, 128), (3, 512, 64), (3, 64, 64), (3, 64, 192), (1, 256, 128), (1, 64, 128), (1, 512, 1024), (1, 256, 512)])
 def test_conv_dgrad_is_transposed_conv(cuda, dtype, k, Cin, Cout):
     ops = _ops()
     rs = np.random.RandomState(k + Cin)

@@ -20,7 +20,7 @@ def t(fn, n=20):
 
 dt = torch.bfloat16
 N = 32
-for (H, Cin, Cout) in [(128, 128, 128), (64, 128, 128), (32, 128, 128), (16, 128, 128), (128, 512, 64), (128, 64, 512), (112, 256, 256)]:
+for (H, Cin, Cout) in [(128, 128, 128), (64, 128, 128), (32, 128, 128), (16, 128, 128), (128, 512, 64), (128, 64, 512), (112, 256, 256), (112, 64, 64), (56, 64, 64)]:
     x = torch.randn(N, H, H, Cin, device='cuda').to(dt)
     pc = ops.PackedConv(torch.randn(3, 3, Cin, Cout, device='cuda') * 0.05, dt)
     aff = ops.Affine(torch.rand(Cin, device='cuda') + 0.5, torch.randn(Cin, device='cuda') * 0.1, 1)
