@@ -258,6 +258,8 @@ def main():
         out["prn"] = prn_benchmark(128)
         from bench_legs import retinanet_benchmark
         out["retinanet"] = retinanet_benchmark(16)               # BASELINE config 4
+        from bench_legs import joint_inference_benchmark
+        out["joint_inference"] = joint_inference_benchmark()     # create_pb.py's graph behind inference/detector.py
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():   # (also the 1-rank rehearsal, MPN_DP_FORCE_COLLECTIVE=1)

@@ -492,3 +492,30 @@ def retinanet_benchmark(batch=16, height=896, width=1408, iters=10):
     del net
     torch.cuda.empty_cache()
     return out
+
+
+def joint_inference_benchmark(height=640, width=640, iters=110, discard=10):
+    """The reference's own latency loop (inference/predict.ipynb cell 16: a 640 x 640 image, 110 calls of `detector(image)`, the
+    first 10 discarded) on the joint graph of create_pb.py:44-153 - uint8 numpy image in, the seven numpy outputs back, ONE
+    backbone pass under the keypoint subnet and the RetinaNet head, NMS, crops, PRN, decode. Random-init weights (a class bias
+    that lets detections through), bf16 storage. Wall clock per call, host round trips included, like the notebook."""
+    import numpy as np
+    from multiposenet_amd.inference import Detector
+    from multiposenet_amd.prn import initial_values as prn_values
+    from multiposenet_amd.retinanet import initial_head_values
+    head = initial_head_values(0)
+    head["class_net/logits/bias"] = np.full(6, -0.5, np.float32)
+    det = Detector(None, dtype=torch.bfloat16, detector_path=head, prn_path=prn_values(seed=0))
+    image = np.random.RandomState(0).randint(0, 256, (height, width, 3)).astype(np.uint8)
+    times, nb = [], 0
+    for i in range(iters):
+        t0 = time.perf_counter()
+        out = det(image, score_threshold=0.0)
+        times.append(time.perf_counter() - t0)
+        nb = int(out["num_boxes"])
+    times = sorted(times[discard:])
+    del det
+    torch.cuda.empty_cache()
+    return {"ms_per_image": round(1e3 * sum(times) / len(times), 3), "median_ms": round(1e3 * times[len(times) // 2], 3),
+            "image": [height, width], "calls": iters - discard, "persons_detected": nb, "dtype": "bf16",
+            "note": "wall clock of Detector(image) with numpy in / numpy out (inference/predict.ipynb cell 16), random-init weights"}

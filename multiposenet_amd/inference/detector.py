@@ -1,74 +1,114 @@
-"""Detector with the reference's surface (inference/detector.py:5-61) for the keypoint outputs of the frozen graph."""
+"""Detector with the reference's surface (inference/detector.py:5-61) over the JOINT inference graph of create_pb.py:44-153:
+
+    uint8 image -> /255 -> ONE MobileNet pass -> keypoint subnet (sigmoid heatmaps, segmentation mask)
+                                              -> RetinaNet head -> NMS (score 0.3, IoU 0.6, 25 boxes: create_pb.py:31-36)
+                -> per-channel min-max normalised heatmaps -> crop_and_resize of every box -> PRN -> softmax / argmax_2d
+
+and returns the seven outputs of OUTPUT_NAMES (create_pb.py:22-26) with the score filter of inference/detector.py:54-59.
+The reference freezes three checkpoints into one `.pb` (create_pb.py:170-185); here the three variable sets are three `.npz`
+files keyed by the reference's variable names (multiposenet_amd.checkpoint)."""
 import numpy as np
 import torch
 
 from ..net import KeypointNet
 
+# create_pb.py:31-36: the thresholds frozen into the graph
+PARAMS = {'depth_multiplier': 1.0, 'score_threshold': 0.3, 'iou_threshold': 0.6, 'max_boxes': 25}
+
+
+def _load(path):
+    """A variable set: the path of an `.npz`, or a dict of arrays already in memory."""
+    if isinstance(path, dict):
+        return path
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
 
 class Detector:
     def __init__(self, model_path, gpu_memory_fraction=0.25, visible_device_list='0', dtype=torch.bfloat16, prn_path=None,
-                 max_boxes=32):
+                 max_boxes=None, detector_path=None, params=None):
         """
         Arguments:
-            model_path: path to a build-native weight file (.npz, keys = the reference's variable names, HWIO kernels:
-                what `KeypointNet.state_dict()` saves / a TF checkpoint exported elsewhere), or None for seeded random
-                weights. (The reference loads a frozen .pb, inference/detector.py:13-19.)
+            model_path: the keypoint model (create_pb.py KEYPOINTS_CHECKPOINT): `.npz`, keys = the reference's variable names,
+                HWIO kernels - what `KeypointNet.state_dict()` saves / a TF checkpoint exported by tools/tf_checkpoint_to_npz.py;
+                None = seeded random weights. (The reference loads ONE frozen .pb, inference/detector.py:13-19.) Its
+                `MobilenetV1/*` variables are the shared backbone (create_pb.py:170-173).
+            detector_path: the person detector's head (PERSON_DETECTOR_CHECKPOINT, variables `fpn/*`, `p{l}_batch_norm/*`,
+                `class_net/*`, `box_net/*`; its own `MobilenetV1/*` copy, if any, is ignored like create_pb.py:178-181 maps
+                only the head scope): `.npz`, a dict of arrays, or None = no boxes are detected (keypoint outputs only).
+            prn_path: the pose residual network (PRN_CHECKPOINT, `PRN/fc{1,2}/{weights,biases}`): `.npz` or None.
             gpu_memory_fraction: accepted for signature compatibility, unused (buffers are sized per input shape).
             visible_device_list: a string, the GPU index.
+            params: overrides of create_pb.py's PARAMS (score_threshold, iou_threshold, max_boxes).
         """
         device = f"cuda:{int(str(visible_device_list).split(',')[0])}"
-        values = None
-        if model_path is not None:
-            with np.load(model_path) as z:
-                values = {k: z[k] for k in z.files}
-        self.net = KeypointNet(values=values, dtype=dtype, device=device)
-        # prn_path: `.npz` with PRN/fc{1,2}/{weights,biases} (the frozen graph of create_pb.py holds both models): with it,
-        # person boxes handed to __call__ get their keypoints assigned (create_pb.py:86-142)
+        self.params = dict(PARAMS, **(params or {}))
+        if max_boxes is not None:
+            self.params['max_boxes'] = int(max_boxes)
+        values = _load(model_path) if model_path is not None else None
+        self.net = KeypointNet(values=values, depth_multiplier=self.params['depth_multiplier'], dtype=dtype, device=device)
+        self.retinanet = None
+        if detector_path is not None:
+            from ..retinanet import PersonDetectorNet
+            head = _load(detector_path)
+            self.retinanet = PersonDetectorNet(backbone=self.net)
+            own = set(self.retinanet.vars) | set(self.retinanet.stats)
+            self.retinanet.load_state_dict({k: v for k, v in head.items() if k in own}, strict=True)
         self.assigner = None
         if prn_path is not None:
             from ..prn import PoseResidualNet
             from ..prn_inference import KeypointAssigner
-            from ..checkpoint import load_npz
-            prn_net = PoseResidualNet(batch=max_boxes, dtype=dtype, device=device)
-            load_npz(prn_path, prn_net, with_optimizer=False)
+            prn_net = PoseResidualNet(values=_load(prn_path), batch=self.params['max_boxes'], dtype=dtype, device=device)
             self.assigner = KeypointAssigner(prn_net)
+
+    def _detect(self, feats, n, h, w):
+        """RetinaNet head + NMS on the shared backbone features (create_pb.py:70-81)."""
+        det = self.retinanet
+        b = det._buffers(n, h, w)
+        det.head_forward({k: feats[k] for k in ("c3", "c4", "c5")}, b, False)
+        p = self.params
+        return det.nms(b, p['score_threshold'], p['iou_threshold'], p['max_boxes'])
 
     def __call__(self, image, score_threshold=0.05, boxes=None, scores=None):
         """
         Arguments:
             image: a numpy uint8 array with shape [height, width, 3], that represents a RGB image.
             score_threshold: a float number.
-        Returns the reference's dict; only the keypoint-path entries are computed:
-            'keypoint_heatmaps' [h/4, w/4, 17] = sigmoid(logits[..., :17]), 'segmentation_masks' [h/4, w/4]
-            (create_pb.py:73-76). Person boxes come from the caller (`boxes`, `scores`: the RetinaNet head is out of scope); with them
-            and `prn_path` the PRN outputs 'keypoint_scores' [n,17] / 'keypoint_positions' [n,17,2] are computed, otherwise empty.
+            boxes, scores: person boxes [n,4] normalised (ymin, xmin, ymax, xmax) (+ scores [n]) from the caller INSTEAD of the
+                RetinaNet head's (for models without a detector_path); not part of the reference's signature.
+        Returns the reference's dict (inference/detector.py:49-61): 'boxes' [n,4], 'scores' [n], 'num_boxes' (the graph's
+        count before the score filter), 'keypoint_heatmaps' [h/4,w/4,17], 'segmentation_masks' [h/4,w/4],
+        'keypoint_scores' [n,17], 'keypoint_positions' [n,17,2].
         """
         h, w, _ = image.shape
         assert h % 128 == 0 and w % 128 == 0                      # inference/detector.py:45
         if image.dtype != np.uint8:
             raise ValueError("image must be uint8")
-        x = torch.from_numpy(np.ascontiguousarray(image[None])).to(self.net.device)
-        heat, seg = self.net.predict(x)                            # uint8 -> /255 -> 2x-1 fused into the stem conv
-        if boxes is not None and self.assigner is not None and len(boxes):
-            # boxes [n,4] normalised (ymin, xmin, ymax, xmax) from a person detector (the reference's RetinaNet head is not
-            # part of this build), scores [n] or None; same filtering as inference/detector.py:55-60
-            boxes = np.asarray(boxes, np.float32).reshape(-1, 4)
-            scores = np.ones(len(boxes), np.float32) if scores is None else np.asarray(scores, np.float32)
-            keep = scores > score_threshold
-            boxes, scores = boxes[keep], scores[keep]
-            kscore = np.zeros([0, 17], np.float32)
-            kpos = np.zeros([0, 17, 2], np.float32)
-            if len(boxes):
-                db = torch.from_numpy(boxes[None]).to(self.net.device)
-                ks, kp = self.assigner(heat.contiguous(), db, torch.tensor([len(boxes)], device=self.net.device), compact=True)
-                kscore, kpos = ks.cpu().numpy(), kp.cpu().numpy()
-            return {
-                'keypoint_heatmaps': heat[0].cpu().numpy(), 'segmentation_masks': seg[0].cpu().numpy(),
-                'boxes': boxes, 'scores': scores, 'num_boxes': np.int32(len(boxes)),
-                'keypoint_scores': kscore, 'keypoint_positions': kpos,
-            }
-        return {
-            'keypoint_heatmaps': heat[0].cpu().numpy(), 'segmentation_masks': seg[0].cpu().numpy(),
-            'boxes': np.zeros([0, 4], np.float32), 'scores': np.zeros([0], np.float32), 'num_boxes': np.int32(0),
-            'keypoint_scores': np.zeros([0], np.float32), 'keypoint_positions': np.zeros([0, 17, 2], np.float32),
-        }
+        net = self.net
+        x = torch.from_numpy(np.ascontiguousarray(image[None])).to(net.device)
+        bufs = net._buffers(1, h, w)
+        feats = net.backbone_forward(x, False, bufs)               # uint8 -> /255 -> 2x-1 fused into the stem conv; ONE pass
+        heat, seg = net.subnet_forward(feats, False, bufs, inference_outputs=True)
+        out = {'keypoint_heatmaps': heat[0].cpu().numpy(), 'segmentation_masks': seg[0].cpu().numpy()}
+        if boxes is not None:
+            gb = np.asarray(boxes, np.float32).reshape(-1, 4)
+            gs = np.ones(len(gb), np.float32) if scores is None else np.asarray(scores, np.float32)
+            n = len(gb)
+            dboxes = torch.from_numpy(gb[None]).to(net.device) if n else None
+        elif self.retinanet is not None:
+            pred = self._detect(feats, 1, h, w)
+            n = int(pred['num_boxes'][0].item())
+            dboxes = pred['boxes']
+            gb, gs = dboxes[0, :n].cpu().numpy(), pred['scores'][0, :n].cpu().numpy()
+        else:
+            n, dboxes = 0, None
+            gb, gs = np.zeros([0, 4], np.float32), np.zeros([0], np.float32)
+        kscore, kpos = np.zeros([0, 17], np.float32), np.zeros([0, 17, 2], np.float32)
+        if n and self.assigner is not None:
+            ks, kp = self.assigner(heat.contiguous(), dboxes, torch.tensor([n], device=net.device), compact=True)
+            kscore, kpos = ks.cpu().numpy(), kp.cpu().numpy()
+        keep = gs > score_threshold                                # inference/detector.py:54-59
+        out.update({'boxes': gb[keep], 'scores': gs[keep], 'num_boxes': np.int32(n),
+                    'keypoint_scores': kscore[keep] if len(kscore) else kscore,
+                    'keypoint_positions': kpos[keep] if len(kpos) else kpos})
+        return out

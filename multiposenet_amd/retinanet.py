@@ -149,16 +149,21 @@ class _Conv:
 @_lib.device_guarded("_init", "load_state_dict", "repack_weights", "forward", "create_targets", "compute_losses", "backward",
                      "optimizer_step", "train_step", "predict", "nms", "head_forward")
 class PersonDetectorNet:
-    def __init__(self, backbone_values=None, head_values=None, depth_multiplier=1.0, dtype=torch.bfloat16, device="cuda:0", seed=0):
-        dev = torch.device(device)
+    def __init__(self, backbone_values=None, head_values=None, depth_multiplier=1.0, dtype=torch.bfloat16, device="cuda:0", seed=0,
+                 backbone=None):
+        """backbone: a KeypointNet whose MobileNet this detector SHARES (the joint inference graph of create_pb.py:64-71 runs
+        one backbone under the keypoint subnet and the RetinaNet head) instead of building its own frozen copy."""
+        dev = torch.device(device) if backbone is None else backbone.device
         if dev.type == "cuda" and dev.index is None:
             dev = torch.device("cuda", torch.cuda.current_device())
+        if backbone is not None:
+            dtype, depth_multiplier = backbone.dtype, backbone.dm
         self.device, self.dtype, self.dm = dev, dtype, depth_multiplier
-        self._init(backbone_values, head_values, seed)
+        self._init(backbone_values, head_values, seed, backbone)
 
-    def _init(self, backbone_values, head_values, seed):
+    def _init(self, backbone_values, head_values, seed, backbone=None):
         # the frozen backbone: a KeypointNet's MobileNet part in inference mode (person_detector_model.py:14-17)
-        self.backbone = KeypointNet(depth_multiplier=self.dm, dtype=self.dtype, device=self.device, seed=seed)
+        self.backbone = backbone if backbone is not None else KeypointNet(depth_multiplier=self.dm, dtype=self.dtype, device=self.device, seed=seed)
         if backbone_values is not None:
             self.backbone.load_state_dict({k: v for k, v in backbone_values.items() if k.startswith("MobilenetV1/")}, strict=False)
         shapes = head_variable_shapes(self.dm)
@@ -251,7 +256,7 @@ class PersonDetectorNet:
         anchors, shapes = generate_anchors(H, W)
         lv = {l: shapes[i] for i, l in enumerate(LEVELS)}
         b = {"shape": key, "lv": lv, "A": anchors.shape[0], "anchors": torch.from_numpy(anchors).to(dev)}
-        b["bb"] = self.backbone._buffers(N, H, W, head=False)
+        b["bb"] = None      # the backbone's buffers: allocated by forward() (head_forward on shared features needs none)
         b["x"] = {l: act(*lv[l], DEPTH) for l in (3, 4, 5)}
         b["p"] = {l: act(*lv[l], DEPTH) for l in LEVELS}
         c5 = self.pconv[6].cin // 9
@@ -330,6 +335,8 @@ class PersonDetectorNet:
         """images [N,H,W,3] f32 in [0,1] (or uint8). Fills the per-level raw outputs b['out'][net][l]; returns the buffer set."""
         N, H, W, _ = images.shape
         b = self._buffers(N, H, W)
+        if b["bb"] is None:
+            b["bb"] = self.backbone._buffers(N, H, W, head=False)
         feats = self.backbone.backbone_forward(images, False, b["bb"])        # frozen: moving statistics
         return self.head_forward(feats, b, is_training, images)
 

@@ -79,7 +79,8 @@ def test_detector_with_prn_assigns_keypoints_to_given_boxes(cuda, tmp_path):
     boxes = np.array([[0.1, 0.1, 0.9, 0.6], [0.3, 0.4, 0.8, 0.95], [0.0, 0.0, 1.0, 1.0]], np.float32)
     scores = np.array([0.9, 0.01, 0.5], np.float32)
     out = det(img, score_threshold=0.05, boxes=boxes, scores=scores)
-    assert out["num_boxes"] == 2 and out["boxes"].shape == (2, 4)            # the 0.01 box is filtered (detector.py:55-60)
+    # the 0.01 box is filtered (inference/detector.py:54-59); 'num_boxes' stays the graph's count, as in the reference
+    assert out["num_boxes"] == 3 and out["boxes"].shape == (2, 4)
     assert out["keypoint_scores"].shape == (2, 17) and out["keypoint_positions"].shape == (2, 17, 2)
     # the same chain on the CPU restatements, from the detector's own heatmaps
     hm = out["keypoint_heatmaps"][None]
@@ -91,6 +92,68 @@ def test_detector_with_prn_assigns_keypoints_to_given_boxes(cuda, tmp_path):
     np.testing.assert_allclose(out["keypoint_scores"], ws, rtol=5e-3)
     assert np.mean(np.all(out["keypoint_positions"] == wp, axis=-1)) >= 0.9
     assert det(img)["keypoint_positions"].shape == (0, 17, 2)                # without boxes: empty, as before
+
+
+def test_detector_joint_graph_matches_the_oracle_chain(cuda, tmp_path):
+    """Detector(model_path, detector_path=, prn_path=) = the joint graph of create_pb.py:44-153: ONE backbone pass under the
+    keypoint subnet and the RetinaNet head, NMS (0.3 / 0.6 / 25), crops of the min-max-normalised heatmaps, PRN, argmax_2d -
+    all seven outputs against the chain of CPU restatements (oracle/network + retinanet + prn_post + prn) on one 256x384 image."""
+    from multiposenet_amd.inference import Detector
+    from multiposenet_amd.prn import initial_values
+    from multiposenet_amd.retinanet import generate_anchors
+    from oracle import prn as oprn, prn_post as opost, retinanet as R
+    from test_retinanet_gpu import _setup
+    H, W = 256, 384
+    bb, hp, _, _, _ = _setup(31, 1, H, W)
+    # lively class logits: enough candidates above the 0.3 threshold, scores spread out (random-init towers give nearly
+    # equal scores, and NMS order among near-ties is not a property of the graph)
+    hp["class_net/logits/kernel"] = (np.random.RandomState(8).randn(3, 3, 64, 6) * 0.4).astype(np.float32)
+    hp["class_net/logits/bias"] = np.full(6, -2.0, np.float32)
+    pvals = initial_values(seed=5)
+    kpath, dpath, ppath = tmp_path / "keypoints.npz", tmp_path / "detector.npz", tmp_path / "prn.npz"
+    np.savez(kpath, **bb); np.savez(dpath, **hp); np.savez(ppath, **pvals)
+    det = Detector(str(kpath), dtype=torch.float32, detector_path=str(dpath), prn_path=str(ppath))
+    img = np.random.RandomState(4).randint(0, 256, (H, W, 3)).astype(np.uint8)
+    out = det(img, score_threshold=0.0)
+    assert set(out) == {"boxes", "scores", "num_boxes", "keypoint_heatmaps", "segmentation_masks", "keypoint_scores", "keypoint_positions"}
+    # ---- the oracle chain
+    x = torch.tensor(img[None].astype(np.float32) * np.float32(1 / 255.0))
+    with torch.no_grad():
+        heat, _ = onet.forward(x, {k: torch.tensor(v) for k, v in bb.items()}, False)
+        enc, cls, _ = R.forward(x, {k: torch.tensor(v) for k, v in bb.items()}, {k: torch.tensor(v) for k, v in hp.items()}, False)
+    anchors, _ = generate_anchors(H, W)
+    wb, ws, wn = R.get_predictions(enc.numpy(), cls.numpy(), anchors, 0.3, 0.6, 25)
+    whm = torch.sigmoid(heat[0, ..., :17]).numpy()
+    np.testing.assert_allclose(out["keypoint_heatmaps"], whm, atol=1e-3)
+    np.testing.assert_allclose(out["segmentation_masks"], heat[0, ..., 17].numpy(), atol=2e-3, rtol=1e-3)
+    n = int(wn[0])
+    assert n >= 3 and int(out["num_boxes"]) == n
+    # detections identical wherever the oracle's scores are not within 1e-3 of a neighbour (a near-tie may swap two slots)
+    gaps = np.abs(np.diff(ws[0, :n]))
+    decided = np.concatenate([[True], gaps > 1e-3]) & np.concatenate([gaps > 1e-3, [True]])
+    assert decided.sum() >= 3, (decided, ws[0, :n])
+    np.testing.assert_allclose(out["scores"][decided], ws[0, :n][decided], atol=1e-3)
+    np.testing.assert_allclose(out["boxes"][decided], wb[0, :n][decided], atol=2e-3)
+    # keypoint assignment: the restatement chain on the detector's own heatmaps and boxes
+    norm, _, _ = opost.normalize_heatmaps(out["keypoint_heatmaps"][None])
+    crops = opost.crop_and_resize(norm, out["boxes"], np.zeros(len(out["boxes"]), np.int32), (56, 36))
+    pt = {k: torch.tensor(v, dtype=torch.float64) for k, v in pvals.items()}
+    wsc, wpos = opost.decode(oprn.prn(torch.tensor(crops, dtype=torch.float64), pt).numpy().astype(np.float32))
+    assert out["keypoint_scores"].shape == (n, 17) and out["keypoint_positions"].shape == (n, 17, 2)
+    np.testing.assert_allclose(out["keypoint_scores"], wsc, rtol=5e-3)
+    assert np.mean(np.all(out["keypoint_positions"] == wpos, axis=-1)) >= 0.9
+    # the score filter of inference/detector.py:54-59 on top of the graph's outputs
+    thr = float(np.median(out["scores"]))
+    flt = det(img, score_threshold=thr)
+    keep = out["scores"] > thr
+    assert int(flt["num_boxes"]) == n and len(flt["boxes"]) == int(keep.sum()) < n
+    np.testing.assert_array_equal(flt["keypoint_positions"], out["keypoint_positions"][keep])
+    # ONE backbone: the detector's head holds no MobileNet of its own
+    assert det.retinanet.backbone is det.net
+    # bf16 build of the same graph: runs, finite, the same number of outputs
+    o16 = Detector(str(kpath), dtype=torch.bfloat16, detector_path=str(dpath), prn_path=str(ppath))(img, score_threshold=0.0)
+    assert np.isfinite(o16["keypoint_heatmaps"]).all() and len(o16["boxes"]) == int(o16["num_boxes"]) > 0
+    assert o16["keypoint_positions"].shape == (len(o16["boxes"]), 17, 2)
 
 
 @pytest.mark.parametrize("image_dtype", [torch.float32, torch.uint8], ids=["f32", "u8"])
