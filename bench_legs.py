@@ -19,7 +19,7 @@ def whole_step_mfma_fraction(batch, size, step_seconds):
 
 
 def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20, b=None):
-    """The dominant kernel of the step is the dense 3x3 implicit-GEMM conv (conv_mfma_kernel, 128->128 channels
+    """The dominant kernel of the step is the dense 3x3 implicit-GEMM conv (conv3x3_kernel of csrc/conv3x3.hip, 128->128 channels
     at stride 4: p2, phi_subnet_2/conv1, conv2 forward and their three data-gradients = 6 launches per step).
     Times that launch with HIP events on the launch stream, on the tensors of the live network - in the form the forward
     runs it (producer's batch-norm affine + ReLU on load, batch-norm partial sums of the output in the epilogue: 3 of the

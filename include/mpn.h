@@ -372,6 +372,8 @@ int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, void* dpre, i
  * 1 / grad_scale to mpn_adam_step) */
 int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const float* labels, int B, int P, int C,
                  float* logits, float* dlogits, float* loss_part, float grad_scale, mpn_stream_t stream);
+/* logits[i] = x[i] + y2[i]: the residual connection of detector/prn.py:24 at inference (create_pb.py:112) */
+int mpn_prn_residual(const float* x, const void* y2, int y2_dtype, long long n, float* logits, mpn_stream_t stream);
 
 /* PRN inference glue (create_pb.py:86-142): what sits between the sigmoid heatmaps / the detector's boxes and the
  * network, and between its logits and the exported `keypoint_scores` / `keypoint_positions`.
@@ -387,6 +389,12 @@ int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const float* labe
 int mpn_heatmap_minmax(const float* heatmaps, int B, int h, int w, int C, void* minmax_keys, mpn_stream_t stream);
 int mpn_prn_crop(const float* heatmaps, const void* minmax_keys, const float* boxes, const int* box_ind, int nb, int B,
                  int h, int w, int C, int crop_h, int crop_w, float threshold, float* crops, mpn_stream_t stream);
+/* mpn_prn_crop for `nb` consecutive slots slot0.. of a detector's padded output (boxes f32 [B,max_boxes,4], num_boxes i32
+ * [B], retinanet.py:60-84): slot s = box s % max_boxes of image s / max_boxes; padding slots and slots past the array give
+ * zero crops - the [:n] slices, box_ind vectors and concat of create_pb.py:96-104 without materialising them. */
+int mpn_prn_crop_slots(const float* heatmaps, const void* minmax_keys, const float* boxes, const int* num_boxes, int slot0,
+                       int nb, int max_boxes, int B, int h, int w, int C, int crop_h, int crop_w, float threshold,
+                       float* crops, mpn_stream_t stream);
 int mpn_prn_decode(const float* logits, int nb, int crop_h, int crop_w, int C, float* scores, float* positions,
                    mpn_stream_t stream);
 
@@ -426,6 +434,14 @@ int mpn_retina_loss(const void* const* logits, const void* const* boxes, void* c
                     const int* matches, const float* targets, const int* num_matched, int B, float gamma, float alpha,
                     float localization_loss_weight, float classification_loss_weight, float* part,
                     mpn_stream_t stream);
+/* The scalar losses of a step from the reduced partial sums (retinanet.py:128-144, person_detector_model.py:33-45):
+ * sums f32 [32] = {cls, loc, dbias_cls[6], dbias_box[24]} (mpn_reduce_partials of mpn_retina_loss's parts);
+ * losses f32 [4] = {localization = sums[1] / max(num_matched, 1), classification = sums[0] / max(num_matched, 1),
+ * regularization (left as the caller accumulated it), total = loc_w * localization + cls_w * classification + regularization};
+ * dbias_cls f32 [6] / dbias_box f32 [24] (may be NULL) receive the output convolutions' bias gradients. */
+int mpn_retina_loss_finalize(const float* sums, const int* num_matched, float localization_loss_weight,
+                             float classification_loss_weight, float* losses, float* dbias_cls, float* dbias_box,
+                             mpn_stream_t stream);
 size_t mpn_retina_nms_workspace_bytes(int B, int A);
 int mpn_retina_nms(const void* const* logits, const void* const* boxes, const int* h, const int* w, int dtype,
                    const float* cls_bias, const float* box_bias, const float* anchors, int B, float score_threshold,

@@ -95,6 +95,9 @@ SIGNATURES = {
     "mpn_heatmap_minmax": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "mpn_prn_crop": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "mpn_prn_decode": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
+    "mpn_prn_crop_slots": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
+    "mpn_prn_residual": (_I, [_P, _P, _I, _L, _P, _P]),
+    "mpn_retina_loss_finalize": (_I, [_P, _P, _F, _F, _P, _P, _P, _P]),
     "mpn_axpy": (_I, [_L, _F, _P, _P, _P]),
     "mpn_patchify3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_unpatchify3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/mpn.h"
 
 // ---------------------------------------------------------------- errors
@@ -36,15 +37,18 @@ void mpn_set_error(const char* fmt, ...);
     } while (0)
 
 // Dynamic-LDS limit of a kernel above the 64 KB default: HIP function attributes are PER DEVICE, so the "already set"
-// record is a bit per device ordinal (one process may drive several GPUs). `mask` is a static of the calling launcher.
-static inline hipError_t mpn_ensure_dynamic_lds(const void* func, int bytes, unsigned long long* mask) {
+// record is a bit per device ordinal (one process may drive several GPUs). `mask` is a static of the calling launcher,
+// atomic: two host threads may race on a kernel's first launch - both then set the (idempotent) attribute, neither
+// launches before it is set, and no bit of another device is lost.
+typedef std::atomic<unsigned long long> mpn_attr_mask_t;
+static inline hipError_t mpn_ensure_dynamic_lds(const void* func, int bytes, mpn_attr_mask_t* mask) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     const unsigned long long bit = 1ull << (dev & 63);
-    if (*mask & bit) return hipSuccess;
+    if (mask->load(std::memory_order_acquire) & bit) return hipSuccess;
     e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) *mask |= bit;
+    if (e == hipSuccess) mask->fetch_or(bit, std::memory_order_release);
     return e;
 }
 

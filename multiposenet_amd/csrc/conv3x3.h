@@ -36,6 +36,14 @@ struct Job {
                           // the tiled kernel writes: mpn_conv_num_parts), or NULL
     int in_act;
     int N, H, W, Cin, Cout, xs, ys;
+    // Data-gradient launches that also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn): y is the gradient w.r.t. the
+    // ACTIVATED output of a batch-norm layer whose raw input is bnr_x [N,H,W,*] (pixel stride bnr_xs, Cout channels). The tile
+    // is written MASKED (g = y where lo < bnr_x * bnr_scale + bnr_shift < hi, else 0: the activation's derivative) and
+    // stats_part receives the partial sums of g and of g * bnr_x (raw: the finalize turns them into sum g * xhat).
+    const void* bnr_x;    // NULL: a plain convolution
+    const float* bnr_scale;
+    const float* bnr_shift;
+    int bnr_act, bnr_xs;
 #ifdef MPN_DIAG
     unsigned long long* dbg;
 #endif

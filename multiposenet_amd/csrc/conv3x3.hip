@@ -117,8 +117,9 @@ __device__ __forceinline__ Tile tile_of(const Group& g, int w) {
 // 64 pixels x 64 channels, stores them straight from the registers (8 bytes per lane: the four 16-channel pieces of a
 // pixel's 128 bytes come from four consecutive stores of one wave and merge in the L2) and - when statistics are asked for -
 // takes them from a wave-private LDS image of 32 pixels at a time in the halo buffer that has just been released.
-template <typename T, bool AFFINE, bool N64>
+template <typename T, bool AFFINE, bool N64, bool BNR = false>
 __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
+    static_assert(!BNR || (!AFFINE && !N64), "the fused batch-norm backward reduction rides on the 128-channel data gradient");
     constexpr int NS = N64 ? 3 : 6;     // weight stages per 64-channel chunk
     constexpr int BN = N64 ? 64 : 128;  // output channels per tile
     using H = H16<T>;
@@ -136,9 +137,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     int w = blockIdx.x;
     if ((gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (w >= total) return;
-#ifdef MPN_DIAG
-    if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-#endif
 #ifdef MPN_DIAG
     if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -178,6 +176,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         if constexpr (AFFINE) {
             if (job != tab_job) {
                 for (int i = tid; i < Cin; i += kThreads) { tab[i] = g.job[job].in_scale[i]; tab[kMaxCin + i] = g.job[job].in_shift[i]; }
+                tab_job = job;
+            }
+        }
+        if constexpr (BNR) {   // (no producer affine in a data gradient: the table holds the fed batch-norm's scale / shift)
+            if (job != tab_job) {
+                for (int i = tid; i < Cout; i += kThreads) { tab[i] = g.job[job].bnr_scale[i]; tab[kMaxCin + i] = g.job[job].bnr_shift[i]; }
                 tab_job = job;
             }
         }
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 
 template <typename T, bool AFFINE, bool N64>
 int launch_t(const Group& g, int blocks, hipStream_t st) {
-    static unsigned long long attr_mask = 0;
+    static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE, N64>, kLds, &attr_mask));
     conv3x3_kernel<T, AFFINE, N64><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
     MPN_LAUNCH_CHECK();

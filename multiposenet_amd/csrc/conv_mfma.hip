@@ -749,7 +749,7 @@ template <typename T, int TAPS, int BN, int RB>
 static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
     constexpr int smem = conv_smem_bytes<TAPS, BN, RB>();
     static_assert(sizeof(T) != 2 || smem >= 128 * (BN * 2 + 8) + 4 * BN * 4, "the output image of the epilogue fits");
-    static unsigned long long attr_mask = 0;
+    static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_kernel<T, TAPS, BN, RB>, smem, &attr_mask));
     conv_mfma_kernel<T, TAPS, BN, RB><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
@@ -841,7 +841,7 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
 template <int BN>
 static int launch_conv_grouped(const ConvGroup& grp, int grid, hipStream_t st) {
     constexpr int smem = conv_smem_bytes<9, BN, 128>();
-    static unsigned long long attr_mask = 0;
+    static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_grouped_kernel<bf16_t, 9, BN, 128>, smem, &attr_mask));
     conv_mfma_grouped_kernel<bf16_t, 9, BN, 128><<<dim3((unsigned)grid), dim3(kThreads), smem, st>>>(grp);
     MPN_LAUNCH_CHECK();

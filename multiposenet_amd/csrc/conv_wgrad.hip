@@ -688,7 +688,7 @@ int launch_wgrad_bf16(const WgradParams& p, hipStream_t st) {
     constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int smem = 2 * NPIXA * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * (RBA / 2) * (int)sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static unsigned long long attr_mask = 0;
+    static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_bf16_kernel<T, TAPS, RBA, RBD, WM, STAGGER>, smem, &attr_mask));
     conv_wgrad_bf16_kernel<T, TAPS, RBA, RBD, WM, STAGGER><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(512), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
@@ -699,7 +699,7 @@ template <typename T, int TAPS, int RBA, int RBD>
 int launch_wgrad_g(const WgradParams& p, hipStream_t st) {
     constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int smem = NPIXA * RBA + 128 * RBD;
-    static unsigned long long attr_mask = 0;
+    static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_kernel<T, TAPS, RBA, RBD>, smem, &attr_mask));
     conv_wgrad_kernel<T, TAPS, RBA, RBD><<<dim3((unsigned)(p.n_cg * p.n_cb * p.nsplit)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
@@ -809,7 +809,7 @@ template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
 int launch_wgrad_bf16_grouped(const WgradGroup& g, int blocks, hipStream_t st) {
     constexpr int NPIXA = TAPS == 9 ? kHaloW * kHaloH : 128;
     constexpr int smem = 2 * NPIXA * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * (RBA / 2) * (int)sizeof(float);
-    static unsigned long long attr_mask = 0;
+    static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_wgrad_bf16_grouped_kernel<T, TAPS, RBA, RBD, WM, STAGGER>, smem, &attr_mask));
     conv_wgrad_bf16_grouped_kernel<T, TAPS, RBA, RBD, WM, STAGGER><<<dim3((unsigned)blocks), dim3(512), smem, st>>>(g);
     MPN_LAUNCH_CHECK();

@@ -1112,7 +1112,7 @@ template <int STRIDE> size_t dw_smem(int ve, int nred, int nvg) {
 }
 
 template <typename K> int set_smem(K kernel, size_t bytes) {
-    static unsigned long long attr_mask = 0;   // (one instance per kernel type K; the sizes used are <= the first one's)
+    static mpn_attr_mask_t attr_mask{0};   // (one instance per kernel type K; the sizes used are <= the first one's)
     if (bytes > 48 * 1024) MPN_HIP(mpn_ensure_dynamic_lds((const void*)kernel, (int)bytes, &attr_mask));
     return MPN_OK;
 }

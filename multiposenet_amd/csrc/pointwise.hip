@@ -431,7 +431,7 @@ int launch_pw(const PwParams& p, hipStream_t st) {
     const int need = BM * (BN * 2 + 8) + (BM == 128 ? 4 * BN * (int)sizeof(float) : 0);   // the epilogue's image (+ red)
     const int bytes = smem > need ? smem : need;
     MPN_REQUIRE(bytes <= 160 * 1024, MPN_ERR_BAD_SHAPE, "pointwise: K = %d needs %d bytes of LDS", p.K, bytes);
-    static unsigned long long attr_mask = 0;
+    static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)pw_gemm_kernel<BM, AFFINE>, 160 * 1024, &attr_mask));
     pw_gemm_kernel<BM, AFFINE><<<dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(kThreads), bytes, st>>>(p);
     MPN_LAUNCH_CHECK();

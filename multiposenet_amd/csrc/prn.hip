@@ -196,6 +196,22 @@ extern "C" int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, vo
     return MPN_OK;
 }
 
+template <typename TS>
+__global__ void prn_residual_kernel(const float* __restrict__ x, const TS* __restrict__ y2, float* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out[i] = x[i] + to_f32(y2[i]);
+}
+
+/* logits = x + y2 (detector/prn.py:24: the residual connection at inference; the loss kernel forms it itself) */
+extern "C" int mpn_prn_residual(const float* x, const void* y2, int y2_dtype, long long n, float* logits, mpn_stream_t stream) {
+    MPN_REQUIRE(x && y2 && logits && n > 0, MPN_ERR_BAD_ARG, "prn_residual: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int g = blocks_for(n);
+    PRN_DISPATCH_ONE(y2_dtype, TS, (prn_residual_kernel<TS><<<g, kThreads, 0, st>>>(x, (const TS*)y2, logits, n)));
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
 /* PRN loss (prn_model.py:16-30): logits = x + y2 [B][P][C]; softmax over P; mean log_loss; C <= 17.
  * logits, dlogits (may be NULL): f32 [B][P][C]; loss_part: f32 [B] (sum = loss).
  * grad_scale: dlogits = grad_scale * dloss/dlogits - the static loss scale of the fp16 build (the unscaled gradient of a

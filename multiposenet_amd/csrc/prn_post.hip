@@ -80,6 +80,7 @@ __global__ __launch_bounds__(kThreads) void minmax_kernel(const float* __restric
 // one thread per crop element, channels fastest (the 17 channels of a tap are 68 contiguous bytes, stores are dense)
 __global__ __launch_bounds__(kThreads) void crop_kernel(const float* __restrict__ hm, const unsigned* __restrict__ keys,
                                                        const float* __restrict__ boxes, const int* __restrict__ box_ind,
+                                                       const int* __restrict__ num_boxes, int max_boxes, int slot0,
                                                        long long total, int B, int H, int W, int C, int CH, int CW,
                                                        float thresh, float* __restrict__ crops) {
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < total; i += (long long)gridDim.x * kThreads) {
@@ -88,10 +89,19 @@ __global__ __launch_bounds__(kThreads) void crop_kernel(const float* __restrict_
         const int x = (int)(r % CW); r /= CW;
         const int y = (int)(r % CH);
         const int n = (int)(r / CH);
-        const int b = box_ind[n];
+        // box of crop n: boxes[n] of image box_ind[n], or (box_ind == NULL) slot slot0 + n of a [B, max_boxes, 4] detection
+        // array - image s / max_boxes, live when s % max_boxes < num_boxes[image] (create_pb.py:96-104)
+        int b, bn = n;
+        if (box_ind != nullptr) {
+            b = box_ind[n];
+        } else {
+            bn = slot0 + n;
+            const int img = bn / max_boxes;
+            b = (img < B && bn - img * max_boxes < num_boxes[img]) ? img : -1;
+        }
         float out = 0.f;   // extrapolation value
         if (b >= 0 && b < B) {
-            const float y1 = boxes[n * 4 + 0], x1 = boxes[n * 4 + 1], y2 = boxes[n * 4 + 2], x2 = boxes[n * 4 + 3];
+            const float y1 = boxes[bn * 4 + 0], x1 = boxes[bn * 4 + 1], y2 = boxes[bn * 4 + 2], x2 = boxes[bn * 4 + 3];
             // tensorflow/core/kernels/crop_and_resize_op.cc (1.15), bilinear
             const float hs = (CH > 1) ? (y2 - y1) * (float)(H - 1) / (float)(CH - 1) : 0.f;
             const float ws = (CW > 1) ? (x2 - x1) * (float)(W - 1) / (float)(CW - 1) : 0.f;
@@ -183,8 +193,27 @@ extern "C" int mpn_prn_crop(const float* heatmaps, const void* minmax_keys, cons
     const long long total = (long long)nb * crop_h * crop_w * C;
     long long blocks = (total + kThreads - 1) / kThreads;
     if (blocks > 16384) blocks = 16384;
-    crop_kernel<<<(unsigned)blocks, kThreads, 0, (hipStream_t)stream>>>(heatmaps, (const unsigned*)minmax_keys, boxes, box_ind, total,
-                                                                       B, h, w, C, crop_h, crop_w, threshold, crops);
+    crop_kernel<<<(unsigned)blocks, kThreads, 0, (hipStream_t)stream>>>(heatmaps, (const unsigned*)minmax_keys, boxes, box_ind, nullptr, 1,
+                                                                       0, total, B, h, w, C, crop_h, crop_w, threshold, crops);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* The same for `nb` consecutive SLOTS slot0 .. slot0 + nb - 1 of a detector's padded output (retinanet.py:60-84): boxes f32
+ * [B,max_boxes,4], num_boxes i32 [B]; slot s is box s % max_boxes of image s / max_boxes and gives a zero crop when it is
+ * padding (s % max_boxes >= num_boxes[image]) or lies past the array: the per-image [:n] slices, the box_ind vectors and the
+ * concat of create_pb.py:96-104 without materialising them. */
+extern "C" int mpn_prn_crop_slots(const float* heatmaps, const void* minmax_keys, const float* boxes, const int* num_boxes,
+                                  int slot0, int nb, int max_boxes, int B, int h, int w, int C, int crop_h, int crop_w,
+                                  float threshold, float* crops, mpn_stream_t stream) {
+    MPN_REQUIRE(heatmaps && minmax_keys && boxes && num_boxes && crops, MPN_ERR_BAD_ARG, "prn_crop_slots: null pointer");
+    MPN_REQUIRE(nb > 0 && slot0 >= 0 && max_boxes > 0 && B > 0 && h > 0 && w > 0 && C > 0 && C <= kMaxC && crop_h > 0 && crop_w > 0,
+                MPN_ERR_BAD_SHAPE, "prn_crop_slots: bad shape");
+    const long long total = (long long)nb * crop_h * crop_w * C;
+    long long blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > 16384) blocks = 16384;
+    crop_kernel<<<(unsigned)blocks, kThreads, 0, (hipStream_t)stream>>>(heatmaps, (const unsigned*)minmax_keys, boxes, nullptr, num_boxes,
+                                                                       max_boxes, slot0, total, B, h, w, C, crop_h, crop_w, threshold, crops);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

@@ -500,6 +500,32 @@ extern "C" int mpn_retina_loss(const void* const* logits, const void* const* box
     return MPN_OK;
 }
 
+__global__ void retina_loss_finalize_kernel(const float* __restrict__ sums, const int* __restrict__ num_matched, float lw, float cw,
+                                            float* __restrict__ losses, float* __restrict__ dbias_cls, float* __restrict__ dbias_box) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        const int nm = num_matched[0];
+        const float inv = 1.0f / (float)(nm > 1 ? nm : 1);      // tf.maximum(num_matches, 1) (retinanet.py:128-131)
+        const float loc = sums[1] * inv, cls = sums[0] * inv;
+        losses[0] = loc;
+        losses[1] = cls;
+        losses[3] = lw * loc + cw * cls + losses[2];
+    }
+    if (dbias_cls != nullptr && t < 6) dbias_cls[t] = sums[2 + t];
+    if (dbias_box != nullptr && t < 24) dbias_box[t] = sums[8 + t];
+}
+
+extern "C" int mpn_retina_loss_finalize(const float* sums, const int* num_matched, float localization_loss_weight,
+                                        float classification_loss_weight, float* losses, float* dbias_cls, float* dbias_box,
+                                        mpn_stream_t stream) {
+    MPN_REQUIRE(sums && num_matched && losses, MPN_ERR_BAD_ARG, "retina_loss_finalize: null pointer");
+    MPN_REQUIRE((dbias_cls == nullptr) == (dbias_box == nullptr), MPN_ERR_BAD_ARG, "retina_loss_finalize: bias gradients");
+    retina_loss_finalize_kernel<<<1, 64, 0, (hipStream_t)stream>>>(sums, num_matched, localization_loss_weight, classification_loss_weight,
+                                                                   losses, dbias_cls, dbias_box);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
 extern "C" size_t mpn_retina_nms_workspace_bytes(int B, int A) { return (size_t)B * A * (sizeof(float) + sizeof(float4)) + 16; }
 
 extern "C" int mpn_retina_nms(const void* const* logits, const void* const* boxes, const int* h, const int* w, int dtype,

@@ -113,6 +113,7 @@ class PoseResidualNet:
         self.dhid = torch.empty((B, hidden), dtype=f32, device=dev)
         self.dpre1 = torch.empty((B, hidden), dtype=dtype, device=dev)
         self.loss_part = torch.zeros(B, dtype=f32, device=dev)
+        self._loss = torch.zeros(1, dtype=f32, device=dev)
         nparts = ops.conv_wgrad_num_parts(1, 1, n, B, hidden, 1, dtype)   # the two K = n contractions
         self.kslab = torch.empty(nparts * B * hidden, dtype=f32, device=dev)
         self._kparts = nparts
@@ -181,13 +182,16 @@ class PoseResidualNet:
             raise ValueError(f"labels must be contiguous float32 [{B},{self.h},{self.w},{self.c}]")
         call("mpn_prn_loss", ptr(self._x), ptr(self.y2), _lib.dtype_code(self.dtype), ptr(labels), B, self.h * self.w, self.c,
              ptr(self.logits), ptr(self.dlogits) if with_grad else None, ptr(self.loss_part), self.loss_scale, stream_ptr())
-        return self.loss_part.sum()
+        ops.reduce_partials(self.loss_part, B, 1, self._loss)      # fixed-order sum of the per-crop terms
+        return self._loss[0]
 
     def predict(self, x):
         """Inference: logits [b,h,w,c] f32 (create_pb.py:112)."""
         self.forward(x)
         v = self.valid
-        return (x.reshape(v, self.n) + self.y2[:v].float()).view(v, self.h, self.w, self.c)
+        out = torch.empty((v, self.h, self.w, self.c), dtype=torch.float32, device=self.device)
+        call("mpn_prn_residual", ptr(self._x), ptr(self.y2), _lib.dtype_code(self.dtype), v * self.n, ptr(out), stream_ptr())
+        return out
 
     def backward(self):
         B, n, hidden, dc = self.B, self.n, self.hidden, _lib.dtype_code(self.dtype)

@@ -53,28 +53,35 @@ class KeypointAssigner:
         call("mpn_prn_decode", ptr(logits), n, h, w, c, ptr(scores), ptr(pos), stream_ptr())
         return scores, pos
 
+    def crops_of_slots(self, heatmaps, boxes, num_boxes, slot0, n):
+        """Crops of slots slot0 .. slot0 + n - 1 of a detector's padded output (boxes [b,max,4], num_boxes int32 [b]); padding slots
+        and slots past the array are zero crops (mpn_prn_crop_slots: create_pb.py:96-104 without slices and concat)."""
+        b, h, w, c = heatmaps.shape
+        if heatmaps.dtype != torch.float32 or not heatmaps.is_contiguous() or c != NUM_KEYPOINTS:
+            raise ValueError("heatmaps must be contiguous float32 [b,h,w,17]")
+        if self._keys is None or self._keys.numel() < b * c * 2:
+            self._keys = torch.empty(b * c * 2, dtype=torch.int32, device=heatmaps.device)
+        call("mpn_heatmap_minmax", ptr(heatmaps), b, h, w, c, ptr(self._keys), stream_ptr())
+        out = torch.empty((n, CROP_SIZE[0], CROP_SIZE[1], c), dtype=torch.float32, device=heatmaps.device)
+        call("mpn_prn_crop_slots", ptr(heatmaps), ptr(self._keys), ptr(boxes), ptr(num_boxes), int(slot0), int(n), boxes.shape[1], b, h, w, c,
+             CROP_SIZE[0], CROP_SIZE[1], self.threshold, ptr(out), stream_ptr())
+        return out
+
     def __call__(self, heatmaps, boxes, num_boxes, compact=False):
         b, max_boxes = boxes.shape[0], boxes.shape[1]
         dev = heatmaps.device
-        nb = torch.as_tensor(num_boxes, device=dev).to(torch.int32).view(b, 1)
-        slot = torch.arange(max_boxes, device=dev, dtype=torch.int32).view(1, max_boxes)
-        img = torch.arange(b, device=dev, dtype=torch.int32).view(b, 1).expand(b, max_boxes)
-        box_ind = torch.where(slot < nb, img, torch.full_like(img, -1)).reshape(-1).contiguous()
-        flat = boxes.reshape(-1, 4).to(torch.float32).contiguous()
-        n, B = flat.shape[0], self.net.valid
+        nb = torch.as_tensor(num_boxes, device=dev).to(torch.int32).contiguous()
+        flat = boxes.to(torch.float32).contiguous()
+        n, B = b * max_boxes, self.net.valid
         scores, positions = [], []
-        for s in range(0, n, B):   # the network is built for a fixed batch: pad the last chunk with zero crops
-            fb, fi = flat[s:s + B], box_ind[s:s + B]
-            k = fb.shape[0]
-            if k < B:
-                fb = torch.cat([fb, torch.zeros(B - k, 4, device=dev)])
-                fi = torch.cat([fi, torch.full((B - k,), -1, dtype=torch.int32, device=dev)])
-            crops = self.crops(heatmaps, fb.contiguous(), fi.contiguous())
-            sc, po = self.decode(self.net.predict(crops))
+        for s in range(0, n, B):   # the network is built for a fixed batch: the last chunk runs past the array (zero crops)
+            k = min(B, n - s)
+            sc, po = self.decode(self.net.predict(self.crops_of_slots(heatmaps, flat, nb, s, B)))
             scores.append(sc[:k])
             positions.append(po[:k])
-        scores, positions = torch.cat(scores), torch.cat(positions)
-        if compact:
-            keep = (box_ind >= 0).nonzero().view(-1)
+        scores, positions = torch.cat(scores), torch.cat(positions)     # (data movement only)
+        if compact:   # the reference's [sum(num_boxes), ...] rows: live slots in (image, slot) order - an index gather
+            slot = torch.arange(max_boxes, device=dev, dtype=torch.int32).view(1, max_boxes)
+            keep = (slot < nb.view(b, 1)).reshape(-1).nonzero().view(-1)
             scores, positions = scores[keep], positions[keep]
         return scores, positions

@@ -425,11 +425,8 @@ class PersonDetectorNet:
              ptr(self.out_bias["box_net"]), ptr(b["matches"]), ptr(b["targets"]), ptr(b["num_matched"]), N,
              float(params.get("gamma", 2.0)), float(params.get("alpha", 0.25)), lw, cw, ptr(b["loss_part"]), stream_ptr())
         ops.reduce_partials(b["loss_part"], b["loss_part"].numel() // 32, 32, b["loss_sums"])
-        inv = 1.0 / torch.clamp(b["num_matched"].float(), min=1.0)
         losses = b["losses"]
-        losses[0:1] = b["loss_sums"][1:2] * inv                      # localization_loss
-        losses[1:2] = b["loss_sums"][0:1] * inv                      # classification_loss
-        losses[2:3].zero_()           # (an element assignment from a Python scalar is a host copy: not capturable)
+        losses[2:3].zero_()           # (a memset: an element assignment from a Python scalar is a host copy, not capturable)
         wd = float(params.get("weight_decay", 0.0))
         if wd > 0.0:   # add_weight_decay (keypoints_model.py:129-138) sees EVERY kernel, the frozen backbone's included
             for k, w in self.vars.items():
@@ -438,10 +435,9 @@ class PersonDetectorNet:
             for k, w in self.backbone.vars.items():
                 if k.startswith("MobilenetV1/") and "weights" in k and "depthwise_weights" not in k:
                     ops.l2_loss_accumulate(w.view(-1), wd, losses[2:3])
-        losses[3:4] = lw * losses[0:1] + cw * losses[1:2] + losses[2:3]
-        if with_grad:
-            self.out_dbias["class_net"].copy_(b["loss_sums"][2:2 + APL])
-            self.out_dbias["box_net"].copy_(b["loss_sums"][8:8 + 4 * APL])
+        # normaliser 1 / max(num_matched, 1), the weighted total and the output convolutions' bias gradients: one launch
+        call("mpn_retina_loss_finalize", ptr(b["loss_sums"]), ptr(b["num_matched"]), lw, cw, ptr(losses),
+             ptr(self.out_dbias["class_net"]) if with_grad else None, ptr(self.out_dbias["box_net"]) if with_grad else None, stream_ptr())
         return losses
 
     # ------------------------------------------------------------------ backward

@@ -30,13 +30,69 @@ def test_anchor_known_answers():
     np.testing.assert_allclose(a[0] * 100, [2 - 16, 2 - 16, 2 + 16, 2 + 16], atol=1e-5)
 
 
-def test_product_anchor_generator_equals_oracle():
+def _anchors_loop_level(image_height, image_width):
+    """A THIRD derivation of the anchor set, written per anchor from anchor_generator.py:44-166 (no vectorised meshgrid /
+    tile / concat: one scalar float32 computation per coordinate), used to pin both the oracle's and the product's
+    generators - which are two vectorised numpy programs by the same author and must not only agree with each other."""
+    f = np.float32
+    strides, scales = [8, 16, 32, 64, 128], [32, 64, 128, 256, 512]                    # :13-14
+    pairs = [(m, a) for m in (1.0, 1.4142) for a in (1.0, 2.0, 0.5)]                   # itertools.product(multipliers, ratios) :72
+    ih, iw = f(image_height), f(image_width)
+    out, shapes = [], []
+    for stride, scale in zip(strides, scales):
+        h, w = int(math.ceil(image_height / stride)), int(math.ceil(image_width / stride))   # :60-61
+        shapes.append((h, w))
+        st = f(stride)
+        oy = f(0.5) * (ih - (f(h) - f(1.0)) * st)                                      # :96-97
+        ox = f(0.5) * (iw - (f(w) - f(1.0)) * st)
+        for y in range(h):                                                             # reshape order: y, x, anchor (:160-165)
+            cy = f(y) * st + oy                                                        # :145
+            for x in range(w):
+                cx = f(x) * st + ox
+                for m, a in pairs:
+                    sc = f(m * scale)                                                  # tf.constant([m * scales[i]], float32) :76
+                    rs = np.sqrt(f(a))                                                 # :139
+                    hh, ww = sc / rs, sc * rs                                          # :140-141
+                    out.append([(cy - f(0.5) * hh) / ih, (cx - f(0.5) * ww) / iw, (cy + f(0.5) * hh) / ih, (cx + f(0.5) * ww) / iw])
+    return np.asarray(out, f), shapes
+
+
+def test_anchor_generators_equal_the_loop_level_derivation():
+    from multiposenet_amd.detector.anchor_generator import AnchorGenerator
     from multiposenet_amd.retinanet import generate_anchors
-    for hw in ((128, 128), (256, 384), (896, 1408)):
+    for hw in ((128, 128), (256, 384), (100, 100), (384, 640)):
+        want, shapes = _anchors_loop_level(*hw)
         a, s = generate_anchors(*hw)
         b, t = R.generate_anchors(*hw)
-        assert s == t
-        np.testing.assert_array_equal(a, b)
+        assert s == shapes and t == shapes
+        np.testing.assert_allclose(a, want, rtol=0, atol=2e-7)       # (the vectorised forms may fuse a multiply differently: 1 ulp)
+        np.testing.assert_allclose(b, want, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(AnchorGenerator()(*hw), want, rtol=0, atol=2e-7)
+
+
+def test_anchors_at_the_detector_bench_size_hand_computed():
+    """896 x 1408 (BASELINE config 4 padded): anchors picked out of the 157 542 by index, values computed by hand."""
+    from multiposenet_amd.retinanet import generate_anchors
+    H, W = 896, 1408
+    for gen in (generate_anchors, R.generate_anchors):
+        a, shapes = gen(H, W)
+        assert shapes == [(112, 176), (56, 88), (28, 44), (14, 22), (7, 11)] and a.shape == (157542, 4)
+        # level 3 (stride 8, scale 32, offset 0.5 * (896 - 111 * 8) = 4): cell (y = 5, x = 170), anchor 2 = (multiplier 1, ratio 0.5):
+        # centre (44, 1364), height 32 / sqrt(0.5) = 45.2548, width 32 * sqrt(0.5) = 22.6274
+        i = ((5 * 176) + 170) * 6 + 2
+        hh, ww = 32 / math.sqrt(0.5), 32 * math.sqrt(0.5)
+        np.testing.assert_allclose(a[i] * [H, W, H, W], [44 - hh / 2, 1364 - ww / 2, 44 + hh / 2, 1364 + ww / 2], atol=2e-3)
+        # level 5 (stride 32, scale 128, offset 16) starts after (112 * 176 + 56 * 88) * 6 anchors: cell (27, 43) = the last one,
+        # anchor 4 = (multiplier 1.4142, ratio 2): centre (880, 1392), scale 181.0176, height / sqrt(2), width * sqrt(2)
+        base5 = (112 * 176 + 56 * 88) * 6
+        i = base5 + ((27 * 44) + 43) * 6 + 4
+        sc = 128 * 1.4142
+        hh, ww = sc / math.sqrt(2), sc * math.sqrt(2)
+        np.testing.assert_allclose(a[i] * [H, W, H, W], [880 - hh / 2, 1392 - ww / 2, 880 + hh / 2, 1392 + ww / 2], atol=5e-3)
+        # level 7 (stride 128, scale 512, offset 64): the very last anchor = cell (6, 10), (1.4142, 0.5): centre (832, 1344)
+        sc = 512 * 1.4142
+        hh, ww = sc / math.sqrt(0.5), sc * math.sqrt(0.5)
+        np.testing.assert_allclose(a[-1] * [H, W, H, W], [832 - hh / 2, 1344 - ww / 2, 832 + hh / 2, 1344 + ww / 2], atol=2e-2)
 
 
 def test_iou_encode_decode_known_answers():
