@@ -115,6 +115,19 @@ int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_p
                          const int* W, int Cin, int Cout, const int* x_stride, const int* y_stride, int ksize, int dtype,
                          const float* const* in_scale, const float* const* in_shift, int in_act,
                          float* const* stats_part, mpn_stream_t stream);
+/* Data gradients of up to five independent 3x3 convolutions in ONE grid (as mpn_conv_fwd_grouped on the transposed packed
+ * weights) that ALSO do the first pass of the batch-norm backward of the layer they feed (keypoint_subnet.py:75-78: conv ->
+ * bn -> relu -> conv; layer_utils.py:9-16): dx[j] is written MASKED - g = dx where lo < bn_x[j] * bn_scale[j] + bn_shift[j] < hi
+ * (the activation bn_act passed), else 0, so mpn_bn_bwd_apply's own mask is a no-op on it - and part[j]
+ * ([mpn_conv_num_parts(N,H[j],W[j],3)][2][C] floats) receives the partial sums of g and of g * bn_x with the RAW x: finish
+ * with a finalize built by mpn_bn_bwd_fin_desc_fill_raw. One tensor read and one launch less than mpn_bn_bwd_reduce behind
+ * the data gradient. dy [N,H,W,K], dx / bn_x [N,H,W,C] (pixel strides as arrays or NULL = dense); 16-bit storage,
+ * K % 64 == 0, K <= 512, C % 128 == 0, C <= 512: mpn_conv_bwd_data_bn_supported(K, C, ksize, dtype) != 0. */
+int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype);
+int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, const void* const* w_packed_t, void* const* dx, int N,
+                                 const int* H, const int* W, int K, int C, const int* dy_stride, const int* dx_stride,
+                                 int dtype, const void* const* bn_x, const int* bn_x_stride, const float* const* bn_scale,
+                                 const float* const* bn_shift, int bn_act, float* const* part, mpn_stream_t stream);
 
 /* Weight gradient of mpn_conv_fwd: dW[tap][ci][co] = sum_pixels act(bn(x))[pixel+tap][ci]*dy[pixel][co].
  * Split-K over pixel tiles: part [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (one HWIO slab
@@ -178,6 +191,11 @@ int mpn_bn_fin_desc_fill(void* desc_host, const float* part, int nparts, int C, 
                          float* save_mean, float* save_invstd, int block_begin);
 int mpn_bn_bwd_fin_desc_fill(void* desc_host, const float* part, int nparts, int C, long long count, float* dgamma,
                              float* dbeta, float* k1, float* k2, int block_begin);
+/* The same for a slab whose second row holds sum g * x with the RAW x (mpn_conv_bwd_data_bn_grouped): mean / invstd = the
+ * layer's saved batch statistics; the finalize forms sum g * xhat = invstd * (sum g x - mean * sum g) in f64. */
+int mpn_bn_bwd_fin_desc_fill_raw(void* desc_host, const float* part, int nparts, int C, long long count, float* dgamma,
+                                 float* dbeta, float* k1, float* k2, const float* mean, const float* invstd,
+                                 int block_begin);
 int mpn_bn_finalize_batched(const void* descs_device, int ndesc, int total_blocks, float momentum, float eps,
                             mpn_stream_t stream);
 int mpn_bn_bwd_finalize_batched(const void* descs_device, int ndesc, int total_blocks, mpn_stream_t stream);

@@ -204,6 +204,7 @@ struct BnFinDesc {
 };
 struct BnBwdFinDesc {
     const float* part; float* dgamma; float* dbeta; float* k1; float* k2;
+    const float* mean; const float* invstd;   // non-NULL: the slab's second row holds sum g * x (RAW x), not sum g * xhat
     double count;
     int nparts, C, block_begin, pad_;
 };
@@ -360,11 +361,14 @@ template <int CPB>
 __device__ __forceinline__ void bn_bwd_finalize_block(int cblock, double (*red)[kFinLanes][16], const float* __restrict__ part,
                                                       int nparts, int C, double count, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta, float* __restrict__ k1,
-                                                      float* __restrict__ k2) {
+                                                      float* __restrict__ k2, const float* __restrict__ mean = nullptr,
+                                                      const float* __restrict__ invstd = nullptr) {
     const int c = cblock * CPB + threadIdx.x;
     double s, q;
     reduce_parts<CPB>(part, nparts, C, cblock, red, s, q);
     if ((int)threadIdx.x < CPB && c < C) {
+        // producers that reduce in their epilogue (mpn_conv_bwd_data_bn) sum g * x: sum g * xhat = invstd * (sum g x - mean * sum g)
+        if (mean != nullptr) q = (q - (double)mean[c] * s) * (double)invstd[c];
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         k1[c] = (float)(s / count);
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_batched_kernel(co
     __shared__ double red[2][kFinLanes][16];
     __shared__ int job_s;
     const BnBwdFinDesc d = descs[fin_job(descs, ndesc, &job_s)];
-    bn_bwd_finalize_block<16>(blockIdx.x - d.block_begin, red, d.part, d.nparts, d.C, d.count, d.dgamma, d.dbeta, d.k1, d.k2);
+    bn_bwd_finalize_block<16>(blockIdx.x - d.block_begin, red, d.part, d.nparts, d.C, d.count, d.dgamma, d.dbeta, d.k1, d.k2, d.mean, d.invstd);
 }
 
 // dx = scale * (g - k1 - xhat*k2), written over dA (same storage type); optional extra gradient
@@ -605,10 +609,24 @@ extern "C" int mpn_bn_bwd_fin_desc_fill(void* desc_host, const float* part, int 
         !mpn_aligned16(part))
         return -1;
     BnBwdFinDesc d;
-    d.part = part; d.dgamma = dgamma; d.dbeta = dbeta; d.k1 = k1; d.k2 = k2; d.count = (double)count;
+    d.part = part; d.dgamma = dgamma; d.dbeta = dbeta; d.k1 = k1; d.k2 = k2; d.mean = nullptr; d.invstd = nullptr; d.count = (double)count;
     d.nparts = nparts; d.C = C; d.block_begin = block_begin; d.pad_ = 0;
     memcpy(desc_host, &d, sizeof(d));
     return (C + 15) / 16;
+}
+/* The same for a slab whose second row holds sum g * x with the RAW x (written by mpn_conv_bwd_data_bn_grouped): mean / invstd
+ * = the layer's saved batch statistics. */
+extern "C" int mpn_bn_bwd_fin_desc_fill_raw(void* desc_host, const float* part, int nparts, int C, long long count, float* dgamma,
+                                            float* dbeta, float* k1, float* k2, const float* mean, const float* invstd,
+                                            int block_begin) {
+    if (!mean || !invstd) return -1;
+    const int blocks = mpn_bn_bwd_fin_desc_fill(desc_host, part, nparts, C, count, dgamma, dbeta, k1, k2, block_begin);
+    if (blocks <= 0) return blocks;
+    BnBwdFinDesc d;
+    memcpy(&d, desc_host, sizeof(d));
+    d.mean = mean; d.invstd = invstd;
+    memcpy(desc_host, &d, sizeof(d));
+    return blocks;
 }
 extern "C" int mpn_bn_finalize_batched(const void* descs_device, int ndesc, int total_blocks, float momentum, float eps,
                                        mpn_stream_t stream) {

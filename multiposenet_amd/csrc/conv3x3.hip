@@ -29,6 +29,7 @@ namespace {
 using namespace mpn_c3;
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kThreads = 512;
 constexpr int kHW = 18;                      // halo width = height
@@ -244,6 +245,24 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         st_dst = nullptr;
     };
 
+    // BNR: the raw tensor of the fed batch-norm at this wave's 64 pixels x 64 channels, in the copy-out layout of the epilogue
+    // (lane = 16-byte piece lane % 8 of image rows lane / 8 + 8 k; two passes of 32 pixels): eight 16-byte loads per lane,
+    // requested under the tile's LAST weight stage and consumed by the epilogue
+    // (the first pass's four loads under the last stage - all eight there spill -, the second pass's at the top of the epilogue)
+    uint4 bx[BNR ? 8 : 1];
+    auto bnr_load = [&](const Tile& t, int hp) {
+        if constexpr (BNR) {
+            const Job& p = g.job[t.job];
+            const T* xb = reinterpret_cast<const T*>(p.bnr_x) + t.ntile * BN + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = (lane >> 3) + 8 * k;
+                const int oy = min(t.oy0 + 4 * wm + hp * 2 + (row >> 4), p.H - 1), ox = min(t.ox0 + (row & 15), p.W - 1);
+                bx[hp * 4 + k] = *reinterpret_cast<const uint4*>(xb + (((long long)t.img * p.H + oy) * p.W + ox) * p.bnr_xs);
+            }
+        }
+    };
+
     Tile cur = tile_of<N64>(g, w);
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
     int cc = 0, ss = 0;        // running chunk / stage counters: halo buffer cc & 1, weight buffer ss & 1
@@ -284,6 +303,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
                 if (sl < NS - 1 || !last_chunk) b_issue(wsrc, chunk * NS + sl + 1, (ss + 1) & 1);
                 else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
+                if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, 0); }
                 if (sl == 0) {
                     // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
                     // the six registers become PHIs, hipcc copies them right behind the loads - and waits for the loads there
@@ -389,6 +409,21 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 Ow = const_cast<unsigned char*>(theirs);
             }
             const bool stats = p.stats_part != nullptr;
+            // BNR: per-lane scale / shift of its 8 channels, and the running sums of g and g * x over the lane's 8 rows
+            f32x2_t bsc[4], bsh[4], bs[4], bq[4];
+            float blo = -INFINITY, bhi = INFINITY;
+            if constexpr (BNR) {
+                bnr_load(cur, 1);
+                const float* ts = tab + cur.ntile * BN + wn * 64 + (lane & 7) * 8;
+                const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(ts), s1 = *reinterpret_cast<const f32x4_t*>(ts + 4);
+                const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin), h1 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin + 4);
+                bsc[0] = (f32x2_t){s0[0], s0[1]}; bsc[1] = (f32x2_t){s0[2], s0[3]}; bsc[2] = (f32x2_t){s1[0], s1[1]}; bsc[3] = (f32x2_t){s1[2], s1[3]};
+                bsh[0] = (f32x2_t){h0[0], h0[1]}; bsh[1] = (f32x2_t){h0[2], h0[3]}; bsh[2] = (f32x2_t){h1[0], h1[1]}; bsh[3] = (f32x2_t){h1[2], h1[3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bs[j] = (f32x2_t){0.f, 0.f}; bq[j] = (f32x2_t){0.f, 0.f}; }
+                blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
+                bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
+            }
             f32x4_t sa[4], ga[4];
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) { sa[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ga[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -411,7 +446,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         store4(reinterpret_cast<T*>(Ow + (ml * 16 + l15) * RSW + (nt * 16 + lq * 4) * 2), v);
                     }
                 }
-                if (stats) {
+                if (stats && !BNR) {
                     // the 32 pixels x 64 channels just written, read back transposed (ds_read_b64_tr_b16): lane 4q+pp of a 16-lane
                     // group supplies the address of block row q, channels 4pp..4pp+3; the k order of a sum is free
                     const unsigned char* tb = Ow + ((lq >> 1) * 2 + 4 * ((lq & 1) * 4 + (l15 >> 2))) * RSW + (4 * (l15 & 3)) * 2;
@@ -436,15 +471,55 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 for (int k = 0; k < 4; ++k) {
                     const int row = crow + 8 * k;                              // image row = (ml, l15)
                     const int oy = cur.oy0 + 4 * wm + hp * 2 + (row >> 4), ox = cur.ox0 + (row & 15);
+                    uint4 o = make_uint4(ca[k].x, ca[k].y, cb[k].x, cb[k].y);
+                    if constexpr (BNR) {
+                        // g = dy where the fed batch-norm's activation passes (lo < x * scale + shift < hi, the test of
+                        // bn_bwd_reduce / bn_bwd_apply, fused multiply-add), else 0; sums of g and g * x (pixels outside the image
+                        // hold dy = 0). 16-bit storage: element pairs per dword.
+                        const uint4 xv = bx[hpi * 4 + k];
+                        const unsigned xu[4] = {xv.x, xv.y, xv.z, xv.w};
+                        unsigned du[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f32x2_t xf = {to_f32(__builtin_bit_cast(T, (unsigned short)(xu[j] & 0xffffu))),
+                                                to_f32(__builtin_bit_cast(T, (unsigned short)(xu[j] >> 16)))};
+                            const f32x2_t pre = xf * bsc[j] + bsh[j];
+                            const unsigned m = ((pre[0] > blo && pre[0] < bhi) ? 0x0000ffffu : 0u) | ((pre[1] > blo && pre[1] < bhi) ? 0xffff0000u : 0u);
+                            du[j] &= m;
+                            const f32x2_t gf = {to_f32(__builtin_bit_cast(T, (unsigned short)(du[j] & 0xffffu))),
+                                                to_f32(__builtin_bit_cast(T, (unsigned short)(du[j] >> 16)))};
+                            bs[j] += gf;
+                            bq[j] += gf * xf;
+                        }
+                        o = make_uint4(du[0], du[1], du[2], du[3]);
+                    }
                     if (oy < p.H && ox < p.W)
-                        *reinterpret_cast<uint4*>(y + (((long long)cur.img * p.H + oy) * p.W + ox) * p.ys + n0 + (N64 ? 0 : wn * 64) + cpiece * 8) =
-                            make_uint4(ca[k].x, ca[k].y, cb[k].x, cb[k].y);
+                        *reinterpret_cast<uint4*>(y + (((long long)cur.img * p.H + oy) * p.W + ox) * p.ys + n0 + (N64 ? 0 : wn * 64) + cpiece * 8) = o;
+                }
+            }
+            if constexpr (BNR) {
+                // the lanes of one 16-byte piece (lane bits 3..5 = the 8 row lanes): fixed butterfly, then lanes 0..7 hold the wave's
+                // sums of their 8 channels
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bs[j][0] += __shfl_xor(bs[j][0], o, 64); bs[j][1] += __shfl_xor(bs[j][1], o, 64);
+                        bq[j][0] += __shfl_xor(bq[j][0], o, 64); bq[j][1] += __shfl_xor(bq[j][1], o, 64);
+                    }
+                if (lane < 8) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int cl = wn * 64 + lane * 8 + 2 * j;
+                        red[(wm * 2 + 0) * 128 + cl] = bs[j][0]; red[(wm * 2 + 0) * 128 + cl + 1] = bs[j][1];
+                        red[(wm * 2 + 1) * 128 + cl] = bq[j][0]; red[(wm * 2 + 1) * 128 + cl + 1] = bq[j][1];
+                    }
                 }
             }
             if (stats) {
                 const int r = l15 & 3;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
+                for (int nt = 0; nt < 4 && !BNR; ++nt) {
                     const float q = r == 0 ? ga[nt][0] : (r == 1 ? ga[nt][1] : (r == 2 ? ga[nt][2] : ga[nt][3]));
                     if (lq == (l15 >> 2)) {
                         if constexpr (N64) {
@@ -490,16 +565,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 #endif
 }
 
-template <typename T, bool AFFINE, bool N64>
+template <typename T, bool AFFINE, bool N64, bool BNR = false>
 int launch_t(const Group& g, int blocks, hipStream_t st) {
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE, N64>, kLds, &attr_mask));
-    conv3x3_kernel<T, AFFINE, N64><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE, N64, BNR>, kLds, &attr_mask));
+    conv3x3_kernel<T, AFFINE, N64, BNR><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
 template <typename T>
-int launch_v(const Group& g, int blocks, bool affine, bool n64, hipStream_t st) {
+int launch_v(const Group& g, int blocks, bool affine, bool n64, bool bnr, hipStream_t st) {
+    if (bnr) return launch_t<T, false, false, true>(g, blocks, st);
     if (n64) return affine ? launch_t<T, true, true>(g, blocks, st) : launch_t<T, false, true>(g, blocks, st);
     return affine ? launch_t<T, true, false>(g, blocks, st) : launch_t<T, false, false>(g, blocks, st);
 }
@@ -530,8 +606,15 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
     MPN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (begin > cus) begin = cus;   // `begin` is the grid size from here on
     const bool n64 = (jobs[0].Cout & 127) != 0;     // (the jobs of a group share Cin and Cout)
-    if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, st);
-    if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, st);
+    const bool bnr = jobs[0].bnr_x != nullptr;
+    for (int j = 0; j < njobs; ++j) {
+        MPN_REQUIRE((jobs[j].bnr_x != nullptr) == bnr, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the fused-reduction variant");
+        MPN_REQUIRE(!bnr || (!affine && !n64 && jobs[j].stats_part && jobs[j].bnr_scale && jobs[j].bnr_shift && jobs[j].bnr_xs >= jobs[j].Cout &&
+                             jobs[j].bnr_xs % 8 == 0 && jobs[j].Cout <= kMaxCin && mpn_aligned16(jobs[j].bnr_x)),
+                    MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a 128-channel-tile data gradient, a partial slab and the layer's affine");
+    }
+    if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, bnr, st);
+    if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, bnr, st);
     MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");
 }
 

@@ -787,6 +787,7 @@ static void c3_fill_job(mpn_c3::Job& j, const void* x, const void* w_packed, voi
     j.x = x; j.wp = w_packed; j.y = y; j.in_scale = in_scale; j.in_shift = in_shift; j.stats_part = stats_part; j.in_act = in_act;
     j.N = N; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout;
     j.xs = x_stride > 0 ? x_stride : Cin; j.ys = y_stride > 0 ? y_stride : Cout;
+    j.bnr_x = nullptr; j.bnr_scale = nullptr; j.bnr_shift = nullptr; j.bnr_act = MPN_ACT_NONE; j.bnr_xs = 0;
 #ifdef MPN_DIAG
     j.dbg = (unsigned long long*)g_conv_dbg;
 #endif
@@ -908,4 +909,42 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
     grp.njobs = njobs;
     hipStream_t st = (hipStream_t)stream;
     return g.BN == 128 ? launch_conv_grouped<128>(grp, begin, st) : launch_conv_grouped<64>(grp, begin, st);
+}
+
+
+/* Data gradients of up to five independent 3x3 convolutions (one grid, as mpn_conv_fwd_grouped on the transposed packed weights)
+ * that ALSO do the first pass of the batch-norm backward of the layer they feed (keypoint_subnet.py:75-78: conv -> bn -> relu ->
+ * conv: the gradient that leaves conv2's data gradient is the gradient w.r.t. relu(bn1(x))): dx[j] is written MASKED
+ * (g = dx where the activation passed, computed from bn_x[j] * bn_scale[j] + bn_shift[j]; bn_bwd_apply's own mask is then a
+ * no-op) and part[j] ([mpn_conv_num_parts(N,H,W,3)][2][C] floats) receives the partial sums of g and of g * bn_x (RAW x:
+ * finish with a mpn_bn_bwd_fin_desc_fill_raw finalize, which forms sum g * xhat = invstd * (sum g x - mean * sum g)).
+ * One tensor read (dx) and one launch less than mpn_bn_bwd_reduce afterwards. 16-bit storage, K % 64 == 0, K <= 512,
+ * C % 128 == 0, C <= 512: mpn_conv_bwd_data_bn_supported says whether a geometry is covered. */
+extern "C" int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype) {
+    return (ksize == 3 && (dtype == MPN_BF16 || dtype == MPN_F16) && mpn_c3::eligible(K, C, 9, 2) && C <= 512) ? 1 : 0;
+}
+
+extern "C" int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, const void* const* w_packed_t, void* const* dx, int N,
+                                            const int* H, const int* W, int K, int C, const int* dy_stride, const int* dx_stride,
+                                            int dtype, const void* const* bn_x, const int* bn_x_stride,
+                                            const float* const* bn_scale, const float* const* bn_shift, int bn_act,
+                                            float* const* part, mpn_stream_t stream) {
+    MPN_REQUIRE(njobs > 0 && njobs <= mpn_c3::kMaxJobs && dy && w_packed_t && dx && H && W && bn_x && bn_scale && bn_shift && part,
+                MPN_ERR_BAD_ARG, "conv_bwd_data_bn: bad arguments");
+    MPN_REQUIRE(mpn_conv_bwd_data_bn_supported(K, C, 3, dtype), MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: geometry not covered (K %d, C %d)", K, C);
+    MPN_REQUIRE(N > 0, MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: bad shape");
+    mpn_c3::Job jobs[mpn_c3::kMaxJobs];
+    for (int j = 0; j < njobs; ++j) {
+        MPN_REQUIRE(dy[j] && w_packed_t[j] && dx[j] && bn_x[j] && bn_scale[j] && bn_shift[j] && part[j] && H[j] > 0 && W[j] > 0,
+                    MPN_ERR_BAD_ARG, "conv_bwd_data_bn: null pointer / bad size");
+        MPN_REQUIRE(mpn_aligned16(dy[j]) && mpn_aligned16(w_packed_t[j]) && mpn_aligned16(dx[j]) && mpn_aligned16(bn_x[j]), MPN_ERR_BAD_ALIGN,
+                    "conv_bwd_data_bn: pointers must be 16-byte aligned");
+        const int ys = dx_stride ? dx_stride[j] : 0, xs = dy_stride ? dy_stride[j] : 0, bs = bn_x_stride ? bn_x_stride[j] : 0;
+        MPN_REQUIRE((ys == 0 || (ys >= C && ys % 8 == 0)) && (xs == 0 || (xs >= K && xs % 8 == 0)) && (bs == 0 || (bs >= C && bs % 8 == 0)),
+                    MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: bad pixel strides %d, %d, %d", xs, ys, bs);
+        c3_fill_job(jobs[j], dy[j], w_packed_t[j], dx[j], N, H[j], W[j], K, C, xs, ys, nullptr, nullptr, MPN_ACT_NONE, part[j]);
+        jobs[j].bnr_x = bn_x[j]; jobs[j].bnr_scale = bn_scale[j]; jobs[j].bnr_shift = bn_shift[j]; jobs[j].bnr_act = bn_act;
+        jobs[j].bnr_xs = bs > 0 ? bs : C;
+    }
+    return mpn_c3::launch(jobs, njobs, dtype, (hipStream_t)stream);
 }

@@ -257,6 +257,9 @@ class KeypointNet:
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
+        # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
+        # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
+        self.fuse_conv_bn = True
         # the stem kernel can write its own batch-norm partial sums (mpn_stem_conv_fwd_stats); OFF: measured a wash - the
         # separate statistics pass (38 us) reads the 134 MB stem output into the memory-side cache, and the first depthwise
         # layer then runs 52 instead of 83 us
@@ -531,10 +534,18 @@ class KeypointNet:
             cnt = N * h * w
             for k, bn in (("p", self.p_bn[l]), ("bn1", self.phi[l]["bn1"]), ("bn2", self.phi[l]["bn2"])):
                 fwd[k].append((bn, b["stat_lv"][l], ops.conv_num_parts(N, h, w, 3), cnt))
-                bwd[k].append((bn, b["stat_lv"][l], nbn(cnt), cnt))
+                # p / bn1: reduced inside the data gradient that produces their gradient (conv rows, sum g * x with the raw x)
+                if k != "bn2" and self._fused_conv_bn():
+                    bwd[k].append((bn, b["stat_lv"][l], ops.conv_num_parts(N, h, w, 3), cnt, True))
+                else:
+                    bwd[k].append((bn, b["stat_lv"][l], nbn(cnt), cnt))
         out = {k: ops.BnFinalizeBatch(v, self.device) for k, v in fwd.items()}
         out.update({"d" + k: ops.BnBwdFinalizeBatch(v, self.device) for k, v in bwd.items()})
         return out
+
+    def _fused_conv_bn(self):
+        """The 3x3 data gradients of the subnet also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn_grouped)."""
+        return self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(DEPTH, DEPTH, 3, self.dtype)
 
     def forward(self, images, is_training):
         """images: [N,H,W,3] f32 in [0,1] (or uint8). Returns (logits [N,H/4,W/4,18] f32 NHWC,
@@ -626,16 +637,23 @@ class KeypointNet:
         ops.bn_bwd_apply_grouped(bn2s, gy2, by2)
         W(lambda: ops.conv_bwd_weight_grouped(by1, gy2, 3, [self.phi[l]["bn1"].affine for l in LV],
                                               [slab[id(self.phi[l]["conv2"].dw)] for l in LV]))
-        ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
-                             [g["y1"][l] for l in LV], none4)
-        ops.bn_bwd_reduce_grouped(bn1s, gy1, by1, sps)
+        fused = self._fused_conv_bn()
+        if fused:   # conv2's data gradient also reduces for bn1 (and writes the gradient masked by bn1's ReLU)
+            ops.conv_bwd_data_bn_grouped(gy2, [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, bn1s, by1, gy1, sps)
+        else:
+            ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
+                                 [g["y1"][l] for l in LV], none4)
+            ops.bn_bwd_reduce_grouped(bn1s, gy1, by1, sps)
         fin["dbn1"].run()
         ops.bn_bwd_apply_grouped(bn1s, gy1, by1)
         W(lambda: ops.conv_bwd_weight_grouped(bp, gy1, 3, [self.p_bn[l].affine for l in LV],
                                               [slab[id(self.phi[l]["conv1"].dw)] for l in LV]))
-        ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
-                             [g["p"][l] for l in LV], none4)
-        ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
+        if fused:
+            ops.conv_bwd_data_bn_grouped(gy1, [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, pbns, bp, gp, sps)
+        else:
+            ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
+                                 [g["p"][l] for l in LV], none4)
+            ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
         fin["dp"].run()
         ops.bn_bwd_apply_grouped(pbns, gp, bp, [g["daux"][l] for l in LV])
         # ---- FPN (top-down path reversed)

@@ -122,6 +122,26 @@ def conv_fwd_grouped(xs, packeds, cout, ksize, affines, outs, stats_parts):
     return outs
 
 
+def conv_bwd_data_bn_supported(k, c, ksize, dtype):
+    return bool(_lib.lib().mpn_conv_bwd_data_bn_supported(int(k), int(c), int(ksize), _lib.dtype_code(dtype)))
+
+
+def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
+    """Data gradients of several independent 3x3 convolutions in one grid that also reduce for the batch-norm layers `bns`
+    they feed (raw tensors xs_bn): outs[j] <- masked gradient, parts[j] <- partial sums of g and g * x (RAW x: finalize with a
+    BnBwdFinalizeBatch job marked raw). Returns the rows each slab holds (conv_num_parts)."""
+    import ctypes
+    n = len(dys)
+    N, _, _, k = dys[0].shape
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    call("mpn_conv_bwd_data_bn_grouped", n, PA(*[ptr(t) for t in dys]), PA(*[ptr(p) for p in packeds_t]), PA(*[ptr(o) for o in outs]), N,
+         IA(*[t.shape[1] for t in dys]), IA(*[t.shape[2] for t in dys]), k, int(c), IA(*[_slice_stride(t, k) for t in dys]),
+         IA(*[_slice_stride(o, c) for o in outs]), _lib.dtype_code(dys[0].dtype), PA(*[ptr(x) for x in xs_bn]),
+         IA(*[_slice_stride(x, c) for x in xs_bn]), PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]), int(bns[0].act),
+         PA(*[ptr(t) for t in parts]), stream_ptr())
+    return [conv_num_parts(N, t.shape[1], t.shape[2], 3) for t in dys]
+
+
 def conv_wgrad_num_parts(N, H, W, cin, cout, ksize, dtype):
     return _lib.lib().mpn_conv_wgrad_num_parts(N, H, W, cin, cout, ksize, _lib.dtype_code(dtype))
 
@@ -259,9 +279,15 @@ class BnBwdFinalizeBatch:
         nb = lib.mpn_bn_bwd_fin_desc_bytes()
         host = (ctypes.c_ubyte * (nb * len(jobs)))()
         begin = 0
-        for j, (bn, part, nparts, count) in enumerate(jobs):
-            blocks = lib.mpn_bn_bwd_fin_desc_fill(ctypes.byref(host, j * nb), ptr(part), int(nparts), bn.C, int(count),
-                                                  ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), begin)
+        for j, job in enumerate(jobs):
+            bn, part, nparts, count = job[:4]
+            if len(job) > 4 and job[4]:      # raw: the slab holds sum g * x (written by conv_bwd_data_bn_grouped)
+                blocks = lib.mpn_bn_bwd_fin_desc_fill_raw(ctypes.byref(host, j * nb), ptr(part), int(nparts), bn.C, int(count),
+                                                          ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), ptr(bn.mean),
+                                                          ptr(bn.invstd), begin)
+            else:
+                blocks = lib.mpn_bn_bwd_fin_desc_fill(ctypes.byref(host, j * nb), ptr(part), int(nparts), bn.C, int(count),
+                                                      ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), begin)
             if blocks <= 0:
                 raise ValueError("bad batch-norm backward finalize job")
             begin += blocks

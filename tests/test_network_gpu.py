@@ -346,6 +346,40 @@ def test_dw_dgrad_fused_bn_reduction_equals_separate_reduction(cuda):
         assert cos > (0.999999 if dt == torch.float32 else 0.999), cos
 
 
+def test_conv_dgrad_fused_bn_reduction_equals_separate_reduction(cuda):
+    """mpn_conv_bwd_data_bn_grouped (3x3 data gradient + batch-norm backward reduction of the fed layer in one launch, the
+    gradient written masked, sums of g * x with the raw x finished by the raw finalize) against the data gradient followed by
+    mpn_bn_bwd_reduce: the same sums up to the summation order and the f64 regrouping, so the same gradients and step."""
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
+    rs = np.random.RandomState(14)
+    B, H, W = 2, 128, 128
+    params = _params(8)
+    img = torch.tensor(rs.rand(B, H, W, 3).astype(np.float32)).cuda()
+    dlab = {k: torch.tensor(val).cuda() for k, val in _labels(rs, B, H // 4, W // 4).items()}
+    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
+    out = {}
+    for fused in (False, True):
+        net = KeypointNet(values=params, dtype=torch.bfloat16)
+        net.fuse_conv_bn = fused
+        assert net._fused_conv_bn() == fused
+        tr = Trainer(net, hp, use_graph=False)
+        loss = tr.step({"images": img}, dlab).cpu().numpy().copy()
+        out[fused] = (loss, net.grad.cpu().numpy().copy(), {k: v.cpu().numpy().copy() for k, v in net.grads.items()})
+    np.testing.assert_array_equal(out[True][0], out[False][0])          # the forward pass is untouched
+    ga, gb = out[False][1], out[True][1]
+    assert np.abs(ga - gb).max() <= 2e-2 * np.abs(ga).max()
+    cos = float((ga * gb).sum() / np.sqrt((ga * ga).sum() * (gb * gb).sum()))
+    assert cos > 0.9995, cos
+    # the two layers' own parameters: dbeta = sum g, dgamma = sum g * xhat straight from the fused sums
+    for k in ("phi_subnet_2/bn1/gamma", "phi_subnet_2/bn1/beta", "p2_batch_norm/gamma", "p5_batch_norm/beta", "phi_subnet_4/bn1/gamma"):
+        a, b_ = out[False][2][k], out[True][2][k]
+        np.testing.assert_allclose(b_, a, rtol=2e-2, atol=2e-3 * np.abs(a).max(), err_msg=k)
+    # f32 storage is not covered: the flag falls back to the separate passes
+    n32 = KeypointNet(values=params, dtype=torch.float32)
+    assert not n32._fused_conv_bn()
+
+
 def test_train_loss_is_not_stale_after_eval_at_another_batch_size(cuda):
     """A replayed TRAIN step returns the loss tensor of ITS buffer set, also after an EVAL call at another batch size
     rebound net._last: train, eval at a different batch, train -> the second train loss equals the eager one."""

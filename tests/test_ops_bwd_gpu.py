@@ -399,3 +399,73 @@ def test_conv_wgrad_grouped_equals_separate_launches(cuda, dtype, k, Cin, Cout):
         ops.reduce_partials(part, np_, n, got)
         scale = float(w_.abs().max())
         assert float((got.view_as(w_) - w_).abs().max()) <= 2e-5 * scale * (N * sizes[0][0] * sizes[0][1]) ** 0.5
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+@pytest.mark.parametrize("act", [1, 2, 0], ids=["relu", "relu6", "none"])
+def test_conv_dgrad_with_fused_bn_reduction(cuda, dtype, act):
+    """mpn_conv_bwd_data_bn_grouped on three jobs (ragged tiles, a channel-slice raw tensor): dx = the plain data gradient
+    masked by the fed layer's activation, BIT FOR BIT; the slab's sums = sum g and sum g * x over all pixels (f64 reference
+    on the kernel's own rounded outputs); the raw finalize gives dgamma / dbeta / k1 / k2 of mpn_bn_bwd_reduce + finalize."""
+    from multiposenet_amd import ops
+    rs = np.random.RandomState(5 + act)
+    N, K, C = 2, 128, 128
+    sizes = [(37, 21), (16, 16), (9, 5)]
+    w = (rs.randn(3, 3, C, K) / np.sqrt(9 * C)).astype(np.float32)        # forward conv C -> K; its data gradient maps K -> C
+    pc = ops.PackedConv(dev(w), dtype)
+    dys, xs, bns, want_dx, outs, parts = [], [], [], [], [], []
+    for j, (h, w_) in enumerate(sizes):
+        dys.append(dev(rnd(rs.randn(N, h, w_, K), dtype), dtype))
+        xw = dev(rnd(rs.randn(N, h, w_, C + 64) * 1.5 + 0.3, dtype), dtype)
+        xs.append(xw[..., 32:32 + C] if j == 0 else xw[..., :C].contiguous())          # job 0: a channel slice (pixel stride C + 64)
+        bn = ops.BNState(dev(torch.tensor(0.5 + rs.rand(C), dtype=torch.float32)), dev(torch.tensor(rs.randn(C) * 0.3, dtype=torch.float32)),
+                         torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), act)
+        # batch statistics of x -> scale / shift / mean / invstd as the forward pass leaves them
+        xf = xs[j].float().reshape(-1, C)
+        mean, var = xf.mean(0), xf.var(0, unbiased=False)
+        bn.mean.copy_(mean); bn.invstd.copy_(1.0 / torch.sqrt(var + 1e-3))
+        bn.scale.copy_(bn.gamma * bn.invstd); bn.shift.copy_(bn.beta - mean * bn.scale)
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        bns.append(bn)
+        want_dx.append(ops.conv_fwd(dys[j], pc.bwd, C, 3))
+        outs.append(torch.full((N, h, w_, C), float("nan"), device="cuda", dtype=dtype))
+        parts.append(torch.full((ops.conv_num_parts(N, h, w_, 3) * 2 * C,), float("nan"), device="cuda"))
+    rows = ops.conv_bwd_data_bn_grouped(dys, [pc.bwd] * 3, C, bns, xs, outs, parts)
+    for j, (h, w_) in enumerate(sizes):
+        bn, x = bns[j], xs[j].float()
+        pre = (x.double() * bn.scale.double() + bn.shift.double()).float()   # (the kernels' fused multiply-add: one rounding)
+        ok = torch.ones_like(pre, dtype=torch.bool)
+        if act != 0:
+            ok = pre > 0
+        if act == 2:
+            ok = ok & (pre < 6)
+        g = torch.where(ok, want_dx[j], torch.zeros_like(want_dx[j]))
+        diff = (outs[j] != g)
+        # an element whose pre-activation sits within one rounding of the threshold may flip with the FMA contraction: none expected
+        assert int(diff.sum()) <= 2, int(diff.sum())
+        part = parts[j].view(rows[j], 2, C).double().sum(0).cpu()
+        gd, xd = outs[j].double().reshape(-1, C).cpu(), x.double().reshape(-1, C).cpu()
+        np.testing.assert_allclose(part[0].numpy(), gd.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(part[1].numpy(), (gd * xd).sum(0).numpy(), rtol=1e-4, atol=2e-3)
+    # finalize (raw) against reduce + finalize on the masked gradient
+    cnts = [N * h * w_ for (h, w_) in sizes]
+    fin = ops.BnBwdFinalizeBatch([(bns[j], parts[j], rows[j], cnts[j], True) for j in range(3)], "cuda")
+    fin.run()
+    got = [(b.dgamma.clone(), b.dbeta.clone(), b.k1.clone(), b.k2.clone()) for b in bns]
+    for j in range(3):
+        bn = bns[j]
+        # f64 reference on the kernel's own masked gradient: dbeta = sum g, dgamma = sum g * xhat, k = sum / count
+        gd, xd = outs[j].double().reshape(-1, C), xs[j].double().reshape(-1, C)
+        xhat = (xd - bn.mean.double()) * bn.invstd.double()
+        ref = ((gd * xhat).sum(0), gd.sum(0), gd.sum(0) / cnts[j], (gd * xhat).sum(0) / cnts[j])
+        for a, b_, name in zip(got[j], ref, ("dgamma", "dbeta", "k1", "k2")):
+            np.testing.assert_allclose(a.cpu().numpy(), b_.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(b_.abs().max() + 1e-6), err_msg=f"job {j} {name}")
+        if dtype != torch.bfloat16:
+            continue          # (the separate batch-norm passes take f32 / bf16 storage)
+        p2 = torch.empty(ops._lib.lib().mpn_bn_stats_num_parts(cnts[j]) * 2 * C, device="cuda")
+        xj = xs[j].contiguous()
+        nparts = ops.bn_bwd_reduce(bn, outs[j], xj, p2)
+        ops.call("mpn_bn_bwd_finalize", ops.ptr(p2), nparts, C, cnts[j], ops.ptr(bn.dgamma), ops.ptr(bn.dbeta), ops.ptr(bn.k1), ops.ptr(bn.k2),
+                 ops.stream_ptr())
+        for a, b_, name in zip(got[j], (bn.dgamma, bn.dbeta, bn.k1, bn.k2), ("dgamma", "dbeta", "k1", "k2")):
+            np.testing.assert_allclose(a.cpu().numpy(), b_.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(b_.abs().max() + 1e-6), err_msg=f"job {j} {name}")
