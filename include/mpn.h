@@ -345,6 +345,12 @@ int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream
  * term tf.losses.get_total_loss(add_regularization_losses=True) adds to the reported loss (keypoints_model.py:79).
  * One block, fixed summation order (f64): deterministic. */
 int mpn_l2_loss_accumulate(long long n, const float* w, float scale, float* acc, mpn_stream_t stream);
+/* The same over `count` tensors (host arrays of device pointers / element counts) in two launches: per-block f64 partial sums
+ * into `workspace` (mpn_l2_loss_batched_workspace_bytes bytes), then one block adds them in a fixed order - the whole
+ * regularisation term of a model (keypoints_model.py:129-138 sums every kernel) without one single-block launch per variable. */
+size_t mpn_l2_loss_batched_workspace_bytes(int count, const long long* n);
+int mpn_l2_loss_batched(int count, const float* const* w, const long long* n, float scale, float* acc, void* workspace,
+                        size_t workspace_bytes, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * L1  target-heatmap rendering (label producer of the keypoint path).

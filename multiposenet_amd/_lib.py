@@ -111,6 +111,8 @@ SIGNATURES = {
     "mpn_retina_nms_workspace_bytes": (_Z, [_I, _I]),
     "mpn_retina_nms": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "mpn_l2_loss_accumulate": (_I, [_L, _P, _F, _P, _P]),
+    "mpn_l2_loss_batched_workspace_bytes": (_Z, [_I, _P]),
+    "mpn_l2_loss_batched": (_I, [_I, _P, _P, _F, _P, _P, _Z, _P]),
 }
 
 _lib = None

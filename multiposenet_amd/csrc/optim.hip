@@ -228,6 +228,45 @@ __global__ __launch_bounds__(1024) void l2_loss_kernel(long long n, const float*
     }
     if (threadIdx.x == 0) acc[0] = (float)((double)acc[0] + scale * 0.5 * red[0]);
 }
+// The regularisation term of a whole model in two launches (add_weight_decay sums tf.nn.l2_loss over every kernel,
+// keypoints_model.py:129-138; the person detector trains with weight_decay 5e-5, train_person_detector.py): one single-block
+// launch per variable took 2.4 ms of the detector's 9 ms step (a 4 MB pointwise kernel through ONE block: 476 us).
+constexpr int kL2Max = 96;             // tensors per launch
+constexpr int kL2Chunk = 16384;        // elements per block
+struct L2Batch { const float* w[kL2Max]; long long n[kL2Max]; int begin[kL2Max + 1]; int count; };
+__global__ __launch_bounds__(256) void l2_partial_kernel(const L2Batch b, double* __restrict__ partial) {
+    __shared__ double red[256];
+    int t = 0;
+    for (int k = 1; k < b.count; ++k)
+        if ((int)blockIdx.x >= b.begin[k]) t = k;                       // block-uniform
+    const long long i0 = (long long)((int)blockIdx.x - b.begin[t]) * kL2Chunk;
+    const long long i1 = i0 + kL2Chunk < b.n[t] ? i0 + kL2Chunk : b.n[t];
+    const float* __restrict__ w = b.w[t];
+    double s = 0.0;
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+        const double v = (double)w[i];
+        s += v * v;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void l2_final_kernel(const double* __restrict__ partial, int n, double scale, float* __restrict__ acc) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partial[i];         // fixed order: deterministic
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if ((int)threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[0] = (float)((double)acc[0] + scale * 0.5 * red[0]);
+}
 }  // namespace
 
 /* step: device int64 global_step (incremented); hyper: device f32[4] -> {lr_t, lr, -, -} */
@@ -328,6 +367,40 @@ extern "C" int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stre
 extern "C" int mpn_l2_loss_accumulate(long long n, const float* w, float scale, float* acc, mpn_stream_t stream) {
     MPN_REQUIRE(w && acc && n > 0, MPN_ERR_BAD_ARG, "l2_loss_accumulate: bad arguments");
     l2_loss_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(n, w, (double)scale, acc);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+
+/* acc[0] += scale * sum_t l2_loss(w[t]) over `count` tensors (host arrays of device pointers / element counts) in two
+ * launches: per-block f64 partial sums of 16 384 elements into `workspace`, then one block adds them in a fixed order.
+ * workspace: mpn_l2_loss_batched_workspace_bytes(count, n) bytes. Deterministic. */
+extern "C" size_t mpn_l2_loss_batched_workspace_bytes(int count, const long long* n) {
+    size_t blocks = 0;
+    for (int t = 0; t < count; ++t) blocks += (size_t)((n[t] + kL2Chunk - 1) / kL2Chunk);
+    return blocks * sizeof(double);
+}
+extern "C" int mpn_l2_loss_batched(int count, const float* const* w, const long long* n, float scale, float* acc, void* workspace,
+                                   size_t workspace_bytes, mpn_stream_t stream) {
+    MPN_REQUIRE(count > 0 && w && n && acc && workspace, MPN_ERR_BAD_ARG, "l2_loss_batched: bad arguments");
+    MPN_REQUIRE(workspace_bytes >= mpn_l2_loss_batched_workspace_bytes(count, n), MPN_ERR_WORKSPACE, "l2_loss_batched: workspace too small");
+    double* partial = reinterpret_cast<double*>(workspace);
+    int total = 0;
+    for (int t0 = 0; t0 < count; t0 += kL2Max) {
+        L2Batch b;
+        b.count = count - t0 < kL2Max ? count - t0 : kL2Max;
+        int begin = 0;
+        for (int k = 0; k < b.count; ++k) {
+            MPN_REQUIRE(w[t0 + k] && n[t0 + k] > 0, MPN_ERR_BAD_ARG, "l2_loss_batched: tensor %d", t0 + k);
+            b.w[k] = w[t0 + k]; b.n[k] = n[t0 + k]; b.begin[k] = begin;
+            begin += (int)((n[t0 + k] + kL2Chunk - 1) / kL2Chunk);
+        }
+        b.begin[b.count] = begin;
+        l2_partial_kernel<<<begin, 256, 0, (hipStream_t)stream>>>(b, partial + total);
+        MPN_LAUNCH_CHECK();
+        total += begin;
+    }
+    l2_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(partial, total, (double)scale, acc);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

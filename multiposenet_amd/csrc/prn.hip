@@ -46,6 +46,36 @@ __global__ __launch_bounds__(kThreads) void bias_relu_fwd_kernel(const TI* __res
     }
 }
 
+// the same, 8 elements (one or two 16-byte vectors) per thread; C % 8 == 0 so a vector never straddles a row
+template <typename TI, typename TO>
+__global__ __launch_bounds__(kThreads) void bias_relu_fwd_vec_kernel(const TI* __restrict__ pre, const float* __restrict__ bias,
+                                                                    TO* __restrict__ y, long long nvec, int cvec) {
+    for (long long v = (long long)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (long long)gridDim.x * kThreads) {
+        const int c0 = (int)(v % cvec) * 8;
+        const float4 b0 = *reinterpret_cast<const float4*>(bias + c0), b1 = *reinterpret_cast<const float4*>(bias + c0 + 4);
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float f[8];
+        if constexpr (sizeof(TI) == 4) {
+            const float4 p0 = *reinterpret_cast<const float4*>(pre + v * 8), p1 = *reinterpret_cast<const float4*>(pre + v * 8 + 4);
+            f[0] = p0.x; f[1] = p0.y; f[2] = p0.z; f[3] = p0.w; f[4] = p1.x; f[5] = p1.y; f[6] = p1.z; f[7] = p1.w;
+        } else {
+            Vec16<TI> q;
+            q.load(pre + v * 8);
+            q.unpack(f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j] + bb[j], 0.f);
+        if constexpr (sizeof(TO) == 4) {
+            *reinterpret_cast<float4*>(y + v * 8) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(y + v * 8 + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        } else {
+            Vec16<TO> q;
+            q.pack(f);
+            q.store(y + v * 8);
+        }
+    }
+}
+
 // dpre[r][c] = y[r][c] > 0 ? dy[r][c] : 0;  dbias[c] = sum_r dpre[r][c]   (one thread per column, R rows: tiny R)
 template <typename TY, typename TD>
 __global__ __launch_bounds__(kThreads) void bias_relu_bwd_kernel(const TY* __restrict__ y, const float* __restrict__ dy,
@@ -60,6 +90,47 @@ __global__ __launch_bounds__(kThreads) void bias_relu_bwd_kernel(const TY* __res
         s += g;   // dbias from the unrounded gradient
     }
     dbias[c] = s;
+}
+
+// the same with 4 row groups per column quad: thread (quad, rg) walks rows rg, rg + 4, ... of columns 4 quad .. 4 quad + 3 (16-byte
+// f32 loads, 4 rows in flight); the four row groups of a quad add their column sums through LDS in a fixed order. C % 4 == 0.
+template <typename TY, typename TD>
+__global__ __launch_bounds__(kThreads) void bias_relu_bwd_vec_kernel(const TY* __restrict__ y, const float* __restrict__ dy,
+                                                                    TD* __restrict__ dpre, float* __restrict__ dbias, int R, int C) {
+    __shared__ float red[4][64][4];
+    const int ql = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + ql) * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        for (int r0 = rg; r0 < R; r0 += 16) {
+            float4 g[4];
+            float yv[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 4 * u < R ? r0 + 4 * u : rg;        // (unconditional loads from a valid row)
+                const long long i = (long long)r * C + c;
+                g[u] = *reinterpret_cast<const float4*>(dy + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) yv[u][j] = to_f32(y[i + j]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + 4 * u >= R) break;
+                const long long i = (long long)(r0 + 4 * u) * C + c;
+                const float gg[4] = {yv[u][0] > 0.f ? g[u].x : 0.f, yv[u][1] > 0.f ? g[u].y : 0.f, yv[u][2] > 0.f ? g[u].z : 0.f,
+                                     yv[u][3] > 0.f ? g[u].w : 0.f};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dpre[i + j] = from_f32<TD>(gg[j]); s[j] += gg[j]; }   // dbias from the unrounded gradient
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[rg][ql][j] = s[j];
+    __syncthreads();
+    if (rg == 0 && c < C) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dbias[c + j] = (red[0][ql][j] + red[1][ql][j]) + (red[2][ql][j] + red[3][ql][j]);
+    }
 }
 
 // logits[b][p][c] = x[b][p][c] + y2[b][p][c];  prob = softmax over p;  loss = mean(log_loss(labels, prob, eps=1e-7));
@@ -135,6 +206,89 @@ __global__ __launch_bounds__(kThreads) void prn_loss_kernel(const float* __restr
     (void)stat;
 }
 
+// The same, coalesced: a block of 1024 threads per crop, of which LT = (1024 / C) * C are active (1020 for 17 channels) - thread t
+// owns elements t, t + LT, t + 2 LT, ... of the crop's flattened [P][C] array, so consecutive threads read consecutive
+// addresses and a thread's channel t % C never changes. The crop's logits (then numerators, then probabilities) live in LDS
+// (56 x 36 x 17 floats = 137 KB: one block per CU): ONE read of x, y2 and labels from memory, one exp per element.
+// Channel reductions: LDS, the LT / C threads of a channel in a fixed order.
+constexpr int kLossThreads = 1024;
+template <typename TY>
+__global__ __launch_bounds__(kLossThreads) void prn_loss_wide_kernel(const float* __restrict__ x, const TY* __restrict__ y2,
+                                                                    const float* __restrict__ labels, int P, int C, float inv_total,
+                                                                    float ginv, float* __restrict__ logits, float* __restrict__ dlogits,
+                                                                    float* __restrict__ loss_part) {
+    extern __shared__ __attribute__((aligned(16))) float zs[];       // [P * C]
+    __shared__ float red[kLossThreads];
+    __shared__ float chan[32];
+    const int t = threadIdx.x;
+    const int per = kLossThreads / C, LT = per * C;      // threads per channel, active threads
+    const bool on = t < LT;
+    const int c = t % C;
+    const long long base = (long long)blockIdx.x * P * C;
+    const int n = P * C;
+    auto reduce_c = [&](float v, bool is_max) -> float {
+        red[t] = v;
+        __syncthreads();
+        if (t < C) {
+            float r = is_max ? -INFINITY : 0.f;
+            for (int k = 0; k < per; ++k) {
+                const float q = red[k * C + t];
+                r = is_max ? fmaxf(r, q) : r + q;
+            }
+            chan[t] = r;
+        }
+        __syncthreads();
+        const float r = chan[c];
+        __syncthreads();
+        return r;
+    };
+    float m = -INFINITY;
+    if (on)
+        for (int i = t; i < n; i += LT) {
+            const float z = x[base + i] + to_f32(y2[base + i]);
+            logits[base + i] = z;
+            zs[i] = z;
+            m = fmaxf(m, z);
+        }
+    m = reduce_c(m, true);
+    float se = 0.f;
+    if (on)
+        for (int i = t; i < n; i += LT) {
+            const float e = expf(zs[i] - m);
+            zs[i] = e;
+            se += e;
+        }
+    se = reduce_c(se, false);
+    const float inv_se = 1.f / se;
+    const float eps = 1e-7f;
+    float l = 0.f, gp = 0.f;
+    if (on)
+        for (int i = t; i < n; i += LT) {
+            const float pr = zs[i] * inv_se;
+            const float yv = labels[base + i];
+            l += -yv * logf(pr + eps) - (1.f - yv) * logf(1.f - pr + eps);
+            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * ginv;
+            gp += g * pr;
+            zs[i] = pr;
+        }
+    gp = reduce_c(gp, false);
+    if (on && dlogits != nullptr)
+        for (int i = t; i < n; i += LT) {        // (the labels once more, out of the L2)
+            const float pr = zs[i];
+            const float yv = labels[base + i];
+            const float g = (-yv / (pr + eps) + (1.f - yv) / (1.f - pr + eps)) * ginv;
+            dlogits[base + i] = pr * (g - gp);
+        }
+    red[t] = on ? l : 0.f;
+    __syncthreads();
+    if (t < 64) {   // fixed order: 16 strided terms per lane, then the butterfly
+        float s = 0.f;
+        for (int k = t; k < kLossThreads; k += 64) s += red[k];
+        s = wave_sum(s);
+        if (t == 0) loss_part[blockIdx.x] = s * inv_total;
+    }
+}
+
 int blocks_for(long long n) {
     long long b = (n + kThreads - 1) / kThreads;
     if (b > 8192) b = 8192;
@@ -179,7 +333,12 @@ extern "C" int mpn_bias_relu_fwd(const void* pre, int pre_dtype, const float* bi
     const long long n = (long long)R * C;
     hipStream_t st = (hipStream_t)stream;
     const int g = blocks_for(n);
-    PRN_DISPATCH_TWO(pre_dtype, out_dtype, (bias_relu_fwd_kernel<TI, TO><<<g, kThreads, 0, st>>>((const TI*)pre, bias, (TO*)y, n, C)));
+    if (C % 8 == 0 && mpn_aligned16(pre) && mpn_aligned16(y) && mpn_aligned16(bias)) {
+        const int gv = blocks_for(n / 8);
+        PRN_DISPATCH_TWO(pre_dtype, out_dtype, (bias_relu_fwd_vec_kernel<TI, TO><<<gv, kThreads, 0, st>>>((const TI*)pre, bias, (TO*)y, n / 8, C / 8)));
+    } else {
+        PRN_DISPATCH_TWO(pre_dtype, out_dtype, (bias_relu_fwd_kernel<TI, TO><<<g, kThreads, 0, st>>>((const TI*)pre, bias, (TO*)y, n, C)));
+    }
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -191,7 +350,12 @@ extern "C" int mpn_bias_relu_bwd(const void* y, int y_dtype, const float* dy, vo
     MPN_REQUIRE(y_dtype == dpre_dtype, MPN_ERR_BAD_DTYPE, "bias_relu_bwd: y and dpre must share one dtype");
     hipStream_t st = (hipStream_t)stream;
     const int g = (C + kThreads - 1) / kThreads;
-    PRN_DISPATCH_ONE(y_dtype, TS, (bias_relu_bwd_kernel<TS, TS><<<g, kThreads, 0, st>>>((const TS*)y, dy, (TS*)dpre, dbias, R, C)));
+    if (C % 4 == 0 && mpn_aligned16(dy)) {
+        const int gv = (C / 4 + 63) / 64;
+        PRN_DISPATCH_ONE(y_dtype, TS, (bias_relu_bwd_vec_kernel<TS, TS><<<gv, kThreads, 0, st>>>((const TS*)y, dy, (TS*)dpre, dbias, R, C)));
+    } else {
+        PRN_DISPATCH_ONE(y_dtype, TS, (bias_relu_bwd_kernel<TS, TS><<<g, kThreads, 0, st>>>((const TS*)y, dy, (TS*)dpre, dbias, R, C)));
+    }
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -224,7 +388,16 @@ extern "C" int mpn_prn_loss(const float* x, const void* y2, int y2_dtype, const 
     MPN_REQUIRE(B > 0 && P > 0 && C > 0 && C * kPL <= kThreads, MPN_ERR_BAD_SHAPE, "prn_loss: C must be <= %d", kThreads / kPL);
     const float inv_total = 1.0f / ((float)B * (float)P * (float)C);
     hipStream_t st = (hipStream_t)stream;
-    PRN_DISPATCH_ONE(y2_dtype, TS, (prn_loss_kernel<TS><<<B, kThreads, 0, st>>>(x, (const TS*)y2, labels, P, C, inv_total, inv_total * grad_scale, logits, dlogits, loss_part)));
+    const size_t zbytes = (size_t)P * C * sizeof(float);
+    if (zbytes <= 150 * 1024) {   // the crop's logits fit the LDS of one CU (56 x 36 x 17 floats = 137 KB do)
+        PRN_DISPATCH_ONE(y2_dtype, TS, {
+            static mpn_attr_mask_t attr_mask{0};
+            MPN_HIP(mpn_ensure_dynamic_lds((const void*)prn_loss_wide_kernel<TS>, 150 * 1024, &attr_mask));
+            prn_loss_wide_kernel<TS><<<B, kLossThreads, zbytes, st>>>(x, (const TS*)y2, labels, P, C, inv_total, inv_total * grad_scale, logits, dlogits, loss_part);
+        });
+    } else {
+        PRN_DISPATCH_ONE(y2_dtype, TS, (prn_loss_kernel<TS><<<B, kThreads, 0, st>>>(x, (const TS*)y2, labels, P, C, inv_total, inv_total * grad_scale, logits, dlogits, loss_part)));
+    }
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

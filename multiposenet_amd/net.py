@@ -201,6 +201,7 @@ class KeypointNet:
             missing = [k for k in list(self.vars) + list(self.stats) if k not in values]
             if missing:
                 raise KeyError(f"missing variables: {missing[:5]}...")
+        self._infer_clean = False
         if hasattr(self, "convs"):
             self.repack_weights()
 
@@ -260,6 +261,9 @@ class KeypointNet:
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
         self.fuse_conv_bn = True
+        self._l2 = None           # the regularisation term's batched launch (add_weight_decay_loss)
+        self.cache_inference_affine = False   # see prepare_inference
+        self._infer_clean = False
         # the stem kernel can write its own batch-norm partial sums (mpn_stem_conv_fwd_stats); OFF: measured a wash - the
         # separate statistics pass (38 us) reads the 134 MB stem output into the memory-side cache, and the first depthwise
         # layer then runs 52 instead of 83 us
@@ -438,9 +442,14 @@ class KeypointNet:
             ops.bn_finalize(bn, b["stat_part"], nparts, count, training=True)
 
     def prepare_inference(self):
-        """is_training=False: every batch-norm becomes the affine of its moving statistics."""
+        """is_training=False: every batch-norm becomes the affine of its moving statistics. With cache_inference_affine (a
+        frozen backbone under the person detector, the joint inference graph) the 40 small launches run once and again only
+        after the variables changed through this object (load_state_dict, a training forward, an optimizer step)."""
+        if self.cache_inference_affine and self._infer_clean:
+            return
         for bn in self.all_bn:
             ops.bn_inference_affine(bn)
+        self._infer_clean = True
 
     def backbone_forward(self, images, is_training, b=None):
         """mobilenet_v1 (detector/backbones/mobilenet_v1.py:11-79). Returns {'c2'..'c5': (raw NHWC tensor, Affine)}."""
@@ -448,6 +457,8 @@ class KeypointNet:
         b = b or self._buffers(N, H, W)
         if not is_training:
             self.prepare_inference()
+        else:
+            self._infer_clean = False       # (the finalizes below overwrite the affines and move the statistics)
         sp = b["stat_part"]
         c0 = self.stem_w.shape[3]
         # training (opt-in, fuse_stem_stats): the stem kernel writes the batch-norm partial sums of its own output
@@ -719,13 +730,15 @@ class KeypointNet:
         (tf.losses.get_total_loss(add_regularization_losses=True), keypoints_model.py:24-27,79). Call after
         compute_losses; the per-term losses stay as they are."""
         total = self._last[0]["losses"][6:7]
-        for k, w in self.vars.items():
-            if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k:
-                ops.l2_loss_accumulate(w.view(-1), weight_decay, total)
+        if self._l2 is None:
+            self._l2 = ops.L2LossBatch([w for k, w in self.vars.items()
+                                        if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k])
+        self._l2.run(weight_decay, total)
 
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, initial_learning_rate, num_steps, grad_scale=1.0):
         """Cosine LR + clip(+-200) + TF-Adam over the flat arena, then refresh the packed weights."""
         ops.adam_prepare(self.global_step, self.hyper, initial_learning_rate, num_steps)
         ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, grad_scale=grad_scale)
+        self._infer_clean = False
         self.repack_weights()

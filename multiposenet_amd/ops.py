@@ -611,6 +611,22 @@ def axpy(a, x, y):
     call("mpn_axpy", x.numel(), float(a), ptr(x), ptr(y), stream_ptr())
 
 
+class L2LossBatch:
+    """acc[0] += scale * sum of tf.nn.l2_loss over a fixed list of tensors, two launches (mpn_l2_loss_batched)."""
+
+    def __init__(self, tensors):
+        n = len(tensors)
+        self._keep = list(tensors)
+        self.n = n
+        self.ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        self.counts = (ctypes.c_longlong * n)(*[t.numel() for t in tensors])
+        nbytes = _lib.lib().mpn_l2_loss_batched_workspace_bytes(n, self.counts)
+        self.ws = torch.empty(max(8, nbytes), dtype=torch.uint8, device=tensors[0].device)
+
+    def run(self, scale, acc):
+        call("mpn_l2_loss_batched", self.n, self.ptrs, self.counts, float(scale), ptr(acc), ptr(self.ws), self.ws.numel(), stream_ptr())
+
+
 def l2_loss_accumulate(w, scale, acc):
     """acc[0] += scale * sum(w^2)/2 (acc: f32 device tensor view of one element)."""
     call("mpn_l2_loss_accumulate", w.numel(), ptr(w), float(scale), ptr(acc), stream_ptr())

@@ -177,6 +177,9 @@ class PersonDetectorNet:
         self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._convs = []
+        self._infer_clean = False
+        self.backbone.cache_inference_affine = True     # frozen here: its inference affines change only with its variables
+        self._l2 = None
         self._built = False
         self.load_state_dict(head_values if head_values is not None else initial_head_values(seed, self.dm))
         self._build_layers()
@@ -204,6 +207,7 @@ class PersonDetectorNet:
             missing = [k for k in list(self.vars) + list(self.stats) if k not in values]
             if missing:
                 raise KeyError(f"missing variables: {missing[:5]}...")
+        self._infer_clean = False
         if self._built:
             self.repack_weights()
 
@@ -343,8 +347,12 @@ class PersonDetectorNet:
     def head_forward(self, feats, b, is_training, images=None):
         """RetinaNet.__init__ (retinanet.py:14-58) on backbone features {'c3','c4','c5': (raw NHWC tensor, Affine)}."""
         if not is_training:
-            for bn in self.all_bn:
-                ops.bn_inference_affine(bn)
+            if not self._infer_clean:      # (45 small launches: once per change of the head's variables)
+                for bn in self.all_bn:
+                    ops.bn_inference_affine(bn)
+                self._infer_clean = True
+        else:
+            self._infer_clean = False
         fin, spl = b["fin"], b["stat_lv"]
         st = (lambda l: spl[l]) if is_training else (lambda l: None)
         prev = None
@@ -429,12 +437,12 @@ class PersonDetectorNet:
         losses[2:3].zero_()           # (a memset: an element assignment from a Python scalar is a host copy, not capturable)
         wd = float(params.get("weight_decay", 0.0))
         if wd > 0.0:   # add_weight_decay (keypoints_model.py:129-138) sees EVERY kernel, the frozen backbone's included
-            for k, w in self.vars.items():
-                if "kernel" in k:
-                    ops.l2_loss_accumulate(w.view(-1), wd, losses[2:3])
-            for k, w in self.backbone.vars.items():
-                if k.startswith("MobilenetV1/") and "weights" in k and "depthwise_weights" not in k:
-                    ops.l2_loss_accumulate(w.view(-1), wd, losses[2:3])
+            if self._l2 is None:
+                ts = [w for k, w in self.vars.items() if "kernel" in k]
+                ts += [w for k, w in self.backbone.vars.items()
+                       if k.startswith("MobilenetV1/") and "weights" in k and "depthwise_weights" not in k]
+                self._l2 = ops.L2LossBatch(ts)
+            self._l2.run(wd, losses[2:3])
         # normaliser 1 / max(num_matched, 1), the weighted total and the output convolutions' bias gradients: one launch
         call("mpn_retina_loss_finalize", ptr(b["loss_sums"]), ptr(b["num_matched"]), lw, cw, ptr(losses),
              ptr(self.out_dbias["class_net"]) if with_grad else None, ptr(self.out_dbias["box_net"]) if with_grad else None, stream_ptr())

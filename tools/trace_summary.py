@@ -6,7 +6,8 @@ import sys
 KEYS = ['conv3x3', 'pw_gemm', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_finalize', 'bn_bwd_finalize', 'bn_act', 'dwconv_fwd', 'dwconv_wgrad',
         'dwconv_dgrad', 'dwconv_bwd', 'conv_wgrad', 'conv_mfma', 'reduce_partials', 'stem_wgrad', 'stem_fwd', 'pack_weights',
         'bilinear_up_fwd', 'bilinear_up_bwd', 'slice_copy', 'slice_affine_store', 'head_bwd', 'head_fwd', 'loss_kernel', 'loss_finalize', 'adam', 'add_inplace',
-        'sumpool', 'bn_stats', 'copyBuffer', 'decode']
+        'sumpool', 'bn_stats', 'copyBuffer', 'decode',
+        'retina_match', 'retina_loss', 'retina_nms', 'retina_', 'patchify', 'prn_loss', 'prn_', 'transpose_cast', 'cast_kernel', 'bias_relu', 'l2_loss', 'axpy']
 
 
 def short(nm):
