@@ -122,7 +122,7 @@ int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_p
  * ([mpn_conv_num_parts(N,H[j],W[j],3)][2][C] floats) receives the partial sums of g and of g * bn_x with the RAW x: finish
  * with a finalize built by mpn_bn_bwd_fin_desc_fill_raw. One tensor read and one launch less than mpn_bn_bwd_reduce behind
  * the data gradient. dy [N,H,W,K], dx / bn_x [N,H,W,C] (pixel strides as arrays or NULL = dense); 16-bit storage,
- * K % 64 == 0, K <= 512, C % 128 == 0, C <= 512: mpn_conv_bwd_data_bn_supported(K, C, ksize, dtype) != 0. */
+ * K % 64 == 0, K <= 512, C % 64 == 0, C <= 512: mpn_conv_bwd_data_bn_supported(K, C, ksize, dtype) != 0. */
 int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype);
 int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, const void* const* w_packed_t, void* const* dx, int N,
                                  const int* H, const int* W, int K, int C, const int* dy_stride, const int* dx_stride,

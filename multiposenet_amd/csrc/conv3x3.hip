@@ -120,7 +120,7 @@ __device__ __forceinline__ Tile tile_of(const Group& g, int w) {
 // takes them from a wave-private LDS image of 32 pixels at a time in the halo buffer that has just been released.
 template <typename T, bool AFFINE, bool N64, bool BNR = false>
 __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
-    static_assert(!BNR || (!AFFINE && !N64), "the fused batch-norm backward reduction rides on the 128-channel data gradient");
+    static_assert(!BNR || !AFFINE, "the fused batch-norm backward reduction rides on a data gradient (no producer affine)");
     constexpr int NS = N64 ? 3 : 6;     // weight stages per 64-channel chunk
     constexpr int BN = N64 ? 64 : 128;  // output channels per tile
     using H = H16<T>;
@@ -249,16 +249,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     // (lane = 16-byte piece lane % 8 of image rows lane / 8 + 8 k; two passes of 32 pixels): eight 16-byte loads per lane,
     // requested under the tile's LAST weight stage and consumed by the epilogue
     // (the first pass's four loads under the last stage - all eight there spill -, the second pass's at the top of the epilogue)
-    uint4 bx[BNR ? 8 : 1];
+    // (N64: a wave finishes ONE pass - rows 2 wn, 2 wn + 1 of its row group, all 64 channels - into bx[0..3])
+    uint4 bx[BNR ? (N64 ? 4 : 8) : 1];
     auto bnr_load = [&](const Tile& t, int hp) {
         if constexpr (BNR) {
             const Job& p = g.job[t.job];
-            const T* xb = reinterpret_cast<const T*>(p.bnr_x) + t.ntile * BN + wn * 64 + (lane & 7) * 8;
+            const T* xb = reinterpret_cast<const T*>(p.bnr_x) + t.ntile * BN + (N64 ? 0 : wn * 64) + (lane & 7) * 8;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = (lane >> 3) + 8 * k;
                 const int oy = min(t.oy0 + 4 * wm + hp * 2 + (row >> 4), p.H - 1), ox = min(t.ox0 + (row & 15), p.W - 1);
-                bx[hp * 4 + k] = *reinterpret_cast<const uint4*>(xb + (((long long)t.img * p.H + oy) * p.W + ox) * p.bnr_xs);
+                bx[(N64 ? 0 : hp * 4) + k] = *reinterpret_cast<const uint4*>(xb + (((long long)t.img * p.H + oy) * p.W + ox) * p.bnr_xs);
             }
         }
     };
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
                 if (sl < NS - 1 || !last_chunk) b_issue(wsrc, chunk * NS + sl + 1, (ss + 1) & 1);
                 else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
-                if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, 0); }
+                if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, N64 ? wn : 0); }
                 if (sl == 0) {
                     // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
                     // the six registers become PHIs, hipcc copies them right behind the loads - and waits for the loads there
@@ -413,8 +414,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             f32x2_t bsc[4], bsh[4], bs[4], bq[4];
             float blo = -INFINITY, bhi = INFINITY;
             if constexpr (BNR) {
-                bnr_load(cur, 1);
-                const float* ts = tab + cur.ntile * BN + wn * 64 + (lane & 7) * 8;
+                if constexpr (!N64) bnr_load(cur, 1);
+                const float* ts = tab + cur.ntile * BN + (N64 ? 0 : wn * 64) + (lane & 7) * 8;
                 const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(ts), s1 = *reinterpret_cast<const f32x4_t*>(ts + 4);
                 const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin), h1 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin + 4);
                 bsc[0] = (f32x2_t){s0[0], s0[1]}; bsc[1] = (f32x2_t){s0[2], s0[3]}; bsc[2] = (f32x2_t){s1[0], s1[1]}; bsc[3] = (f32x2_t){s1[2], s1[3]};
@@ -510,9 +511,15 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 if (lane < 8) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const int cl = wn * 64 + lane * 8 + 2 * j;
-                        red[(wm * 2 + 0) * 128 + cl] = bs[j][0]; red[(wm * 2 + 0) * 128 + cl + 1] = bs[j][1];
-                        red[(wm * 2 + 1) * 128 + cl] = bq[j][0]; red[(wm * 2 + 1) * 128 + cl + 1] = bq[j][1];
+                        if constexpr (N64) {      // red [8 waves][2][64]
+                            const int cl = lane * 8 + 2 * j;
+                            red[(wave * 2 + 0) * 64 + cl] = bs[j][0]; red[(wave * 2 + 0) * 64 + cl + 1] = bs[j][1];
+                            red[(wave * 2 + 1) * 64 + cl] = bq[j][0]; red[(wave * 2 + 1) * 64 + cl + 1] = bq[j][1];
+                        } else {
+                            const int cl = wn * 64 + lane * 8 + 2 * j;
+                            red[(wm * 2 + 0) * 128 + cl] = bs[j][0]; red[(wm * 2 + 0) * 128 + cl + 1] = bs[j][1];
+                            red[(wm * 2 + 1) * 128 + cl] = bq[j][0]; red[(wm * 2 + 1) * 128 + cl + 1] = bq[j][1];
+                        }
                     }
                 }
             }
@@ -575,7 +582,7 @@ int launch_t(const Group& g, int blocks, hipStream_t st) {
 }
 template <typename T>
 int launch_v(const Group& g, int blocks, bool affine, bool n64, bool bnr, hipStream_t st) {
-    if (bnr) return launch_t<T, false, false, true>(g, blocks, st);
+    if (bnr) return n64 ? launch_t<T, false, true, true>(g, blocks, st) : launch_t<T, false, false, true>(g, blocks, st);
     if (n64) return affine ? launch_t<T, true, true>(g, blocks, st) : launch_t<T, false, true>(g, blocks, st);
     return affine ? launch_t<T, true, false>(g, blocks, st) : launch_t<T, false, false>(g, blocks, st);
 }
@@ -609,9 +616,9 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
     const bool bnr = jobs[0].bnr_x != nullptr;
     for (int j = 0; j < njobs; ++j) {
         MPN_REQUIRE((jobs[j].bnr_x != nullptr) == bnr, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the fused-reduction variant");
-        MPN_REQUIRE(!bnr || (!affine && !n64 && jobs[j].stats_part && jobs[j].bnr_scale && jobs[j].bnr_shift && jobs[j].bnr_xs >= jobs[j].Cout &&
+        MPN_REQUIRE(!bnr || (!affine && jobs[j].stats_part && jobs[j].bnr_scale && jobs[j].bnr_shift && jobs[j].bnr_xs >= jobs[j].Cout &&
                              jobs[j].bnr_xs % 8 == 0 && jobs[j].Cout <= kMaxCin && mpn_aligned16(jobs[j].bnr_x)),
-                    MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a 128-channel-tile data gradient, a partial slab and the layer's affine");
+                    MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a data gradient (no producer affine), a partial slab and the layer's affine");
     }
     if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, bnr, st);
     if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, bnr, st);

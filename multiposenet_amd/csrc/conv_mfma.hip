@@ -919,9 +919,9 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
  * no-op) and part[j] ([mpn_conv_num_parts(N,H,W,3)][2][C] floats) receives the partial sums of g and of g * bn_x (RAW x:
  * finish with a mpn_bn_bwd_fin_desc_fill_raw finalize, which forms sum g * xhat = invstd * (sum g x - mean * sum g)).
  * One tensor read (dx) and one launch less than mpn_bn_bwd_reduce afterwards. 16-bit storage, K % 64 == 0, K <= 512,
- * C % 128 == 0, C <= 512: mpn_conv_bwd_data_bn_supported says whether a geometry is covered. */
+ * C % 64 == 0, C <= 512: mpn_conv_bwd_data_bn_supported says whether a geometry is covered. */
 extern "C" int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype) {
-    return (ksize == 3 && (dtype == MPN_BF16 || dtype == MPN_F16) && mpn_c3::eligible(K, C, 9, 2) && C <= 512) ? 1 : 0;
+    return (ksize == 3 && (dtype == MPN_BF16 || dtype == MPN_F16) && (mpn_c3::eligible(K, C, 9, 2) || mpn_c3::eligible64(K, C, 9, 2)) && C <= 512) ? 1 : 0;
 }
 
 extern "C" int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, const void* const* w_packed_t, void* const* dx, int N,

@@ -177,6 +177,7 @@ class PersonDetectorNet:
         self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._convs = []
+        self.fuse_conv_bn = True       # set before the first backward pass of a shape (the finalize tables are built once)
         self._infer_clean = False
         self.backbone.cache_inference_affine = True     # frozen here: its inference affines change only with its variables
         self._l2 = None
@@ -245,6 +246,10 @@ class PersonDetectorNet:
         for c in self._convs:
             c.repack()
 
+    def _fused_conv_bn(self):
+        """The towers' 3x3 data gradients also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn_grouped)."""
+        return self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(TOWER_DEPTH, TOWER_DEPTH, 3, self.dtype)
+
     # ------------------------------------------------------------------ buffers
     def _buffers(self, N, H, W):
         key = (N, H, W)
@@ -284,7 +289,11 @@ class PersonDetectorNet:
         for net, _, _ in NETS:
             for i in range(4):
                 fin[(net, i)] = ops.BnFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], fwd3[l], cnt[l]) for l in LEVELS], dev)
-                fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
+                # batch_norm_0..2 are reduced inside the data gradient of the tower convolution above them (conv rows, raw x)
+                if i < 3 and self._fused_conv_bn():
+                    fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], fwd3[l], cnt[l], True) for l in LEVELS], dev)
+                else:
+                    fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
         fin["dp"] = ops.BnBwdFinalizeBatch([(self.p_bn[l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
         b["fin"] = fin
         b["levels_hw"] = ((ctypes.c_int * 5)(*[lv[l][0] for l in LEVELS]), (ctypes.c_int * 5)(*[lv[l][1] for l in LEVELS]))
@@ -464,10 +473,12 @@ class PersonDetectorNet:
                                         [bn3[l].affine for l in LEVELS], [slab[(oc.name, l)] for l in LEVELS])
             ops.conv_fwd_grouped([g["out"][net][l] for l in LEVELS], [oc.packed.bwd] * 5, TOWER_DEPTH, 3, none5,
                                  [g["t"][net][3][l] for l in LEVELS], none5)
+            fused = self._fused_conv_bn()
             for i in (3, 2, 1, 0):
                 bns = [self.tower_bn[net][i][l] for l in LEVELS]
                 dAs, xs = [g["t"][net][i][l] for l in LEVELS], [b["t"][net][i][l] for l in LEVELS]
-                ops.bn_bwd_reduce_grouped(bns, dAs, xs, sps)
+                if not (fused and i < 3):      # (else: reduced by the data gradient of conv3x3_{i+1} below)
+                    ops.bn_bwd_reduce_grouped(bns, dAs, xs, sps)
                 fin[("d", net, i)].run()
                 ops.bn_bwd_apply_grouped(bns, dAs, xs)
                 c = self.tower[net][i]
@@ -478,7 +489,10 @@ class PersonDetectorNet:
                     xin, ain = [b["p"][l] for l in LEVELS], [self.p_bn[l].affine for l in LEVELS]
                     dst = [g["pn"][net][l] for l in LEVELS]
                 ops.conv_bwd_weight_grouped(xin, dAs, 3, ain, [slab[(c.name, l)] for l in LEVELS])
-                ops.conv_fwd_grouped(dAs, [c.packed.bwd] * 5, c.cin, 3, none5, dst, none5)
+                if fused and i > 0:   # the data gradient also reduces for batch_norm_{i-1} (and writes its gradient masked)
+                    ops.conv_bwd_data_bn_grouped(dAs, [c.packed.bwd] * 5, c.cin, [self.tower_bn[net][i - 1][l] for l in LEVELS], xin, dst, sps)
+                else:
+                    ops.conv_fwd_grouped(dAs, [c.packed.bwd] * 5, c.cin, 3, none5, dst, none5)
         # the two towers meet at act(bn(p_l)): sum, then through p{l}_batch_norm
         gp = [g["pn"]["box_net"][l] for l in LEVELS]
         for l in LEVELS:
