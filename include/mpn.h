@@ -124,6 +124,12 @@ int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_p
  * the data gradient. dy [N,H,W,K], dx / bn_x [N,H,W,C] (pixel strides as arrays or NULL = dense); 16-bit storage,
  * K % 64 == 0, K <= 512, C % 64 == 0, C <= 512: mpn_conv_bwd_data_bn_supported(K, C, ksize, dtype) != 0. */
 int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype);
+/* One layer: 3x3 as above, or a deep 1x1 layer through the GEMM kernel (bf16, K >= 256, K % 64 == 0, C % 256 == 0: the data
+ * gradients of Conv2d_5..13_pointwise, which feed the depthwise layers' batch-norms, mobilenet_v1.py:66-74). part:
+ * [mpn_conv_num_parts(N,H,W,ksize)][2][C]; finish with mpn_bn_bwd_finalize_raw. */
+int mpn_conv_bwd_data_bn(const void* dy, const void* w_packed_t, void* dx, int N, int H, int W, int K, int C, int dy_stride,
+                         int dx_stride, int ksize, int dtype, const void* bn_x, int bn_x_stride, const float* bn_scale,
+                         const float* bn_shift, int bn_act, float* part, mpn_stream_t stream);
 int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, const void* const* w_packed_t, void* const* dx, int N,
                                  const int* H, const int* W, int K, int C, const int* dy_stride, const int* dx_stride,
                                  int dtype, const void* const* bn_x, const int* bn_x_stride, const float* const* bn_scale,
@@ -211,6 +217,10 @@ int mpn_bn_bwd_reduce(const void* dA, const void* x, long long M, int C, int dty
                       const float* invstd, int act, float* part, mpn_stream_t stream);
 int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
                         float* dbeta, float* k1, float* k2, mpn_stream_t stream);
+/* mpn_bn_bwd_finalize for a slab whose second row holds sum g * x with the RAW x (mpn_conv_bwd_data_bn): mean / invstd = the
+ * layer's saved batch statistics. */
+int mpn_bn_bwd_finalize_raw(const float* part, int nparts, int C, long long count, float* dgamma, float* dbeta, float* k1,
+                            float* k2, const float* mean, const float* invstd, mpn_stream_t stream);
 /* dA <- scale*(g - k1 - xhat*k2) in place; add_ch0 (NULL or [M] f32) is added to channel 0 */
 int mpn_bn_bwd_apply(void* dA, const void* x, long long M, int C, int dtype, const float* scale,
                      const float* shift, const float* mean, const float* invstd, const float* k1,

@@ -96,6 +96,8 @@ SIGNATURES = {
     "mpn_prn_crop": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "mpn_prn_decode": (_I, [_P, _I, _I, _I, _I, _P, _P, _P]),
     "mpn_conv_bwd_data_bn_supported": (_I, [_I, _I, _I, _I]),
+    "mpn_conv_bwd_data_bn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P]),
+    "mpn_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P]),
     "mpn_conv_bwd_data_bn_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P]),
     "mpn_bn_bwd_fin_desc_fill_raw": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I]),
     "mpn_prn_crop_slots": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),

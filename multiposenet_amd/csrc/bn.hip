@@ -379,9 +379,10 @@ template <int CPB>
 __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nparts, int C,
                                                                       double count, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta,
-                                                                      float* __restrict__ k1, float* __restrict__ k2) {
+                                                                      float* __restrict__ k1, float* __restrict__ k2,
+                                                                      const float* __restrict__ mean, const float* __restrict__ invstd) {
     __shared__ double red[2][kFinLanes][16];
-    bn_bwd_finalize_block<CPB>(blockIdx.x, red, part, nparts, C, count, dgamma, dbeta, k1, k2);
+    bn_bwd_finalize_block<CPB>(blockIdx.x, red, part, nparts, C, count, dgamma, dbeta, k1, k2, mean, invstd);
 }
 __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_batched_kernel(const BnBwdFinDesc* __restrict__ descs, int ndesc) {
     __shared__ double red[2][kFinLanes][16];
@@ -773,7 +774,20 @@ extern "C" int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long lo
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_bwd_finalize: bad sizes");
     MPN_REQUIRE(C % 4 == 0 && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "bn_bwd_finalize: C must be a multiple of 4 and part 16-byte aligned");
     bn_bwd_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
-                                                                               dgamma, dbeta, k1, k2);
+                                                                               dgamma, dbeta, k1, k2, nullptr, nullptr);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* The same for a slab whose second row holds sum g * x with the RAW x (mpn_conv_bwd_data_bn): mean / invstd = the layer's saved
+ * batch statistics; sum g * xhat = invstd * (sum g x - mean * sum g) in f64. */
+extern "C" int mpn_bn_bwd_finalize_raw(const float* part, int nparts, int C, long long count, float* dgamma, float* dbeta, float* k1,
+                                       float* k2, const float* mean, const float* invstd, mpn_stream_t stream) {
+    MPN_REQUIRE(part && dgamma && dbeta && k1 && k2 && mean && invstd, MPN_ERR_BAD_ARG, "bn_bwd_finalize_raw: null pointer");
+    MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_bwd_finalize_raw: bad sizes");
+    MPN_REQUIRE(C % 4 == 0 && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "bn_bwd_finalize_raw: C must be a multiple of 4 and part 16-byte aligned");
+    bn_bwd_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
+                                                                               dgamma, dbeta, k1, k2, mean, invstd);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

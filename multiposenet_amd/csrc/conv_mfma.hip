@@ -921,6 +921,7 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
  * One tensor read (dx) and one launch less than mpn_bn_bwd_reduce afterwards. 16-bit storage, K % 64 == 0, K <= 512,
  * C % 64 == 0, C <= 512: mpn_conv_bwd_data_bn_supported says whether a geometry is covered. */
 extern "C" int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype) {
+    if (ksize == 1) return (dtype == MPN_BF16 && pw_gemm_eligible(K, C, 1, 2)) ? 1 : 0;   // the deep 1x1 layers (pointwise.hip)
     return (ksize == 3 && (dtype == MPN_BF16 || dtype == MPN_F16) && (mpn_c3::eligible(K, C, 9, 2) || mpn_c3::eligible64(K, C, 9, 2)) && C <= 512) ? 1 : 0;
 }
 
@@ -947,4 +948,25 @@ extern "C" int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, co
         jobs[j].bnr_xs = bs > 0 ? bs : C;
     }
     return mpn_c3::launch(jobs, njobs, dtype, (hipStream_t)stream);
+}
+
+/* One layer (1x1 through the GEMM kernel of pointwise.hip: the data gradients of Conv2d_5..13_pointwise, which feed the
+ * depthwise layers' batch-norms, mobilenet_v1.py:66-74; or 3x3): dy [N,H,W,K] -> dx [N,H,W,C] masked, part
+ * [mpn_conv_num_parts(N,H,W,ksize)][2][C] = partial sums of g and g * bn_x (raw x). */
+extern "C" int mpn_conv_bwd_data_bn(const void* dy, const void* w_packed_t, void* dx, int N, int H, int W, int K, int C,
+                                    int dy_stride, int dx_stride, int ksize, int dtype, const void* bn_x, int bn_x_stride,
+                                    const float* bn_scale, const float* bn_shift, int bn_act, float* part, mpn_stream_t stream) {
+    MPN_REQUIRE(mpn_conv_bwd_data_bn_supported(K, C, ksize, dtype), MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: geometry not covered (K %d, C %d, k %d)", K, C, ksize);
+    if (ksize == 3) {
+        const int h = H, w = W;
+        return mpn_conv_bwd_data_bn_grouped(1, &dy, &w_packed_t, &dx, N, &h, &w, K, C, &dy_stride, &dx_stride, dtype, &bn_x, &bn_x_stride,
+                                            &bn_scale, &bn_shift, bn_act, &part, stream);
+    }
+    MPN_REQUIRE(dy && w_packed_t && dx && bn_x && bn_scale && bn_shift && part && N > 0 && H > 0 && W > 0, MPN_ERR_BAD_ARG, "conv_bwd_data_bn: bad arguments");
+    MPN_REQUIRE(mpn_aligned16(dy) && mpn_aligned16(w_packed_t) && mpn_aligned16(dx) && mpn_aligned16(bn_x) && mpn_aligned16(bn_scale) && mpn_aligned16(bn_shift),
+                MPN_ERR_BAD_ALIGN, "conv_bwd_data_bn: pointers must be 16-byte aligned");
+    MPN_REQUIRE((dy_stride == 0 || (dy_stride >= K && dy_stride % 8 == 0)) && (dx_stride == 0 || (dx_stride >= C && dx_stride % 8 == 0)) &&
+                (bn_x_stride == 0 || (bn_x_stride >= C && bn_x_stride % 8 == 0)), MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: bad pixel strides");
+    return pw_gemm_launch(dy, w_packed_t, dx, (long long)N * H * W, K, C, dy_stride > 0 ? dy_stride : K, dx_stride > 0 ? dx_stride : C, nullptr, nullptr,
+                          MPN_ACT_NONE, part, (hipStream_t)stream, bn_x, bn_x_stride > 0 ? bn_x_stride : C, bn_scale, bn_shift, bn_act);
 }

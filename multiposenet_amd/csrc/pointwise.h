@@ -7,4 +7,6 @@
 __attribute__((visibility("hidden"))) bool pw_gemm_eligible(int K, int N, int taps, int es);
 __attribute__((visibility("hidden"))) int pw_gemm_launch(const void* x, const void* w_nk, void* y, long long M, int K, int N,
                                                          int x_stride, int y_stride, const float* in_scale,
-                                                         const float* in_shift, int in_act, float* stats_part, hipStream_t st);
+                                                         const float* in_shift, int in_act, float* stats_part, hipStream_t st,
+                                                         const void* bnr_x = nullptr, int bnr_xs = 0, const float* bnr_scale = nullptr,
+                                                         const float* bnr_shift = nullptr, int bnr_act = 0);

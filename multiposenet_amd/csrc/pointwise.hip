@@ -46,6 +46,12 @@ struct PwParams {
     float* stats_part;
     long long M;
     int K, N, x_stride, y_stride, n_tiles, m_tiles;
+    // data gradients that also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn): y is written MASKED by that layer's
+    // activation (computed from bnr_x * bnr_scale + bnr_shift) and stats_part receives the sums of g and g * bnr_x (raw x)
+    const bf16_t* bnr_x;
+    const float* bnr_scale;
+    const float* bnr_shift;
+    int bnr_act, bnr_xs;
 #ifdef MPN_DIAG
     unsigned long long* dbg;   // diagnostic build only: 8 u64 per block (s_memtime at the phase boundaries; [6], [7]: s_memrealtime)
 #endif
@@ -86,7 +92,7 @@ __device__ __forceinline__ void glds16(const void* src, void* dst) {
 
 // ================= epilogue shared by the kernels below: bf16 image of the tile in LDS (over the dead staging buffers:
 // the caller has passed a barrier after the last fragment read), statistics on the matrix unit, 16-byte row stores
-template <int BM>
+template <int BM, bool BNR>
 __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* smem, f32x4_t (&acc)[BM / 32][4], const int mtile,
                                             const int n0, const long long m0) {
     constexpr int MT = BM / 32, NT = 4;
@@ -97,6 +103,7 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* sm
     constexpr int RSO = BN * 2 + 8;
     unsigned char* O = smem;
     float* red = reinterpret_cast<float*>(smem + BM * RSO);   // BM == 128 only: [2 wm][2][BN]
+
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = wm * (BM / 2) + mt * 16 + l15;
@@ -109,7 +116,7 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* sm
         }
     }
     PW_STAMP(3);
-    if (p.stats_part != nullptr) {
+    if (!BNR && p.stats_part != nullptr) {
         f32x4_t sa[NT], ga[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) { sa[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ga[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -156,18 +163,96 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* sm
         const unsigned char* Ow = O + (wm * (BM / 2)) * RSO + wn * 128;
         bf16_t* yw = p.y + n0 + wn * 64;
         const int prow = lane >> 3, piece = lane & 7;
+        f32x2_t bsc[4], bsh[4], bs[4], bq[4];
+        float blo = -INFINITY, bhi = INFINITY;
+        if constexpr (BNR) {
+            const float* sc = p.bnr_scale + n0 + wn * 64 + piece * 8;
+            const float* sh = p.bnr_shift + n0 + wn * 64 + piece * 8;
+            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sc), s1 = *reinterpret_cast<const f32x4_t*>(sc + 4);
+            const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(sh), h1 = *reinterpret_cast<const f32x4_t*>(sh + 4);
+            bsc[0] = (f32x2_t){s0[0], s0[1]}; bsc[1] = (f32x2_t){s0[2], s0[3]}; bsc[2] = (f32x2_t){s1[0], s1[1]}; bsc[3] = (f32x2_t){s1[2], s1[3]};
+            bsh[0] = (f32x2_t){h0[0], h0[1]}; bsh[1] = (f32x2_t){h0[2], h0[3]}; bsh[2] = (f32x2_t){h1[0], h1[1]}; bsh[3] = (f32x2_t){h1[2], h1[3]};
 #pragma unroll
-        for (int i = 0; i < BM / 16; ++i) {
+            for (int j = 0; j < 4; ++j) { bs[j] = (f32x2_t){0.f, 0.f}; bq[j] = (f32x2_t){0.f, 0.f}; }
+            blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
+            bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
+        }
+        // BNR: the fed layer's raw tensor at this wave's pixels x 64 channels in the copy-out layout (lane = 16-byte piece lane % 8
+        // of rows lane / 8 + 8 i), eight rows (32 registers) at a time behind a fence - all BM / 16 at once, or hoisted above
+        // the image stores next to the live accumulators, they spill
+        uint4 bx[BNR ? 8 : 1];
+        // (BNR: a REAL loop over groups of eight rows - fully unrolled, hipcc hoists every group's LDS reads to the top and
+        //  spills the running sums)
+#pragma unroll 1
+        for (int i0 = 0; i0 < (BNR ? BM / 16 : 1); i0 += 8) {
+        if constexpr (BNR) {
+            const bf16_t* xw = p.bnr_x + n0 + wn * 64 + piece * 8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                long long px = m0 + wm * (BM / 2) + (i0 + u) * 8 + prow;
+                if (px >= p.M) px = p.M - 1;       // (rows past the end hold dy = 0)
+                bx[u] = *reinterpret_cast<const uint4*>(xw + px * p.bnr_xs);
+            }
+        }
+#pragma unroll
+        for (int iu = 0; iu < (BNR ? 8 : BM / 16); ++iu) {
+            const int i = i0 + iu;
             const int row = i * 8 + prow;
             const long long pixel = m0 + wm * (BM / 2) + row;
-            if (pixel < p.M) {
-                const uint2 a = *reinterpret_cast<const uint2*>(Ow + row * RSO + piece * 16);
-                const uint2 b = *reinterpret_cast<const uint2*>(Ow + row * RSO + piece * 16 + 8);
+            if (BNR || pixel < p.M) {
+                uint2 a = *reinterpret_cast<const uint2*>(Ow + row * RSO + piece * 16);
+                uint2 b = *reinterpret_cast<const uint2*>(Ow + row * RSO + piece * 16 + 8);
+                if constexpr (BNR) {
+                    // g = dy where the fed batch-norm's activation passes (the test of bn_bwd_reduce / bn_bwd_apply), else 0;
+                    // sums of g and g * x (rows past the end hold dy = 0)
+                    const unsigned xu[4] = {bx[iu & 7].x, bx[iu & 7].y, bx[iu & 7].z, bx[iu & 7].w};
+                    unsigned du[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2_t xf = {__uint_as_float(xu[j] << 16), __uint_as_float(xu[j] & 0xffff0000u)};
+                        const f32x2_t pre = xf * bsc[j] + bsh[j];
+                        const unsigned m = ((pre[0] > blo && pre[0] < bhi) ? 0x0000ffffu : 0u) | ((pre[1] > blo && pre[1] < bhi) ? 0xffff0000u : 0u);
+                        du[j] &= m;
+                        const f32x2_t gf = {__uint_as_float(du[j] << 16), __uint_as_float(du[j] & 0xffff0000u)};
+                        bs[j] += gf;
+                        bq[j] += gf * xf;
+                    }
+                    a = make_uint2(du[0], du[1]); b = make_uint2(du[2], du[3]);
+                }
+                if (pixel < p.M) {
 // non-temporal: 33 MB of plain stores stay dirty in the L2s and are written back when the kernel ends, in front
                 // of the next launch; streamed out they leave during the copy-out (2-10 % per launch, measured)
                 typedef unsigned u32x4n_t __attribute__((ext_vector_type(4)));
                 const u32x4n_t v4 = {a.x, a.y, b.x, b.y};
                 __builtin_nontemporal_store(v4, reinterpret_cast<u32x4n_t*>(yw + pixel * p.y_stride + piece * 8));
+                }
+            }
+        }
+        }
+        if constexpr (BNR) {
+            // the 8 row lanes of a piece (lane bits 3..5), fixed butterfly; lanes 0..7 then hold the wave's sums of 8 channels each
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bs[j][0] += __shfl_xor(bs[j][0], o, 64); bs[j][1] += __shfl_xor(bs[j][1], o, 64);
+                    bq[j][0] += __shfl_xor(bq[j][0], o, 64); bq[j][1] += __shfl_xor(bq[j][1], o, 64);
+                }
+            if (lane < 8) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int cl = wn * 64 + lane * 8 + 2 * j;
+                    if (BM == 256) {   // wave row wm = one 128-pixel statistics row of its own
+                        const long long srow = (long long)mtile * 2 + wm;
+                        if (srow * 128 < p.M) {
+                            p.stats_part[(srow * 2 + 0) * p.N + n0 + cl] = bs[j][0]; p.stats_part[(srow * 2 + 0) * p.N + n0 + cl + 1] = bs[j][1];
+                            p.stats_part[(srow * 2 + 1) * p.N + n0 + cl] = bq[j][0]; p.stats_part[(srow * 2 + 1) * p.N + n0 + cl + 1] = bq[j][1];
+                        }
+                    } else {
+                        red[(wm * 2 + 0) * BN + cl] = bs[j][0]; red[(wm * 2 + 0) * BN + cl + 1] = bs[j][1];
+                        red[(wm * 2 + 1) * BN + cl] = bq[j][0]; red[(wm * 2 + 1) * BN + cl + 1] = bq[j][1];
+                    }
+                }
             }
         }
     }
@@ -181,8 +266,9 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* sm
 }
 
 // BM: pixels per block (256 or 128); AFFINE: A rows through registers with batch-norm affine + activation, else LDS-DMA
-template <int BM, bool AFFINE>
+template <int BM, bool AFFINE, bool BNR = false>
 __global__ __launch_bounds__(kThreads, 2) void pw_gemm_kernel(const PwParams p) {
+    static_assert(!BNR || !AFFINE, "the fused batch-norm backward reduction rides on a data gradient (no producer affine)");
     constexpr int MT = BM / 32;                  // 16-pixel m-tiles per wave (waves: 2 along M x 4 along N)
     constexpr int NT = 4;                        // 16-channel n-tiles per wave
     constexpr int A_BYTES = BM * KB, B_BYTES = BN * KB;
@@ -422,18 +508,18 @@ __global__ __launch_bounds__(kThreads, 2) void pw_gemm_kernel(const PwParams p) 
     PW_STAMP(2);
     __syncthreads();   // every wave is done with the staging buffers: the output image may overwrite them
 
-    pw_epilogue<BM>(p, smem, acc, mtile, n0, m0);
+    pw_epilogue<BM, BNR>(p, smem, acc, mtile, n0, m0);
 }
 
-template <int BM, bool AFFINE>
+template <int BM, bool AFFINE, bool BNR = false>
 int launch_pw(const PwParams& p, hipStream_t st) {
     const int smem = 2 * BM * KB + 2 * BN * KB + (AFFINE ? 2 * p.K * (int)sizeof(float) : 0);
     const int need = BM * (BN * 2 + 8) + (BM == 128 ? 4 * BN * (int)sizeof(float) : 0);   // the epilogue's image (+ red)
     const int bytes = smem > need ? smem : need;
     MPN_REQUIRE(bytes <= 160 * 1024, MPN_ERR_BAD_SHAPE, "pointwise: K = %d needs %d bytes of LDS", p.K, bytes);
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)pw_gemm_kernel<BM, AFFINE>, 160 * 1024, &attr_mask));
-    pw_gemm_kernel<BM, AFFINE><<<dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(kThreads), bytes, st>>>(p);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)pw_gemm_kernel<BM, AFFINE, BNR>, 160 * 1024, &attr_mask));
+    pw_gemm_kernel<BM, AFFINE, BNR><<<dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(kThreads), bytes, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -453,8 +539,10 @@ bool pw_gemm_eligible(int K, int N, int taps, int es) {
 }
 
 int pw_gemm_launch(const void* x, const void* w_nk, void* y, long long M, int K, int N, int x_stride, int y_stride,
-                   const float* in_scale, const float* in_shift, int in_act, float* stats_part, hipStream_t st) {
+                   const float* in_scale, const float* in_shift, int in_act, float* stats_part, hipStream_t st,
+                   const void* bnr_x, int bnr_xs, const float* bnr_scale, const float* bnr_shift, int bnr_act) {
     PwParams p;
+    p.bnr_x = (const bf16_t*)bnr_x; p.bnr_scale = bnr_scale; p.bnr_shift = bnr_shift; p.bnr_act = bnr_act; p.bnr_xs = bnr_xs;
     p.x = (const bf16_t*)x; p.w = (const bf16_t*)w_nk; p.y = (bf16_t*)y;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.stats_part = stats_part;
     p.M = M; p.K = K; p.N = N; p.x_stride = x_stride; p.y_stride = y_stride;
@@ -467,6 +555,11 @@ int pw_gemm_launch(const void* x, const void* w_nk, void* y, long long M, int K,
     const bool big = t256 * p.n_tiles >= 256;
     p.m_tiles = (int)(big ? t256 : (M + 127) / 128);
     const bool affine = in_scale != nullptr;
+    if (bnr_x != nullptr) {
+        MPN_REQUIRE(!affine && stats_part && bnr_scale && bnr_shift && bnr_xs >= N && bnr_xs % 8 == 0, MPN_ERR_BAD_ARG,
+                    "pointwise: the fused batch-norm reduction needs a data gradient (no producer affine), a partial slab and the layer's affine");
+        return big ? launch_pw<256, false, true>(p, st) : launch_pw<128, false, true>(p, st);
+    }
     if (big) return affine ? launch_pw<256, true>(p, st) : launch_pw<256, false>(p, st);
     return affine ? launch_pw<128, true>(p, st) : launch_pw<128, false>(p, st);
 }

@@ -689,8 +689,13 @@ class KeypointNet:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
             ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced)
             W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
-            ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
-            ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
+            # the deep pointwise layers' data gradients also reduce for the depthwise batch-norm they feed
+            if self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(blk["pw"].cout, blk["pw"].cin, 1, self.dtype):
+                rows = ops.conv_bwd_data_bn(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, blk["dw_bn"], b["dw"][i], g["dw"][i], sp)
+                ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, reduced_parts=rows, raw=True)
+            else:
+                ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
+                ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
             W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))

@@ -126,6 +126,16 @@ def conv_bwd_data_bn_supported(k, c, ksize, dtype):
     return bool(_lib.lib().mpn_conv_bwd_data_bn_supported(int(k), int(c), int(ksize), _lib.dtype_code(dtype)))
 
 
+def conv_bwd_data_bn(dy, packed_t, c, ksize, bn, x_bn, out, part):
+    """Data gradient of one convolution (3x3, or a deep 1x1 layer) that also reduces for the batch-norm layer `bn` it feeds
+    (raw tensor x_bn): out <- masked gradient, part <- partial sums of g and g * x (raw x: bn_backward(..., reduced_parts=rows,
+    raw=True)). Returns the rows the slab holds."""
+    N, H, W, k = dy.shape
+    call("mpn_conv_bwd_data_bn", ptr(dy), ptr(packed_t), ptr(out), N, H, W, k, int(c), _slice_stride(dy, k), _slice_stride(out, c), int(ksize),
+         _lib.dtype_code(dy.dtype), ptr(x_bn), _slice_stride(x_bn, c), ptr(bn.scale), ptr(bn.shift), int(bn.act), ptr(part), stream_ptr())
+    return conv_num_parts(N, H, W, ksize)
+
+
 def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
     """Data gradients of several independent 3x3 convolutions in one grid that also reduce for the batch-norm layers `bns`
     they feed (raw tensors xs_bn): outs[j] <- masked gradient, parts[j] <- partial sums of g and g * x (RAW x: finalize with a
@@ -355,14 +365,18 @@ def bn_act_apply(x, affine, out=None):
     return out
 
 
-def bn_backward(bn, dA, x, part, add_ch0=None, reduced_parts=0):
+def bn_backward(bn, dA, x, part, add_ch0=None, reduced_parts=0, raw=False):
     """In place: dA (gradient w.r.t. act(bn(x))) -> gradient w.r.t. the raw conv output x.
     Writes bn.dgamma / bn.dbeta. `part` must hold mpn_bn_stats_num_parts(M)*2*C floats.
-    reduced_parts > 0: the producer of dA already wrote that many partial rows into `part` (dwconv_bwd_data(..., bn=...))."""
+    reduced_parts > 0: the producer of dA already wrote that many partial rows into `part` (dwconv_bwd_data(..., bn=...);
+    raw: conv_bwd_data_bn, whose slab holds sum g * x with the raw x)."""
     M, C = x.numel() // x.shape[-1], x.shape[-1]
     dc = _lib.dtype_code(x.dtype)
     nparts = _lib.lib().mpn_bn_stats_num_parts(M)
-    if reduced_parts:
+    if reduced_parts and raw:
+        call("mpn_bn_bwd_finalize_raw", ptr(part), int(reduced_parts), C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2),
+             ptr(bn.mean), ptr(bn.invstd), stream_ptr())
+    elif reduced_parts:
         call("mpn_bn_bwd_finalize", ptr(part), int(reduced_parts), C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), stream_ptr())
     else:
         call("mpn_bn_bwd_reduce", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),

@@ -471,3 +471,55 @@ def test_conv_dgrad_with_fused_bn_reduction(cuda, dtype, act, K, C):
                  ops.stream_ptr())
         for a, b_, name in zip(got[j], (bn.dgamma, bn.dbeta, bn.k1, bn.k2), ("dgamma", "dbeta", "k1", "k2")):
             np.testing.assert_allclose(a.cpu().numpy(), b_.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(b_.abs().max() + 1e-6), err_msg=f"job {j} {name}")
+
+
+@pytest.mark.parametrize("N,H,W,K,C,act", [(2, 16, 16, 512, 512, 2), (1, 13, 11, 256, 256, 2), (8, 96, 96, 512, 256, 1), (3, 16, 16, 1024, 1024, 0),
+                                           (9, 85, 83, 256, 256, 2)],
+                         ids=["512to512", "ragged-256", "big-tiles", "1024-none", "big-ragged"])
+def test_pointwise_dgrad_with_fused_bn_reduction(cuda, N, H, W, K, C, act):
+    """mpn_conv_bwd_data_bn, 1x1 through the GEMM kernel (the data gradients of Conv2d_5..13_pointwise feed the depthwise
+    batch-norms): dx = the plain data gradient masked by the fed layer's activation, bit for bit; slab sums and the raw finalize
+    against f64 references on the kernel's own outputs; 128- and 256-pixel tiles, ragged M, a channel-slice raw tensor."""
+    from multiposenet_amd import ops
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(K + C + H)
+    assert ops.conv_bwd_data_bn_supported(K, C, 1, dtype) and not ops.conv_bwd_data_bn_supported(128, 64, 1, dtype)
+    w = (rs.randn(1, 1, C, K) / np.sqrt(C)).astype(np.float32)           # forward conv C -> K; its data gradient maps K -> C
+    pc = ops.PackedConv(dev(w), dtype)
+    dy = dev(rnd(rs.randn(N, H, W, K), dtype), dtype)
+    xw = dev(rnd(rs.randn(N, H, W, C + 64) * 1.5 + 0.3, dtype), dtype)
+    x = xw[..., 64:64 + C]                                                # a channel slice (pixel stride C + 64)
+    bn = ops.BNState(dev(torch.tensor(0.5 + rs.rand(C), dtype=torch.float32)), dev(torch.tensor(rs.randn(C) * 0.3, dtype=torch.float32)),
+                     torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), act)
+    xf = x.float().reshape(-1, C)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    bn.mean.copy_(mean); bn.invstd.copy_(1.0 / torch.sqrt(var + 1e-3))
+    bn.scale.copy_(bn.gamma * bn.invstd); bn.shift.copy_(bn.beta - mean * bn.scale)
+    bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    want = ops.conv_fwd(dy, pc.bwd, C, 1)
+    out = torch.full((N, H, W, C), float("nan"), device="cuda", dtype=dtype)
+    part = torch.full((ops.conv_num_parts(N, H, W, 1) * 2 * C,), float("nan"), device="cuda")
+    rows = ops.conv_bwd_data_bn(dy, pc.bwd, C, 1, bn, x, out, part)
+    pre = (x.double() * bn.scale.double() + bn.shift.double()).float()
+    ok = torch.ones_like(pre, dtype=torch.bool)
+    if act != 0:
+        ok = pre > 0
+    if act == 2:
+        ok = ok & (pre < 6)
+    g = torch.where(ok, want, torch.zeros_like(want))
+    assert int((out != g).sum()) <= 2
+    cnt = N * H * W
+    ps = part.view(rows, 2, C).double().sum(0).cpu()
+    gd, xd = out.double().reshape(-1, C).cpu(), x.double().reshape(-1, C).cpu()
+    np.testing.assert_allclose(ps[0].numpy(), gd.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(ps[1].numpy(), (gd * xd).sum(0).numpy(), rtol=1e-4, atol=3e-3)
+    # in place through bn_backward (raw finalize + apply) against the separate three passes on the masked gradient
+    ref = out.clone()
+    sp = torch.empty(ops._lib.lib().mpn_bn_stats_num_parts(cnt) * 2 * C, device="cuda")
+    xc = x.contiguous()
+    ops.bn_backward(bn, ref, xc, sp)
+    want_dg, want_db = bn.dgamma.clone(), bn.dbeta.clone()
+    ops.bn_backward(bn, out, xc, part, reduced_parts=rows, raw=True)
+    np.testing.assert_allclose(bn.dgamma.cpu().numpy(), want_dg.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_dg.abs().max()))
+    np.testing.assert_allclose(bn.dbeta.cpu().numpy(), want_db.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_db.abs().max()))
+    assert float((out.float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())
