@@ -124,9 +124,10 @@ int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_p
  * the data gradient. dy [N,H,W,K], dx / bn_x [N,H,W,C] (pixel strides as arrays or NULL = dense); 16-bit storage,
  * K % 64 == 0, K <= 512, C % 64 == 0, C <= 512: mpn_conv_bwd_data_bn_supported(K, C, ksize, dtype) != 0. */
 int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype);
-/* One layer: 3x3 as above, or a deep 1x1 layer through the GEMM kernel (bf16, K >= 256, K % 64 == 0, C % 256 == 0: the data
- * gradients of Conv2d_5..13_pointwise, which feed the depthwise layers' batch-norms, mobilenet_v1.py:66-74). part:
- * [mpn_conv_num_parts(N,H,W,ksize)][2][C]; finish with mpn_bn_bwd_finalize_raw. */
+/* One layer: 3x3 as above, or a 1x1 layer (bf16, K and C multiples of 8: the data gradients of Conv2d_1..13_pointwise, which
+ * feed the depthwise layers' batch-norms, mobilenet_v1.py:66-74, and of the FPN's lateral of c5, fpn.py:38) - through the GEMM
+ * kernel where mpn_conv_fwd routes the geometry there, else the tiled kernel. part: [mpn_conv_num_parts(N,H,W,ksize)][2][C];
+ * finish with mpn_bn_bwd_finalize_raw. */
 int mpn_conv_bwd_data_bn(const void* dy, const void* w_packed_t, void* dx, int N, int H, int W, int K, int C, int dy_stride,
                          int dx_stride, int ksize, int dtype, const void* bn_x, int bn_x_stride, const float* bn_scale,
                          const float* bn_shift, int bn_act, float* part, mpn_stream_t stream);

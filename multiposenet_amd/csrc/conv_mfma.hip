@@ -71,6 +71,12 @@ struct ConvParams {
     int n_tiles;
     long long wp_tile_bytes;  // packed bytes per n-tile
     int xcd_remap;            // XCD-aware block -> tile map
+    // data gradients that also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn, thin 1x1 layers): y is written MASKED
+    // by that layer's activation (from bnr_x * bnr_scale + bnr_shift) and stats_part receives the sums of g and g * bnr_x
+    const void* bnr_x;
+    const float* bnr_scale;
+    const float* bnr_shift;
+    int bnr_act, bnr_xs;
 #ifdef MPN_DIAG
     unsigned long long* dbg;  // diagnostic build only (tools/build_variant.sh -DMPN_DIAG): per-block s_memtime stamps, or NULL
 #endif
@@ -143,8 +149,9 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
 //  index and block count)
 // Variants that were built, measured and removed again (256-pixel tiles, a 3-slot / 5-slot weight ring, the 32x32x16
 // MFMA shape, a warp-specialised persistent kernel, batch-norm finalizes fused into the last-finishing blocks): DESIGN.md 4c.
-template <typename T, int TAPS, int BN, int RB>
+template <typename T, int TAPS, int BN, int RB, bool BNR = false>
 __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int blk, const int nwg_job) {
+    static_assert(!BNR || (TAPS == 1 && sizeof(T) == 2), "the fused batch-norm backward reduction: thin 1x1 data gradients, 16-bit storage");
     constexpr int MT = 4;                       // 16-pixel m-tiles per wave
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
@@ -357,7 +364,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                 }
             }
             MPN_STAMP(3);
-            if (p.stats_part != nullptr) {
+            if (!BNR && p.stats_part != nullptr) {
                 f32x4_t sa[NT], ga[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) { sa[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; ga[nt] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
@@ -396,6 +403,30 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                 constexpr int PPP = kThreads / SL;    // pixel rows per pass
                 const int slot = tid % SL;
                 const bool cok = n0 + slot * 8 < p.Cout;
+                // BNR: a thread keeps its 16-byte piece (8 channels) over its ROWS / PPP rows: the fed layer's raw rows (requested
+                // up front), the mask, and the running sums of g and g * x
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                uint4 bx[BNR ? ROWS / PPP : 1];
+                f32x2_t bsc[4], bsh[4], bs[4], bq[4];
+                float blo = -INFINITY, bhi = INFINITY;
+                if constexpr (BNR) {
+                    const int cch = cok ? n0 + slot * 8 : 0;
+                    const T* xw = reinterpret_cast<const T*>(p.bnr_x) + cch;
+#pragma unroll
+                    for (int i = 0; i < ROWS / PPP; ++i) {
+                        long long px = m0 + tid / SL + i * PPP;
+                        if (px >= p.M) px = p.M - 1;                  // (rows past the end hold dy = 0)
+                        bx[i] = *reinterpret_cast<const uint4*>(xw + px * p.bnr_xs);
+                    }
+                    const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(p.bnr_scale + cch), s1 = *reinterpret_cast<const f32x4_t*>(p.bnr_scale + cch + 4);
+                    const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(p.bnr_shift + cch), h1 = *reinterpret_cast<const f32x4_t*>(p.bnr_shift + cch + 4);
+                    bsc[0] = (f32x2_t){s0[0], s0[1]}; bsc[1] = (f32x2_t){s0[2], s0[3]}; bsc[2] = (f32x2_t){s1[0], s1[1]}; bsc[3] = (f32x2_t){s1[2], s1[3]};
+                    bsh[0] = (f32x2_t){h0[0], h0[1]}; bsh[1] = (f32x2_t){h0[2], h0[3]}; bsh[2] = (f32x2_t){h1[0], h1[1]}; bsh[3] = (f32x2_t){h1[2], h1[3]};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { bs[j] = (f32x2_t){0.f, 0.f}; bq[j] = (f32x2_t){0.f, 0.f}; }
+                    blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
+                    bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
+                }
 #pragma unroll
                 for (int i = 0; i < ROWS / PPP; ++i) {
                     const int row = tid / SL + i * PPP;
@@ -409,10 +440,53 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                         pixel = m0 + row;
                         ok = pixel < p.M;
                     }
-                    if (ok && cok) {
-                        const uint2 a = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16);
-                        const uint2 b = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16 + 8);
-                        *reinterpret_cast<uint4*>(y + pixel * p.y_stride + n0 + slot * 8) = make_uint4(a.x, a.y, b.x, b.y);
+                    if ((BNR || ok) && cok) {
+                        uint2 a = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16);
+                        uint2 b = *reinterpret_cast<const uint2*>(O + row * RSO + slot * 16 + 8);
+                        if constexpr (BNR) {
+                            // g = dy where the fed batch-norm's activation passes (the test of bn_bwd_reduce / bn_bwd_apply), else 0
+                            const unsigned xu[4] = {bx[i].x, bx[i].y, bx[i].z, bx[i].w};
+                            unsigned du[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const f32x2_t xf = {to_f32(__builtin_bit_cast(T, (unsigned short)(xu[j] & 0xffffu))),
+                                                    to_f32(__builtin_bit_cast(T, (unsigned short)(xu[j] >> 16)))};
+                                const f32x2_t pre = xf * bsc[j] + bsh[j];
+                                const unsigned m = ((pre[0] > blo && pre[0] < bhi) ? 0x0000ffffu : 0u) | ((pre[1] > blo && pre[1] < bhi) ? 0xffff0000u : 0u);
+                                du[j] &= m;
+                                const f32x2_t gf = {to_f32(__builtin_bit_cast(T, (unsigned short)(du[j] & 0xffffu))),
+                                                    to_f32(__builtin_bit_cast(T, (unsigned short)(du[j] >> 16)))};
+                                bs[j] += gf;
+                                bq[j] += gf * xf;
+                            }
+                            a = make_uint2(du[0], du[1]); b = make_uint2(du[2], du[3]);
+                        }
+                        if (ok) *reinterpret_cast<uint4*>(y + pixel * p.y_stride + n0 + slot * 8) = make_uint4(a.x, a.y, b.x, b.y);
+                    }
+                }
+                if constexpr (BNR) {
+                    // the row lanes of a piece inside a wave (lane bits above log2 SL), fixed butterfly; then the four waves through
+                    // `red` in a fixed order: (wave 0 + wave 1) + (wave 2 + wave 3)
+#pragma unroll
+                    for (int o = SL; o < 64; o <<= 1)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            bs[j][0] += __shfl_xor(bs[j][0], o, 64); bs[j][1] += __shfl_xor(bs[j][1], o, 64);
+                            bq[j][0] += __shfl_xor(bq[j][0], o, 64); bq[j][1] += __shfl_xor(bq[j][1], o, 64);
+                        }
+                    const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph) {
+                        if ((wv & 1) == ph && ln < SL) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                float* r0 = red + ((wv >> 1) * 2 + 0) * BN + ln * 8 + 2 * j;
+                                float* r1 = red + ((wv >> 1) * 2 + 1) * BN + ln * 8 + 2 * j;
+                                if (ph == 0) { r0[0] = bs[j][0]; r0[1] = bs[j][1]; r1[0] = bq[j][0]; r1[1] = bq[j][1]; }
+                                else { r0[0] += bs[j][0]; r0[1] += bs[j][1]; r1[0] += bq[j][0]; r1[1] += bq[j][1]; }
+                            }
+                        }
+                        __syncthreads();
                     }
                 }
             }
@@ -506,9 +580,9 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
     MPN_STAMP(4);
 }
 
-template <typename T, int TAPS, int BN, int RB>
+template <typename T, int TAPS, int BN, int RB, bool BNR = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_kernel(const ConvParams p) {
-    conv_mfma_body<T, TAPS, BN, RB>(p, blockIdx.x, gridDim.x);
+    conv_mfma_body<T, TAPS, BN, RB, BNR>(p, blockIdx.x, gridDim.x);
 }
 
 // up to five independent jobs of one kernel instance in one grid (largest first): the small pyramid levels are a few
@@ -745,13 +819,13 @@ template <int TAPS, int BN, int RB> constexpr int conv_smem_bytes() {
     return (TAPS == 9 ? kHaloW * kHaloH : 128) * a_row_stride(RB) + 2 * (2 * BN * 64);
 }
 
-template <typename T, int TAPS, int BN, int RB>
+template <typename T, int TAPS, int BN, int RB, bool BNR = false>
 static int launch_conv_rb(const ConvParams& p, int m_tiles, hipStream_t st) {
     constexpr int smem = conv_smem_bytes<TAPS, BN, RB>();
     static_assert(sizeof(T) != 2 || smem >= 128 * (BN * 2 + 8) + 4 * BN * 4, "the output image of the epilogue fits");
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_kernel<T, TAPS, BN, RB>, smem, &attr_mask));
-    conv_mfma_kernel<T, TAPS, BN, RB><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_kernel<T, TAPS, BN, RB, BNR>, smem, &attr_mask));
+    conv_mfma_kernel<T, TAPS, BN, RB, BNR><<<dim3((unsigned)(m_tiles * p.n_tiles)), dim3(kThreads), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -768,6 +842,7 @@ static int conv_fill_params(ConvParams& p, const PackGeom& g, const void* x, con
     p.x = x; p.wp = w_packed; p.y = y;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
     p.stats_part = stats_part; p.up_res = up_res;
+    p.bnr_x = nullptr; p.bnr_scale = nullptr; p.bnr_shift = nullptr; p.bnr_act = MPN_ACT_NONE; p.bnr_xs = 0;
 #ifdef MPN_DIAG
     p.dbg = (unsigned long long*)g_conv_dbg;
 #endif
@@ -921,7 +996,11 @@ extern "C" int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void*
  * One tensor read (dx) and one launch less than mpn_bn_bwd_reduce afterwards. 16-bit storage, K % 64 == 0, K <= 512,
  * C % 64 == 0, C <= 512: mpn_conv_bwd_data_bn_supported says whether a geometry is covered. */
 extern "C" int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype) {
-    if (ksize == 1) return (dtype == MPN_BF16 && pw_gemm_eligible(K, C, 1, 2)) ? 1 : 0;   // the deep 1x1 layers (pointwise.hip)
+    if (ksize == 1) {
+        if (dtype != MPN_BF16 || K % 8 != 0 || C % 8 != 0) return 0;
+        if (pw_gemm_eligible(K, C, 1, 2)) return 1;                     // the deep 1x1 layers (pointwise.hip)
+        return pack_geom(K, C, 1, 2, dtype).row_bytes == 128 ? 1 : 0;   // thin ones: the tiled kernel with 128-byte chunks
+    }
     return (ksize == 3 && (dtype == MPN_BF16 || dtype == MPN_F16) && (mpn_c3::eligible(K, C, 9, 2) || mpn_c3::eligible64(K, C, 9, 2)) && C <= 512) ? 1 : 0;
 }
 
@@ -967,6 +1046,14 @@ extern "C" int mpn_conv_bwd_data_bn(const void* dy, const void* w_packed_t, void
                 MPN_ERR_BAD_ALIGN, "conv_bwd_data_bn: pointers must be 16-byte aligned");
     MPN_REQUIRE((dy_stride == 0 || (dy_stride >= K && dy_stride % 8 == 0)) && (dx_stride == 0 || (dx_stride >= C && dx_stride % 8 == 0)) &&
                 (bn_x_stride == 0 || (bn_x_stride >= C && bn_x_stride % 8 == 0)), MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: bad pixel strides");
-    return pw_gemm_launch(dy, w_packed_t, dx, (long long)N * H * W, K, C, dy_stride > 0 ? dy_stride : K, dx_stride > 0 ? dx_stride : C, nullptr, nullptr,
-                          MPN_ACT_NONE, part, (hipStream_t)stream, bn_x, bn_x_stride > 0 ? bn_x_stride : C, bn_scale, bn_shift, bn_act);
+    if (pw_gemm_eligible(K, C, 1, 2))
+        return pw_gemm_launch(dy, w_packed_t, dx, (long long)N * H * W, K, C, dy_stride > 0 ? dy_stride : K, dx_stride > 0 ? dx_stride : C, nullptr, nullptr,
+                              MPN_ACT_NONE, part, (hipStream_t)stream, bn_x, bn_x_stride > 0 ? bn_x_stride : C, bn_scale, bn_shift, bn_act);
+    const PackGeom g = pack_geom(K, C, 1, 2, dtype);
+    ConvParams p;
+    conv_fill_params(p, g, dy, w_packed_t, dx, N, H, W, K, C, dy_stride, dx_stride, 1, nullptr, nullptr, MPN_ACT_NONE, part, nullptr);
+    p.bnr_x = bn_x; p.bnr_scale = bn_scale; p.bnr_shift = bn_shift; p.bnr_act = bn_act; p.bnr_xs = bn_x_stride > 0 ? bn_x_stride : C;
+    const int m_tiles = mpn_conv_num_parts(N, H, W, 1);
+    return g.BN == 128 ? launch_conv_rb<bf16_t, 1, 128, 128, true>(p, m_tiles, (hipStream_t)stream)
+                       : launch_conv_rb<bf16_t, 1, 64, 128, true>(p, m_tiles, (hipStream_t)stream);
 }

@@ -677,17 +677,25 @@ class KeypointNet:
                 ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample
             raw, aff = feats[f"c{l}"]
             W(lambda: ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, slab[id(self.lateral[l].dw)], reduce=False))
-            ops.conv_fwd(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, None, out=g["c"][f"c{l}"])
+            # c5 has one consumer (lateral5): its data gradient also reduces for Conv2d_13_pointwise's batch-norm - the backbone's
+            # backward pass starts from that finalize (`sp` is not touched in between)
+            g["c5_reduced"] = 0
+            if l == 5 and self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(DEPTH, raw.shape[3], 1, self.dtype):
+                g["c5_reduced"] = ops.conv_bwd_data_bn(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, self.blocks[-1]["pw_bn"], raw,
+                                                       g["c"][f"c{l}"], sp)
+            else:
+                ops.conv_fwd(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, None, out=g["c"][f"c{l}"])
 
     def _backward_backbone(self, b, g, images, sp, slab, W):
         dA = g["c"]["c5"]
-        reduced = 0
+        reduced, raw_sums = g.get("c5_reduced", 0), True       # (the lateral's data gradient may have reduced for the last batch-norm)
         lateral_added = False
         for i in range(len(self.blocks) - 1, -1, -1):
             blk = self.blocks[i]
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13 and not lateral_added:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
-            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced)
+            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced, raw=raw_sums and reduced > 0)
+            raw_sums = False                                    # (depthwise data gradients sum g * xhat themselves)
             W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
             # the deep pointwise layers' data gradients also reduce for the depthwise batch-norm they feed
             if self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(blk["pw"].cout, blk["pw"].cin, 1, self.dtype):

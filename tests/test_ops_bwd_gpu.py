@@ -474,8 +474,12 @@ def test_conv_dgrad_with_fused_bn_reduction(cuda, dtype, act, K, C):
 
 
 @pytest.mark.parametrize("N,H,W,K,C,act", [(2, 16, 16, 512, 512, 2), (1, 13, 11, 256, 256, 2), (8, 96, 96, 512, 256, 1), (3, 16, 16, 1024, 1024, 0),
-                                           (9, 85, 83, 256, 256, 2)],
-                         ids=["512to512", "ragged-256", "big-tiles", "1024-none", "big-ragged"])
+                                           (9, 85, 83, 256, 256, 2),
+                                           # thin layers: the tiled kernel (Conv2d_1..4_pointwise's data gradients, the lateral of c5)
+                                           (2, 32, 32, 64, 32, 2), (3, 21, 19, 128, 64, 2), (2, 16, 24, 128, 128, 2), (2, 16, 16, 256, 128, 1),
+                                           (1, 8, 8, 128, 1024, 2), (2, 9, 7, 72, 40, 2)],
+                         ids=["512to512", "ragged-256", "big-tiles", "1024-none", "big-ragged", "thin-64to32", "thin-ragged-128to64",
+                              "thin-128to128", "thin-256to128", "thin-128to1024", "thin-partial-tiles"])
 def test_pointwise_dgrad_with_fused_bn_reduction(cuda, N, H, W, K, C, act):
     """mpn_conv_bwd_data_bn, 1x1 through the GEMM kernel (the data gradients of Conv2d_5..13_pointwise feed the depthwise
     batch-norms): dx = the plain data gradient masked by the fed layer's activation, bit for bit; slab sums and the raw finalize
@@ -483,7 +487,8 @@ def test_pointwise_dgrad_with_fused_bn_reduction(cuda, N, H, W, K, C, act):
     from multiposenet_amd import ops
     dtype = torch.bfloat16
     rs = np.random.RandomState(K + C + H)
-    assert ops.conv_bwd_data_bn_supported(K, C, 1, dtype) and not ops.conv_bwd_data_bn_supported(128, 64, 1, dtype)
+    assert ops.conv_bwd_data_bn_supported(K, C, 1, dtype) and not ops.conv_bwd_data_bn_supported(100, 64, 1, dtype)
+    assert not ops.conv_bwd_data_bn_supported(K, C, 1, torch.float32)
     w = (rs.randn(1, 1, C, K) / np.sqrt(C)).astype(np.float32)           # forward conv C -> K; its data gradient maps K -> C
     pc = ops.PackedConv(dev(w), dtype)
     dy = dev(rnd(rs.randn(N, H, W, K), dtype), dtype)
