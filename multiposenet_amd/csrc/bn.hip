@@ -104,28 +104,32 @@ constexpr int kFinThreads = 1024, kFinLanes = 64;   // 64 part-lanes x 16 channe
 // CPB = channels per block: 16, or 4 when there are thousands of partial rows (16 384 after a 1x1 conv at 256x256): the
 // reduction is then bound by how many CUs pull on the slab, and C/16 = 4 blocks took 54 us for 8 MB.
 template <int CPB>
-__device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int nparts, int C, int cblock,
-                                             double (*red)[kFinLanes][16], double& s, double& q) {
+__device__ __forceinline__ void reduce_parts(const float* __restrict__ part_, int nparts, int C_, int cblock,
+                                             double (*red)[kFinLanes][16], double& s, double& q, int rstride = 1) {
+    // rstride > 1: a compacted slab (slab_compact_kernel) - live rows 0, rstride, 2 rstride, ...
+    const float* __restrict__ part = part_;
+    const long long C = (long long)C_ * rstride;           // (row p of the walk below lives at p * rstride * 2 * C_)
+    const int Cc = C_;
     constexpr int G4 = CPB / 4;
     constexpr int kRowLanes = kFinThreads / G4;
     const int t = threadIdx.x, g4 = t & (G4 - 1), r = t / G4;
     const int c4 = cblock * CPB + g4 * 4;
     double sa[4] = {0.0, 0.0, 0.0, 0.0}, qa[4] = {0.0, 0.0, 0.0, 0.0};
-    if (c4 < C) {
+    if (c4 < Cc) {
         int p = r;
         for (; p + kRowLanes < nparts; p += 2 * kRowLanes) {   // 4 independent 16-byte loads in flight
-            const float4 a0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 0) * C + c4);
-            const float4 b0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 1) * C + c4);
-            const float4 a1 = *reinterpret_cast<const float4*>(part + ((long long)(p + kRowLanes) * 2 + 0) * C + c4);
-            const float4 b1 = *reinterpret_cast<const float4*>(part + ((long long)(p + kRowLanes) * 2 + 1) * C + c4);
+            const float4 a0 = *reinterpret_cast<const float4*>(part + (long long)p * 2 * C + c4);
+            const float4 b0 = *reinterpret_cast<const float4*>(part + (long long)p * 2 * C + Cc + c4);
+            const float4 a1 = *reinterpret_cast<const float4*>(part + (long long)(p + kRowLanes) * 2 * C + c4);
+            const float4 b1 = *reinterpret_cast<const float4*>(part + (long long)(p + kRowLanes) * 2 * C + Cc + c4);
             sa[0] += (double)a0.x + (double)a1.x; sa[1] += (double)a0.y + (double)a1.y;
             sa[2] += (double)a0.z + (double)a1.z; sa[3] += (double)a0.w + (double)a1.w;
             qa[0] += (double)b0.x + (double)b1.x; qa[1] += (double)b0.y + (double)b1.y;
             qa[2] += (double)b0.z + (double)b1.z; qa[3] += (double)b0.w + (double)b1.w;
         }
         for (; p < nparts; p += kRowLanes) {
-            const float4 a0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 0) * C + c4);
-            const float4 b0 = *reinterpret_cast<const float4*>(part + ((long long)p * 2 + 1) * C + c4);
+            const float4 a0 = *reinterpret_cast<const float4*>(part + (long long)p * 2 * C + c4);
+            const float4 b0 = *reinterpret_cast<const float4*>(part + (long long)p * 2 * C + Cc + c4);
             sa[0] += (double)a0.x; sa[1] += (double)a0.y; sa[2] += (double)a0.z; sa[3] += (double)a0.w;
             qa[0] += (double)b0.x; qa[1] += (double)b0.y; qa[2] += (double)b0.z; qa[3] += (double)b0.w;
         }
@@ -147,6 +151,46 @@ __device__ __forceinline__ void reduce_parts(const float* __restrict__ part, int
     }
 }
 
+// Thousands of partial rows (a 1x1 layer at 256 x 256 leaves 16 384) make the finalize a 45-55 us launch of a few blocks pulling on
+// megabytes: first add groups of kCompact consecutive rows IN PLACE (f64 inside a group, the group's sum rounded to f32 into
+// its first row), one block per group - hundreds of blocks - then finalize rows 0, kCompact, 2 kCompact, ...
+constexpr int kCompact = 32, kCompactFrom = 4096;
+__global__ __launch_bounds__(256) void slab_compact_kernel(float* __restrict__ part, int nparts, int C) {
+    __shared__ double red[256][4];
+    const int cols4 = (2 * C) >> 2;                               // float4 columns of a row ([2][C] floats)
+    const int r0 = blockIdx.x * kCompact, r1 = min(r0 + kCompact, nparts);
+    for (int cb = 0; cb < cols4; cb += 256) {                     // (a row is wider than the block only from C = 512 on)
+        const int span = min(cols4 - cb, 256);
+        const int lanes = 256 / span > 0 ? 256 / span : 1;        // row lanes per column
+        const int col = threadIdx.x % span, rl = threadIdx.x / span;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        if (rl < lanes)
+            for (int r = r0 + rl; r < r1; r += lanes) {
+                const float4 v = *reinterpret_cast<const float4*>(part + (long long)r * 2 * C + (cb + col) * 4);
+                a[0] += (double)v.x; a[1] += (double)v.y; a[2] += (double)v.z; a[3] += (double)v.w;
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[threadIdx.x][j] = a[j];
+        __syncthreads();
+        if (rl == 0) {
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = 0; k < lanes; ++k)                       // fixed order
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] += red[k * span + col][j];
+            *reinterpret_cast<float4*>(part + (long long)r0 * 2 * C + (cb + col) * 4) = make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+        }
+        __syncthreads();
+    }
+}
+// returns the row stride the finalize must walk with (1: untouched) and updates nparts
+static int compact_slab(float* part, int& nparts, int C, hipStream_t st) {
+    if (nparts < kCompactFrom || C % 2 != 0) return 1;
+    const int groups = (nparts + kCompact - 1) / kCompact;
+    slab_compact_kernel<<<groups, 256, 0, st>>>(part, nparts, C);
+    nparts = groups;
+    return kCompact;
+}
+
 // part [nparts][2][C] -> mean, biased var -> scale/shift (+ moving-average update with the
 // unbiased variance, TF-1.15 fused batch-norm semantic).
 template <int CPB>
@@ -155,10 +199,10 @@ __device__ __forceinline__ void bn_finalize_block(
     const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
     float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
-    float* __restrict__ save_invstd) {
+    float* __restrict__ save_invstd, int rstride = 1) {
     const int c = cblock * CPB + threadIdx.x;
     double s, q;
-    reduce_parts<CPB>(part, nparts, C, cblock, red, s, q);
+    reduce_parts<CPB>(part, nparts, C, cblock, red, s, q, rstride);
     if ((int)threadIdx.x < CPB && c < C) {
         const double mean = s / count;
         double var = q / count - mean * mean;
@@ -182,7 +226,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(
     const float* __restrict__ part, int nparts, int C, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ mov_mean, float* __restrict__ mov_var, float momentum,
     float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
-    float* __restrict__ save_invstd) {
+    float* __restrict__ save_invstd, int rstride) {
     __shared__ double red[2][kFinLanes][16];
     // blocks are dealt round-robin over the 8 XCDs (one L2 each) and every block reads a 16- or 64-byte piece of EVERY slab
     // row: give the blocks of one XCD NEIGHBOURING channel groups, so that they share 128-byte lines in their L2 instead of
@@ -190,7 +234,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_finalize_kernel(
     int cblock = blockIdx.x;
     if ((gridDim.x & 7) == 0) cblock = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     bn_finalize_block<CPB>(cblock, red, part, nparts, C, count, gamma, beta, mov_mean, mov_var, momentum, eps, scale, shift,
-                           save_mean, save_invstd);
+                           save_mean, save_invstd, rstride);
 }
 
 // ---- several independent layers' finalizes in ONE launch (the four pyramid levels of the subnet produce their
@@ -362,10 +406,10 @@ __device__ __forceinline__ void bn_bwd_finalize_block(int cblock, double (*red)[
                                                       int nparts, int C, double count, float* __restrict__ dgamma,
                                                       float* __restrict__ dbeta, float* __restrict__ k1,
                                                       float* __restrict__ k2, const float* __restrict__ mean = nullptr,
-                                                      const float* __restrict__ invstd = nullptr) {
+                                                      const float* __restrict__ invstd = nullptr, int rstride = 1) {
     const int c = cblock * CPB + threadIdx.x;
     double s, q;
-    reduce_parts<CPB>(part, nparts, C, cblock, red, s, q);
+    reduce_parts<CPB>(part, nparts, C, cblock, red, s, q, rstride);
     if ((int)threadIdx.x < CPB && c < C) {
         // producers that reduce in their epilogue (mpn_conv_bwd_data_bn) sum g * x: sum g * xhat = invstd * (sum g x - mean * sum g)
         if (mean != nullptr) q = (q - (double)mean[c] * s) * (double)invstd[c];
@@ -380,9 +424,9 @@ __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const floa
                                                                       double count, float* __restrict__ dgamma,
                                                                       float* __restrict__ dbeta,
                                                                       float* __restrict__ k1, float* __restrict__ k2,
-                                                                      const float* __restrict__ mean, const float* __restrict__ invstd) {
+                                                                      const float* __restrict__ mean, const float* __restrict__ invstd, int rstride) {
     __shared__ double red[2][kFinLanes][16];
-    bn_bwd_finalize_block<CPB>(blockIdx.x, red, part, nparts, C, count, dgamma, dbeta, k1, k2, mean, invstd);
+    bn_bwd_finalize_block<CPB>(blockIdx.x, red, part, nparts, C, count, dgamma, dbeta, k1, k2, mean, invstd, rstride);
 }
 __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_batched_kernel(const BnBwdFinDesc* __restrict__ descs, int ndesc) {
     __shared__ double red[2][kFinLanes][16];
@@ -567,7 +611,7 @@ extern "C" int mpn_bn_stats(const void* x, long long M, int C, int dtype, float*
     return MPN_OK;
 }
 
-extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long count, const float* gamma,
+extern "C" int mpn_bn_finalize(float* part, int nparts, int C, long long count, const float* gamma,
                                const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
                                float* scale, float* shift, float* save_mean, float* save_invstd,
                                mpn_stream_t stream) {
@@ -575,13 +619,10 @@ extern "C" int mpn_bn_finalize(const float* part, int nparts, int C, long long c
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_finalize: bad sizes");
     MPN_REQUIRE(C % 4 == 0 && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "bn_finalize: C must be a multiple of 4 and part 16-byte aligned");
     MPN_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), MPN_ERR_BAD_ARG, "bn_finalize: moving stats");
-    if (nparts >= 4096)   // many rows, few channels: 4 channels per block so that C/4 CUs pull on the slab
-        bn_finalize_kernel<4><<<(C + 3) / 4, kFinThreads, 0, (hipStream_t)stream>>>(
-            part, nparts, C, (double)count, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift, save_mean, save_invstd);
-    else
+    const int rstride = compact_slab(part, nparts, C, (hipStream_t)stream);      // (thousands of rows: groups of 32 added in place first)
     bn_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(
         part, nparts, C, (double)count, gamma, beta, moving_mean, moving_var, momentum, eps, scale, shift, save_mean,
-        save_invstd);
+        save_invstd, rstride);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -768,26 +809,28 @@ extern "C" int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* 
     return MPN_OK;
 }
 
-extern "C" int mpn_bn_bwd_finalize(const float* part, int nparts, int C, long long count, float* dgamma,
+extern "C" int mpn_bn_bwd_finalize(float* part, int nparts, int C, long long count, float* dgamma,
                                    float* dbeta, float* k1, float* k2, mpn_stream_t stream) {
     MPN_REQUIRE(part && dgamma && dbeta && k1 && k2, MPN_ERR_BAD_ARG, "bn_bwd_finalize: null pointer");
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_bwd_finalize: bad sizes");
     MPN_REQUIRE(C % 4 == 0 && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "bn_bwd_finalize: C must be a multiple of 4 and part 16-byte aligned");
+    const int rstride = compact_slab(part, nparts, C, (hipStream_t)stream);
     bn_bwd_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
-                                                                               dgamma, dbeta, k1, k2, nullptr, nullptr);
+                                                                               dgamma, dbeta, k1, k2, nullptr, nullptr, rstride);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
 
 /* The same for a slab whose second row holds sum g * x with the RAW x (mpn_conv_bwd_data_bn): mean / invstd = the layer's saved
  * batch statistics; sum g * xhat = invstd * (sum g x - mean * sum g) in f64. */
-extern "C" int mpn_bn_bwd_finalize_raw(const float* part, int nparts, int C, long long count, float* dgamma, float* dbeta, float* k1,
+extern "C" int mpn_bn_bwd_finalize_raw(float* part, int nparts, int C, long long count, float* dgamma, float* dbeta, float* k1,
                                        float* k2, const float* mean, const float* invstd, mpn_stream_t stream) {
     MPN_REQUIRE(part && dgamma && dbeta && k1 && k2 && mean && invstd, MPN_ERR_BAD_ARG, "bn_bwd_finalize_raw: null pointer");
     MPN_REQUIRE(nparts > 0 && C > 0 && count > 0, MPN_ERR_BAD_SHAPE, "bn_bwd_finalize_raw: bad sizes");
     MPN_REQUIRE(C % 4 == 0 && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "bn_bwd_finalize_raw: C must be a multiple of 4 and part 16-byte aligned");
+    const int rstride = compact_slab(part, nparts, C, (hipStream_t)stream);
     bn_bwd_finalize_kernel<16><<<(C + 15) / 16, kFinThreads, 0, (hipStream_t)stream>>>(part, nparts, C, (double)count,
-                                                                               dgamma, dbeta, k1, k2, mean, invstd);
+                                                                               dgamma, dbeta, k1, k2, mean, invstd, rstride);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

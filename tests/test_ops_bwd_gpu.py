@@ -266,7 +266,8 @@ def test_batched_bn_finalizes_equal_per_layer_launches(cuda):
         bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
         return bn
 
-    shapes = [(128, 4096, 524288), (128, 37, 1000), (64, 1024, 8192), (24, 5, 77)]   # (C, nparts, count)
+    # (C, nparts, count); below the 4096 rows from which the per-layer finalizes compact the slab in place first
+    shapes = [(128, 4000, 512000), (128, 37, 1000), (64, 1024, 8192), (24, 5, 77)]
     parts = [torch.tensor(rs.randn(n, 2, C).astype(np.float32)).cuda() for (C, n, _) in shapes]
     st = rs.get_state()
     a = [mk(C) for (C, _, _) in shapes]
@@ -528,3 +529,44 @@ def test_pointwise_dgrad_with_fused_bn_reduction(cuda, N, H, W, K, C, act):
     np.testing.assert_allclose(bn.dgamma.cpu().numpy(), want_dg.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_dg.abs().max()))
     np.testing.assert_allclose(bn.dbeta.cpu().numpy(), want_db.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_db.abs().max()))
     assert float((out.float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())
+
+
+@pytest.mark.parametrize("nparts,C", [(16384, 32), (4096, 64), (5000, 1024), (4097, 8)], ids=["16384x32", "4096x64", "5000x1024", "4097x8"])
+def test_finalizes_over_thousands_of_partial_rows(cuda, nparts, C):
+    """From 4096 partial rows on (a 1x1 layer at 256 x 256 leaves 16 384) the finalizes first add groups of 32 rows in place:
+    forward affine / moving statistics and backward sums (plain and raw) against f64 numpy on the same slab; twice the same
+    result (no atomics)."""
+    from multiposenet_amd import ops
+    rs = np.random.RandomState(nparts + C)
+    count = nparts * 128
+    slab = (rs.rand(nparts, 2, C) * 100 + 20).astype(np.float32)
+    slab[:, 1] = slab[:, 0] ** 2 / 128 + rs.rand(nparts, C).astype(np.float32) * 50          # sum x^2 >= (sum x)^2 / n
+    s64 = slab.astype(np.float64).sum(0)
+    mean = s64[0] / count
+    var = np.maximum(s64[1] / count - mean * mean, 0)
+
+    def run_fwd():
+        bn = ops.BNState(torch.ones(C, device="cuda") * 1.5, torch.ones(C, device="cuda") * 0.25, torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), 1)
+        ops.bn_finalize(bn, torch.tensor(slab).cuda().view(-1), nparts, count, training=True)
+        return bn
+    bn = run_fwd()
+    np.testing.assert_allclose(bn.mean.cpu().numpy(), mean, rtol=1e-5)
+    np.testing.assert_allclose(bn.invstd.cpu().numpy(), 1 / np.sqrt(var + 1e-3), rtol=2e-4)
+    np.testing.assert_allclose(bn.scale.cpu().numpy(), 1.5 / np.sqrt(var + 1e-3), rtol=2e-4)
+    b2 = run_fwd()
+    assert torch.equal(bn.scale, b2.scale) and torch.equal(bn.moving_var, b2.moving_var)
+    # backward: plain (second row = sum g * xhat) and raw (second row = sum g * x with saved mean / invstd)
+    g = (rs.randn(nparts, 2, C) * 3).astype(np.float32)
+    g64 = g.astype(np.float64).sum(0)
+    bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    ops.call("mpn_bn_bwd_finalize", ops.ptr(torch.tensor(g).cuda()), nparts, C, count, ops.ptr(bn.dgamma), ops.ptr(bn.dbeta), ops.ptr(bn.k1), ops.ptr(bn.k2),
+             ops.stream_ptr())
+    tol = 1e-5 * float(np.abs(g).sum(0).max())
+    np.testing.assert_allclose(bn.dbeta.cpu().numpy(), g64[0], atol=tol)
+    np.testing.assert_allclose(bn.dgamma.cpu().numpy(), g64[1], atol=tol)
+    np.testing.assert_allclose(bn.k2.cpu().numpy(), g64[1] / count, atol=tol / count)
+    m_, i_ = bn.mean.double().cpu().numpy(), bn.invstd.double().cpu().numpy()
+    ops.call("mpn_bn_bwd_finalize_raw", ops.ptr(torch.tensor(g).cuda()), nparts, C, count, ops.ptr(bn.dgamma), ops.ptr(bn.dbeta), ops.ptr(bn.k1), ops.ptr(bn.k2),
+             ops.ptr(bn.mean), ops.ptr(bn.invstd), ops.stream_ptr())
+    want = (g64[1] - m_ * g64[0]) * i_
+    np.testing.assert_allclose(bn.dgamma.cpu().numpy(), want, atol=1e-5 * float(np.abs(want).max()) + tol * float(np.abs(m_ * i_).max() + i_.max()))
