@@ -78,35 +78,32 @@ __global__ __launch_bounds__(kThreads) void decode_kernel(
         // aligned) per pixel, a wave covers 4352 contiguous bytes per pixel row so every fetched byte is used - two
         // pixels in flight per lane, no LDS staging and no barrier in the streaming loop.
         const float* __restrict__ img = reinterpret_cast<const float*>(hm + img_byte0);
-        for (int p0 = pix_begin + tid; p0 < pix_end; p0 += 2 * kThreads) {
-            const int p1 = p0 + kThreads;
-            const bool has1 = p1 < pix_end;
-            float v0[kC + 3], v1[kC + 3];
-            const float* s0 = img + (long long)p0 * kC;
-            const float* s1 = img + (long long)(has1 ? p1 : p0) * kC;
+        // (two pixels in flight per lane; four measured slower: 11.8 vs 11.1 us at B = 32, 48.7 vs 44.7 at B = 256)
+        constexpr int U = 2;
+        for (int p0 = pix_begin + tid; p0 < pix_end; p0 += U * kThreads) {
+            float v[U][kC + 3];
+            int px[U];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 a = *reinterpret_cast<const float4*>(s0 + 4 * q);
-                const float4 b = *reinterpret_cast<const float4*>(s1 + 4 * q);
-                v0[4 * q] = a.x; v0[4 * q + 1] = a.y; v0[4 * q + 2] = a.z; v0[4 * q + 3] = a.w;
-                v1[4 * q] = b.x; v1[4 * q + 1] = b.y; v1[4 * q + 2] = b.z; v1[4 * q + 3] = b.w;
+            for (int u = 0; u < U; ++u) {
+                px[u] = p0 + u * kThreads;
+                const float* sp = img + (long long)(px[u] < pix_end ? px[u] : p0) * kC;      // (unconditional loads from a valid pixel)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = *reinterpret_cast<const float4*>(sp + 4 * q);
+                    v[u][4 * q] = a.x; v[u][4 * q + 1] = a.y; v[u][4 * q + 2] = a.z; v[u][4 * q + 3] = a.w;
+                }
+                v[u][16] = sp[16];
             }
-            v0[16] = s0[16];
-            v1[16] = s1[16];
 #pragma unroll
-            for (int c = 0; c < kC; ++c) {
-                const unsigned k = ordered_key(v0[c]);
-                const bool gt = k > best_hi[c];  // strict: keeps the first occurrence (pixels ascend per lane)
-                best_hi[c] = gt ? k : best_hi[c];
-                best_idx[c] = gt ? (unsigned)p0 : best_idx[c];
-            }
-            if (has1) {
+            for (int u = 0; u < U; ++u) {
+                if (px[u] < pix_end) {
 #pragma unroll
-                for (int c = 0; c < kC; ++c) {
-                    const unsigned k = ordered_key(v1[c]);
-                    const bool gt = k > best_hi[c];
-                    best_hi[c] = gt ? k : best_hi[c];
-                    best_idx[c] = gt ? (unsigned)p1 : best_idx[c];
+                    for (int c = 0; c < kC; ++c) {
+                        const unsigned k = ordered_key(v[u][c]);
+                        const bool gt = k > best_hi[c];  // strict: keeps the first occurrence (pixels ascend per lane)
+                        best_hi[c] = gt ? k : best_hi[c];
+                        best_idx[c] = gt ? (unsigned)px[u] : best_idx[c];
+                    }
                 }
             }
         }
@@ -236,7 +233,13 @@ extern "C" int mpn_heatmap_decode(const void* heatmaps, int dtype, int B, int h,
                 "decode: unsupported dtype %d", dtype);
     const int npix = h * w;
     const int nchunks = mpn_div_up(npix, kPix);
-    int splits = 1024 / B;  // ~1k blocks of >= 4 chunks: the block-level reduction is amortised over more pixels
+    // blocks per image. The tail of a launch is a chain of dependent atomics (17 atomicMax per block, a ticket, the last block's
+    // exchanges) whose cost grows with the blocks that contend: measured at 128 x 128 (us per launch by total blocks) B = 1: 10.0
+    // (32) / 12.8 (64); B = 32: 11.1 (256) / 11.9 (512) / 17.5 (1024) / 34.9 (2048); B = 256: 44.7 (512) / 46.7 (1024) / 62 (256)
+    int target = 8 * B;
+    if (target < 32) target = 32;
+    if (target > 512) target = 512;
+    int splits = (target + B - 1) / B;
     if (splits < 1) splits = 1;
     if (splits > nchunks) splits = nchunks;
     const int cpb = mpn_div_up(nchunks, splits);
