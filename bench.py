@@ -244,6 +244,8 @@ def main():
         from bench_legs import dominant_kernel_roofline, whole_step_mfma_fraction
         out["roofline"] = dominant_kernel_roofline(net, args.batch, args.size, dt, b=trainer._static_bufs())
         out["config"]["step_mfma_frac_of_peak"] = whole_step_mfma_fraction(args.batch, args.size, dt_s / args.steps)
+        from bench_legs import conv_wgrad_roofline
+        out["roofline_wgrad"] = conv_wgrad_roofline(net, args.batch, args.size, dt, b=trainer._static_bufs())   # the largest family by time
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from bench_legs import cpu_baseline, decode_benchmark, render_benchmark, prn_benchmark
         from bench_legs import host_fed_rate

@@ -66,6 +66,37 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20, b=Non
             "frac_without_statistics": round(flops / sec_plain / 1e12 / peak, 4)}
 
 
+def conv_wgrad_roofline(net, batch, size, dtype, iters=30, warmup=10, b=None):
+    """The largest kernel FAMILY of the step by time is the dense weight gradient (conv_wgrad_bf16_kernel, 17 % of the step): its
+    3x3 128->128 @ stride 4 instance (phi_subnet_2/conv1: input = p2 through p2_batch_norm's affine + ReLU), timed alone with
+    HIP events on the launch stream, against the bf16 MFMA peak. Algorithmic FLOPs = those of the forward convolution."""
+    h = w = size // 4
+    b = b if b is not None else net._bufs[(batch, size, size)]
+    x = b["p"][2]
+    conv = net.phi[2]["conv1"]
+    dy = torch.randn_like(x, dtype=torch.float32).to(x.dtype)
+    nparts = ops.conv_wgrad_num_parts(batch, h, w, 128, 128, 3, dtype)
+    part = torch.empty(nparts * 9 * 128 * 128, dtype=torch.float32, device=x.device)
+    stream = torch.cuda.current_stream()
+
+    def run():
+        ops.conv_bwd_weight(x, dy, 3, net.p_bn[2].affine, conv.dw, part, reduce=False)
+    for _ in range(warmup):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        run()
+    e1.record(stream)
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / iters
+    flops = 2.0 * batch * h * w * 128 * 128 * 9
+    peak = PEAK_BF16_TFLOPS if dtype == torch.bfloat16 else PEAK_F32_TFLOPS
+    return {"kernel": "conv_wgrad_bf16_kernel (3x3 128->128 weight gradient, split-K over 128-pixel tiles) @ [%d,%d,%d,128]" % (batch, h, w),
+            "bound": "mfma", "achieved": round(flops / sec / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(flops / sec / 1e12 / peak, 4), "launch_us": round(sec * 1e6, 2), "split_k_slabs": int(nparts)}
+
+
 def north_star_kernels(batch=32, iters=20):
     """The two kernel families the north star sets targets for, at the bench shape (bs32 @ 512x512, bf16), each launch
     timed alone with HIP events on the launch stream: the depthwise 3x3 path against the 8 TB/s HBM peak (algorithmic
@@ -277,6 +308,20 @@ def prn_benchmark(batch=128, iters=20, dtype=torch.float16):
            "ms_per_step": round(ms, 3), "crops_per_s": round(batch / ms * 1e3, 1), "batch": batch,
            "alg_GB_per_step": round(byt / 1e9, 3), "hbm_GBps": round(byt / ms / 1e6, 1),
            "hbm_frac_of_8TBps": round(byt / ms / 1e6 / 8000.0, 4), "final_loss": round(float(loss), 5)}
+    # the step's dominant kernel: the fused Adam pass over the 70 M parameters (HBM: 5 f32 streams), timed alone
+    from multiposenet_amd import ops as _ops
+    for _ in range(3):
+        _ops.adam_step(net.theta, net.grad, net.adam_m, net.adam_v, net.hyper, grad_scale=1.0, clip=float("inf"))
+    e0.record()
+    for _ in range(iters):
+        _ops.adam_step(net.theta, net.grad, net.adam_m, net.adam_v, net.hyper, grad_scale=1.0, clip=float("inf"))
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    ab = 5 * 4 * net.theta.numel()
+    out["dominant_kernel"] = {"kernel": "adam_apply (TF-Adam over the flat f32 arena: theta, grad, m, v read, theta, m, v written)", "bound": "hbm",
+                              "launch_us": round(us, 1), "achieved": round(ab / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
+                              "frac": round(ab / us / 1e3 / 8000.0, 4), "share_of_step": round(us / (ms * 1e3), 3)}
     out["assign"] = prn_assign_benchmark(net, iters=iters)
     return out
 
@@ -489,6 +534,29 @@ def retinanet_benchmark(batch=16, height=896, width=1408, iters=10):
     e1.record()
     torch.cuda.synchronize()
     out["inference_ms_per_batch"] = round(e0.elapsed_time(e1) / iters, 3)
+    # the head's dominant kernel: the grouped 3x3 tower convolution over the five levels (64 -> 64, the 64-channel-tile variant
+    # of the persistent kernel), forward with affine + statistics, timed alone
+    net_i = "box_net"
+    xs = [b["t"][net_i][0][l] for l in LEVELS]
+    affs = [net.tower_bn[net_i][0][l].affine for l in LEVELS]
+    outs = [b["t"][net_i][1][l] for l in LEVELS]
+    sts = [b["stat_lv"][l] for l in LEVELS]
+    c = net.tower[net_i][1]
+
+    def tower():
+        ops.conv_fwd_grouped(xs, [c.packed.fwd] * 5, 64, 3, affs, outs, sts)
+    for _ in range(5):
+        tower()
+    e0.record()
+    for _ in range(iters):
+        tower()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    fl = 2.0 * batch * sum(px.values()) * 9 * 64 * 64
+    out["dominant_kernel"] = {"kernel": "conv3x3_kernel<bf16, affine, 64-channel tiles> (tower conv3x3 64->64, five levels in one grid)",
+                              "bound": "mfma", "launch_us": round(us, 1), "achieved": round(fl / us / 1e6, 1), "peak": PEAK_BF16_TFLOPS,
+                              "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4)}
     del net
     torch.cuda.empty_cache()
     return out
