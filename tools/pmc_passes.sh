@@ -5,6 +5,7 @@
 tag=$1; counters=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 root=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $root/gpurun_out/pmc_$tag
 for c in $counters; do
   rocprofv3 --pmc ${c//,/ } --kernel-trace --output-format csv -d $root/gpurun_out/pmc_$tag/$c -o run -- python3 $root/$1 "${@:2}" > $root/gpurun_out/pmc_$tag/$c.log 2>&1 || { echo "pass $c failed"; tail -5 $root/gpurun_out/pmc_$tag/$c.log; }
 done
