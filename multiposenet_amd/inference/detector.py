@@ -47,6 +47,9 @@ class Detector:
             self.params['max_boxes'] = int(max_boxes)
         values = _load(model_path) if model_path is not None else None
         self.net = KeypointNet(values=values, depth_multiplier=self.params['depth_multiplier'], dtype=dtype, device=device)
+        self.net.cache_inference_affine = True      # inference only: the batch-norm affines change with the variables alone
+        self.use_graph = True                       # the device side of a call replays from a hipGraph per image shape
+        self._graphs = {}
         self.retinanet = None
         if detector_path is not None:
             from ..retinanet import PersonDetectorNet
@@ -85,30 +88,67 @@ class Detector:
         if image.dtype != np.uint8:
             raise ValueError("image must be uint8")
         net = self.net
-        x = torch.from_numpy(np.ascontiguousarray(image[None])).to(net.device)
-        bufs = net._buffers(1, h, w)
-        feats = net.backbone_forward(x, False, bufs)               # uint8 -> /255 -> 2x-1 fused into the stem conv; ONE pass
-        heat, seg = net.subnet_forward(feats, False, bufs, inference_outputs=True)
+        if boxes is None and self.use_graph:
+            dev = self._replay(image)
+        else:
+            dev = self._device_side(torch.from_numpy(np.ascontiguousarray(image[None])).to(net.device), boxes is None)
+        heat, seg = dev['heat'], dev['seg']
         out = {'keypoint_heatmaps': heat[0].cpu().numpy(), 'segmentation_masks': seg[0].cpu().numpy()}
+        kscore, kpos = np.zeros([0, 17], np.float32), np.zeros([0, 17, 2], np.float32)
         if boxes is not None:
             gb = np.asarray(boxes, np.float32).reshape(-1, 4)
             gs = np.ones(len(gb), np.float32) if scores is None else np.asarray(scores, np.float32)
             n = len(gb)
-            dboxes = torch.from_numpy(gb[None]).to(net.device) if n else None
-        elif self.retinanet is not None:
-            pred = self._detect(feats, 1, h, w)
+            if n and self.assigner is not None:
+                dboxes = torch.from_numpy(gb[None]).to(net.device)
+                ks, kp = self.assigner(heat.contiguous(), dboxes, torch.tensor([n], device=net.device), compact=True)
+                kscore, kpos = ks.cpu().numpy(), kp.cpu().numpy()
+        elif 'pred' in dev:
+            pred = dev['pred']
             n = int(pred['num_boxes'][0].item())
-            dboxes = pred['boxes']
-            gb, gs = dboxes[0, :n].cpu().numpy(), pred['scores'][0, :n].cpu().numpy()
+            gb, gs = pred['boxes'][0, :n].cpu().numpy(), pred['scores'][0, :n].cpu().numpy()
+            if n and 'kscore' in dev:       # the padded slots (>= n) hold the results of zero crops: drop them
+                kscore, kpos = dev['kscore'][:n].cpu().numpy(), dev['kpos'][:n].cpu().numpy()
         else:
-            n, dboxes = 0, None
+            n = 0
             gb, gs = np.zeros([0, 4], np.float32), np.zeros([0], np.float32)
-        kscore, kpos = np.zeros([0, 17], np.float32), np.zeros([0, 17, 2], np.float32)
-        if n and self.assigner is not None:
-            ks, kp = self.assigner(heat.contiguous(), dboxes, torch.tensor([n], device=net.device), compact=True)
-            kscore, kpos = ks.cpu().numpy(), kp.cpu().numpy()
         keep = gs > score_threshold                                # inference/detector.py:54-59
         out.update({'boxes': gb[keep], 'scores': gs[keep], 'num_boxes': np.int32(n),
                     'keypoint_scores': kscore[keep] if len(kscore) else kscore,
                     'keypoint_positions': kpos[keep] if len(kpos) else kpos})
         return out
+
+    def _device_side(self, x, detect):
+        """Everything of create_pb.py:44-153 that runs on the device, static shapes throughout (the PRN runs on all max_boxes
+        slots: padding slots are zero crops, dropped on the host): {'heat', 'seg'[, 'pred'[, 'kscore', 'kpos']]}."""
+        net = self.net
+        _, h, w, _ = x.shape
+        bufs = net._buffers(1, h, w)
+        feats = net.backbone_forward(x, False, bufs)               # uint8 -> /255 -> 2x-1 fused into the stem conv; ONE pass
+        heat, seg = net.subnet_forward(feats, False, bufs, inference_outputs=True)
+        dev = {'heat': heat, 'seg': seg}
+        if detect and self.retinanet is not None:
+            pred = self._detect(feats, 1, h, w)
+            dev['pred'] = pred
+            if self.assigner is not None:
+                dev['kscore'], dev['kpos'] = self.assigner(heat.contiguous(), pred['boxes'], pred['num_boxes'], compact=False)
+        return dev
+
+    def _replay(self, image):
+        """The device side of a call from a hipGraph captured once per image shape (an eager call first: it sizes the buffers and
+        sets kernel attributes); the host copies the image into the graph's input and reads its outputs."""
+        h, w, _ = image.shape
+        ent = self._graphs.get((h, w))
+        src = torch.from_numpy(np.ascontiguousarray(image[None]))
+        if ent is None:
+            x = src.to(self.net.device)
+            self._device_side(x, True)                              # eager warm-up
+            torch.cuda.synchronize(self.net.device)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._device_side(x, True)
+            ent = self._graphs[(h, w)] = (graph, x, outs)
+        graph, x, outs = ent
+        x.copy_(src)
+        graph.replay()
+        return outs

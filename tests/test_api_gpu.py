@@ -150,6 +150,16 @@ def test_detector_joint_graph_matches_the_oracle_chain(cuda, tmp_path):
     np.testing.assert_array_equal(flt["keypoint_positions"], out["keypoint_positions"][keep])
     # ONE backbone: the detector's head holds no MobileNet of its own
     assert det.retinanet.backbone is det.net
+    # the device side replays from a hipGraph captured per image shape: the same outputs as the eager call, bit for bit, also
+    # for a second image through the same graph
+    eager = Detector(str(kpath), dtype=torch.float32, detector_path=str(dpath), prn_path=str(ppath))
+    eager.use_graph = False
+    img2 = np.random.RandomState(5).randint(0, 256, (H, W, 3)).astype(np.uint8)
+    for im in (img, img2):
+        a, b_ = det(im, score_threshold=0.0), eager(im, score_threshold=0.0)
+        for k in a:
+            np.testing.assert_array_equal(a[k], b_[k], err_msg=k)
+    assert len(det._graphs) == 1 and not eager._graphs
     # bf16 build of the same graph: runs, finite, the same number of outputs
     o16 = Detector(str(kpath), dtype=torch.bfloat16, detector_path=str(dpath), prn_path=str(ppath))(img, score_threshold=0.0)
     assert np.isfinite(o16["keypoint_heatmaps"]).all() and len(o16["boxes"]) == int(o16["num_boxes"]) > 0
