@@ -45,7 +45,10 @@ def _worker_main():
     """Entry point of a spawned rank (python tests/test_dp_gpu.py <out_prefix>); env: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_*."""
     sys.path.insert(0, ROOT)
     from multiposenet_amd.parallel import init_distributed
-    rank, local_rank, world = init_distributed("nccl")
+    # MPN_TEST_BACKEND=gloo: two ranks that SHARE one device (a 1-GPU box: RCCL refuses two ranks on one GPU, gloo moves the
+    # buckets through the host) - the same three-graph step, bucketed exchange and 1/world average with a real second rank
+    backend = os.environ.get("MPN_TEST_BACKEND", "nccl")
+    rank, local_rank, world = init_distributed(backend)
     torch.cuda.set_device(local_rank)
     out = _run_steps(f"cuda:{local_rank}", distributed=True)
     np.savez(f"{sys.argv[1]}.rank{rank}.npz", world=world, **out)
@@ -94,6 +97,44 @@ def test_two_rank_rccl_step_equals_single_rank_step(cuda, tmp_path):
         for k in ("losses", "theta", "m", "v", "moving"):
             np.testing.assert_array_equal(g[k], want[k], err_msg=f"rank {r}: {k}")
         # the arena holds the all-reduced SUM (the 1/world average is folded into the Adam kernel): exactly 2 x one rank's
+        np.testing.assert_array_equal(g["grad"], 2.0 * want["grad"], err_msg=f"rank {r}: grad")
+
+
+def test_two_ranks_on_one_device_over_gloo_equal_single_rank_step(cuda, tmp_path):
+    """World size 2 on ONE device (both ranks LOCAL_RANK 0, backend gloo): what a 1-GPU box can check of the data-parallel step
+    with a real second rank - identical batches on both ranks, so the all-reduced sum is exactly twice each rank's gradient and
+    the averaged step reproduces the single-rank step bit for bit (variables, Adam slots, per-replica moving statistics)."""
+    want = _run_steps("cuda:0", distributed=False)
+    port = _free_port()
+    procs = []
+    prefix = str(tmp_path / "dpg")
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2",
+                   MPN_TEST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), prefix], env=env, cwd=ROOT))
+    import time
+    deadline = time.monotonic() + 300
+    try:
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs) or time.monotonic() > deadline:
+                break
+            time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    assert [p.returncode for p in procs] == [0, 0]
+    for r in range(2):
+        g = dict(np.load(f"{prefix}.rank{r}.npz"))
+        assert int(g["world"]) == 2
+        for k in ("losses", "theta", "m", "v", "moving"):
+            np.testing.assert_array_equal(g[k], want[k], err_msg=f"rank {r}: {k}")
         np.testing.assert_array_equal(g["grad"], 2.0 * want["grad"], err_msg=f"rank {r}: grad")
 
 
