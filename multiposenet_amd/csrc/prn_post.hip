@@ -127,43 +127,57 @@ __global__ __launch_bounds__(kThreads) void crop_kernel(const float* __restrict_
     }
 }
 
-// one block per crop; thread (channel, lane) walks positions lane, lane + 15, ...
-__global__ __launch_bounds__(kThreads) void decode_kernel(const float* __restrict__ logits, int P, int CW, int CH, int C,
-                                                         float* __restrict__ scores, float* __restrict__ positions) {
-    __shared__ float redv[kThreads];
-    __shared__ int redi[kThreads];
+// one block of 1024 threads per crop, LT = (1024 / C) * C of them active: thread t owns elements t, t + LT, ... of the crop's
+// flattened [P][C] logits (consecutive threads read consecutive addresses; a thread's channel t % C never changes). Channel
+// reductions through LDS in a fixed order; the softmax is never formed: score = 1 / sum exp(z - max), position = the first
+// arg-max (tf.argmax: smallest index among equal maxima).
+constexpr int kDecThreads = 1024;
+__global__ __launch_bounds__(kDecThreads) void decode_kernel(const float* __restrict__ logits, int P, int CW, int CH, int C,
+                                                            float* __restrict__ scores, float* __restrict__ positions) {
+    __shared__ float redv[kDecThreads];
+    __shared__ int redi[kDecThreads];
+    __shared__ float chan[32];
     const int n = blockIdx.x;
-    const int c = threadIdx.x / kPL, pl = threadIdx.x % kPL;
-    const bool on = c < C;
-    const float* z = logits + (long long)n * P * C + c;
+    const int t = threadIdx.x;
+    const int per = kDecThreads / C, LT = per * C;
+    const bool on = t < LT;
+    const int c = t % C;
+    const float* z = logits + (long long)n * P * C;
+    const int total = P * C;
     float m = -INFINITY;
     if (on)
-        for (int p = pl; p < P; p += kPL) m = fmaxf(m, z[(long long)p * C]);
-    redv[threadIdx.x] = m;
+        for (int i = t; i < total; i += LT) m = fmaxf(m, z[i]);
+    redv[t] = m;
     __syncthreads();
-    if (on)
-        for (int k = 0; k < kPL; ++k) m = fmaxf(m, redv[c * kPL + k]);
+    if (t < C) {
+        float r = -INFINITY;
+        for (int k = 0; k < per; ++k) r = fmaxf(r, redv[k * C + t]);
+        chan[t] = r;
+    }
+    __syncthreads();
+    m = chan[c];
     __syncthreads();
     // softmax numerators exp(z - m): their sum, and the FIRST position whose numerator is the maximum (= 1.0f)
     float se = 0.f;
     int first = 0x7fffffff;
     if (on)
-        for (int p = pl; p < P; p += kPL) {
-            const float e = expf(z[(long long)p * C] - m);
+        for (int i = t; i < total; i += LT) {
+            const float e = expf(z[i] - m);
             se += e;
+            const int p = i / C;
             if (e == 1.0f && p < first) first = p;
         }
-    redv[threadIdx.x] = se;
-    redi[threadIdx.x] = first;
+    redv[t] = se;
+    redi[t] = first;
     __syncthreads();
-    if (on && pl == 0) {
-        float s = 0.f;
+    if (t < C) {
+        float sum = 0.f;
         int f = 0x7fffffff;
-        for (int k = 0; k < kPL; ++k) { s += redv[c * kPL + k]; f = min(f, redi[c * kPL + k]); }
+        for (int k = 0; k < per; ++k) { sum += redv[k * C + t]; f = min(f, redi[k * C + t]); }
         if (f == 0x7fffffff) f = 0;   // all-NaN column: tf.argmax returns 0
-        scores[(long long)n * C + c] = 1.0f / s;
-        positions[((long long)n * C + c) * 2 + 0] = (float)(f / CW) / (float)CH;
-        positions[((long long)n * C + c) * 2 + 1] = (float)(f % CW) / (float)CW;
+        scores[(long long)n * C + t] = 1.0f / sum;
+        positions[((long long)n * C + t) * 2 + 0] = (float)(f / CW) / (float)CH;
+        positions[((long long)n * C + t) * 2 + 1] = (float)(f % CW) / (float)CW;
     }
 }
 
@@ -176,9 +190,12 @@ extern "C" int mpn_heatmap_minmax(const float* heatmaps, int B, int h, int w, in
     hipStream_t st = (hipStream_t)stream;
     const int n = B * C * 2;
     minmax_init_kernel<<<(n + 255) / 256, 256, 0, st>>>((unsigned*)minmax_keys, n);
-    int splits = (h * w + 3839) / 3840;   // 16 chunks of 240 pixels per block
+    int splits = (h * w + 3839) / 3840;   // 16 chunks of 240 pixels per block ...
+    const int chunks = (h * w + 239) / 240;
+    if (B * splits < 256) splits = (256 + B - 1) / B;    // ... fewer where that leaves CUs idle (one image: 7 blocks took 35 us)
+    if (splits > chunks) splits = chunks;
     if (splits < 1) splits = 1;
-    if (splits > 64) splits = 64;
+    if (splits > 64 && B * 64 >= 256) splits = 64;
     minmax_kernel<<<dim3((unsigned)splits, (unsigned)B), kThreads, 0, st>>>(heatmaps, h * w, C, splits, (unsigned*)minmax_keys);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
@@ -223,7 +240,7 @@ extern "C" int mpn_prn_decode(const float* logits, int nb, int crop_h, int crop_
                               mpn_stream_t stream) {
     MPN_REQUIRE(logits && scores && positions, MPN_ERR_BAD_ARG, "prn_decode: null pointer");
     MPN_REQUIRE(nb > 0 && crop_h > 0 && crop_w > 0 && C > 0 && C <= kMaxC, MPN_ERR_BAD_SHAPE, "prn_decode: bad shape (C <= 17)");
-    decode_kernel<<<(unsigned)nb, kThreads, 0, (hipStream_t)stream>>>(logits, crop_h * crop_w, crop_w, crop_h, C, scores, positions);
+    decode_kernel<<<(unsigned)nb, kDecThreads, 0, (hipStream_t)stream>>>(logits, crop_h * crop_w, crop_w, crop_h, C, scores, positions);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
