@@ -45,6 +45,8 @@ struct DwParams {
     int bnr_act;
     const void* addend; // stride-2 sliding-window data gradient: a tensor of dx's shape added before the store (and before BNR)
     int xcd_remap;      // sliding-window kernels: XCD-aware block -> strip map
+    int swr;            // forward sliding window: output rows per strip (0: sw_rows(OH)); shorter strips where a launch without
+                        // statistics would leave CUs idle (batch-1 inference: 13 launches of ~16 us each at 640 x 640)
 };
 
 // 4-channel (one LDS float4) accessors of the storage type: the COMPUTE granule. 72 weight registers per thread
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw_kernel(const DwParams 
     const float lo = (aff && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
     const float hi = (aff && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
 
-    const int swr = sw_rows(p.OH, STRIDE);
+    const int swr = p.swr > 0 ? p.swr : sw_rows(p.OH, STRIDE);
     const int oy_begin = yb * swr, oy_end = min(oy_begin + swr, p.OH);
     const int ix0 = ox * STRIDE - p.pad_l;                            // leftmost input column of the window
     const T* ximg = x + (long long)img * p.H * p.W * p.C + cc;
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw2_kernel(const DwParams
     const float lo = (aff && p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
     const float hi = (aff && p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
 
-    const int swr = sw_rows(p.OH, 1);
+    const int swr = p.swr > 0 ? p.swr : sw_rows(p.OH, 1);
     const int oy_begin = yb * swr, oy_end = min(oy_begin + swr, p.OH);
     const int ix0 = ox - p.pad_l;                                     // leftmost input column of the 4-column window
     const T* ximg = x + (long long)img * p.H * p.W * p.C + cc;
@@ -1314,7 +1316,8 @@ static DwSwGeom dw_sw_geom(const DwParams& p) {
     g.cols = kThreads / g.ncg;
     g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
     g.xblocks = (p.OW + g.cols * dw_xt(p) - 1) / (g.cols * dw_xt(p));
-    g.yblocks = (p.OH + sw_rows(p.OH, p.H == p.OH ? 1 : 2) - 1) / sw_rows(p.OH, p.H == p.OH ? 1 : 2);
+    const int swr = p.swr > 0 ? p.swr : sw_rows(p.OH, p.H == p.OH ? 1 : 2);
+    g.yblocks = (p.OH + swr - 1) / swr;
     return g;
 }
 
@@ -1339,7 +1342,15 @@ extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int
     p.x = x; p.w = w; p.y = y; p.part = stats_part;
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.flip = flip;
     hipStream_t st = (hipStream_t)stream;
-    const DwSwGeom g = dw_sw_geom(p);
+    DwSwGeom g = dw_sw_geom(p);
+    if (stats_part == nullptr) {   // (with statistics the strip height fixes the slab rows: mpn_dwconv_num_parts)
+        int swr = sw_rows(p.OH, stride);
+        while (swr > 4 && (long long)p.N * g.cblocks * g.yblocks * g.xblocks < 512) {
+            swr >>= 1;
+            p.swr = swr;
+            g = dw_sw_geom(p);
+        }
+    }
     p.cblocks = g.cblocks;
     const long long blocks = (long long)p.N * g.cblocks * g.yblocks * g.xblocks;
     MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_fwd: grid too large");

@@ -177,6 +177,7 @@ class PersonDetectorNet:
         self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._convs = []
+        self._wversion = 0
         self.fuse_conv_bn = True       # set before the first backward pass of a shape (the finalize tables are built once)
         self._infer_clean = False
         self.backbone.cache_inference_affine = True     # frozen here: its inference affines change only with its variables
@@ -243,6 +244,7 @@ class PersonDetectorNet:
         self._built = True
 
     def repack_weights(self):
+        self._wversion += 1
         for c in self._convs:
             c.repack()
 
@@ -372,8 +374,11 @@ class PersonDetectorNet:
         ops.conv_fwd_grouped([b["x"][l] for l in (3, 4, 5)], [self.pconv[l].packed.fwd for l in (3, 4, 5)], DEPTH, 3, [None] * 3,
                              [b["p"][l] for l in (3, 4, 5)], [st(l) for l in (3, 4, 5)])                             # fpn.py:39,52
         raw5, aff5 = feats["c5"]
-        ops.patchify3x3s2(raw5, b["patches6"], aff5)
-        ops.conv_fwd(b["patches6"], self.pconv[6].packed.fwd, DEPTH, 1, None, out=b["p"][6], stats_part=st(6))       # fpn.py:43
+        if not is_training and self._p6_skinny(b):
+            self._p6_split_k(raw5, aff5, b)                                                                           # fpn.py:43
+        else:
+            ops.patchify3x3s2(raw5, b["patches6"], aff5)
+            ops.conv_fwd(b["patches6"], self.pconv[6].packed.fwd, DEPTH, 1, None, out=b["p"][6], stats_part=st(6))   # fpn.py:43
         if is_training:
             fin["p345"].run()
             fin["p6"].run()                                                                                           # p6_batch_norm and pre_p7_bn
@@ -394,6 +399,36 @@ class PersonDetectorNet:
             ops.conv_fwd_grouped(xs, [oc.packed.fwd] * 5, oc.cout, 3, affs, [b["out"][net][l] for l in LEVELS], [None] * 5)
         self._last = (b, feats, images)
         return b
+
+    # ---- fpn/p6 at small batch (inference): a 9 * 1024-deep contraction over a few dozen pixels - as a 1x1 convolution that is ONE
+    # 128-pixel tile on ONE CU (167 us at 640 x 640, batch 1). Same trick as the PRN's K = 34 272 contractions: the split-K
+    # "weight gradient" of a 1x1 convolution whose pixel axis is K, operands K-major (X^T and the HWIO matrix as it is stored).
+    def _p6_skinny(self, b):
+        n, (h6, w6) = b["shape"][0], b["lv"][6]
+        return self.dtype != torch.float32 and n * h6 * w6 <= 256
+
+    def _p6_split_k(self, raw5, aff5, b):
+        c6 = self.pconv[6]
+        n, (h6, w6) = b["shape"][0], b["lv"][6]
+        M, K, dc, f32c = n * h6 * w6, c6.cin, _lib.dtype_code(self.dtype), _lib.dtype_code(torch.float32)
+        s = b.get("p6_sk")
+        if s is None:
+            Mp = (M + 7) // 8 * 8
+            dev = self.device
+            s = b["p6_sk"] = {"Mp": Mp, "xpad": torch.zeros((Mp, K), dtype=self.dtype, device=dev),
+                              "xt": torch.empty((K, Mp), dtype=self.dtype, device=dev),
+                              "out": torch.empty((Mp, DEPTH), dtype=torch.float32, device=dev),
+                              "wop": torch.empty((K, DEPTH), dtype=self.dtype, device=dev), "wver": -1}
+            nparts = ops.conv_wgrad_num_parts(1, 1, K, Mp, DEPTH, 1, self.dtype)
+            s["slab"] = torch.empty(nparts * Mp * DEPTH, dtype=torch.float32, device=dev)
+        if s["wver"] != self._wversion:       # the HWIO matrix [9 * C5, 128] in the storage type, refreshed with the variables
+            call("mpn_cast", ptr(c6.src), f32c, ptr(s["wop"]), dc, K * DEPTH, stream_ptr())
+            s["wver"] = self._wversion
+        Mp = s["Mp"]
+        ops.patchify3x3s2(raw5, s["xpad"][:M].view(n, h6, w6, K), aff5)                 # rows M..Mp stay zero
+        call("mpn_transpose_cast", ptr(s["xpad"]), dc, ptr(s["xt"]), dc, Mp, K, stream_ptr())
+        ops.conv_bwd_weight(s["xt"].view(1, 1, K, Mp), s["wop"].view(1, 1, K, DEPTH), 1, None, s["out"].view(1, 1, Mp, DEPTH), s["slab"])
+        call("mpn_cast", ptr(s["out"]), f32c, ptr(b["p"][6]), dc, M * DEPTH, stream_ptr())
 
     def raw_predictions(self, b):
         """{'encoded_boxes': [N,A,4], 'class_predictions': [N,A]} f32 in the reference's anchor order (box_predictor.py:55-90),

@@ -309,3 +309,32 @@ def test_detector_step_replays_from_a_hipgraph(cuda):
     for a, b_ in zip(want, got):
         np.testing.assert_array_equal(a, b_)
     assert torch.equal(ref.theta, net.theta) and torch.equal(ref.moving, net.moving)
+
+
+def test_p6_split_k_path_at_small_batch_equals_the_1x1_path(cuda):
+    """fpn/p6 at inference with a few dozen output pixels runs as a split-K contraction (the PRN's trick) instead of ONE 128-pixel
+    tile on one CU: the same p6 (bf16 rounding of an f32 sum in another order) and the same detections as the 1x1 path."""
+    from multiposenet_amd.retinanet import PersonDetectorNet
+    B, H, W = 1, 256, 384
+    bb, hp, img, _, _ = _setup(23, B, H, W)
+    hp["class_net/logits/kernel"] = (np.random.RandomState(8).randn(3, 3, 64, 6) * 0.4).astype(np.float32)
+    hp["class_net/logits/bias"] = np.full(6, -2.0, np.float32)
+    images = torch.tensor(img).cuda()
+    out = {}
+    for skinny in (True, False):
+        net = PersonDetectorNet(backbone_values=bb, head_values=hp, dtype=torch.bfloat16)
+        if not skinny:
+            net._p6_skinny = lambda b: False
+        else:
+            assert net._p6_skinny(net._buffers(B, H, W))
+        bset = net.forward(images, False)
+        pred = net.nms(bset, 0.3, 0.6, 25)
+        out[skinny] = (bset["p"][6].float().cpu().numpy().copy(), bset["p"][7].float().cpu().numpy().copy(),
+                       int(pred["num_boxes"][0]), pred["scores"][0].cpu().numpy().copy())
+    a, b_ = out[True], out[False]
+    assert np.abs(a[0]).max() > 0
+    np.testing.assert_allclose(a[0], b_[0], atol=1.2e-2 * np.abs(b_[0]).max(), rtol=1.2e-2)
+    np.testing.assert_allclose(a[1], b_[1], atol=3e-2 * np.abs(b_[1]).max(), rtol=3e-2)
+    assert abs(a[2] - b_[2]) <= 1
+    k = min(a[2], b_[2])
+    np.testing.assert_allclose(a[3][:k], b_[3][:k], atol=2e-2)
