@@ -63,10 +63,12 @@ def launch_ranks(n, argv, dry_run=False, timeout_s=1500.0):
             return 2
     cmds = rank_commands(n, argv, _free_port())
     procs = []
+    import tempfile
+    out0 = tempfile.TemporaryFile()      # (a file, not a pipe: nobody reads while the ranks run, and a full pipe would block rank 0)
     try:
         for r, (cmd, env) in enumerate(cmds):
             # rank 0's stdout carries the JSON line; the other ranks print nothing on stdout
-            procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+            procs.append(subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=out0 if r == 0 else subprocess.DEVNULL))
         deadline = time.monotonic() + timeout_s
         rcs = [None] * n
         line = None
@@ -79,10 +81,10 @@ def launch_ranks(n, argv, dry_run=False, timeout_s=1500.0):
             if time.monotonic() > deadline:
                 sys.stderr.write(f"bench.py: ranks still running after {timeout_s:.0f} s\n")
                 break
-            if all(rc is None for rc in rcs) or rcs[0] is None:
-                time.sleep(0.05)
+            time.sleep(0.05)
         if rcs[0] == 0:
-            line = procs[0].stdout.read().decode()
+            out0.seek(0)
+            line = out0.read().decode()
     finally:
         for p in procs:
             if p.poll() is None:
