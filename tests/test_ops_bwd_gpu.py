@@ -403,8 +403,8 @@ def test_conv_wgrad_grouped_equals_separate_launches(cuda, dtype, k, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("act,K,C", [(1, 128, 128), (2, 128, 128), (0, 128, 128), (1, 64, 64), (1, 128, 64), (2, 64, 192)],
-                         ids=["relu", "relu6", "none", "relu-64to64", "relu-128to64", "relu6-64to192"])
+@pytest.mark.parametrize("act,K,C", [(1, 128, 128), (2, 128, 128), (0, 128, 128), (1, 64, 64), (1, 128, 64), (2, 64, 192), (1, 128, 256)],
+                         ids=["relu", "relu6", "none", "relu-64to64", "relu-128to64", "relu6-64to192", "relu-128to256"])
 def test_conv_dgrad_with_fused_bn_reduction(cuda, dtype, act, K, C):
     """mpn_conv_bwd_data_bn_grouped on three jobs (ragged tiles, a channel-slice raw tensor): dx = the plain data gradient
     masked by the fed layer's activation, BIT FOR BIT; the slab's sums = sum g and sum g * x over all pixels (f64 reference

@@ -3,7 +3,7 @@ import collections
 import csv
 import sys
 
-KEYS = ['l2_loss', 'l2_partial', 'l2_final', 'conv3x3', 'pw_gemm', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_finalize', 'bn_bwd_finalize', 'bn_act', 'dwconv_fwd', 'dwconv_wgrad',
+KEYS = ['slab_compact', 'l2_loss', 'l2_partial', 'l2_final', 'conv3x3', 'pw_gemm', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_finalize', 'bn_bwd_finalize', 'bn_act', 'dwconv_fwd', 'dwconv_wgrad',
         'dwconv_dgrad', 'dwconv_bwd', 'conv_wgrad', 'conv_mfma', 'reduce_partials', 'stem_wgrad', 'stem_fwd', 'pack_weights',
         'bilinear_up_fwd', 'bilinear_up_bwd', 'slice_copy', 'slice_affine_store', 'head_bwd', 'head_fwd', 'loss_kernel', 'loss_finalize', 'adam', 'add_inplace',
         'sumpool', 'bn_stats', 'copyBuffer', 'decode',
