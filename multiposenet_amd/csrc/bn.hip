@@ -15,6 +15,7 @@
 namespace {
 
 constexpr int kThreads = 256;
+constexpr long long kApplyBlocks = 16384;   // bn_bwd_apply: 4 x 256 vectors per block and iteration
 
 // thread -> (row lane, channel vector) mapping shared by the streaming kernels below
 struct RowMap {
@@ -455,7 +456,10 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     // a thread keeps its channel vector, so the six per-channel parameters fold into registers ONCE:
     //   out = sc*(g - k1 - xhat*k2) = sc*g + cb*x + cc,  cb = -sc*k2*invstd,  cc = -sc*(k1 - mean*invstd*k2)
     // (re-loading them per element was 48 dword loads per 16-byte vector: bound by the texture unit, not by HBM)
-    const long long i0 = (long long)blk * kThreads + threadIdx.x;
+    // a block takes U consecutive 256-vector pieces per iteration: 16 KB of contiguous addresses per operand (the four vectors
+    // of a thread one grid stride apart - four 4-KB pieces per block, 8 MB from each other - ran 13-17 % slower on every
+    // layer shape, tools/bench_apply.py; with up to 16 384 blocks the big layers are one iteration)
+    const long long i0 = (long long)blk * (U * kThreads) + threadIdx.x;
     const int vg = (int)(i0 % cvec);
     float sc[VE], sh[VE], cb[VE], cc[VE];
 #pragma unroll
@@ -476,8 +480,9 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     }
     const float lo = (act != MPN_ACT_NONE) ? 0.f : -INFINITY;
     const float hi = (act == MPN_ACT_RELU6) ? 6.f : INFINITY;
-    const long long stride = (long long)nblk * kThreads;
-    for (long long i = i0; i < nvec; i += U * stride) {
+    constexpr long long stride = kThreads;
+    const long long step = (long long)nblk * (U * kThreads);
+    for (long long i = i0; i < nvec; i += step) {
         Vec16<T> vd[U], vx[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -797,7 +802,7 @@ extern "C" int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* 
                     "bn_bwd_apply_grouped: bad row stride");
         const long long nvec = M[j] * (C / ve);
         long long blocks = (nvec + 4 * kThreads - 1) / (4 * kThreads);   // as the per-layer launch
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > kApplyBlocks) blocks = kApplyBlocks;
         g.begin[j] = begin;
         begin += (int)blocks;
     }
@@ -845,7 +850,7 @@ extern "C" int mpn_bn_bwd_apply(void* dA, const void* x, long long M, int C, int
     hipStream_t st = (hipStream_t)stream;
     if (kThreads % (C / ve) == 0) {
         long long blocks = (nvec + 4 * kThreads - 1) / (4 * kThreads);   // 4 vectors per thread and iteration
-        if (blocks > 2048) blocks = 2048;
+        if (blocks > kApplyBlocks) blocks = kApplyBlocks;
         MPN_DISPATCH_DTYPE(dtype, (bn_bwd_apply_kernel<T><<<(unsigned)blocks, kThreads, 0, st>>>(
                                       (T*)dA, (const T*)x, nvec, C, scale, shift, mean, invstd, k1, k2, act, add_ch0)));
     } else {
