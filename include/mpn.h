@@ -355,6 +355,9 @@ int mpn_reduce_desc_fill(void* desc_host, const float* part, int nparts, long lo
                          int block_begin);
 int mpn_reduce_partials_batched(const void* descs_device, int ndesc, int total_blocks, mpn_stream_t stream);
 int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stream_t stream);
+/* y[t][i] += a * x[t][i] over `count` tensors (host arrays of device pointers / element counts), one launch per 64 tensors:
+ * the gradient of add_weight_decay's term for every regularised variable at once (keypoints_model.py:129-138). */
+int mpn_axpy_batched(int count, const float* const* x, float* const* y, const long long* n, float a, mpn_stream_t stream);
 /* acc[0] += scale * sum(w^2)/2 - `weight_decay * tf.nn.l2_loss(k)` of add_weight_decay (keypoints_model.py:129-138), the
  * term tf.losses.get_total_loss(add_regularization_losses=True) adds to the reported loss (keypoints_model.py:79).
  * One block, fixed summation order (f64): deterministic. */

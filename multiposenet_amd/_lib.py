@@ -104,6 +104,7 @@ SIGNATURES = {
     "mpn_prn_residual": (_I, [_P, _P, _I, _L, _P, _P]),
     "mpn_retina_loss_finalize": (_I, [_P, _P, _F, _F, _P, _P, _P, _P]),
     "mpn_axpy": (_I, [_L, _F, _P, _P, _P]),
+    "mpn_axpy_batched": (_I, [_I, _P, _P, _P, _F, _P]),
     "mpn_patchify3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_unpatchify3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mpn_retina_match_workspace_bytes": (_Z, [_I, _I]),

@@ -282,6 +282,21 @@ __global__ __launch_bounds__(256) void l2_final_kernel(const double* __restrict_
     }
     if (threadIdx.x == 0) acc[0] = (float)((double)acc[0] + scale * 0.5 * red[0]);
 }
+// y[t] += a * x[t] for up to kAxpyMax tensors in one grid (the weight-decay gradients of the detector head were 18 launches
+// of ~5 us each); blocks of kAxpyChunk elements, job table in the kernel arguments.
+constexpr int kAxpyMax = 64;
+constexpr int kAxpyChunk = 4096;
+struct AxpyBatch { const float* x[kAxpyMax]; float* y[kAxpyMax]; long long n[kAxpyMax]; int begin[kAxpyMax + 1]; int count; };
+__global__ __launch_bounds__(256) void axpy_batched_kernel(const AxpyBatch b, float a) {
+    int t = 0;
+    for (int k = 1; k < b.count; ++k)
+        if ((int)blockIdx.x >= b.begin[k]) t = k;                       // block-uniform
+    const long long i0 = (long long)((int)blockIdx.x - b.begin[t]) * kAxpyChunk;
+    const long long i1 = i0 + kAxpyChunk < b.n[t] ? i0 + kAxpyChunk : b.n[t];
+    const float* __restrict__ x = b.x[t];
+    float* __restrict__ y = b.y[t];
+    for (long long i = i0 + threadIdx.x; i < i1; i += 256) y[i] += a * x[i];
+}
 }  // namespace
 
 /* step: device int64 global_step (incremented); hyper: device f32[4] -> {lr_t, lr, -, -} */
@@ -375,6 +390,27 @@ extern "C" int mpn_axpy(long long n, float a, const float* x, float* y, mpn_stre
     if (blocks > 2048) blocks = 2048;
     axpy_kernel<<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(n, a, x, y);
     MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* y[t][i] += a * x[t][i] for `count` tensors (host arrays of device pointers / element counts): one launch per 64 tensors.
+ * The gradient of the weight-decay term, keypoints_model.py:129-138. */
+extern "C" int mpn_axpy_batched(int count, const float* const* x, float* const* y, const long long* n, float a,
+                                mpn_stream_t stream) {
+    MPN_REQUIRE(count > 0 && x && y && n, MPN_ERR_BAD_ARG, "axpy_batched: bad arguments");
+    for (int t0 = 0; t0 < count; t0 += kAxpyMax) {
+        AxpyBatch b;
+        b.count = count - t0 < kAxpyMax ? count - t0 : kAxpyMax;
+        int begin = 0;
+        for (int k = 0; k < b.count; ++k) {
+            MPN_REQUIRE(x[t0 + k] && y[t0 + k] && n[t0 + k] > 0, MPN_ERR_BAD_ARG, "axpy_batched: tensor %d", t0 + k);
+            b.x[k] = x[t0 + k]; b.y[k] = y[t0 + k]; b.n[k] = n[t0 + k]; b.begin[k] = begin;
+            begin += (int)((n[t0 + k] + kAxpyChunk - 1) / kAxpyChunk);
+        }
+        b.begin[b.count] = begin;
+        axpy_batched_kernel<<<begin, 256, 0, (hipStream_t)stream>>>(b, a);
+        MPN_LAUNCH_CHECK();
+    }
     return MPN_OK;
 }
 

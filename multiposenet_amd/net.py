@@ -262,6 +262,7 @@ class KeypointNet:
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
         self.fuse_conv_bn = True
         self._l2 = None           # the regularisation term's batched launch (add_weight_decay_loss)
+        self._wd = None           # ... and its gradient's (add_weight_decay_gradients)
         self.cache_inference_affine = False   # see prepare_inference
         self._infer_clean = False
         # the stem kernel can write its own batch-norm partial sums (mpn_stem_conv_fwd_stats); OFF: measured a wash - the
@@ -734,9 +735,10 @@ class KeypointNet:
 
     def add_weight_decay_gradients(self, weight_decay):
         """keypoints_model.py:129-138: + wd * l2_loss(k) for every 'weights'/'kernel' variable except depthwise."""
-        for k, w in self.vars.items():
-            if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k:
-                ops.axpy(weight_decay, w.view(-1), self.grads[k].view(-1))
+        if self._wd is None:
+            ks = [k for k in self.vars if ("weights" in k or "kernel" in k) and "depthwise_weights" not in k]
+            self._wd = ops.AxpyBatch([self.vars[k] for k in ks], [self.grads[k] for k in ks])
+        self._wd.run(weight_decay)
 
     def add_weight_decay_loss(self, weight_decay):
         """The regularisation term itself: total_loss += sum_k wd * l2_loss(k) over the same variables

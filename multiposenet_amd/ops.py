@@ -625,6 +625,22 @@ def axpy(a, x, y):
     call("mpn_axpy", x.numel(), float(a), ptr(x), ptr(y), stream_ptr())
 
 
+class AxpyBatch:
+    """ys[t] += a * xs[t] for a fixed list of float32 tensor pairs in one launch (mpn_axpy_batched)."""
+
+    def __init__(self, xs, ys):
+        n = len(xs)
+        assert n == len(ys) and all(x.numel() == y.numel() for x, y in zip(xs, ys))
+        self._keep = (list(xs), list(ys))
+        self.n = n
+        self.xp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in xs])
+        self.yp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ys])
+        self.counts = (ctypes.c_longlong * n)(*[t.numel() for t in xs])
+
+    def run(self, a):
+        call("mpn_axpy_batched", self.n, self.xp, self.yp, self.counts, float(a), stream_ptr())
+
+
 class L2LossBatch:
     """acc[0] += scale * sum of tf.nn.l2_loss over a fixed list of tensors, two launches (mpn_l2_loss_batched)."""
 

@@ -182,6 +182,7 @@ class PersonDetectorNet:
         self._infer_clean = False
         self.backbone.cache_inference_affine = True     # frozen here: its inference affines change only with its variables
         self._l2 = None
+        self._wd = None
         self._built = False
         self.load_state_dict(head_values if head_values is not None else initial_head_values(seed, self.dm))
         self._build_layers()
@@ -559,9 +560,10 @@ class PersonDetectorNet:
         oc = self.out_conv["class_net"]
         oc.dw.copy_(oc.dpad[..., :oc.w.shape[3]])                     # drop the two padding columns
         if weight_decay > 0.0:
-            for k, w in self.vars.items():
-                if "kernel" in k:
-                    ops.axpy(weight_decay, w.view(-1), self.grads[k].view(-1))
+            if self._wd is None:
+                ks = [k for k in self.vars if "kernel" in k]
+                self._wd = ops.AxpyBatch([self.vars[k] for k in ks], [self.grads[k] for k in ks])
+            self._wd.run(weight_decay)
 
     def optimizer_step(self, initial_learning_rate, num_steps, grad_scale=1.0):
         """person_detector_model.py:59-75: cosine decay, TF-Adam (NO gradient clipping in this model), head variables only."""

@@ -570,3 +570,20 @@ def test_finalizes_over_thousands_of_partial_rows(cuda, nparts, C):
              ops.ptr(bn.mean), ops.ptr(bn.invstd), ops.stream_ptr())
     want = (g64[1] - m_ * g64[0]) * i_
     np.testing.assert_allclose(bn.dgamma.cpu().numpy(), want, atol=1e-5 * float(np.abs(want).max()) + tol * float(np.abs(m_ * i_).max() + i_.max()))
+
+
+def test_axpy_batched_equals_per_tensor_axpy(cuda):
+    """mpn_axpy_batched (the weight-decay gradient of every regularised variable in one launch, keypoints_model.py:129-138)
+    on 70 tensors of ragged sizes (two launches of <= 64 jobs): bit for bit the per-tensor mpn_axpy, nothing outside."""
+    ops = _ops()
+    rs = np.random.RandomState(3)
+    sizes = [int(s) for s in rs.randint(1, 20000, size=68)] + [4096, 1]
+    xs = [dev(rs.randn(n).astype(np.float32)) for n in sizes]
+    ys = [dev(rs.randn(n + 8).astype(np.float32)) for n in sizes]          # 8 guard elements behind each
+    want = [y.clone() for y in ys]
+    for x, w in zip(xs, want):
+        ops.axpy(5e-5, x, w[:x.numel()])
+    ops.AxpyBatch(xs, [y[:x.numel()] for x, y in zip(xs, ys)]).run(5e-5)
+    for y, w in zip(ys, want):
+        assert torch.equal(y, w)
+    assert not torch.equal(ys[0][:sizes[0]], dev(np.zeros(sizes[0], np.float32)))
