@@ -129,15 +129,17 @@ def test_bn_backward(cuda, dtype, M, C, act, ch0):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("u", [1, 2, 4, 8])
-def test_bilinear_backward(cuda, dtype, u):
+@pytest.mark.parametrize("N,h,w,C", [(2, 6, 10, 128), (1, 3, 37, 64), (1, 4, 5, 24)], ids=["128ch", "wide-64ch", "24ch"])
+def test_bilinear_backward(cuda, dtype, u, N, h, w, C):
+    """The transposed legacy resize on a channel slice of the 512-channel concat gradient (one partial block per row, several
+    blocks per row, a channel count that is not a power of two) against autograd through the oracle's forward."""
     ops = _ops()
     rs = np.random.RandomState(u)
-    N, h, w, C = 2, 6, 10, 128
     a = torch.zeros(N, C, h, w, requires_grad=True)
     out = onet.resize_bilinear_legacy(a, h * u, w * u)
     dyfull = rnd(rs.randn(N, h * u, w * u, 512), dtype)
-    out.backward(nchw(dyfull[..., 128:256]))
-    got = ops.bilinear_up_bwd(dev(dyfull, dtype), u, 128, 128)
+    out.backward(nchw(dyfull[..., 128:128 + C]))
+    got = ops.bilinear_up_bwd(dev(dyfull, dtype), u, 128, C)
     assert_close(got, nhwc(a.grad), dtype, 4 * u * u)
 
 
