@@ -78,17 +78,22 @@ def test_dwconv_backward(cuda, dtype, N, H, W, C, stride):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (1, 64, 48), (1, 30, 34), (3, 128, 128)])
-def test_stem_wgrad(cuda, dtype, N, H, W):
+@pytest.mark.parametrize("N,H,W,u8", [(2, 32, 32, False), (1, 64, 48, False), (1, 30, 34, False), (3, 128, 128, False), (2, 70, 34, True)])
+def test_stem_wgrad(cuda, dtype, N, H, W, u8):
+    """f32 tolerance in both builds: the bf16 build's matrix-core kernel splits the image patch into bf16 hi + lo parts."""
     ops = _ops()
     rs = np.random.RandomState(H)
-    img = torch.tensor(rs.rand(N, H, W, 3).astype(np.float32))
+    if u8:
+        img8 = rs.randint(0, 256, (N, H, W, 3)).astype(np.uint8)
+        img = torch.tensor(img8.astype(np.float32) * np.float32(1 / 255.0))
+    else:
+        img = torch.tensor(rs.rand(N, H, W, 3).astype(np.float32))
     w = torch.zeros(3, 3, 3, 32, requires_grad=True)
     out = onet.conv2d_tf_same(nchw(2.0 * img - 1.0), w, 2)
     dy = rnd(rs.randn(*nhwc(out).shape), dtype)
     out.backward(nchw(dy))
     dw = torch.full((3, 3, 3, 32), float("nan"), device="cuda")
-    ops.stem_conv_bwd_weight(dev(img), dev(dy, dtype), dw)
+    ops.stem_conv_bwd_weight(dev(img8) if u8 else dev(img), dev(dy, dtype), dw)
     assert_close(dw, w.grad, torch.float32, N * H * W // 4, scale=float(w.grad.abs().max()))
 
 
