@@ -163,6 +163,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-fuse-stem-stats", action="store_true", help="A/B: batch-norm statistics of the stem output as a separate pass")
     ap.add_argument("--no-fuse-conv-bn", action="store_true", help="A/B: batch-norm reductions behind the 3x3 data gradients as separate passes")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse launcher + exchange on CPU over gloo (tests)")
     args = ap.parse_args()
@@ -188,6 +189,8 @@ def main():
     net = KeypointNet(dtype=dt, device=dev, seed=0)          # identical replicas on every rank
     if args.no_fuse_conv_bn:
         net.fuse_conv_bn = False
+    if args.no_fuse_stem_stats:
+        net.fuse_stem_stats = False
     params = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}
     force_dp = os.environ.get("MPN_DP_FORCE_COLLECTIVE", "0") == "1"   # rehearse the data-parallel path with one rank
     trainer = Trainer(net, params, use_graph=not args.no_graph, distributed=world > 1 or force_dp)

@@ -317,6 +317,14 @@ int mpn_heatmap_head_bwd_num_parts(long long M);
 int mpn_heatmap_head_bwd(const void* x, const float* dlogits, const float* w, long long M, int Cin,
                          int dtype, const float* in_scale, const float* in_shift, int in_act,
                          void* dA, float* part, mpn_stream_t stream);
+/* The same with the reduction pass of the batch-norm the head reads through (final_bn, keypoint_subnet.py:42-47) fused in:
+ * dA comes out masked by that layer's activation and bn_part [mpn_heatmap_head_bwd_num_parts(M)][2][Cin] receives per-block
+ * sums of g and g * x (raw x); finish with mpn_bn_bwd_finalize_raw + mpn_bn_bwd_apply. bf16, Cin = 16 / 32 / 64
+ * (mpn_heatmap_head_bwd_bn_supported). */
+int mpn_heatmap_head_bwd_bn_supported(int Cin, int dtype);
+int mpn_heatmap_head_bwd_bn(const void* x, const float* dlogits, const float* w, long long M, int Cin, int dtype,
+                            const float* in_scale, const float* in_shift, int in_act, void* dA, float* part,
+                            float* bn_part, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K12  fused losses + gradients (keypoints_model.py:43-90,141-178).

@@ -71,6 +71,8 @@ SIGNATURES = {
     "mpn_heatmap_head_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _I, _I, _P, _P, _P]),
     "mpn_heatmap_head_bwd_num_parts": (_I, [_L]),
     "mpn_heatmap_head_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "mpn_heatmap_head_bwd_bn_supported": (_I, [_I, _I]),
+    "mpn_heatmap_head_bwd_bn": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "mpn_keypoint_loss_num_parts": (_I, [_I, _I, _I]),
     "mpn_keypoint_loss": (_I, [_P] * 9 + [_I, _I] + [_P] * 7 + [_I, _I, _I, _P]),
     "mpn_adam_prepare": (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),

@@ -265,10 +265,10 @@ class KeypointNet:
         self._wd = None           # ... and its gradient's (add_weight_decay_gradients)
         self.cache_inference_affine = False   # see prepare_inference
         self._infer_clean = False
-        # the stem kernel can write its own batch-norm partial sums (mpn_stem_conv_fwd_stats); OFF: measured a wash - the
-        # separate statistics pass (38 us) reads the 134 MB stem output into the memory-side cache, and the first depthwise
-        # layer then runs 52 instead of 83 us
-        self.fuse_stem_stats = False
+        # the stem kernel writes its own batch-norm partial sums (mpn_stem_conv_fwd_stats). With the VALU stem kernel this was a
+        # wash (the separate 38 us statistics pass left the 134 MB stem output in the memory-side cache for the first depthwise
+        # layer); behind the matrix-core kernel it is worth 15 us per step (same-box A/B, round 3)
+        self.fuse_stem_stats = True
         self.fuse_lateral_add = True   # ... and add the FPN lateral's gradient into c2..c4 (mpn_dwconv_bwd_data_add)
         self._build_pack_table()   # (outside any graph capture: it copies a small table to the device)
         self.all_bn = [self.stem_bn] + [b[k] for b in self.blocks for k in ("dw_bn", "pw_bn")] + \
@@ -626,9 +626,15 @@ class KeypointNet:
 
     def _backward_head(self, b, g, feats, sp, slab, W):
         # ---- head + final conv
-        ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
-                             slab[id(self._head_grad)], reduce=False)
-        ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
+        if self._fused_conv_bn() and ops.heatmap_head_bwd_bn_supported(b["final"].shape[3], self.dtype):
+            # the head's backward kernel also reduces for final_bn (its input's batch-norm): one launch and one pass less
+            rows = ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
+                                        slab[id(self._head_grad)], reduce=False, bn_part=sp)
+            ops.bn_backward(self.final_bn, g["final"], b["final"], sp, reduced_parts=rows, raw=True)
+        else:
+            ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
+                                 slab[id(self._head_grad)], reduce=False)
+            ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
         W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, self.concat_affine, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
         ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm, stage by stage over the four levels (see subnet_forward): reductions into

@@ -569,8 +569,15 @@ def heatmap_head_fwd(x, w, bias, affine, inference=False, out=None, out_seg=None
     return (out, out_seg) if inference else out
 
 
-def heatmap_head_bwd(x, dlogits, w, affine, dA, dw_db_out, part=None, reduce=True):
-    """dA <- gradient w.r.t. the activated input; dw_db_out: flat f32 view [Cin*18 + 18]."""
+def heatmap_head_bwd_bn_supported(cin, dtype):
+    return bool(_lib.lib().mpn_heatmap_head_bwd_bn_supported(int(cin), _lib.dtype_code(dtype)))
+
+
+def heatmap_head_bwd(x, dlogits, w, affine, dA, dw_db_out, part=None, reduce=True, bn_part=None):
+    """dA <- gradient w.r.t. the activated input; dw_db_out: flat f32 view [Cin*18 + 18].
+    bn_part (f32, heatmap_head_bwd_num_parts(M) * 2 * Cin): also run the reduction of the batch-norm behind `affine` - dA
+    comes out masked by its activation and the slab takes the per-block sums of g and g * x (raw x); returns the number
+    of slab rows (bn_backward(..., reduced_parts=rows, raw=True) finishes)."""
     N, H, W, cin = x.shape
     M = N * H * W
     nparts = _lib.lib().mpn_heatmap_head_bwd_num_parts(M)
@@ -578,11 +585,17 @@ def heatmap_head_bwd(x, dlogits, w, affine, dA, dw_db_out, part=None, reduce=Tru
     if part is None:
         part = _f32(nparts * nout, x.device)
     sc, sh, act = _aff(affine)
-    call("mpn_heatmap_head_bwd", ptr(x), ptr(dlogits), ptr(w), M, cin, _lib.dtype_code(x.dtype), sc, sh, act, ptr(dA),
-         ptr(part), stream_ptr())
+    if bn_part is not None:
+        if bn_part.numel() < nparts * 2 * cin:
+            raise ValueError("heatmap_head_bwd: bn_part too small")
+        call("mpn_heatmap_head_bwd_bn", ptr(x), ptr(dlogits), ptr(w), M, cin, _lib.dtype_code(x.dtype), sc, sh, act, ptr(dA),
+             ptr(part), ptr(bn_part), stream_ptr())
+    else:
+        call("mpn_heatmap_head_bwd", ptr(x), ptr(dlogits), ptr(w), M, cin, _lib.dtype_code(x.dtype), sc, sh, act, ptr(dA),
+             ptr(part), stream_ptr())
     if reduce:
         call("mpn_reduce_partials", ptr(part), nparts, nout, ptr(dw_db_out), 0, 1.0, stream_ptr())
-    return dA
+    return nparts if bn_part is not None else dA
 
 
 LOSS_NAMES = ["focal_loss", "regression_loss", "segmentation_loss_at_level_2", "segmentation_loss_at_level_3",

@@ -594,3 +594,53 @@ def test_axpy_batched_equals_per_tensor_axpy(cuda):
     for y, w in zip(ys, want):
         assert torch.equal(y, w)
     assert not torch.equal(ys[0][:sizes[0]], dev(np.zeros(sizes[0], np.float32)))
+
+
+@pytest.mark.parametrize("M,C,act", [(128 * 5, 64, 1), (1000, 64, 2), (128 * 300 + 77, 64, 1), (900, 32, 1), (333, 16, 0)])
+def test_heatmap_head_backward_with_fused_bn_reduction(cuda, M, C, act):
+    """mpn_heatmap_head_bwd_bn (bf16, matrix cores): the same dW / db slab as mpn_heatmap_head_bwd; dA = its dA masked by
+    the activation of the batch-norm the head reads through, bit for bit; the second slab's sums = sum g and sum g * x over
+    all pixels (f64 on the kernel's rounded outputs); the raw finalize gives the dgamma / dbeta of the separate passes."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    assert ops.heatmap_head_bwd_bn_supported(C, dtype) and not ops.heatmap_head_bwd_bn_supported(48, dtype)
+    assert not ops.heatmap_head_bwd_bn_supported(C, torch.float32)
+    rs = np.random.RandomState(M % 1000 + C)
+    x = dev(rnd(rs.randn(1, 1, M, C) * 1.5 + 0.3, dtype), dtype)
+    wnp = dev((rs.randn(1, 1, C, 18) * 0.1).astype(np.float32))
+    dl = dev(rs.randn(1, 1, M, 18).astype(np.float32))
+    bn = ops.BNState(dev(torch.tensor(0.5 + rs.rand(C), dtype=torch.float32)), dev(torch.tensor(rs.randn(C) * 0.3, dtype=torch.float32)),
+                     torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), act)
+    xf = x.float().reshape(-1, C)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    bn.mean.copy_(mean); bn.invstd.copy_(1.0 / torch.sqrt(var + 1e-3))
+    bn.scale.copy_(bn.gamma * bn.invstd); bn.shift.copy_(bn.beta - mean * bn.scale)
+    bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    want_dA = torch.empty((1, 1, M, C), dtype=dtype, device="cuda")
+    want_dw = torch.full((C * 18 + 18,), float("nan"), device="cuda")
+    ops.heatmap_head_bwd(x, dl, wnp, bn.affine, want_dA, want_dw)
+    got_dA = torch.full((1, 1, M, C), float("nan"), dtype=dtype, device="cuda")
+    got_dw = torch.full((C * 18 + 18,), float("nan"), device="cuda")
+    rows_max = ops._lib.lib().mpn_heatmap_head_bwd_num_parts(M)
+    part = torch.full((rows_max * 2 * C,), float("nan"), device="cuda")
+    rows = ops.heatmap_head_bwd(x, dl, wnp, bn.affine, got_dA, got_dw, bn_part=part)
+    assert rows == rows_max and torch.equal(got_dw, want_dw)
+    pre = (x.double() * bn.scale.double() + bn.shift.double()).float()
+    ok = torch.ones_like(pre, dtype=torch.bool)
+    if act != 0:
+        ok = pre > 0
+    if act == 2:
+        ok = ok & (pre < 6)
+    assert torch.equal(got_dA, torch.where(ok, want_dA, torch.zeros_like(want_dA)))
+    ps = part.view(rows, 2, C).double().sum(0).cpu()
+    gd, xd = got_dA.double().reshape(-1, C).cpu(), x.double().reshape(-1, C).cpu()
+    np.testing.assert_allclose(ps[0].numpy(), gd.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(ps[1].numpy(), (gd * xd).sum(0).numpy(), rtol=1e-4, atol=3e-3)
+    ref = got_dA.clone()
+    sp = torch.empty(ops._lib.lib().mpn_bn_stats_num_parts(M) * 2 * C, device="cuda")
+    ops.bn_backward(bn, ref, x, sp)
+    want_dg, want_db = bn.dgamma.clone(), bn.dbeta.clone()
+    ops.bn_backward(bn, got_dA, x, part, reduced_parts=rows, raw=True)
+    np.testing.assert_allclose(bn.dgamma.cpu().numpy(), want_dg.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_dg.abs().max()))
+    np.testing.assert_allclose(bn.dbeta.cpu().numpy(), want_db.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_db.abs().max()))
+    assert float((got_dA.float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())

@@ -228,17 +228,19 @@ def test_sumpool2x2(cuda, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
-@pytest.mark.parametrize("M", [256 * 3, 1000])
-def test_heatmap_head_fwd(cuda, dtype, M):
+@pytest.mark.parametrize("M,C", [(256 * 3, 64), (1000, 64), (777, 32), (300, 16)])
+def test_heatmap_head_fwd(cuda, dtype, M, C):
+    """f32 tolerance in both builds: the bf16 build's matrix-core kernel (C = 16 / 32 / 64) splits activations and weights
+    into bf16 hi + lo parts."""
     ops = _ops()
     rs = np.random.RandomState(M)
-    x = rnd(rs.randn(1, 1, M, 64), dtype)
-    w = (rs.randn(1, 1, 64, 18) * 0.1).astype(np.float32)
+    x = rnd(rs.randn(1, 1, M, C), dtype)
+    w = (rs.randn(1, 1, C, 18) * 0.1).astype(np.float32)
     b = rs.randn(18).astype(np.float32)
-    sc = torch.tensor(0.5 + rs.rand(64), dtype=torch.float32)
-    sh = torch.tensor(rs.randn(64) * 0.5, dtype=torch.float32)
-    a = torch.relu(x * sc + sh).reshape(M, 64)
-    want = a @ torch.tensor(w).reshape(64, 18) + torch.tensor(b)
+    sc = torch.tensor(0.5 + rs.rand(C), dtype=torch.float32)
+    sh = torch.tensor(rs.randn(C) * 0.5, dtype=torch.float32)
+    a = torch.relu(x * sc + sh).reshape(M, C)
+    want = a @ torch.tensor(w).reshape(C, 18) + torch.tensor(b)
     aff = ops.Affine(dev(sc), dev(sh), 1)
     got = ops.heatmap_head_fwd(dev(x, dtype), dev(w), dev(b), aff)
     assert_close(got.reshape(M, 18), want, torch.float32, 64)
