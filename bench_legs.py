@@ -280,8 +280,9 @@ def prn_benchmark(batch=128, iters=20, dtype=torch.float16):
     """BASELINE config 5: pose residual network train step (fwd + loss + bwd + Adam + operand refresh) on `batch` person
     crops of 56x36x17, fp16 operands (the type config 5 names; same kernels on v_mfma_f32_16x16x32_f16) / f32 accumulate
     and masters, replayed from a hipGraph. The step is weight-bandwidth bound: algorithmic bytes = the 2 x 35.1 M weights
-    read twice as 16-bit operands (fwd, dgrad / as fc1 operand), their f32 gradients written, 5 f32 Adam streams,
-    3 operand refreshes (read f32, write 16-bit)."""
+    read twice as 16-bit operands (fwd, dgrad / as fc1 operand), their f32 gradients written, 7 f32 Adam streams (theta,
+    grad, m, v read; theta, m, v written) + the two 16-bit operand copies the Adam kernel writes itself, one transposing
+    refresh of W2 (read f32, write 16-bit)."""
     from multiposenet_amd.prn import PoseResidualNet
     net = PoseResidualNet(batch=batch, dtype=dtype)
     x = torch.rand(batch, net.h, net.w, net.c, device="cuda")
@@ -303,23 +304,29 @@ def prn_benchmark(batch=128, iters=20, dtype=torch.float16):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     nw = 2 * net.n * net.hidden
-    byt = nw * (2 * 3 + 4 + 5 * 4 + 3 * (4 + 2))      # operand reads, f32 grads, Adam, refreshes
+    byt = nw * (2 * 3 + 4 + 7 * 4 + 2) + (nw // 2) * (4 + 2)      # operand reads, f32 grads, Adam + its casts, W2^T refresh
     out = {"dtype": {torch.float16: "fp16", torch.bfloat16: "bf16", torch.float32: "f32"}[dtype],
            "ms_per_step": round(ms, 3), "crops_per_s": round(batch / ms * 1e3, 1), "batch": batch,
            "alg_GB_per_step": round(byt / 1e9, 3), "hbm_GBps": round(byt / ms / 1e6, 1),
            "hbm_frac_of_8TBps": round(byt / ms / 1e6 / 8000.0, 4), "final_loss": round(float(loss), 5)}
     # the step's dominant kernel: the fused Adam pass over the 70 M parameters (HBM: 5 f32 streams), timed alone
     from multiposenet_amd import ops as _ops
+    def adam():
+        if net._adam_cast is not None:
+            _ops.adam_step_cast(net.theta, net.grad, net.adam_m, net.adam_v, net.hyper, net._adam_cast, grad_scale=1.0, clip=float("inf"))
+        else:
+            _ops.adam_step(net.theta, net.grad, net.adam_m, net.adam_v, net.hyper, grad_scale=1.0, clip=float("inf"))
     for _ in range(3):
-        _ops.adam_step(net.theta, net.grad, net.adam_m, net.adam_v, net.hyper, grad_scale=1.0, clip=float("inf"))
+        adam()
     e0.record()
     for _ in range(iters):
-        _ops.adam_step(net.theta, net.grad, net.adam_m, net.adam_v, net.hyper, grad_scale=1.0, clip=float("inf"))
+        adam()
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
-    ab = 5 * 4 * net.theta.numel()
-    out["dominant_kernel"] = {"kernel": "adam_apply (TF-Adam over the flat f32 arena: theta, grad, m, v read, theta, m, v written)", "bound": "hbm",
+    ab = 7 * 4 * net.theta.numel() + (2 * nw if net._adam_cast is not None else 0)
+    out["dominant_kernel"] = {"kernel": "adam_apply (TF-Adam over the flat f32 arena: theta, grad, m, v read, theta, m, v written, the two weight "
+                                        "matrices also as 16-bit operand copies)", "bound": "hbm",
                               "launch_us": round(us, 1), "achieved": round(ab / us / 1e3, 1), "peak": 8000.0, "unit": "GB/s",
                               "frac": round(ab / us / 1e3 / 8000.0, 4), "share_of_step": round(us / (ms * 1e3), 3)}
     out["assign"] = prn_assign_benchmark(net, iters=iters)

@@ -350,6 +350,12 @@ int mpn_adam_prepare(long long* step, float* hyper, double initial_learning_rate
 int mpn_adam_step(float* params, const float* grads, float* m, float* v, long long n,
                   const float* hyper, float beta1, float beta2, float eps, float clip,
                   float grad_scale, mpn_stream_t stream);
+/* mpn_adam_step that also writes 16-bit copies (fp16 / bf16 by cast_dtype) of up to 4 ranges of the UPDATED arena:
+ * cast_dst[r][i] = (T) params[cast_begin[r] + i], i < cast_count[r] - the storage-dtype GEMM operand of a dense layer without a
+ * second pass over its f32 master. begin / count multiples of 4, dst 8-byte aligned. */
+int mpn_adam_step_cast(float* params, const float* grads, float* m, float* v, long long n, const float* hyper, float beta1,
+                       float beta2, float eps, float clip, float grad_scale, int ncast, const long long* cast_begin,
+                       const long long* cast_count, void* const* cast_dst, int cast_dtype, mpn_stream_t stream);
 /* out[j] (+)= scale * sum_p part[p][j] in a fixed order (deterministic). `part` is scratch: large slabs are
  * reduced in two passes and the first pass folds range sums into the slab itself (its contents are clobbered). */
 int mpn_reduce_partials(const float* part, int nparts, long long n, float* out, int accumulate,

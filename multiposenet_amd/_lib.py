@@ -77,6 +77,7 @@ SIGNATURES = {
     "mpn_keypoint_loss": (_I, [_P] * 9 + [_I, _I] + [_P] * 7 + [_I, _I, _I, _P]),
     "mpn_adam_prepare": (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),
     "mpn_adam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _P]),
+    "mpn_adam_step_cast": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _I, _P, _P, _P, _I, _P]),
     "mpn_reduce_partials": (_I, [_P, _I, _L, _P, _I, _F, _P]),
     "mpn_reduce_desc_bytes": (_Z, []),
     "mpn_reduce_desc_fill": (_I, [_P, _P, _I, _L, _P, _F, _I]),

@@ -26,11 +26,23 @@ __global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restr
 
 // A block takes U consecutive 256-vector pieces per iteration (contiguous 8 KB per stream) and issues all its loads first:
 // 52 M floats cold 282 -> 259 us against one vector per thread at grid stride (tools/bench_adam.py).
-template <int U>
+// CAST: the updated values of up to kAdamCast ranges of the arena also leave as 16-bit copies (dst[i - begin] = (T) theta[i]) -
+// the GEMM operand of a dense layer in the storage dtype without a second pass over its f32 master (the pose residual
+// network refreshed its two 35 M-element operands with a 61 us cast pass and a 145 us pack pass per step)
+constexpr int kAdamCast = 4;
+struct AdamCast { long long begin4[kAdamCast], end4[kAdamCast]; void* dst[kAdamCast]; int count, dtype; };
+template <typename T> __device__ __forceinline__ void adam_cast_store(void* dst, long long i4, const float4& q) {
+    const T a = (T)q.x, b = (T)q.y, c = (T)q.z, d = (T)q.w;
+    uint2 o;
+    o.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+    o.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    reinterpret_cast<uint2*>(dst)[i4] = o;
+}
+template <int U, bool CAST>
 __global__ __launch_bounds__(kThreads) void adam_apply_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                                       float* __restrict__ m, float* __restrict__ v, long long n4,
                                                                       const float* __restrict__ hyper, float beta1, float beta2,
-                                                                      float eps, float clip, float grad_scale) {
+                                                                      float eps, float clip, float grad_scale, const AdamCast cj) {
     const float lr_t = hyper[0];
     for (long long i0 = (long long)blockIdx.x * (U * kThreads) + threadIdx.x; i0 < n4; i0 += (long long)gridDim.x * (U * kThreads)) {
         float4 pp[U], gg[U], mm[U], vv[U];
@@ -62,6 +74,14 @@ __global__ __launch_bounds__(kThreads) void adam_apply_kernel(float* __restrict_
                 reinterpret_cast<float4*>(p)[i] = pp[u];
                 reinterpret_cast<float4*>(m)[i] = mm[u];
                 reinterpret_cast<float4*>(v)[i] = vv[u];
+                if (CAST) {
+#pragma unroll
+                    for (int r = 0; r < kAdamCast; ++r)
+                        if (r < cj.count && i >= cj.begin4[r] && i < cj.end4[r]) {
+                            if (cj.dtype == MPN_F16) adam_cast_store<half_t>(cj.dst[r], i - cj.begin4[r], pp[u]);
+                            else adam_cast_store<bf16_t>(cj.dst[r], i - cj.begin4[r], pp[u]);
+                        }
+                }
             }
         }
     }
@@ -320,8 +340,39 @@ extern "C" int mpn_adam_step(float* params, const float* grads, float* m, float*
     constexpr int U = 2;
     long long blocks = (n4 + U * kThreads - 1) / (U * kThreads);
     if (blocks > 4096) blocks = 4096;
-    adam_apply_kernel<U><<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(params, grads, m, v, n4, hyper, beta1, beta2, eps,
-                                                                           clip, grad_scale);
+    adam_apply_kernel<U, false><<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(params, grads, m, v, n4, hyper, beta1, beta2, eps,
+                                                                                  clip, grad_scale, AdamCast{});
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* mpn_adam_step that also writes 16-bit copies of `ncast` (<= 4) ranges of the updated arena: dst[r][i] = (T) params[begin[r] + i]
+ * for i < count[r], T = fp16 / bf16 by cast_dtype. begin / count multiples of 4 (the arena's tensors start on 16 bytes),
+ * dst 8-byte aligned. */
+extern "C" int mpn_adam_step_cast(float* params, const float* grads, float* m, float* v, long long n, const float* hyper,
+                                  float beta1, float beta2, float eps, float clip, float grad_scale, int ncast,
+                                  const long long* cast_begin, const long long* cast_count, void* const* cast_dst, int cast_dtype,
+                                  mpn_stream_t stream) {
+    MPN_REQUIRE(params && grads && m && v && hyper, MPN_ERR_BAD_ARG, "adam_step_cast: null pointer");
+    MPN_REQUIRE(n > 0 && n % 4 == 0, MPN_ERR_BAD_SHAPE, "adam_step_cast: n must be a positive multiple of 4");
+    MPN_REQUIRE(mpn_aligned16(params) && mpn_aligned16(grads) && mpn_aligned16(m) && mpn_aligned16(v), MPN_ERR_BAD_ALIGN,
+                "adam_step_cast: arenas must be 16-byte aligned");
+    MPN_REQUIRE(ncast >= 1 && ncast <= kAdamCast && cast_begin && cast_count && cast_dst, MPN_ERR_BAD_ARG, "adam_step_cast: 1..4 ranges");
+    MPN_REQUIRE(cast_dtype == MPN_F16 || cast_dtype == MPN_BF16, MPN_ERR_BAD_DTYPE, "adam_step_cast: 16-bit copies only (dtype %d)", cast_dtype);
+    AdamCast cj = {};
+    cj.count = ncast; cj.dtype = cast_dtype;
+    for (int r = 0; r < ncast; ++r) {
+        MPN_REQUIRE(cast_begin[r] >= 0 && cast_count[r] > 0 && cast_begin[r] % 4 == 0 && cast_count[r] % 4 == 0 &&
+                        cast_begin[r] + cast_count[r] <= n && cast_dst[r] && (((uintptr_t)cast_dst[r]) & 7u) == 0,
+                    MPN_ERR_BAD_ARG, "adam_step_cast: range %d", r);
+        cj.begin4[r] = cast_begin[r] / 4; cj.end4[r] = (cast_begin[r] + cast_count[r]) / 4; cj.dst[r] = cast_dst[r];
+    }
+    const long long n4 = n / 4;
+    constexpr int U = 2;
+    long long blocks = (n4 + U * kThreads - 1) / (U * kThreads);
+    if (blocks > 4096) blocks = 4096;
+    adam_apply_kernel<U, true><<<(int)blocks, kThreads, 0, (hipStream_t)stream>>>(params, grads, m, v, n4, hyper, beta1, beta2, eps,
+                                                                                 clip, grad_scale, cj);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

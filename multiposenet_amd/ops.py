@@ -630,6 +630,27 @@ def adam_step(params, grads, m, v, hyper, grad_scale=1.0, beta1=0.9, beta2=0.999
          float(grad_scale), stream_ptr())
 
 
+class AdamCastJobs:
+    """Ranges of a flat f32 arena whose updated values adam_step also writes as 16-bit operand copies (mpn_adam_step_cast):
+    jobs = [(offset, count, dst tensor of dtype float16 / bfloat16 with `count` elements)]."""
+
+    def __init__(self, jobs):
+        n = len(jobs)
+        assert 1 <= n <= 4 and len({d.dtype for _, _, d in jobs}) == 1
+        assert all(d.numel() == c and d.is_contiguous() for _, c, d in jobs)
+        self._keep = [d for _, _, d in jobs]
+        self.n = n
+        self.begin = (ctypes.c_longlong * n)(*[int(o) for o, _, _ in jobs])
+        self.count = (ctypes.c_longlong * n)(*[int(c) for _, c, _ in jobs])
+        self.dst = (ctypes.c_void_p * n)(*[d.data_ptr() for _, _, d in jobs])
+        self.dtype = _lib.dtype_code(jobs[0][2].dtype)
+
+
+def adam_step_cast(params, grads, m, v, hyper, jobs, grad_scale=1.0, beta1=0.9, beta2=0.999, eps=1e-8, clip=200.0):
+    call("mpn_adam_step_cast", ptr(params), ptr(grads), ptr(m), ptr(v), params.numel(), ptr(hyper), beta1, beta2, eps, clip,
+         float(grad_scale), jobs.n, jobs.begin, jobs.count, jobs.dst, jobs.dtype, stream_ptr())
+
+
 def reduce_partials(part, nparts, n, out, accumulate=False, scale=1.0):
     call("mpn_reduce_partials", ptr(part), nparts, n, ptr(out), int(accumulate), float(scale), stream_ptr())
 

@@ -85,16 +85,22 @@ class PoseResidualNet:
             self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
             self.load_state_dict(values if values is not None else initial_values(seed, h=h, w=w, c=c, hidden=hidden))
             W1, W2 = self.vars["PRN/fc1/weights"], self.vars["PRN/fc2/weights"]
-            # operand copies in the storage dtype: W1 [n,1024] (K-major as stored), W2^T [n,1024], W2 packed for conv_fwd
+            # operand copies in the storage dtype: W1 [n,1024] and W2 [1024,n] as stored (written by the Adam kernel itself,
+            # mpn_adam_step_cast), W2^T [n,1024] (one transposing pass per step)
             self.w1_op = W1 if dtype == torch.float32 else torch.empty((n, hidden), dtype=dtype, device=dev)
+            self.w2_op = W2 if dtype == torch.float32 else torch.empty((hidden, n), dtype=dtype, device=dev)
             self.w2t_op = torch.empty((n, hidden), dtype=dtype, device=dev)
-            self.w2_conv = ops.PackedConv(W2.view(1, 1, hidden, n), dtype)
+            self._adam_cast = None
+            if dtype != torch.float32:
+                o1, n1, _ = self._arena.offsets["PRN/fc1/weights"]
+                o2, n2, _ = self._arena.offsets["PRN/fc2/weights"]
+                self._adam_cast = ops.AdamCastJobs([(o1, n1, self.w1_op), (o2, n2, self.w2_op)])
             self._siblings = {self.valid: self}
         else:
             if (share.h, share.w, share.c, share.hidden, share.dtype) != (h, w, c, hidden, dtype):
                 raise ValueError("share_variables_of: geometry / dtype differ")
             for a in ("_arena", "theta", "grad", "adam_m", "adam_v", "vars", "grads", "global_step", "hyper", "w1_op",
-                      "w2t_op", "w2_conv", "_siblings"):
+                      "w2_op", "w2t_op", "_adam_cast", "_siblings"):
                 setattr(self, a, getattr(share, a))
             self._siblings[self.valid] = self
             # the fp16 loss scale is a function of the batch size; Adam divides by the scale of the instance that steps
@@ -103,7 +109,8 @@ class PoseResidualNet:
         self.x_op = torch.empty((B, n), dtype=dtype, device=dev)          # X in the storage dtype (fc1 wgrad operand)
         self.pre1 = torch.empty((B, hidden), dtype=f32, device=dev)
         self.hid = torch.empty((B, hidden), dtype=dtype, device=dev)
-        self.pre2 = torch.empty((B, n), dtype=dtype, device=dev)
+        self.hidt = torch.empty((hidden, B), dtype=dtype, device=dev)     # H^T: fc2 as a contraction over its 1024 rows
+        self.pre2 = torch.empty((B, n), dtype=f32, device=dev)
         self.y2 = torch.empty((B, n), dtype=dtype, device=dev)
         self.logits = torch.empty((B, n), dtype=f32, device=dev)
         self.dlogits = torch.zeros((B, n), dtype=f32, device=dev)     # (rows >= valid are never written: stay zero)
@@ -120,6 +127,9 @@ class PoseResidualNet:
         for name, cin, cout in (("PRN/fc1/weights", n, hidden), ("PRN/fc2/weights", hidden, n)):
             if ops.conv_wgrad_num_parts(1, 1, B, cin, cout, 1, dtype) != 1:
                 raise RuntimeError("weight-gradient geometry changed: expected one slab for " + name)
+        # fc2 forward: K = 1024 rows, output [B, n] - one slab (the output itself) in the 16-bit builds; the f32 kernel splits K
+        self._fc2_parts = ops.conv_wgrad_num_parts(1, 1, hidden, B, n, 1, dtype)
+        self.fc2_slab = torch.empty(self._fc2_parts * B * n, dtype=f32, device=dev) if self._fc2_parts != 1 else None
         if share is None:
             self.refresh_operands()
 
@@ -137,17 +147,18 @@ class PoseResidualNet:
             if a.shape != tuple(v.shape):
                 raise ValueError(f"{k}: shape {a.shape} != {tuple(v.shape)}")
             v.copy_(torch.from_numpy(a))
-        if hasattr(self, "w2_conv"):
+        if hasattr(self, "w2t_op"):
             self.refresh_operands()
 
-    def refresh_operands(self):
-        """Operand copies of the f32 masters (after every optimizer step)."""
-        dc = _lib.dtype_code(self.dtype)
+    def refresh_operands(self, casts=True):
+        """Operand copies of the f32 masters. casts=False (after an optimizer step): the Adam kernel has already written the
+        two plain casts (mpn_adam_step_cast); what remains is the transposed copy of W2."""
+        dc, f32c = _lib.dtype_code(self.dtype), _lib.dtype_code(torch.float32)
         W1, W2 = self.vars["PRN/fc1/weights"], self.vars["PRN/fc2/weights"]
-        if self.dtype != torch.float32:
-            call("mpn_cast", ptr(W1), _lib.dtype_code(torch.float32), ptr(self.w1_op), dc, W1.numel(), stream_ptr())
-        call("mpn_transpose_cast", ptr(W2), _lib.dtype_code(torch.float32), ptr(self.w2t_op), dc, self.hidden, self.n, stream_ptr())
-        self.w2_conv.repack(with_bwd=False)
+        if casts and self.dtype != torch.float32:
+            call("mpn_cast", ptr(W1), f32c, ptr(self.w1_op), dc, W1.numel(), stream_ptr())
+            call("mpn_cast", ptr(W2), f32c, ptr(self.w2_op), dc, W2.numel(), stream_ptr())
+        call("mpn_transpose_cast", ptr(W2), f32c, ptr(self.w2t_op), dc, self.hidden, self.n, stream_ptr())
 
     # ---------------------------------------------------------------- forward / loss / backward
     def _kgemm(self, at, bmat, out):
@@ -170,8 +181,16 @@ class PoseResidualNet:
         call("mpn_cast", ptr(x), f32c, ptr(self.x_op), dc, B * n, stream_ptr())
         self._kgemm(self.xt, self.w1_op, self.pre1)
         call("mpn_bias_relu_fwd", ptr(self.pre1), f32c, ptr(self.vars["PRN/fc1/biases"]), ptr(self.hid), dc, B, self.hidden, stream_ptr())
-        ops.conv_fwd(self.hid.view(1, 1, B, self.hidden), self.w2_conv.fwd, n, 1, None, out=self.pre2.view(1, 1, B, n))
-        call("mpn_bias_relu_fwd", ptr(self.pre2), dc, ptr(self.vars["PRN/fc2/biases"]), ptr(self.y2), dc, B, n, stream_ptr())
+        # fc2 as the same kind of contraction over rows (here the 1024 hidden units): W2 is read as stored - its operand copy is
+        # a plain cast, which the Adam kernel writes itself; the packed image of a 1x1 convolution was a 145 us pass per step
+        call("mpn_transpose_cast", ptr(self.hid), dc, ptr(self.hidt), dc, B, self.hidden, stream_ptr())
+        if self.fc2_slab is None:
+            ops.conv_bwd_weight(self.hidt.view(1, 1, self.hidden, B), self.w2_op.view(1, 1, self.hidden, n), 1, None,
+                                self.pre2.view(1, 1, B, n), self.pre2.view(-1), reduce=False)
+        else:
+            ops.conv_bwd_weight(self.hidt.view(1, 1, self.hidden, B), self.w2_op.view(1, 1, self.hidden, n), 1, None,
+                                self.pre2.view(1, 1, B, n), self.fc2_slab)
+        call("mpn_bias_relu_fwd", ptr(self.pre2), f32c, ptr(self.vars["PRN/fc2/biases"]), ptr(self.y2), dc, B, n, stream_ptr())
         self._x = x
         return self.y2
 
@@ -210,8 +229,12 @@ class PoseResidualNet:
 
     def optimizer_step(self, initial_learning_rate, num_steps):
         ops.adam_prepare(self.global_step, self.hyper, initial_learning_rate, num_steps)
-        ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, grad_scale=1.0 / self.loss_scale, clip=float("inf"))
-        self.refresh_operands()
+        if self._adam_cast is not None:
+            ops.adam_step_cast(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, self._adam_cast,
+                               grad_scale=1.0 / self.loss_scale, clip=float("inf"))
+        else:
+            ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, grad_scale=1.0 / self.loss_scale, clip=float("inf"))
+        self.refresh_operands(casts=False)
 
     def train_step(self, x, labels, initial_learning_rate, num_steps):
         self.forward(x)

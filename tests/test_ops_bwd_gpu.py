@@ -644,3 +644,27 @@ def test_heatmap_head_backward_with_fused_bn_reduction(cuda, M, C, act):
     np.testing.assert_allclose(bn.dgamma.cpu().numpy(), want_dg.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_dg.abs().max()))
     np.testing.assert_allclose(bn.dbeta.cpu().numpy(), want_db.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(want_db.abs().max()))
     assert float((got_dA.float() - ref.float()).abs().max()) <= 2e-2 * float(ref.float().abs().max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+def test_adam_step_with_operand_casts(cuda, dtype):
+    """mpn_adam_step_cast: the same theta / m / v as mpn_adam_step bit for bit, and the named ranges of the UPDATED arena as
+    16-bit copies (what a separate cast pass over the f32 master would give), nothing written outside them."""
+    ops = _ops()
+    rs = np.random.RandomState(9)
+    n = 4 * 50_021
+    mk = lambda s: dev((rs.randn(n) * s).astype(np.float32))
+    p0, g, m0 = mk(1.0), mk(0.01), mk(0.01)
+    v0 = dev((rs.rand(n) * 1e-4).astype(np.float32))
+    hyper = dev(np.array([1e-3, 1e-3, 0, 0], np.float32))
+    p1, m1, v1 = p0.clone(), m0.clone(), v0.clone()
+    ops.adam_step(p1, g, m1, v1, hyper, grad_scale=0.5, clip=float("inf"))
+    ranges = [(0, 1024), (4096, 4 * 30_001), (n - 8, 8)]
+    dsts = [torch.full((c + 8,), 7.0, dtype=dtype, device="cuda") for _, c in ranges]      # 8 guard elements behind each
+    jobs = ops.AdamCastJobs([(o, c, d[:c]) for (o, c), d in zip(ranges, dsts)])
+    p2, m2, v2 = p0.clone(), m0.clone(), v0.clone()
+    ops.adam_step_cast(p2, g, m2, v2, hyper, jobs, grad_scale=0.5, clip=float("inf"))
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and not torch.equal(p0, p2)
+    for (o, c), d in zip(ranges, dsts):
+        assert torch.equal(d[:c], p2[o:o + c].to(dtype))
+        assert bool((d[c:] == 7.0).all())
