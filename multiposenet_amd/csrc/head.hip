@@ -335,7 +335,6 @@ __global__ __launch_bounds__(kThreads, 2) void head_bwd_mfma_kernel(const bf16_t
                                                                  float* __restrict__ bn_part) {
     typedef H16<bf16_t> HT;
     typedef HT::x8 x8;
-    typedef HT::x4 x4;
     typedef HT::acc_t acc_t;
     constexpr int Cin = 16 * CB;
     constexpr int CV = Cin / 8;                                              // 16-byte vectors per pixel row of x
