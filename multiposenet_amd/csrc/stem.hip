@@ -209,29 +209,28 @@ __global__ __launch_bounds__(kThreads) void stem_fwd_mfma_kernel(const void* __r
     const int tx = b % tiles_x; b /= tiles_x;
     const int ty = b % tiles_y;
     const int img = b / tiles_y;
-    // ---- patch: every load issued before the first use
+    // ---- patch: every load issued before the first use. Thread t < 195 owns float t of every patch row (its column and channel
+    //      are fixed, the row is the unrolled loop variable): no index arithmetic per element - with element i = t + 256 k
+    //      spread over rows the divisions by 195 and 3 made the kernel VALU-bound (PMC: 70 % of the issue slots)
     {
         const int iy0 = ty * kTile * 2 - pad_t, ix0 = tx * kFwdTW * 2 - pad_l;
-        constexpr int NEL = kPR * kPC;
-        constexpr int PER = (NEL + kThreads - 1) / kThreads;               // 26
-        float v[PER];
+        const int pc = threadIdx.x < kPC ? threadIdx.x : 0;
+        const int ix = ix0 + pc / 3;
+        const bool col_ok = threadIdx.x < kPC && ix >= 0 && ix < W;
+        float v[kPR];
+        const long long base = ((long long)img * H * W + ix0) * 3 + pc;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * kThreads;
-            const int py = i / kPC, pc = i - py * kPC;
-            const int px = pc / 3;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool ok = i < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const long long off = ok ? (((long long)img * H + iy) * W + ix0) * 3 + pc : 0;   // (unpredicated load, valid address)
+        for (int py = 0; py < kPR; ++py) {
+            const int iy = iy0 + py;                                             // (uniform)
+            const bool ok = col_ok && iy >= 0 && iy < H;
+            const long long off = ok ? base + (long long)iy * W * 3 : 0;        // (unpredicated load, valid address)
             const float raw = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] * (1.0f / 255.0f)
                                  : reinterpret_cast<const float*>(images)[off];
-            v[k] = ok ? 2.0f * raw - 1.0f : 0.0f;                           // SAME padding: zeros of the STANDARDISED tensor
+            v[py] = ok ? 2.0f * raw - 1.0f : 0.0f;                              // SAME padding: zeros of the STANDARDISED tensor
         }
+        if (threadIdx.x < kPC) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = threadIdx.x + k * kThreads;
-            const int py = i / kPC, pc = i - py * kPC;
-            if (i < NEL) patch[py * kPS + pc] = v[k];
+            for (int py = 0; py < kPR; ++py) patch[py * kPS + pc] = v[py];
         }
     }
     // ---- weight fragments (A: row = output channel m of block mb, k = 8 * kg .. + 7), hi / lo
@@ -462,33 +461,37 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_mfma_kernel(const void* _
     const int ntiles = N * tiles_y * tiles_x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n = lane & 15, kg = lane >> 4, q = n >> 2, pq = n & 3;
-    constexpr int NEL = kPR * kPC;
-    constexpr int PER = (NEL + kThreads - 1) / kThreads;                   // 26 patch dwords per thread
     constexpr int VPP = C0 / 8;                                             // 16-byte dY vectors per pixel
     constexpr int DV = kTile * kFwdTW * VPP / kThreads;                     // 4 * MB per thread
-    float pv[PER];
+    // patch: thread t < 195 owns float t of every patch row (as in the forward kernel: no index arithmetic per element)
+    float pv[kPR];
     uint4 dv[DV];
-    unsigned pmask = 0u, dmask = 0u;
+    unsigned long long pmask = 0ull;
+    unsigned dmask = 0u;
+    const int p_pc = threadIdx.x < kPC ? threadIdx.x : 0;
     auto load_tile = [&](int t) __attribute__((always_inline)) {
         const int tx = t % tiles_x;
         const int t2 = t / tiles_x;
         const int ty = t2 % tiles_y;
         const int img = t2 / tiles_y;
         const int iy0 = ty * kTile * 2 - pad_t, ix0 = tx * kFwdTW * 2 - pad_l;
-        pmask = 0u;
+        pmask = 0ull;
         dmask = 0u;
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));   // per-call index arithmetic: hoisted out of the tile loop it pins ~100 address registers
+        {
+            const int ix = ix0 + p_pc / 3;
+            const bool col_ok = tid < kPC && ix >= 0 && ix < W;
+            const long long base = ((long long)img * H * W + ix0) * 3 + p_pc;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + k * kThreads;
-            const int py = i / kPC, pc = i - py * kPC;
-            const int iy = iy0 + py, ix = ix0 + pc / 3;
-            const bool ok = i < NEL && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const long long off = ok ? (((long long)img * H + iy) * W + ix0) * 3 + pc : 0;
-            pv[k] = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] * (1.0f / 255.0f)
-                       : reinterpret_cast<const float*>(images)[off];
-            pmask |= (ok ? 1u : 0u) << k;
+            for (int py = 0; py < kPR; ++py) {
+                const int iy = iy0 + py;
+                const bool ok = col_ok && iy >= 0 && iy < H;
+                const long long off = ok ? base + (long long)iy * W * 3 : 0;
+                pv[py] = U8 ? (float)reinterpret_cast<const unsigned char*>(images)[off] * (1.0f / 255.0f)
+                            : reinterpret_cast<const float*>(images)[off];
+                pmask |= (unsigned long long)(ok ? 1u : 0u) << py;
+            }
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k) {
@@ -503,12 +506,10 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_mfma_kernel(const void* _
     auto commit_tile = [&]() __attribute__((always_inline)) {
         int tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
+        if (tid < kPC) {
 #pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int i = tid + k * kThreads;
-            const int py = i / kPC, pc = i - py * kPC;
-            // SAME padding is zeros of the STANDARDISED tensor
-            if (i < NEL) patch[py * kPS + pc] = ((pmask >> k) & 1u) ? 2.0f * pv[k] - 1.0f : 0.0f;
+            for (int py = 0; py < kPR; ++py)   // SAME padding is zeros of the STANDARDISED tensor
+                patch[py * kPS + p_pc] = ((pmask >> py) & 1ull) ? 2.0f * pv[py] - 1.0f : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < DV; ++k) {
