@@ -131,20 +131,29 @@ __global__ __launch_bounds__(kThreads) void match_anchor_kernel(const float* __r
     extern __shared__ float sgt[];   // [maxN][4]
     for (int i = threadIdx.x; i < N * 4; i += kThreads) sgt[i] = gt[(long long)b * maxN * 4 + i];
     __syncthreads();
-    if (a >= A) return;
-    const float4 av = *reinterpret_cast<const float4*>(anchors + (long long)a * 4);
+    const bool live = a < A;                                       // (no early return: the wave reductions below need every lane)
+    const float4 av = *reinterpret_cast<const float4*>(anchors + (long long)(live ? a : 0) * 4);
     const Box an = {av.x, av.y, av.z, av.w};
     int best = 0;
     float best_v = -1.f;
     for (int n = 0; n < N; ++n) {
         const Box g = {sgt[n * 4], sgt[n * 4 + 1], sgt[n * 4 + 2], sgt[n * 4 + 3]};
-        const float v = iou_f32(g, an);
+        const float v = live ? iou_f32(g, an) : 0.f;
         if (v > best_v) { best_v = v; best = n; }
         // anchors that do not overlap the box cannot become its forced match (a forced match needs iou >= 0.05): only the
         // few thousand overlapping ones issue an atomic. A box nothing overlaps keeps key 0 = "no anchor".
-        if (v > 0.f) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)a);
-            atomicMax(&keys[(long long)b * maxN + n], key);
+        // One atomic per wave and box: the lanes' keys are reduced first (a box overlapped by a few thousand anchors drew as
+        // many contended atomics: 112 us of the detector step).
+        unsigned long long key = v > 0.f ? ((unsigned long long)__float_as_uint(v) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)a) : 0ull;
+        if (__any(key != 0ull)) {   // (wave-uniform)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo = __shfl_xor((unsigned)key, o, 64);
+                const unsigned hi = __shfl_xor((unsigned)(key >> 32), o, 64);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                key = other > key ? other : key;
+            }
+            if ((threadIdx.x & 63) == 0) atomicMax(&keys[(long long)b * maxN + n], key);
         }
     }
     int m = -1;
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void match_anchor_kernel(const float* __r
         if (pos_thr == neg_thr) m = pos ? best : -1;
         else m = pos ? best : (neg_thr > best_v ? -1 : -2);
     }
-    matches[(long long)b * A + a] = m;
+    if (live) matches[(long long)b * A + a] = m;
 }
 
 // pass 2: forced matches (training_target_creation.py:101-121): groundtruth box n forces its best anchor f(n); the anchor
