@@ -151,7 +151,7 @@ __device__ __forceinline__ f32x4_t load4(const bf16_t* p) {
 // MFMA shape, a warp-specialised persistent kernel, batch-norm finalizes fused into the last-finishing blocks): DESIGN.md 4c.
 template <typename T, int TAPS, int BN, int RB, bool BNR = false>
 __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int blk, const int nwg_job) {
-    static_assert(!BNR || (TAPS == 1 && sizeof(T) == 2), "the fused batch-norm backward reduction: thin 1x1 data gradients, 16-bit storage");
+    static_assert(!BNR || sizeof(T) == 2, "the fused batch-norm backward reduction: 16-bit storage");
     constexpr int MT = 4;                       // 16-pixel m-tiles per wave
     constexpr int ES = (int)sizeof(T);
     constexpr int VE = 16 / ES;
@@ -414,8 +414,15 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                     const T* xw = reinterpret_cast<const T*>(p.bnr_x) + cch;
 #pragma unroll
                     for (int i = 0; i < ROWS / PPP; ++i) {
-                        long long px = m0 + tid / SL + i * PPP;
-                        if (px >= p.M) px = p.M - 1;                  // (rows past the end hold dy = 0)
+                        long long px;
+                        if (TAPS == 9) {                              // (tile pixels outside the image: a valid address, masked below)
+                            const int row = tid / SL + i * PPP;
+                            const int oy = min(oy0 + (row >> 4), p.H - 1), ox = min(ox0 + (row & 15), p.W - 1);
+                            px = ((long long)img * p.H + oy) * p.W + ox;
+                        } else {
+                            px = m0 + tid / SL + i * PPP;
+                            if (px >= p.M) px = p.M - 1;              // (rows past the end hold dy = 0)
+                        }
                         bx[i] = *reinterpret_cast<const uint4*>(xw + px * p.bnr_xs);
                     }
                     const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(p.bnr_scale + cch), s1 = *reinterpret_cast<const f32x4_t*>(p.bnr_scale + cch + 4);
@@ -447,6 +454,7 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
                             // g = dy where the fed batch-norm's activation passes (the test of bn_bwd_reduce / bn_bwd_apply), else 0
                             const unsigned xu[4] = {bx[i].x, bx[i].y, bx[i].z, bx[i].w};
                             unsigned du[4] = {a.x, a.y, b.x, b.y};
+                            if (TAPS == 9 && !ok) { du[0] = 0u; du[1] = 0u; du[2] = 0u; du[3] = 0u; }   // (a 3x3 tile past the image edge is not zero)
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 const f32x2_t xf = {to_f32(__builtin_bit_cast(T, (unsigned short)(xu[j] & 0xffffu))),
@@ -594,13 +602,13 @@ struct ConvGroup {
     int begin[kMaxGroup + 1];   // first block of each job; begin[njobs] = grid size
     int njobs;
 };
-template <typename T, int TAPS, int BN, int RB>
+template <typename T, int TAPS, int BN, int RB, bool BNR = false>
 __global__ __launch_bounds__(kThreads, 2) void conv_mfma_grouped_kernel(const ConvGroup g) {
     int job = 0;
 #pragma unroll
     for (int j = 1; j < kMaxGroup; ++j)
         if (j < g.njobs && (int)blockIdx.x >= g.begin[j]) job = j;   // wave-uniform
-    conv_mfma_body<T, TAPS, BN, RB>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
+    conv_mfma_body<T, TAPS, BN, RB, BNR>(g.p[job], (int)blockIdx.x - g.begin[job], g.begin[job + 1] - g.begin[job]);
 }
 
 
@@ -914,12 +922,12 @@ extern "C" int mpn_conv_fwd(const void* x, const void* w_packed, void* y, int N,
     return g.BN == 128 ? launch_conv<bf16_t, 1, 128>(p, m_tiles, st) : launch_conv<bf16_t, 1, 64>(p, m_tiles, st);
 }
 
-template <int BN>
+template <int BN, bool BNR = false>
 static int launch_conv_grouped(const ConvGroup& grp, int grid, hipStream_t st) {
     constexpr int smem = conv_smem_bytes<9, BN, 128>();
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_grouped_kernel<bf16_t, 9, BN, 128>, smem, &attr_mask));
-    conv_mfma_grouped_kernel<bf16_t, 9, BN, 128><<<dim3((unsigned)grid), dim3(kThreads), smem, st>>>(grp);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv_mfma_grouped_kernel<bf16_t, 9, BN, 128, BNR>, smem, &attr_mask));
+    conv_mfma_grouped_kernel<bf16_t, 9, BN, 128, BNR><<<dim3((unsigned)grid), dim3(kThreads), smem, st>>>(grp);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -1001,7 +1009,10 @@ extern "C" int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype
         if (pw_gemm_eligible(K, C, 1, 2)) return 1;                     // the deep 1x1 layers (pointwise.hip)
         return pack_geom(K, C, 1, 2, dtype).row_bytes == 128 ? 1 : 0;   // thin ones: the tiled kernel with 128-byte chunks
     }
-    return (ksize == 3 && (dtype == MPN_BF16 || dtype == MPN_F16) && (mpn_c3::eligible(K, C, 9, 2) || mpn_c3::eligible64(K, C, 9, 2)) && C <= 512) ? 1 : 0;
+    if (ksize != 3) return 0;
+    if ((dtype == MPN_BF16 || dtype == MPN_F16) && (mpn_c3::eligible(K, C, 9, 2) || mpn_c3::eligible64(K, C, 9, 2)) && C <= 512) return 1;
+    // thin 3x3 data gradients (the detector's output convolutions: 8 / 24 -> 64 channels) on the tiled kernel
+    return (dtype == MPN_BF16 && K % 8 == 0 && C % 8 == 0 && pack_geom(K, C, 9, 2, dtype).row_bytes == 128) ? 1 : 0;
 }
 
 extern "C" int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, const void* const* w_packed_t, void* const* dx, int N,
@@ -1013,6 +1024,31 @@ extern "C" int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, co
                 MPN_ERR_BAD_ARG, "conv_bwd_data_bn: bad arguments");
     MPN_REQUIRE(mpn_conv_bwd_data_bn_supported(K, C, 3, dtype), MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: geometry not covered (K %d, C %d)", K, C);
     MPN_REQUIRE(N > 0, MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: bad shape");
+    const PackGeom pg = pack_geom(K, C, 9, 2, dtype);
+    if (pg.row_bytes == 128) {   // the tiled kernel (thin K: not a geometry of the persistent 3x3 kernel)
+        MPN_REQUIRE(njobs <= kMaxGroup, MPN_ERR_BAD_ARG, "conv_bwd_data_bn: at most %d jobs", kMaxGroup);
+        ConvGroup grp = {};
+        int begin = 0;
+        for (int j = 0; j < njobs; ++j) {
+            MPN_REQUIRE(dy[j] && w_packed_t[j] && dx[j] && bn_x[j] && bn_scale[j] && bn_shift[j] && part[j] && H[j] > 0 && W[j] > 0,
+                        MPN_ERR_BAD_ARG, "conv_bwd_data_bn: null pointer / bad size");
+            MPN_REQUIRE(mpn_aligned16(dy[j]) && mpn_aligned16(w_packed_t[j]) && mpn_aligned16(dx[j]) && mpn_aligned16(bn_x[j]) &&
+                            mpn_aligned16(bn_scale[j]) && mpn_aligned16(bn_shift[j]), MPN_ERR_BAD_ALIGN, "conv_bwd_data_bn: pointers must be 16-byte aligned");
+            const int ys = dx_stride ? dx_stride[j] : 0, xs = dy_stride ? dy_stride[j] : 0, bs = bn_x_stride ? bn_x_stride[j] : 0;
+            MPN_REQUIRE((ys == 0 || (ys >= C && ys % 8 == 0)) && (xs == 0 || (xs >= K && xs % 8 == 0)) && (bs == 0 || (bs >= C && bs % 8 == 0)),
+                        MPN_ERR_BAD_SHAPE, "conv_bwd_data_bn: bad pixel strides %d, %d, %d", xs, ys, bs);
+            conv_fill_params(grp.p[j], pg, dy[j], w_packed_t[j], dx[j], N, H[j], W[j], K, C, xs, ys, 3, nullptr, nullptr, MPN_ACT_NONE,
+                             part[j], nullptr);
+            grp.p[j].bnr_x = bn_x[j]; grp.p[j].bnr_scale = bn_scale[j]; grp.p[j].bnr_shift = bn_shift[j]; grp.p[j].bnr_act = bn_act;
+            grp.p[j].bnr_xs = bs > 0 ? bs : C;
+            grp.p[j].xcd_remap = 0;
+            grp.begin[j] = begin;
+            begin += mpn_conv_num_parts(N, H[j], W[j], 3) * pg.n_tiles;
+        }
+        for (int j = njobs; j <= kMaxGroup; ++j) grp.begin[j] = begin;
+        grp.njobs = njobs;
+        return pg.BN == 128 ? launch_conv_grouped<128, true>(grp, begin, (hipStream_t)stream) : launch_conv_grouped<64, true>(grp, begin, (hipStream_t)stream);
+    }
     mpn_c3::Job jobs[mpn_c3::kMaxJobs];
     for (int j = 0; j < njobs; ++j) {
         MPN_REQUIRE(dy[j] && w_packed_t[j] && dx[j] && bn_x[j] && bn_scale[j] && bn_shift[j] && part[j] && H[j] > 0 && W[j] > 0,

@@ -249,6 +249,10 @@ class PersonDetectorNet:
         for c in self._convs:
             c.repack()
 
+    def _fused_out_bn(self, net):
+        """The output convolution's data gradient also reduces for the tower's last batch-norm."""
+        return self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(self.out_conv[net].cout, TOWER_DEPTH, 3, self.dtype)
+
     def _fused_conv_bn(self):
         """The towers' 3x3 data gradients also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn_grouped)."""
         return self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(TOWER_DEPTH, TOWER_DEPTH, 3, self.dtype)
@@ -292,8 +296,9 @@ class PersonDetectorNet:
         for net, _, _ in NETS:
             for i in range(4):
                 fin[(net, i)] = ops.BnFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], fwd3[l], cnt[l]) for l in LEVELS], dev)
-                # batch_norm_0..2 are reduced inside the data gradient of the tower convolution above them (conv rows, raw x)
-                if i < 3 and self._fused_conv_bn():
+                # batch_norm_0..2 are reduced inside the data gradient of the tower convolution above them (conv rows, raw x),
+                # batch_norm_3 inside the data gradient of the output convolution (the tiled kernel: 8 / 24 -> 64 channels)
+                if (i < 3 and self._fused_conv_bn()) or (i == 3 and self._fused_out_bn(net)):
                     fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], fwd3[l], cnt[l], True) for l in LEVELS], dev)
                 else:
                     fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
@@ -507,13 +512,17 @@ class PersonDetectorNet:
             bn3 = self.tower_bn[net][3]
             ops.conv_bwd_weight_grouped([b["t"][net][3][l] for l in LEVELS], [g["out"][net][l] for l in LEVELS], 3,
                                         [bn3[l].affine for l in LEVELS], [slab[(oc.name, l)] for l in LEVELS])
-            ops.conv_fwd_grouped([g["out"][net][l] for l in LEVELS], [oc.packed.bwd] * 5, TOWER_DEPTH, 3, none5,
-                                 [g["t"][net][3][l] for l in LEVELS], none5)
-            fused = self._fused_conv_bn()
+            fused, fused_out = self._fused_conv_bn(), self._fused_out_bn(net)
+            if fused_out:
+                ops.conv_bwd_data_bn_grouped([g["out"][net][l] for l in LEVELS], [oc.packed.bwd] * 5, TOWER_DEPTH, [bn3[l] for l in LEVELS],
+                                             [b["t"][net][3][l] for l in LEVELS], [g["t"][net][3][l] for l in LEVELS], sps)
+            else:
+                ops.conv_fwd_grouped([g["out"][net][l] for l in LEVELS], [oc.packed.bwd] * 5, TOWER_DEPTH, 3, none5,
+                                     [g["t"][net][3][l] for l in LEVELS], none5)
             for i in (3, 2, 1, 0):
                 bns = [self.tower_bn[net][i][l] for l in LEVELS]
                 dAs, xs = [g["t"][net][i][l] for l in LEVELS], [b["t"][net][i][l] for l in LEVELS]
-                if not (fused and i < 3):      # (else: reduced by the data gradient of conv3x3_{i+1} below)
+                if not ((fused and i < 3) or (fused_out and i == 3)):      # (else: reduced by the data gradient above)
                     ops.bn_bwd_reduce_grouped(bns, dAs, xs, sps)
                 fin[("d", net, i)].run()
                 ops.bn_bwd_apply_grouped(bns, dAs, xs)

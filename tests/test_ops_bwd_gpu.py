@@ -410,8 +410,10 @@ def test_conv_wgrad_grouped_equals_separate_launches(cuda, dtype, k, Cin, Cout):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-@pytest.mark.parametrize("act,K,C", [(1, 128, 128), (2, 128, 128), (0, 128, 128), (1, 64, 64), (1, 128, 64), (2, 64, 192), (1, 128, 256)],
-                         ids=["relu", "relu6", "none", "relu-64to64", "relu-128to64", "relu6-64to192", "relu-128to256"])
+@pytest.mark.parametrize("act,K,C", [(1, 128, 128), (2, 128, 128), (0, 128, 128), (1, 64, 64), (1, 128, 64), (2, 64, 192), (1, 128, 256),
+                                          (1, 8, 64), (1, 24, 64), (2, 24, 72)],
+                         ids=["relu", "relu6", "none", "relu-64to64", "relu-128to64", "relu6-64to192", "relu-128to256",
+                              "thin-8to64", "thin-24to64", "thin-24to72"])
 def test_conv_dgrad_with_fused_bn_reduction(cuda, dtype, act, K, C):
     """mpn_conv_bwd_data_bn_grouped on three jobs (ragged tiles, a channel-slice raw tensor): dx = the plain data gradient
     masked by the fed layer's activation, BIT FOR BIT; the slab's sums = sum g and sum g * x over all pixels (f64 reference
@@ -419,7 +421,10 @@ def test_conv_dgrad_with_fused_bn_reduction(cuda, dtype, act, K, C):
     from multiposenet_amd import ops
     rs = np.random.RandomState(5 + act + K + C)
     N = 2
-    assert ops.conv_bwd_data_bn_supported(K, C, 3, dtype) and not ops.conv_bwd_data_bn_supported(K, 72, 3, dtype)
+    if K < 64 and dtype != torch.bfloat16:
+        assert not ops.conv_bwd_data_bn_supported(K, C, 3, dtype)      # thin K: the tiled kernel, bf16 only
+        pytest.skip("thin-K fused reduction is a bf16 path")
+    assert ops.conv_bwd_data_bn_supported(K, C, 3, dtype) and not ops.conv_bwd_data_bn_supported(K, 68, 3, dtype)
     sizes = [(37, 21), (16, 16), (9, 5)]
     w = (rs.randn(3, 3, C, K) / np.sqrt(9 * C)).astype(np.float32)        # forward conv C -> K; its data gradient maps K -> C
     pc = ops.PackedConv(dev(w), dtype)
