@@ -307,7 +307,9 @@ __global__ __launch_bounds__(kThreads) void stem_wgrad_kernel(const void* __rest
     float* g = dyn_smem + kIn * kIn * 3 + 1;      // [256][C0]  (16-byte aligned: 3268 floats)
     const int ncq = C0 / 8;                       // 8-channel groups
     const int tpp = 9 * ncq;                      // threads per phase
-    const int nphase = kThreads / tpp;
+    // (at most 9 phases: their sums meet in the dY tile's 256 * C0 floats of LDS, 27 * C0 per phase - with C0 = 16 the 14 phases
+    //  that fit the block overran it)
+    const int nphase = min(kThreads / tpp, kTile * kTile / 27);
     const int ph = threadIdx.x / tpp;
     const int r = threadIdx.x - ph * tpp;
     const int pos = r / ncq, cq = r - pos * ncq;  // pos = ky*3+kx

@@ -78,9 +78,11 @@ def test_dwconv_backward(cuda, dtype, N, H, W, C, stride):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("C0", [32, 16, 64])
 @pytest.mark.parametrize("N,H,W,u8", [(2, 32, 32, False), (1, 64, 48, False), (1, 30, 34, False), (3, 128, 128, False), (2, 70, 34, True)])
-def test_stem_wgrad(cuda, dtype, N, H, W, u8):
-    """f32 tolerance in both builds: the bf16 build's matrix-core kernel splits the image patch into bf16 hi + lo parts."""
+def test_stem_wgrad(cuda, dtype, N, H, W, u8, C0):
+    """f32 tolerance in both builds: the bf16 build's matrix-core kernel splits the image patch into bf16 hi + lo parts.
+    C0 = 16 (depth_multiplier 0.5) once overran the VALU kernel's phase buffer in LDS."""
     ops = _ops()
     rs = np.random.RandomState(H)
     if u8:
@@ -88,11 +90,15 @@ def test_stem_wgrad(cuda, dtype, N, H, W, u8):
         img = torch.tensor(img8.astype(np.float32) * np.float32(1 / 255.0))
     else:
         img = torch.tensor(rs.rand(N, H, W, 3).astype(np.float32))
-    w = torch.zeros(3, 3, 3, 32, requires_grad=True)
+    w = torch.zeros(3, 3, 3, C0, requires_grad=True)
     out = onet.conv2d_tf_same(nchw(2.0 * img - 1.0), w, 2)
     dy = rnd(rs.randn(*nhwc(out).shape), dtype)
     out.backward(nchw(dy))
-    dw = torch.full((3, 3, 3, 32), float("nan"), device="cuda")
+    dw = torch.full((3, 3, 3, C0), float("nan"), device="cuda")
+    if C0 == 64 and dtype == torch.float32:       # the f32 build's VALU kernel keeps a 256 x C0 f32 tile in 64 KB of LDS
+        with pytest.raises(ValueError, match="C0 too large"):
+            ops.stem_conv_bwd_weight(dev(img), dev(dy, dtype), dw)
+        return
     ops.stem_conv_bwd_weight(dev(img8) if u8 else dev(img), dev(dy, dtype), dw)
     assert_close(dw, w.grad, torch.float32, N * H * W // 4, scale=float(w.grad.abs().max()))
 

@@ -127,11 +127,12 @@ def test_dwconv_fwd(cuda, dtype, N, H, W, C, stride):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("C0", [32, 16, 64])
 @pytest.mark.parametrize("N,H,W,u8", [(2, 32, 32, False), (1, 64, 48, False), (1, 30, 34, True), (1, 17, 9, False)])
-def test_stem_fwd(cuda, dtype, N, H, W, u8):
+def test_stem_fwd(cuda, dtype, N, H, W, u8, C0):
     ops = _ops()
     rs = np.random.RandomState(H)
-    w = rs.randn(3, 3, 3, 32).astype(np.float32) / 5
+    w = rs.randn(3, 3, 3, C0).astype(np.float32) / 5
     if u8:
         img8 = rs.randint(0, 256, (N, H, W, 3)).astype(np.uint8)
         img = torch.tensor(img8.astype(np.float32) * np.float32(1 / 255.0))
@@ -140,7 +141,7 @@ def test_stem_fwd(cuda, dtype, N, H, W, u8):
         img = torch.tensor(rs.rand(N, H, W, 3).astype(np.float32))
         d_img = dev(img)
     want = nhwc(onet.conv2d_tf_same(nchw(2.0 * img - 1.0), torch.tensor(w), 2))
-    y = ops.stem_conv_fwd(d_img, dev(w), 32, dtype)
+    y = ops.stem_conv_fwd(d_img, dev(w), C0, dtype)
     assert_close(y, want, dtype, 27)
     if dtype == torch.bfloat16:
         # the matrix-core kernel splits image and weights into bf16 hi + lo parts: the sums keep f32 accuracy, so the stored
@@ -148,19 +149,19 @@ def test_stem_fwd(cuda, dtype, N, H, W, u8):
         assert float((y.cpu() == want.to(torch.bfloat16)).float().mean()) > 0.995
     # the same launch with its batch-norm partial sums: identical output; the slab finalizes to the mean / variance of the
     # stored (rounded) output, exactly what mpn_bn_stats on that tensor gives (up to the f32 summation order)
-    rows = ops.stem_conv_fwd_num_parts(N, H, W, 32, dtype)
+    rows = ops.stem_conv_fwd_num_parts(N, H, W, C0, dtype)
     assert rows > 0
-    slab = torch.full((rows * 2 * 32,), float("nan"), device="cuda")
-    y2 = ops.stem_conv_fwd(d_img, dev(w), 32, dtype, stats_part=slab)
+    slab = torch.full((rows * 2 * C0,), float("nan"), device="cuda")
+    y2 = ops.stem_conv_fwd(d_img, dev(w), C0, dtype, stats_part=slab)
     assert torch.equal(y, y2)
-    M = y.numel() // 32
-    one = lambda: torch.ones(32, device="cuda")
-    bn_a = ops.BNState(one(), torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda"), one(), 2)
-    bn_b = ops.BNState(one(), torch.zeros(32, device="cuda"), torch.zeros(32, device="cuda"), one(), 2)
+    M = y.numel() // C0
+    one = lambda: torch.ones(C0, device="cuda")
+    bn_a = ops.BNState(one(), torch.zeros(C0, device="cuda"), torch.zeros(C0, device="cuda"), one(), 2)
+    bn_b = ops.BNState(one(), torch.zeros(C0, device="cuda"), torch.zeros(C0, device="cuda"), one(), 2)
     ops.bn_finalize(bn_a, slab, rows, M)
     part, nparts = ops.bn_stats(y)
     ops.bn_finalize(bn_b, part, nparts, M)
-    yd = y.double().reshape(M, 32)
+    yd = y.double().reshape(M, C0)
     np.testing.assert_allclose(bn_a.mean.cpu().numpy(), yd.mean(0).cpu().numpy(), atol=1e-5)
     np.testing.assert_allclose(bn_a.mean.cpu().numpy(), bn_b.mean.cpu().numpy(), atol=2e-6)
     np.testing.assert_allclose(bn_a.invstd.cpu().numpy(), bn_b.invstd.cpu().numpy(), rtol=1e-5)
