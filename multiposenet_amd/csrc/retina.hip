@@ -412,17 +412,19 @@ __global__ __launch_bounds__(kNmsThreads) void retina_nms_kernel(const NmsCand* 
     }
     __syncthreads();
     int n_out = 0;
-    for (int it = 0; it < max_det; ++it) {
-        unsigned long long key = 0;
-        int slot = -1;
-        for (int i = threadIdx.x; i < C; i += kNmsThreads) {
-            const float s = in_lds ? lsc[i] : gw[i].score;
-            if (s > 0.f) {
-                const int an = in_lds ? lan[i] : gw[i].anchor;
-                const unsigned long long k2 = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)an);
-                if (k2 > key) { key = k2; slot = i; }
-            }
+    // this thread's best surviving candidate: found by a scan before the first selection, afterwards by the suppression pass
+    // of the previous selection itself (one pass over the candidates per detection instead of two)
+    unsigned long long key = 0;
+    int slot = -1;
+    for (int i = threadIdx.x; i < C; i += kNmsThreads) {
+        const float s = in_lds ? lsc[i] : gw[i].score;
+        if (s > 0.f) {
+            const int an = in_lds ? lan[i] : gw[i].anchor;
+            const unsigned long long k2 = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)an);
+            if (k2 > key) { key = k2; slot = i; }
         }
+    }
+    for (int it = 0; it < max_det; ++it) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned long long other = __shfl_xor(key, o, 64);
@@ -450,11 +452,22 @@ __global__ __launch_bounds__(kNmsThreads) void retina_nms_kernel(const NmsCand* 
         if (best_key == 0) break;      // (block-uniform)
         ++n_out;
         const float4 bb = best_box;
+        key = 0;
+        slot = -1;
         for (int i = threadIdx.x; i < C; i += kNmsThreads) {
-            if (in_lds) { if (lsc[i] > 0.f && nms_iou(lbox[i], bb) > iou_thr) lsc[i] = -1.f; }
-            else if (gw[i].score > 0.f && nms_iou(gw[i].box, bb) > iou_thr) gw[i].score = -1.f;
+            float sc = in_lds ? lsc[i] : gw[i].score;      // (the selected one was marked dead before the barrier above)
+            if (sc > 0.f && nms_iou(in_lds ? lbox[i] : gw[i].box, bb) > iou_thr) {
+                sc = -1.f;
+                if (in_lds) lsc[i] = -1.f; else gw[i].score = -1.f;
+            }
+            if (sc > 0.f) {
+                const int an = in_lds ? lan[i] : gw[i].anchor;
+                const unsigned long long k2 = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)an);
+                if (k2 > key) { key = k2; slot = i; }
+            }
         }
-        __syncthreads();
+        // (no barrier here: a thread reads and writes only its own candidates in this pass, and the next selection's barriers
+        //  order wkey / best_key)
     }
     for (int i = n_out * 4 + threadIdx.x; i < max_det * 4; i += kNmsThreads) out_boxes[(long long)b * max_det * 4 + i] = 0.f;   // zero padding (nms.py:49-51)
     for (int i = n_out + threadIdx.x; i < max_det; i += kNmsThreads) out_scores[(long long)b * max_det + i] = 0.f;
