@@ -410,6 +410,12 @@ int mpn_heatmap_render(const int32_t* keypoints, const float* boxes, const int32
                        int B, int total_persons, int width, int height, int downsample, float* out,
                        void* workspace, size_t workspace_bytes, mpn_stream_t stream);
 
+/* Skinny "NT" GEMM split over K: part[s][M][N] (f32, s < mpn_gemm_nt_num_parts(K)) = A[M][K] * B[N][K]^T over the s-th K range.
+ * A, B 16-bit (MPN_BF16 / MPN_F16), row-major with K contiguous - the order the reference's variables already have for
+ * dH = dPre2 * W2^T in the pose residual network (prn.py:11-33: fc2's data gradient), so no transposed copy of the weights is
+ * made. K % 8 == 0, N % 4 == 0; finish with mpn_reduce_partials(part, parts, M * N, out, ...). */
+int mpn_gemm_nt_num_parts(int K);
+int mpn_gemm_nt(const void* a, const void* b, float* part, int M, int N, int K, int dtype, mpn_stream_t stream);
 /* ------------------------------------------------------------------------------------
  * L2  PRN - pose residual network (BASELINE config 5).
  * Replaces detector/prn.py:5-25 (flatten -> fc1 34272->1024 + ReLU -> fc2 1024->34272 + ReLU -> x + y) and the loss of

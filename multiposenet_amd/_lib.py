@@ -82,6 +82,8 @@ SIGNATURES = {
     "mpn_reduce_desc_bytes": (_Z, []),
     "mpn_reduce_desc_fill": (_I, [_P, _P, _I, _L, _P, _F, _I]),
     "mpn_reduce_partials_batched": (_I, [_P, _I, _I, _P]),
+    "mpn_gemm_nt_num_parts": (_I, [_I]),
+    "mpn_gemm_nt": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "mpn_transpose_cast": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "mpn_cast": (_I, [_P, _I, _P, _I, _L, _P]),
     "mpn_bias_relu_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _P]),

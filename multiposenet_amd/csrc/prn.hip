@@ -306,6 +306,102 @@ int blocks_for(long long n) {
     } while (0)
 #define PRN_DISPATCH_TWO(dt_in, dt_out, ...) PRN_DISPATCH_ONE(dt_in, TI, PRN_DISPATCH_ONE(dt_out, TO, __VA_ARGS__))
 
+// ---------------------------------------------------------------- skinny "NT" GEMM, split over K
+// C[M][N] = A[M][K] * B[N][K]^T with both operands stored K-contiguous (16-bit): exactly the MFMA's fragment order, so a lane
+// loads its 8 consecutive k of a row straight from HBM - no LDS, no transposed copy of the big operand. The PRN's fc2 data
+// gradient dH[B,1024] = dPre2[B,n] * W2[1024,n]^T took a transposed 16-bit copy of W2 per step (69-90 us for 35 M elements)
+// plus a transposed dPre2; here W2 is read as stored (the plain cast the Adam kernel writes).
+// Block = 128 x 128 outputs over one K range (4 waves of 64 x 64: 4 + 4 fragment loads per 16 MFMAs and 32-deep step, next
+// step's fragments in flight); partials [split][M][N] f32, finished by mpn_reduce_partials (fixed order).
+namespace {
+constexpr int kNtK = 512;       // K per split (a multiple of 64): two blocks per CU at the PRN's size (1024: one, 54 us; 512: see DESIGN)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void gemm_nt_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ part,
+                                                           int M, int N, int K, int n_tiles, int m_tiles) {
+    typedef H16<T> HT;
+    typedef typename HT::x8 x8;
+    typedef typename HT::acc_t acc_t;
+    int bid = blockIdx.x;
+    const int nt = bid % n_tiles; bid /= n_tiles;
+    const int mt = bid % m_tiles;
+    const int split = bid / m_tiles;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int wm = wv & 1, wn = wv >> 1;
+    const int k_begin = split * kNtK, k_end = min(K, k_begin + kNtK);
+    // rows of this lane's fragments (clamped: rows past the edge are loaded from row 0 and never stored)
+    const T* ap[4];
+    const T* bp[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mt * 128 + wm * 64 + i * 16 + l15, n = nt * 128 + wn * 64 + i * 16 + l15;
+        ap[i] = a + (long long)(m < M ? m : 0) * K + 8 * kg;
+        bp[i] = b + (long long)(n < N ? n : 0) * K + 8 * kg;
+    }
+    acc_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (acc_t){0.f, 0.f, 0.f, 0.f};
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    auto ld = [&](const T* p, int k) __attribute__((always_inline)) -> x8 {
+        // (K % 8 == 0: a lane's 8 elements are all inside or all outside)
+        const u32x4_t q = (k + 8 * kg < k_end) ? *reinterpret_cast<const u32x4_t*>(p + k) : (u32x4_t){0u, 0u, 0u, 0u};
+        return __builtin_bit_cast(x8, q);
+    };
+    x8 fa[4], fb[4], ga[4], gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fa[i] = ld(ap[i], k_begin); fb[i] = ld(bp[i], k_begin); }
+    for (int k = k_begin; k < k_end; k += 64) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ga[i] = ld(ap[i], k + 32); gb[i] = ld(bp[i], k + 32); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = HT::mfma(fb[j], fa[i], acc[i][j]);   // D[n][m]: a lane ends up with 4 consecutive n of one m
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { fa[i] = ld(ap[i], k + 64); fb[i] = ld(bp[i], k + 64); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = HT::mfma(gb[j], ga[i], acc[i][j]);
+    }
+    float* dst = part + (long long)split * M * N;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = mt * 128 + wm * 64 + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n0 = nt * 128 + wn * 64 + j * 16 + 4 * kg;
+            if (m < M && n0 < N)   // (N % 4 == 0)
+                *reinterpret_cast<float4*>(dst + (long long)m * N + n0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+}  // namespace
+
+/* K ranges (= rows of the partial slab) of mpn_gemm_nt */
+extern "C" int mpn_gemm_nt_num_parts(int K) { return K > 0 ? (K + kNtK - 1) / kNtK : 0; }
+
+/* part[s][M][N] (f32, s < mpn_gemm_nt_num_parts(K)) = A[M][K] * B[N][K]^T over the s-th K range; A, B 16-bit (MPN_BF16 / MPN_F16),
+ * row-major with K contiguous, K % 8 == 0, N % 4 == 0; finish with mpn_reduce_partials(part, parts, M * N, out). */
+extern "C" int mpn_gemm_nt(const void* a, const void* b, float* part, int M, int N, int K, int dtype, mpn_stream_t stream) {
+    MPN_REQUIRE(a && b && part, MPN_ERR_BAD_ARG, "gemm_nt: null pointer");
+    MPN_REQUIRE(M > 0 && N > 0 && K > 0 && K % 8 == 0 && N % 4 == 0, MPN_ERR_BAD_SHAPE, "gemm_nt: needs K %% 8 == 0 and N %% 4 == 0 (M %d, N %d, K %d)", M, N, K);
+    MPN_REQUIRE(dtype == MPN_BF16 || dtype == MPN_F16, MPN_ERR_BAD_DTYPE, "gemm_nt: 16-bit operands only (dtype %d)", dtype);
+    MPN_REQUIRE(mpn_aligned16(a) && mpn_aligned16(b) && mpn_aligned16(part), MPN_ERR_BAD_ALIGN, "gemm_nt: pointers must be 16-byte aligned");
+    const int n_tiles = (N + 127) / 128, m_tiles = (M + 127) / 128, splits = mpn_gemm_nt_num_parts(K);
+    const long long blocks = (long long)n_tiles * m_tiles * splits;
+    MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "gemm_nt: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MPN_BF16)
+        gemm_nt_kernel<bf16_t><<<(unsigned)blocks, kThreads, 0, st>>>((const bf16_t*)a, (const bf16_t*)b, part, M, N, K, n_tiles, m_tiles);
+    else
+        gemm_nt_kernel<half_t><<<(unsigned)blocks, kThreads, 0, st>>>((const half_t*)a, (const half_t*)b, part, M, N, K, n_tiles, m_tiles);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
 /* out[C][R] = cast(in[R][C]); in_dtype / out_dtype: MPN_F32, MPN_BF16 or MPN_F16 */
 extern "C" int mpn_transpose_cast(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, mpn_stream_t stream) {
     MPN_REQUIRE(in && out && R > 0 && C > 0, MPN_ERR_BAD_ARG, "transpose_cast: bad arguments");

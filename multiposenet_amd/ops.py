@@ -630,6 +630,24 @@ def adam_step(params, grads, m, v, hyper, grad_scale=1.0, beta1=0.9, beta2=0.999
          float(grad_scale), stream_ptr())
 
 
+def gemm_nt_num_parts(k):
+    return _lib.lib().mpn_gemm_nt_num_parts(int(k))
+
+
+def gemm_nt(a, b, out, slab):
+    """out[M,N] (f32) = a[M,K] @ b[N,K]^T, a / b 16-bit with K contiguous (mpn_gemm_nt + the fixed-order slab reduction).
+    slab: f32, gemm_nt_num_parts(K) * M * N elements."""
+    (M, K), (N, K2) = a.shape, b.shape
+    if K != K2 or a.dtype != b.dtype or not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("gemm_nt: a [M,K] and b [N,K] must be contiguous, of one 16-bit dtype")
+    parts = gemm_nt_num_parts(K)
+    if slab.numel() < parts * M * N:
+        raise ValueError("gemm_nt: slab too small")
+    call("mpn_gemm_nt", ptr(a), ptr(b), ptr(slab), M, N, K, _lib.dtype_code(a.dtype), stream_ptr())
+    call("mpn_reduce_partials", ptr(slab), parts, M * N, ptr(out), 0, 1.0, stream_ptr())
+    return out
+
+
 class AdamCastJobs:
     """Ranges of a flat f32 arena whose updated values adam_step also writes as 16-bit operand copies (mpn_adam_step_cast):
     jobs = [(offset, count, dst tensor of dtype float16 / bfloat16 with `count` elements)]."""

@@ -89,7 +89,9 @@ class PoseResidualNet:
             # mpn_adam_step_cast), W2^T [n,1024] (one transposing pass per step)
             self.w1_op = W1 if dtype == torch.float32 else torch.empty((n, hidden), dtype=dtype, device=dev)
             self.w2_op = W2 if dtype == torch.float32 else torch.empty((hidden, n), dtype=dtype, device=dev)
-            self.w2t_op = torch.empty((n, hidden), dtype=dtype, device=dev)
+            # W2^T [n,1024]: only the f32 build's data gradient of fc2 still contracts over rows of a transposed copy; the
+            # 16-bit builds read W2 as stored (mpn_gemm_nt)
+            self.w2t_op = torch.empty((n, hidden), dtype=dtype, device=dev) if dtype == torch.float32 else None
             self._adam_cast = None
             if dtype != torch.float32:
                 o1, n1, _ = self._arena.offsets["PRN/fc1/weights"]
@@ -116,7 +118,8 @@ class PoseResidualNet:
         self.dlogits = torch.zeros((B, n), dtype=f32, device=dev)     # (rows >= valid are never written: stay zero)
         self._xpad = torch.zeros((B, h, w, c), dtype=f32, device=dev) if self.valid != B else None
         self.dpre2 = torch.empty((B, n), dtype=dtype, device=dev)
-        self.dpre2t = torch.empty((n, B), dtype=dtype, device=dev)
+        self.dpre2t = torch.empty((n, B), dtype=dtype, device=dev) if dtype == torch.float32 else None
+        self.nt_slab = None if dtype == torch.float32 else torch.empty(ops.gemm_nt_num_parts(n) * B * hidden, dtype=f32, device=dev)
         self.dhid = torch.empty((B, hidden), dtype=f32, device=dev)
         self.dpre1 = torch.empty((B, hidden), dtype=dtype, device=dev)
         self.loss_part = torch.zeros(B, dtype=f32, device=dev)
@@ -152,13 +155,14 @@ class PoseResidualNet:
 
     def refresh_operands(self, casts=True):
         """Operand copies of the f32 masters. casts=False (after an optimizer step): the Adam kernel has already written the
-        two plain casts (mpn_adam_step_cast); what remains is the transposed copy of W2."""
+        two plain casts (mpn_adam_step_cast) - in the 16-bit builds nothing remains to refresh."""
         dc, f32c = _lib.dtype_code(self.dtype), _lib.dtype_code(torch.float32)
         W1, W2 = self.vars["PRN/fc1/weights"], self.vars["PRN/fc2/weights"]
         if casts and self.dtype != torch.float32:
             call("mpn_cast", ptr(W1), f32c, ptr(self.w1_op), dc, W1.numel(), stream_ptr())
             call("mpn_cast", ptr(W2), f32c, ptr(self.w2_op), dc, W2.numel(), stream_ptr())
-        call("mpn_transpose_cast", ptr(W2), f32c, ptr(self.w2t_op), dc, self.hidden, self.n, stream_ptr())
+        if self.w2t_op is not None:
+            call("mpn_transpose_cast", ptr(W2), f32c, ptr(self.w2t_op), dc, self.hidden, self.n, stream_ptr())
 
     # ---------------------------------------------------------------- forward / loss / backward
     def _kgemm(self, at, bmat, out):
@@ -219,9 +223,13 @@ class PoseResidualNet:
         # fc2 weight gradient: dW2[1024,n] = H^T dPre2 (one slab = the gradient itself)
         ops.conv_bwd_weight(self.hid.view(1, 1, B, hidden), self.dpre2.view(1, 1, B, n), 1, None,
                             g["PRN/fc2/weights"].view(1, 1, hidden, n), g["PRN/fc2/weights"].view(-1), reduce=False)
-        # fc2 data gradient: dH = dPre2 W2^T (K = n)
-        call("mpn_transpose_cast", ptr(self.dpre2), dc, ptr(self.dpre2t), dc, B, n, stream_ptr())
-        self._kgemm(self.dpre2t, self.w2t_op, self.dhid)
+        # fc2 data gradient: dH = dPre2 W2^T (K = n). 16-bit builds: both operands as stored, K contiguous (mpn_gemm_nt) - the
+        # transposed copy of W2 (a 69-90 us pass per step) and of dPre2 are gone
+        if self.nt_slab is not None:
+            ops.gemm_nt(self.dpre2, self.w2_op, self.dhid, self.nt_slab)
+        else:
+            call("mpn_transpose_cast", ptr(self.dpre2), dc, ptr(self.dpre2t), dc, B, n, stream_ptr())
+            self._kgemm(self.dpre2t, self.w2t_op, self.dhid)
         call("mpn_bias_relu_bwd", ptr(self.hid), dc, ptr(self.dhid), ptr(self.dpre1), dc, ptr(g["PRN/fc1/biases"]), B, hidden, stream_ptr())
         # fc1 weight gradient: dW1[n,1024] = X^T dPre1
         ops.conv_bwd_weight(self.x_op.view(1, 1, B, n), self.dpre1.view(1, 1, B, hidden), 1, None,

@@ -147,3 +147,23 @@ def test_prn_model_fn_eval_at_another_batch_size_scores_the_trained_variables(cu
     model_fn(x3, y3, ModeKeys.TRAIN, hp)        # a partial train batch steps the SAME model
     assert int(base.global_step.item()) == 4
     prn_model.reset_registry()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("M,N,K", [(128, 1024, 34272), (24, 256, 2056), (130, 132, 72), (8, 4, 8)])
+def test_gemm_nt_split_k(cuda, dtype, M, N, K):
+    """mpn_gemm_nt (C = A B^T, both operands K-contiguous, split over K, partial slab + fixed-order reduction) against a
+    float64 product of the same 16-bit operands; ragged M / N tiles, a K tail that is not a multiple of the 32-deep step."""
+    from multiposenet_amd import ops
+    rs = np.random.RandomState(M + N + K)
+    a = torch.tensor(rs.randn(M, K).astype(np.float32)).to(dtype).cuda()
+    b = torch.tensor((rs.randn(N, K) / np.sqrt(K)).astype(np.float32)).to(dtype).cuda()
+    slab = torch.full((ops.gemm_nt_num_parts(K) * M * N + 16,), float("nan"), device="cuda")
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt(a, b, out, slab)
+    want = a.double().cpu() @ b.double().cpu().t()
+    np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=2e-4, atol=2e-5 * float(want.abs().max()) * np.sqrt(K / 32))
+    assert bool(torch.isnan(slab[-16:]).all())                      # nothing written behind the slab
+    out2 = torch.empty_like(out)
+    ops.gemm_nt(a, b, out2, slab)
+    assert torch.equal(out, out2)                                   # deterministic
