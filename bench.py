@@ -54,10 +54,37 @@ def rank_commands(n, argv, port, base_env=None):
     return out
 
 
+def visible_gpu_count(kfd_root="/sys/class/kfd/kfd/topology/nodes", env=None):
+    """GPUs this process' children will see, counted WITHOUT the HIP / HSA runtime: the kfd topology nodes that have SIMDs
+    (CPU nodes have simd_count 0), narrowed by the *_VISIBLE_DEVICES lists the runtime honours. 0 when there is no kfd
+    topology at all (without the kfd driver ROCm offers no device either)."""
+    env = os.environ if env is None else env
+    try:
+        nodes = sorted(os.listdir(kfd_root), key=lambda s: int(s) if s.isdigit() else 1 << 30)
+    except OSError:
+        return 0
+    have = 0
+    for nd in nodes:
+        try:
+            with open(os.path.join(kfd_root, nd, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+        except OSError:
+            continue              # a node this user may not read is a device the runtime will not offer either
+        if int(props.get("simd_count", "0")) > 0:
+            have += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is not None:
+            have = min(have, len([x for x in v.split(",") if x.strip() != ""]))
+    return have
+
+
 def launch_ranks(n, argv, dry_run=False, timeout_s=1500.0):
-    """The launcher (parent of the ranks). Makes no GPU call: counting devices does not initialise the runtime."""
+    """The launcher (parent of the ranks). Makes no GPU call: devices are counted from the kfd topology in sysfs, never
+    through torch / HIP (torch's own count falls back to hipGetDeviceCount when amdsmi is missing, which would bring
+    the runtime up in a process that forks)."""
     if not dry_run:
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < n:
             sys.stderr.write(f"bench.py: --gpus {n} needs {n} devices, {have} visible\n")
             return 2
@@ -169,7 +196,14 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    ws = os.environ.get("WORLD_SIZE")
+    is_rank = ws is not None and "RANK" in os.environ and int(ws) == args.gpus
+    if args.gpus > 1 and not is_rank:
+        if ws is not None and "RANK" in os.environ:
+            # started by an outer launcher whose world is not the one asked for: refuse rather than run fewer ranks silently
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but the environment says WORLD_SIZE={ws}\n")
+            sys.exit(2)
+        # a WORLD_SIZE some scheduler exported without RANK is not a rank's environment: launch our own ranks
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.dry_run_cpu))    # before anything touches the GPU
     if args.dry_run_cpu:
         sys.exit(dry_run_cpu(args))

@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPN_LIB: an alternative build of the same library (diagnostic A/B of compile-time variants, tools/build_variant.sh)
 LIB_PATH = os.environ.get("MPN_LIB") or os.path.join(_HERE, "libmpn_hip.so")
 
+MPN_VERSION = 400     # the ABI revision this binding was written against (include/mpn.h); lib() refuses another
 MPN_F32, MPN_BF16, MPN_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
@@ -146,6 +147,12 @@ def lib():
         if os.path.exists(hip_rt):
             ctypes.CDLL(hip_rt, mode=ctypes.RTLD_GLOBAL)
         l = ctypes.CDLL(LIB_PATH)
+        l.mpn_version.restype = _I
+        if l.mpn_version() != MPN_VERSION:
+            # exported signatures change between revisions (r3 -> r4: scratch slabs became writable, batch-norm finalizes
+            # moved into consumer kernels): a stale build would be handed the wrong argument lists
+            raise MpnError(f"{LIB_PATH} is ABI revision {l.mpn_version()}, this binding needs {MPN_VERSION}: "
+                           "rebuild with `python -m multiposenet_amd.build --force`")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
             fn.restype = res

@@ -55,6 +55,7 @@ class Detector:
             from ..retinanet import PersonDetectorNet
             head = _load(detector_path)
             self.retinanet = PersonDetectorNet(backbone=self.net)
+            self.retinanet.cache_inference_affine = True    # as for the backbone; _replay compares the variable versions
             own = set(self.retinanet.vars) | set(self.retinanet.stats)
             self.retinanet.load_state_dict({k: v for k, v in head.items() if k in own}, strict=True)
         self.assigner = None
@@ -140,15 +141,27 @@ class Detector:
         h, w, _ = image.shape
         ent = self._graphs.get((h, w))
         src = torch.from_numpy(np.ascontiguousarray(image[None]))
+        ver = self._variable_versions()
         if ent is None:
             x = src.to(self.net.device)
-            self._device_side(x, True)                              # eager warm-up
+            self._device_side(x, True)                              # eager warm-up (also fills the inference caches)
             torch.cuda.synchronize(self.net.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 outs = self._device_side(x, True)
-            ent = self._graphs[(h, w)] = (graph, x, outs)
-        graph, x, outs = ent
+            ent = self._graphs[(h, w)] = [graph, x, outs, ver]
+        graph, x, outs, captured_ver = ent
         x.copy_(src)
+        if captured_ver != ver:
+            # variables changed since this graph last ran (load_state_dict, a train step on the shared backbone ...): the
+            # batch-norm affines and the cast operands the captured launches read are host-cached and NOT in the graph. One
+            # eager pass refreshes them through the normal code path into the same persistent buffers the graph reads.
+            self._device_side(x, True)
+            ent[3] = ver
         graph.replay()
         return outs
+
+    def _variable_versions(self):
+        prn = self.assigner.net if self.assigner is not None else None
+        return (self.net.var_version, self.retinanet.var_version if self.retinanet is not None else -1,
+                getattr(prn, "var_version", -1))

@@ -201,9 +201,17 @@ class KeypointNet:
             missing = [k for k in list(self.vars) + list(self.stats) if k not in values]
             if missing:
                 raise KeyError(f"missing variables: {missing[:5]}...")
-        self._infer_clean = False
+        self.mark_variables_changed()
         if hasattr(self, "convs"):
             self.repack_weights()
+
+    def mark_variables_changed(self):
+        """Variables or moving statistics changed: cached inference affines are stale and `var_version` moves (users that
+        replay captured device work - inference/detector.py - compare it). Every method of this object that changes them
+        calls this; so must whoever changes them from outside: a replayed hipGraph of a train step (train.Trainer.step does),
+        a direct write into `vars` / `stats`."""
+        self.var_version = getattr(self, "var_version", 0) + 1
+        self._infer_clean = False
 
     def _bn(self, prefix, act):
         bn = ops.BNState(self.vars[prefix + "/gamma"], self.vars[prefix + "/beta"], self.stats[prefix + "/moving_mean"],
@@ -445,7 +453,10 @@ class KeypointNet:
     def prepare_inference(self):
         """is_training=False: every batch-norm becomes the affine of its moving statistics. With cache_inference_affine (a
         frozen backbone under the person detector, the joint inference graph) the 40 small launches run once and again only
-        after the variables changed through this object (load_state_dict, a training forward, an optimizer step)."""
+        after the variables changed (mark_variables_changed: load_state_dict, a training forward, an optimizer step, a
+        replayed train step). The flag is host state and NOT part of a hipGraph: whoever captures an inference pass with the
+        cache on owns the refresh - compare `var_version` before every replay and run this method eagerly when it moved (the
+        affines live in persistent buffers, so an eager refresh serves the captured launches too): inference/detector.py."""
         if self.cache_inference_affine and self._infer_clean:
             return
         for bn in self.all_bn:
@@ -459,7 +470,7 @@ class KeypointNet:
         if not is_training:
             self.prepare_inference()
         else:
-            self._infer_clean = False       # (the finalizes below overwrite the affines and move the statistics)
+            self.mark_variables_changed()   # (the finalizes below overwrite the affines and move the statistics)
         sp = b["stat_part"]
         c0 = self.stem_w.shape[3]
         # training (opt-in, fuse_stem_stats): the stem kernel writes the batch-norm partial sums of its own output
@@ -761,5 +772,5 @@ class KeypointNet:
         """Cosine LR + clip(+-200) + TF-Adam over the flat arena, then refresh the packed weights."""
         ops.adam_prepare(self.global_step, self.hyper, initial_learning_rate, num_steps)
         ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, grad_scale=grad_scale)
-        self._infer_clean = False
+        self.mark_variables_changed()
         self.repack_weights()

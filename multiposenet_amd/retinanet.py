@@ -179,7 +179,12 @@ class PersonDetectorNet:
         self._convs = []
         self._wversion = 0
         self.fuse_conv_bn = True       # set before the first backward pass of a shape (the finalize tables are built once)
+        # the head's inference affines (45 small launches) and the p6 operand cast are recomputed on EVERY inference pass
+        # unless the owner opts in (inference/detector.py does and compares `var_version` before each graph replay): the clean
+        # flag is host state, a replayed hipGraph of a train step cannot clear it
+        self.cache_inference_affine = False
         self._infer_clean = False
+        self.var_version = 0
         self.backbone.cache_inference_affine = True     # frozen here: its inference affines change only with its variables
         self._l2 = None
         self._wd = None
@@ -210,9 +215,14 @@ class PersonDetectorNet:
             missing = [k for k in list(self.vars) + list(self.stats) if k not in values]
             if missing:
                 raise KeyError(f"missing variables: {missing[:5]}...")
-        self._infer_clean = False
+        self.mark_variables_changed()
         if self._built:
             self.repack_weights()
+
+    def mark_variables_changed(self):
+        """The head's variables or moving statistics changed (see KeypointNet.mark_variables_changed)."""
+        self.var_version = getattr(self, "var_version", 0) + 1
+        self._infer_clean = False
 
     def _bn(self, prefix, act=ACT_RELU):
         bn = ops.BNState(self.vars[prefix + "/gamma"], self.vars[prefix + "/beta"], self.stats[prefix + "/moving_mean"],
@@ -364,12 +374,12 @@ class PersonDetectorNet:
     def head_forward(self, feats, b, is_training, images=None):
         """RetinaNet.__init__ (retinanet.py:14-58) on backbone features {'c3','c4','c5': (raw NHWC tensor, Affine)}."""
         if not is_training:
-            if not self._infer_clean:      # (45 small launches: once per change of the head's variables)
+            if not (self.cache_inference_affine and self._infer_clean):      # (45 small launches)
                 for bn in self.all_bn:
                     ops.bn_inference_affine(bn)
                 self._infer_clean = True
         else:
-            self._infer_clean = False
+            self.mark_variables_changed()   # (the finalizes move the statistics and overwrite the affines)
         fin, spl = b["fin"], b["stat_lv"]
         st = (lambda l: spl[l]) if is_training else (lambda l: None)
         prev = None
@@ -427,7 +437,9 @@ class PersonDetectorNet:
                               "wop": torch.empty((K, DEPTH), dtype=self.dtype, device=dev), "wver": -1}
             nparts = ops.conv_wgrad_num_parts(1, 1, K, Mp, DEPTH, 1, self.dtype)
             s["slab"] = torch.empty(nparts * Mp * DEPTH, dtype=torch.float32, device=dev)
-        if s["wver"] != self._wversion:       # the HWIO matrix [9 * C5, 128] in the storage type, refreshed with the variables
+        # the HWIO matrix [9 * C5, 128] in the storage type: refreshed on every pass, or (owner opted in, as for the affines)
+        # once per repack of the variables
+        if not self.cache_inference_affine or s["wver"] != self._wversion:
             call("mpn_cast", ptr(c6.src), f32c, ptr(s["wop"]), dc, K * DEPTH, stream_ptr())
             s["wver"] = self._wversion
         Mp = s["Mp"]
@@ -578,6 +590,7 @@ class PersonDetectorNet:
         """person_detector_model.py:59-75: cosine decay, TF-Adam (NO gradient clipping in this model), head variables only."""
         ops.adam_prepare(self.global_step, self.hyper, initial_learning_rate, num_steps)
         ops.adam_step(self.theta, self.grad, self.adam_m, self.adam_v, self.hyper, grad_scale=grad_scale, clip=float("inf"))
+        self.mark_variables_changed()
         self.repack_weights()
 
     def train_step(self, images, groundtruth, params):

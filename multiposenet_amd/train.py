@@ -127,6 +127,7 @@ class Trainer:
                     e1.record()
                     self.comm_events.append((e0, e1))
                 self._graph_opt.replay()
+            self.net.mark_variables_changed()    # (a replay does not run the Python that does this in the eager path)
         return self._losses
 
     def _static_bufs(self):

@@ -45,7 +45,10 @@ def test_no_environment_switches_in_launch_paths():
 
 def test_version_and_error_string():
     l = _lib.lib()
-    assert l.mpn_version() == 200
+    import re
+    hdr = open(os.path.join(ROOT, "include", "mpn.h")).read()
+    declared = int(re.search(r"#define\s+MPN_VERSION\s+(\d+)", hdr).group(1))
+    assert l.mpn_version() == declared == _lib.MPN_VERSION == 400
     assert isinstance(_lib.last_error(), str)
 
 

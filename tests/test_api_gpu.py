@@ -166,6 +166,88 @@ def test_detector_joint_graph_matches_the_oracle_chain(cuda, tmp_path):
     assert o16["keypoint_positions"].shape == (len(o16["boxes"]), 17, 2)
 
 
+def test_detector_graph_follows_reloaded_and_trained_variables(cuda, tmp_path):
+    """the batch-norm inference affines and the p6 operand cast are host-cached and not part of the
+    captured graph. After load_state_dict on either net - and after a replayed train step on the shared backbone - a
+    replay must give what a freshly built eager Detector gives on the new variables, bit for bit."""
+    from multiposenet_amd.inference import Detector
+    from multiposenet_amd.prn import initial_values
+    from multiposenet_amd.synthetic import synthetic_batch
+    from multiposenet_amd.train import Trainer
+    from test_retinanet_gpu import _setup
+    H, W = 128, 256
+    paths = {}
+    for tag, seed in (("a", 31), ("b", 47)):
+        bb, hp, _, _, _ = _setup(seed, 1, H, W)
+        hp["class_net/logits/kernel"] = (np.random.RandomState(seed).randn(3, 3, 64, 6) * 0.4).astype(np.float32)
+        hp["class_net/logits/bias"] = np.full(6, -2.0, np.float32)
+        kp, dp = tmp_path / f"k{tag}.npz", tmp_path / f"d{tag}.npz"
+        np.savez(kp, **bb); np.savez(dp, **hp)
+        paths[tag] = (str(kp), str(dp), bb, hp)
+    ppath = tmp_path / "prn.npz"
+    np.savez(ppath, **initial_values(seed=5))
+    img = np.random.RandomState(4).randint(0, 256, (H, W, 3)).astype(np.uint8)
+
+    def eager_reference(kp, dp):
+        e = Detector(kp, dtype=torch.float32, detector_path=dp, prn_path=str(ppath))
+        e.use_graph = False
+        return e(img, score_threshold=0.0)
+
+    det = Detector(paths["a"][0], dtype=torch.float32, detector_path=paths["a"][1], prn_path=str(ppath))
+    first = det(img, score_threshold=0.0)                                   # captures the graph on variables A
+    for k, v in eager_reference(*paths["a"][:2]).items():
+        np.testing.assert_array_equal(first[k], v, err_msg=k)
+    # reload BOTH variable sets through the objects the graph was captured over
+    det.net.load_state_dict(paths["b"][2])
+    own = set(det.retinanet.vars) | set(det.retinanet.stats)
+    det.retinanet.load_state_dict({k: v for k, v in paths["b"][3].items() if k in own})
+    second = det(img, score_threshold=0.0)
+    assert len(det._graphs) == 1                                            # the same graph, refreshed caches
+    want = eager_reference(*paths["b"][:2])
+    assert not np.array_equal(first["keypoint_heatmaps"], second["keypoint_heatmaps"])
+    for k, v in want.items():
+        np.testing.assert_array_equal(second[k], v, err_msg=k)
+    # a train step replayed from the Trainer's hipGraph on the SHARED backbone: no Python of the net runs in a replay
+    trainer = Trainer(det.net, {"initial_learning_rate": 1e-2, "num_steps": 1000, "weight_decay": 0.0}, use_graph=True)
+    feats, labels = synthetic_batch(2, 128, 128, rank=0, device=det.net.device)
+    for _ in range(3):
+        trainer.step(feats, labels)
+    third = det(img, score_threshold=0.0)
+    kp3 = tmp_path / "k3.npz"
+    np.savez(kp3, **det.net.state_dict())
+    want3 = eager_reference(str(kp3), paths["b"][1])
+    assert not np.array_equal(third["keypoint_heatmaps"], second["keypoint_heatmaps"])
+    for k, v in want3.items():
+        np.testing.assert_array_equal(third[k], v, err_msg=k)
+
+
+def test_detector_head_inference_follows_replayed_train_steps(cuda):
+    """ADVICE r3 case (b): eval, train steps replayed from a hipGraph, eval - the second eval scores with the trained
+    variables' affines (the head's cache is opt-in and off here)."""
+    from multiposenet_amd.retinanet import PersonDetectorNet
+    from test_retinanet_gpu import _setup, HP
+    B, H, W = 2, 128, 256
+    bb, hp, img, boxes, num = _setup(5, B, H, W)
+    net = PersonDetectorNet(backbone_values=bb, head_values=hp, dtype=torch.float32)
+    x = torch.tensor(img, device="cuda")
+    gt = {"boxes": torch.tensor(boxes, device="cuda"), "num_boxes": torch.tensor(num, device="cuda")}
+    params = dict(HP, initial_learning_rate=1e-2, num_steps=1000)
+    b0 = net.forward(x, False)
+    before = net.raw_predictions(b0)["class_predictions"].clone()
+    net.train_step(x, gt, params)                                            # eager warm-up
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        net.train_step(x, gt, params)
+    for _ in range(3):
+        g.replay()
+    got = net.raw_predictions(net.forward(x, False))["class_predictions"].clone()
+    fresh = PersonDetectorNet(backbone_values=bb, head_values={k: v for k, v in net.state_dict().items()}, dtype=torch.float32)
+    want = fresh.raw_predictions(fresh.forward(x, False))["class_predictions"]
+    assert not torch.equal(got, before)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("image_dtype", [torch.float32, torch.uint8], ids=["f32", "u8"])
 def test_host_batch_feeder_equals_device_resident_steps(cuda, image_dtype):
     """HostBatchFeeder (pinned slots, copies on a side stream, the previous step still running): four steps on four
