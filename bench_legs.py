@@ -607,3 +607,92 @@ def joint_inference_benchmark(height=640, width=640, iters=110, discard=10):
             "device_ms_per_image": round(device_ms, 3),
             "image": [height, width], "calls": iters - discard, "persons_detected": nb, "dtype": "bf16",
             "note": "wall clock of Detector(image) with numpy in / numpy out (inference/predict.ipynb cell 16), random-init weights"}
+
+
+def trained_bf16_parity(steps=300, batch=8, size=256, persons=1, seed=0, lr=1e-3):
+    """do the two builds decode the SAME keypoints on trained-like (sharp) heatmaps? The f32 build (the one
+    that meets 1e-3 against the oracle) trains `steps` steps on one fixed batch whose labels are the renderer's Gaussian blobs
+    (peaks exactly 1.0, detector/input_pipeline/heatmap_creation.py); the SAME variables then go into the bf16 build; both
+    run the training images in inference mode -> sigmoid heatmaps -> get_keypoints at threshold 0.2 (inference/utils.py:29-52)
+    over the whole map (one person per image: with several, whose blob wins the arg-max is a coin toss in ANY arithmetic -
+    three persons: top-2 gap 0.0035 in the median, the two builds pick different persons in 38 % of the channels - which is why
+    the reference decodes inside a person's box).
+    A channel is DECIDED when the f32 build's top-2 gap exceeds twice the measured bf16 heatmap error and its peak is further
+    than that from the threshold; returns the agreement overall and on the decided set, with what the comparison rests on."""
+    import numpy as np
+    from multiposenet_amd.detector.input_pipeline.heatmap_creation import get_heatmaps_batch
+    from multiposenet_amd.inference.utils import KeypointDecoder
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
+    rs = np.random.RandomState(seed)
+    h = size // 4
+    people = []
+    for _ in range(batch):
+        kp = np.zeros((persons, 17, 3), np.int32)
+        bx = np.zeros((persons, 4), np.float32)
+        for p in range(persons):
+            hh, ww = rs.randint(size // 3, size), rs.randint(size // 4, size // 2)
+            y0, x0 = rs.randint(0, size - hh + 1), rs.randint(0, size - ww + 1)
+            bx[p] = [y0, x0, y0 + hh, x0 + ww]
+            kp[p, :, 0] = rs.randint(y0, y0 + hh, 17)
+            kp[p, :, 1] = rs.randint(x0, x0 + ww, 17)
+            kp[p, :, 2] = (rs.rand(17) < 0.8).astype(np.int32)
+        people.append((kp, bx))
+    heat = get_heatmaps_batch(people, size, size, 4).clone()
+    assert float(heat.max()) == 1.0
+    g = torch.Generator(device="cuda")
+    g.manual_seed(100 + seed)
+    images = torch.rand((batch, size, size, 3), generator=g, device="cuda")
+    labels = {"heatmaps": heat, "loss_masks": torch.ones((batch, h, h), device="cuda"),
+              "segmentation_masks": (heat.amax(-1) > 0.5).float(),
+              "num_boxes": torch.full((batch,), persons, dtype=torch.int32, device="cuda")}
+    net = KeypointNet(dtype=torch.float32, seed=seed)
+    tr = Trainer(net, {"initial_learning_rate": lr, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}, use_graph=True)
+    feats, labs = tr.input_buffers({"images": images}, labels)
+    first = last = None
+    for i in range(steps):
+        l = tr.step(feats, labs)
+        if i == 0:
+            first = float(l[6])
+    last = float(l[6])
+    values = net.state_dict()
+    del tr, net
+    torch.cuda.empty_cache()
+    dec = KeypointDecoder(batch)
+    box_hw = torch.tensor([[float(size), float(size)]] * batch, dtype=torch.float64, device="cuda")
+    res = {}
+    for dt in (torch.float32, torch.bfloat16):
+        n2 = KeypointNet(values=values, dtype=dt)
+        hm, _ = n2.predict(images)
+        hm = hm.float().contiguous()
+        xyv, score, index = dec(hm, box_hw, float(np.float32(0.2)))
+        res[dt] = (hm.cpu().numpy().copy(), xyv.cpu().numpy().copy(), index.cpu().numpy().copy())
+        del n2
+        torch.cuda.empty_cache()
+    (ha, xa, ia), (hb, xb, ib) = res[torch.float32], res[torch.bfloat16]
+    err = float(np.abs(ha - hb).max())
+    flat = ha.reshape(batch, -1, 17)
+    part = np.partition(flat, flat.shape[1] - 2, axis=1)
+    peak, gap = part[:, -1, :], part[:, -1, :] - part[:, -2, :]
+    decided = (gap > 2 * err) & (np.abs(peak - 0.2) > err)
+    same = np.all(xa == xb, axis=-1) & (ia == ib)
+    # how far apart the two builds' peaks lie (heatmap pixels, Chebyshev): a trained blob is flat-topped - its two largest values
+    # are neighbours a few 1e-2 apart - so the bf16 build may pick the pixel next door
+    dist = np.maximum(np.abs(ia // h - ib // h), np.abs(ia % h - ib % h))
+    both_visible = (xa[..., 2] == 1) & (xb[..., 2] == 1)
+    # where the label has a keypoint the trained f32 heatmap should peak on one of the label's peaks (several persons per
+    # channel: any of them): how trained-like the maps are
+    lab = heat.cpu().numpy().reshape(batch, -1, 17)
+    has_kp = lab.max(1) == 1.0
+    lab_at_peak = np.take_along_axis(lab, ia[:, None, :], axis=1)[:, 0, :]
+    return {"trained_steps": steps, "batch": batch, "image": size, "total_loss_first_last": [round(first, 3), round(last, 4)],
+            "channels": int(same.size), "keypoints_identical": round(float(same.mean()), 4),
+            "visibility_identical": round(float((xa[..., 2] == xb[..., 2]).mean()), 4),
+            "peak_within_1px": round(float((dist[both_visible] <= 1).mean()), 4) if both_visible.any() else None,
+            "peak_distance_px_p95": float(np.percentile(dist[both_visible], 95)) if both_visible.any() else None,
+            "max_abs_heatmap_diff": round(err, 5), "f32_peak_median": round(float(np.median(peak)), 3),
+            "f32_top2_gap_median": round(float(np.median(gap)), 4),
+            "f32_peak_on_a_label_blob": round(float((lab_at_peak >= 0.5)[has_kp].mean()), 3),
+            "decided_channels": int(decided.sum()),
+            "identical_on_decided": round(float(same[decided].mean()), 4) if decided.any() else None,
+            "_same": same, "_decided": decided}

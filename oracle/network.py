@@ -128,6 +128,58 @@ def randomize_bn(params, seed=1):
     return params
 
 
+# ----------------------------------------------------------------------------- 16-bit storage emulation (tests only)
+# The throughput build keeps every tensor that crosses a kernel boundary in bf16 (raw conv outputs,
+# the FPN sums, the upsampled concat slices; backward: the gradients written by the data-gradient and batch-norm-apply
+# kernels) and multiplies bf16 copies of the dense kernels; accumulation, batch-norm arithmetic, depthwise / stem / head
+# weights and all master variables stay f32. `storage_emulation(torch.bfloat16)` makes this restatement round at the same
+# places (autograd: the value is rounded on the way forward, the gradient on the way back), so that a bf16 step can be held
+# against an oracle that differs from it by summation order only - at random initialisation the gradients are small
+# residuals of large cancelling sums, and a few percent of storage error in the activations moves them by O(1) against the
+# UNROUNDED oracle (tests/test_network_gpu.py::test_bf16_step_fused_and_unfused_reductions_against_the_oracle).
+_STORAGE = None
+
+
+class storage_emulation:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _STORAGE
+        self.prev, _STORAGE = _STORAGE, self.dtype
+        return self
+
+    def __exit__(self, *a):
+        global _STORAGE
+        _STORAGE = self.prev
+
+
+class _Round(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype, fwd, bwd):
+        ctx.dtype, ctx.bwd = dtype, bwd
+        return x.to(dtype).to(x.dtype) if fwd else x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g.to(ctx.dtype).to(g.dtype) if ctx.bwd else g), None, None, None
+
+
+def _raw(x):
+    """A tensor a kernel writes to HBM (rounded forward; its gradient is what a batch-norm-apply / data-gradient kernel wrote)."""
+    return x if _STORAGE is None else _Round.apply(x, _STORAGE, True, True)
+
+
+def _act(x):
+    """A normalised activation: never stored (consumers re-create it on load), but its GRADIENT is a stored tensor."""
+    return x if _STORAGE is None else _Round.apply(x, _STORAGE, False, True)
+
+
+def _w16(w):
+    """The 16-bit copy of a dense kernel that the matrix cores multiply (the gradient reaches the f32 master unrounded)."""
+    return w if _STORAGE is None else _Round.apply(w, _STORAGE, True, False)
+
+
 # ----------------------------------------------------------------------------- TF-1.15 op semantics
 def _hwio_to_oihw(w):
     return w.permute(3, 2, 0, 1)
@@ -225,22 +277,22 @@ def mobilenet_v1(images, p, is_training, depth_multiplier=1.0, updates=None, tap
     x = 2.0 * images - 1.0                                          # :41
     x = x.permute(0, 3, 1, 2)                                       # :53
     name = "MobilenetV1/Conv2d_0"
-    x = conv2d_tf_same(x, p[name + "/weights"], 2)                  # :56
+    x = _raw(conv2d_tf_same(x, p[name + "/weights"], 2))            # :56
     if taps is not None:
         taps[name + "/raw"] = x
-    x = F.relu6(batch_norm(x, p, name + "/BatchNorm", is_training, updates))
+    x = _act(F.relu6(batch_norm(x, p, name + "/BatchNorm", is_training, updates)))
     feats = {}
     for i, (stride, _) in enumerate(STRIDES_AND_FILTERS, 1):        # :66-74
         name = f"MobilenetV1/Conv2d_{i}_depthwise"
-        x = depthwise_conv2d_tf_same(x, p[name + "/depthwise_weights"], stride)
+        x = _raw(depthwise_conv2d_tf_same(x, p[name + "/depthwise_weights"], stride))
         if taps is not None:
             taps[name + "/raw"] = x
-        x = F.relu6(batch_norm(x, p, name + "/BatchNorm", is_training, updates))
+        x = _act(F.relu6(batch_norm(x, p, name + "/BatchNorm", is_training, updates)))
         name = f"MobilenetV1/Conv2d_{i}_pointwise"
-        x = conv2d_tf_same(x, p[name + "/weights"], 1)
+        x = _raw(conv2d_tf_same(x, _w16(p[name + "/weights"]), 1))
         if taps is not None:
             taps[name + "/raw"] = x
-        x = F.relu6(batch_norm(x, p, name + "/BatchNorm", is_training, updates))
+        x = _act(F.relu6(batch_norm(x, p, name + "/BatchNorm", is_training, updates)))
         feats[name] = x
     return {"c2": feats["MobilenetV1/Conv2d_3_pointwise"], "c3": feats["MobilenetV1/Conv2d_5_pointwise"],
             "c4": feats["MobilenetV1/Conv2d_11_pointwise"], "c5": feats["MobilenetV1/Conv2d_13_pointwise"]}
@@ -248,37 +300,38 @@ def mobilenet_v1(images, p, is_training, depth_multiplier=1.0, updates=None, tap
 
 def feature_pyramid_network(features, p, scope="keypoint_fpn", min_level=2, taps=None):
     """fpn.py:36-55 with add_coarse_features=False (the keypoint configuration)."""
-    x = conv2d_same(features["c5"], p[f"{scope}/lateral5/kernel"])          # :38
+    x = _raw(conv2d_same(features["c5"], _w16(p[f"{scope}/lateral5/kernel"])))          # :38
     if taps is not None:
         taps["x5"] = x
-    enriched = {"p5": conv2d_same(x, p[f"{scope}/p5/kernel"])}              # :39
+    enriched = {"p5": _raw(conv2d_same(x, _w16(p[f"{scope}/p5/kernel"])))}              # :39
     for i in reversed(range(min_level, 5)):                                 # :49-53
-        lateral = conv2d_same(features[f"c{i}"], p[f"{scope}/lateral{i}/kernel"])
-        x = nearest_neighbor_upsample(x) + lateral
+        lateral = conv2d_same(features[f"c{i}"], _w16(p[f"{scope}/lateral{i}/kernel"]))
+        x = _raw(nearest_neighbor_upsample(x) + lateral)                    # (one store: the lateral's epilogue adds the upsampled sum)
         if taps is not None:
             taps[f"x{i}"] = x
-        enriched[f"p{i}"] = conv2d_same(x, p[f"{scope}/p{i}/kernel"])
+        enriched[f"p{i}"] = _raw(conv2d_same(x, _w16(p[f"{scope}/p{i}/kernel"])))
     return enriched
 
 
 def phi_subnet(x, p, scope, is_training, upsample, updates=None, taps=None):
     """keypoint_subnet.py:65-91."""
-    x = conv2d_same(x, p[scope + "/conv1/kernel"])
+    x = _raw(conv2d_same(x, _w16(p[scope + "/conv1/kernel"])))
     if taps is not None:
         taps[scope + "/y1"] = x
-    x = F.relu(batch_norm(x, p, scope + "/bn1", is_training, updates))
-    x = conv2d_same(x, p[scope + "/conv2/kernel"])
+    x = _act(F.relu(batch_norm(x, p, scope + "/bn1", is_training, updates)))
+    x = _raw(conv2d_same(x, _w16(p[scope + "/conv2/kernel"])))
     if taps is not None:
         taps[scope + "/y2"] = x
-    x = F.relu(batch_norm(x, p, scope + "/bn2", is_training, updates))
-    return resize_bilinear_legacy(x, upsample * x.shape[2], upsample * x.shape[3])   # :86
+    x = _act(F.relu(batch_norm(x, p, scope + "/bn2", is_training, updates)))
+    x = resize_bilinear_legacy(x, upsample * x.shape[2], upsample * x.shape[3])      # :86
+    return _raw(x) if upsample > 1 else x      # (the upsampled levels are stored activated; level 2 stays the raw y2)
 
 
 def keypoint_subnet(backbone_features, p, is_training, updates=None, taps=None):
     """keypoint_subnet.py:11-62. Returns (heatmaps NHWC [b,h/4,w/4,18] logits,
     enriched_features NHWC dict p2..p5 - the PRE-batch-norm FPN outputs)."""
     enriched = feature_pyramid_network(backbone_features, p, taps=taps)     # :20-23
-    normalized = {n: F.relu(batch_norm(x, p, f"{n}_batch_norm", is_training, updates))
+    normalized = {n: _act(F.relu(batch_norm(x, p, f"{n}_batch_norm", is_training, updates)))
                   for n, x in enriched.items()}                             # :24-27
     ups = []
     for level in range(2, 6):                                               # :30-35
@@ -287,10 +340,10 @@ def keypoint_subnet(backbone_features, p, is_training, updates=None, taps=None):
     x = torch.cat(ups, dim=1)                                               # :37
     if taps is not None:
         taps["concat"] = x
-    x = conv2d_same(x, p["final_conv3x3/kernel"])                           # :38
+    x = _raw(conv2d_same(x, _w16(p["final_conv3x3/kernel"])))               # :38
     if taps is not None:
         taps["final"] = x
-    x = F.relu(batch_norm(x, p, "final_bn", is_training, updates))          # :39
+    x = _act(F.relu(batch_norm(x, p, "final_bn", is_training, updates)))    # :39
     heat = conv2d_same(x, p["heatmaps/kernel"], bias=p["heatmaps/bias"])    # :49-54
     return heat.permute(0, 2, 3, 1), {n: v.permute(0, 2, 3, 1) for n, v in enriched.items()}   # :56-62
 

@@ -119,3 +119,20 @@ def test_bf16_build_argmax_agreement_rate(cuda):
     assert err < 0.25                      # logits of O(1): a few bf16 ulps through ~45 layers
     assert rate >= 0.5
     assert not (rate_clear < 1.0)          # where the gap is larger than the error the arg-max cannot move (NaN = no such channel)
+
+
+def test_bf16_build_decodes_trained_heatmaps_like_the_f32_build(cuda):
+    """on TRAINED-like heatmaps (the f32 build overfits one batch of rendered Gaussian-blob labels, peaks
+    exactly 1.0; the same variables then run in both builds) get_keypoints at threshold 0.2 returns identical [17,3] rows and
+    peak indices from the bf16 build on every decided channel - top-2 gap of the f32 heatmap above twice the measured bf16
+    error, peak further than that from the threshold. The overall agreement is printed (bench.py prints it too)."""
+    import bench_legs
+    r = bench_legs.trained_bf16_parity(steps=300, batch=8, size=256)
+    same, decided = r.pop("_same"), r.pop("_decided")
+    print("\n[bf16 vs f32 build on trained heatmaps]", r)
+    assert r["total_loss_first_last"][1] < 0.05 * r["total_loss_first_last"][0]       # the maps are trained, not random
+    assert r["f32_peak_on_a_label_blob"] >= 0.8 and r["f32_peak_median"] > 0.3        # ... and peak where the labels do
+    assert decided.sum() >= 5, "too few decided channels: the comparison would say nothing"
+    assert same[decided].all()
+    # what bf16 storage delivers beyond the decided set, stated and bounded: the same person's blob (a pixel next door at most)
+    assert r["visibility_identical"] >= 0.95 and r["peak_within_1px"] >= 0.9

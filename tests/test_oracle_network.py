@@ -256,3 +256,27 @@ def test_torch_oracle_agrees_with_loop_restatement():
     for u in (2, 4, 8):
         got = onet.resize_bilinear_legacy(_t(xs).permute(0, 3, 1, 2), 5 * u, 7 * u).permute(0, 2, 3, 1).numpy()
         np.testing.assert_allclose(got, tfnp.resize_bilinear_tf(xs, 5 * u, 7 * u), rtol=0, atol=1e-14)
+
+
+def test_storage_emulation_rounds_where_the_16_bit_build_stores():
+    """oracle.network.storage_emulation(bf16): every raw conv output is exactly representable in bf16, the f32 heads are
+    not rounded, gradients still reach every master variable, and outside the context nothing changes."""
+    rs = np.random.RandomState(0)
+    p = onet.randomize_bn(onet.init_params(3), 4)
+    pt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=onet.is_trainable(k)) for k, v in p.items()}
+    x = torch.tensor(rs.rand(1, 64, 64, 3), dtype=torch.float64)
+    taps0, taps1 = {}, {}
+    h0, _ = onet.forward(x, pt, True, taps=taps0)
+    with onet.storage_emulation(torch.bfloat16):
+        h1, _ = onet.forward(x, pt, True, taps=taps1)
+    h2, _ = onet.forward(x, pt, True)
+    assert torch.equal(h0, h2) and not torch.equal(h0, h1)
+    for k, v in taps1.items():
+        if k == "concat":
+            continue          # (level 2's slice holds activated f32 values in the oracle: the build keeps the raw tensor)
+        assert torch.equal(v, v.to(torch.bfloat16).to(v.dtype)), k
+    assert not torch.equal(taps0["MobilenetV1/Conv2d_3_pointwise/raw"], taps1["MobilenetV1/Conv2d_3_pointwise/raw"])
+    rel = float((h1 - h0).norm() / h0.norm())
+    assert 1e-6 < rel < 0.2, rel          # (the logits are mostly their bias at initialisation)
+    h1.sum().backward()
+    assert all(v.grad is not None and torch.isfinite(v.grad).all() for k, v in pt.items() if onet.is_trainable(k))

@@ -1,0 +1,119 @@
+// What bounds the depthwise sliding-window walk when its tensors are cold: a stand-alone model of the
+// kernel's MEMORY shape only - a thread owns VEC bytes of channels of one column pair and walks down a strip of rows, per
+// output row it loads the 4 window pieces of the new input row and stores 2 output pieces - with the arithmetic reduced to a
+// few adds. Knobs: P = input rows in flight per thread (the shipped kernel: 3), VEC = 8 or 16 bytes per piece, and the
+// number of rows per strip. Buffers rotate over sets far larger than the 256 MB memory-side cache.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/walk_ceiling.hip -o tools/build/walk_ceiling && tools/build/walk_ceiling
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+template <int VEC> struct Piece;
+template <> struct Piece<8> { uint2 v; __device__ void add(const Piece& o) { v.x += o.v.x; v.y ^= o.v.y; } };
+template <> struct Piece<16> { uint4 v; __device__ void add(const Piece& o) { v.x += o.v.x; v.y ^= o.v.y; v.z += o.v.z; v.w ^= o.v.w; } };
+
+// x, y: [N][H][W][C] 16-bit elements. Block = 256 threads = ncg channel groups x cols column pairs; grid = N * yblocks * xblocks * cblocks
+template <int P, int VEC>
+__global__ __launch_bounds__(256) void walk(const unsigned char* __restrict__ x, unsigned char* __restrict__ y, int H, int W, int C,
+                                             int rows, int ncg, int cols, int xblocks, int yblocks, int cblocks) {
+    int b = blockIdx.x;
+    const int xb = b % xblocks; b /= xblocks;
+    const int yb = b % yblocks; b /= yblocks;
+    const int cgb = b % cblocks;
+    const int img = b / cblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;
+    const long long cbyte = (long long)(cgb * ncg + cgl) * VEC;
+    const int ox = (xb * cols + col) * 2;
+    if (ox >= W || col >= cols) return;
+    const long long rowb = (long long)W * C * 2, pixb = (long long)C * 2;
+    const unsigned char* xi = x + (long long)img * H * rowb + cbyte;
+    unsigned char* yo = y + (long long)img * H * rowb + cbyte + (long long)ox * pixb;
+    long long xoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xoff[k] = (long long)std::min(std::max(ox - 1 + k, 0), W - 1) * pixb;
+    const int oy0 = yb * rows, oy1 = std::min(oy0 + rows, H);
+    Piece<VEC> buf[P][4];
+    auto load = [&](Piece<VEC> (&r)[4], int iy) {
+        const unsigned char* rp = xi + (long long)std::min(std::max(iy, 0), H - 1) * rowb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = *reinterpret_cast<const Piece<VEC>*>(rp + xoff[k]);
+    };
+#pragma unroll
+    for (int j = 0; j < P; ++j) load(buf[j], oy0 - 1 + j);
+    Piece<VEC> w0 = buf[0][0], w1 = buf[0][3];          // stand-in for the window carried across rows
+    for (int oy = oy0; oy < oy1; oy += P) {
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            if (oy + j < oy1) {
+                Piece<VEC> a = buf[j][0], c = buf[j][2];
+                a.add(buf[j][1]); a.add(w0);
+                c.add(buf[j][3]); c.add(w1);
+                w0 = buf[j][1]; w1 = buf[j][2];
+                load(buf[j], oy + j + P - 1);
+                unsigned char* yp = yo + (long long)(oy + j) * rowb;
+                *reinterpret_cast<Piece<VEC>*>(yp) = a;
+                if (ox + 1 < W) *reinterpret_cast<Piece<VEC>*>(yp + pixb) = c;
+            }
+        }
+    }
+}
+
+template <int P, int VEC>
+static double run(int N, int H, int W, int C, int rows, std::vector<unsigned char*>& xs, std::vector<unsigned char*>& ys, int iters) {
+    int ncg = C * 2 / VEC; if (ncg > 32 * 8 / VEC) ncg = 32 * 8 / VEC;      // blocks of at most 128 channels
+    const int cblocks = (C * 2 / VEC) / ncg, cols = 256 / ncg;
+    const int xblocks = (W / 2 + cols - 1) / cols, yblocks = (H + rows - 1) / rows;
+    const int grid = N * yblocks * xblocks * cblocks;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int ns = (int)xs.size();
+    for (int i = 0; i < ns; ++i) walk<P, VEC><<<grid, 256>>>(xs[i], ys[i], H, W, C, rows, ncg, cols, xblocks, yblocks, cblocks);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) walk<P, VEC><<<grid, 256>>>(xs[i % ns], ys[i % ns], H, W, C, rows, ncg, cols, xblocks, yblocks, cblocks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e-3 / iters;
+}
+
+__global__ void copy16(const uint4* __restrict__ a, uint4* __restrict__ b, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
+int main() {
+    const int N = 32;
+    struct L { int H, C; } layers[] = {{256, 32}, {128, 128}, {64, 256}};
+    for (auto l : layers) {
+        const int H = l.H, W = l.H, C = l.C;
+        const size_t bytes = (size_t)N * H * W * C * 2;
+        const int ns = (int)std::max<size_t>(2, std::min<size_t>(12, (size_t)1.5e9 / (2 * bytes)));
+        std::vector<unsigned char*> xs(ns), ys(ns);
+        for (int i = 0; i < ns; ++i) { CK(hipMalloc(&xs[i], bytes)); CK(hipMalloc(&ys[i], bytes)); CK(hipMemset(xs[i], i + 1, bytes)); }
+        const int iters = 3 * ns;
+        const double tb = 2.0 * bytes;
+        printf("[%d,%d,%d,%d] bf16, %d sets of %.0f MB, cold:\n", N, H, W, C, ns, 2 * bytes / 1e6);
+        {
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < ns; ++i) copy16<<<256 * 16, 256>>>((const uint4*)xs[i], (uint4*)ys[i], bytes / 16);
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) copy16<<<256 * 16, 256>>>((const uint4*)xs[i % ns], (uint4*)ys[i % ns], bytes / 16);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("  grid-stride 16-byte copy: %.1f us  %.3f of 8 TB/s\n", ms * 1e3 / iters, tb / (ms * 1e-3 / iters) / 8e12);
+        }
+        for (int rows : {32, 64}) {
+            if (rows > H) continue;
+#define RUN(P, V) { const double t = run<P, V>(N, H, W, C, rows, xs, ys, iters); \
+            printf("  rows/strip %2d  P=%d rows in flight  %2d-byte pieces: %6.1f us  %.3f of 8 TB/s\n", rows, P, V, t * 1e6, tb / t / 8e12); fflush(stdout); }
+            RUN(2, 8) RUN(3, 8) RUN(4, 8) RUN(6, 8) RUN(8, 8)
+            RUN(2, 16) RUN(3, 16) RUN(4, 16) RUN(6, 16)
+        }
+        for (int i = 0; i < ns; ++i) { CK(hipFree(xs[i])); CK(hipFree(ys[i])); }
+    }
+    return 0;
+}
