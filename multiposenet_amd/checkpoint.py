@@ -28,6 +28,7 @@ def save_npz(path, net, with_optimizer=True, beta1=0.9, beta2=0.999):
         views = net._train_arena if hasattr(net, "_train_arena") else net._arena
         for slot, flat in enumerate((net.adam_m, net.adam_v)):
             for k, v in views.views(flat).items():
+                v = net.unpad(k, v) if hasattr(net, "unpad") else v        # (reference shapes: net.internal_shapes)
                 out[slot_name(k, slot)] = v.detach().cpu().numpy().copy()
         out["global_step"] = np.int64(step)
         # tf.train.AdamOptimizer creates the powers as beta and multiplies them after every apply: after `step` applies the
@@ -69,6 +70,9 @@ def load_npz(path, net, scopes=None, strict=True, with_optimizer=True):
                 name = slot_name(k, slot)
                 if name in values and (scopes is None or any(k.startswith(s) for s in scopes)):
                     v = np.asarray(values[name], np.float32)
+                    if hasattr(net, "unpad") and k in getattr(net, "_pads", {}):
+                        dst.zero_()
+                        dst = net.unpad(k, dst)
                     if tuple(v.shape) != tuple(dst.shape):
                         raise ValueError(f"{name}: shape {v.shape} != {tuple(dst.shape)}")
                     dst.copy_(torch.from_numpy(v))

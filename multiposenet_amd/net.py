@@ -75,6 +75,34 @@ def variable_shapes(depth_multiplier=1.0):
     return s
 
 
+def internal_shapes(depth_multiplier=1.0):
+    """(shapes as the arena holds them, {name: (axis, reference size)} of the padded ones). The stem's matrix-core kernels
+    work on 16-channel blocks; mobilenet_v1.py:25-27 gives the stem max(int(32 m), 8) channels - 24 at depth_multiplier 0.75,
+    8 at 0.25. The variables that carry that width (Conv2d_0 and its batch-norm, Conv2d_1_depthwise and its batch-norm, the
+    input side of Conv2d_1_pointwise) are PADDED to the next multiple of 16 inside the arena. The pad is all zeros (gamma
+    and beta too), which is a fixed point of the step: zero stem kernels give a zero raw output, x-hat = 0, activation 0; every
+    gradient of a pad element is a product with one of those zeros (dx carries gamma * invstd = 0, the masks are closed at
+    0 < 0), so Adam's slots and updates stay exactly 0. state_dict / checkpoints see the reference shapes only."""
+    ref = variable_shapes(depth_multiplier)
+    c0 = depth(32, depth_multiplier)
+    c0p = (c0 + 15) // 16 * 16
+    if c0p == c0:
+        return ref, {}
+    shapes, pads = OrderedDict(), {}
+    for name, shape in ref.items():
+        axis = None
+        if name.startswith("MobilenetV1/Conv2d_0/") or name.startswith("MobilenetV1/Conv2d_1_depthwise/BatchNorm/"):
+            axis = len(shape) - 1
+        elif name in ("MobilenetV1/Conv2d_1_depthwise/depthwise_weights", "MobilenetV1/Conv2d_1_pointwise/weights"):
+            axis = 2
+        if axis is not None:
+            assert shape[axis] == c0
+            pads[name] = (axis, c0)
+            shape = tuple(c0p if i == axis else d for i, d in enumerate(shape))
+        shapes[name] = shape
+    return shapes, pads
+
+
 def is_trainable(name):
     return not (name.endswith("moving_mean") or name.endswith("moving_variance"))
 
@@ -153,12 +181,12 @@ class KeypointNet:
         self._init(values, depth_multiplier, dtype, seed)
 
     def _init(self, values, depth_multiplier, dtype, seed):
-        shapes = variable_shapes(depth_multiplier)
+        shapes, self._pads = internal_shapes(depth_multiplier)
         ve = 8 if dtype == torch.bfloat16 else 4
         for n, s in shapes.items():
-            if n.endswith("gamma") and (s[0] % 16 != 0):
-                raise ValueError(f"depth_multiplier={depth_multiplier}: {n} has {s[0]} channels; the MFMA kernels need "
-                                 f"multiples of 16 (and of {ve} for {dtype})")
+            if n.endswith("gamma") and (s[0] % ve != 0):
+                raise ValueError(f"depth_multiplier={depth_multiplier}: {n} has {s[0]} channels; {dtype} storage moves "
+                                 f"{ve}-channel vectors")
         self._train_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if is_trainable(k)), self.device)
         self._stat_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if not is_trainable(k)), self.device)
         self.theta = self._train_arena.new()
@@ -183,8 +211,15 @@ class KeypointNet:
         """{reference variable name: numpy array} (HWIO kernels, as in a TF checkpoint)."""
         out = OrderedDict()
         for k, v in list(self.vars.items()) + list(self.stats.items()):
-            out[k] = v.detach().cpu().numpy().copy()
+            out[k] = self.unpad(k, v).detach().cpu().numpy().copy()
         return out
+
+    def unpad(self, name, t):
+        """The reference-shaped part of an arena view (variable, gradient or Adam slot) of `name` (internal_shapes)."""
+        if name in self._pads:
+            axis, n = self._pads[name]
+            return t.narrow(axis, 0, n)
+        return t
 
     def load_state_dict(self, values, strict=True):
         for k, v in values.items():
@@ -194,6 +229,9 @@ class KeypointNet:
                     raise KeyError(f"unknown variable {k}")
                 continue
             v = np.asarray(v, dtype=np.float32)
+            if k in self._pads:
+                dst.zero_()                      # the pad: zeros, gamma included (see internal_shapes)
+                dst = self.unpad(k, dst)
             if tuple(v.shape) != tuple(dst.shape):
                 raise ValueError(f"{k}: shape {v.shape} != {tuple(dst.shape)}")
             dst.copy_(torch.from_numpy(v))

@@ -82,3 +82,31 @@ def test_product_package_never_imports_the_oracle():
                 if any(n == "oracle" or n.startswith("oracle.") for n in names):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_launchers_refuse_channel_counts_their_lds_buffers_do_not_cover():
+    """VERDICT r3 item 7 (the class of bug fe23e08 fixed: a template's LDS phase buffer overrun at an unusual width): every
+    launcher ties the runtime channel count to its kernel's compile-time LDS geometry BEFORE any HIP call - exercised here
+    without a GPU, with a non-null dummy pointer where the pointer check comes first."""
+    import ctypes
+    import pytest
+    P = ctypes.c_void_p(4096)
+    call = _lib.call
+    # stem: at most 64 output channels (the patch / output-tile images are sized for kMaxC0)
+    with pytest.raises(ValueError, match="C0"):
+        call("mpn_stem_conv_fwd", P, 0, P, P, 1, 64, 64, 128, _lib.MPN_BF16, None)
+    with pytest.raises(ValueError, match="C0"):
+        call("mpn_stem_conv_fwd", P, 0, P, P, 1, 64, 64, 20, _lib.MPN_BF16, None)          # not a multiple of 8
+    # batch-norm passes: a row of C / vector-width lanes must fit one block
+    with pytest.raises(ValueError, match="C too large|multiple"):
+        call("mpn_bn_stats", P, 1024, 4096, _lib.MPN_F32, P, None)
+    # depthwise: C must be whole channel vectors
+    with pytest.raises(ValueError):
+        call("mpn_dwconv_fwd", P, P, P, 1, 32, 32, 36, 1, _lib.MPN_BF16, None, None, 0, 0, None, None)
+    # dense convolution: channel counts in vectors of the storage type, kernel size 1 or 3
+    with pytest.raises(ValueError):
+        call("mpn_conv_fwd", P, P, P, 1, 16, 16, 20, 64, 0, 0, 1, _lib.MPN_BF16, None, None, 0, None, None, None)
+    # fused batch-norm reduction behind a data gradient: only the geometries mpn_conv_bwd_data_bn_supported lists
+    assert _lib.lib().mpn_conv_bwd_data_bn_supported(128, 128, 3, _lib.MPN_BF16) == 1
+    assert _lib.lib().mpn_conv_bwd_data_bn_supported(128, 1024, 3, _lib.MPN_BF16) == 0        # the affine table holds 512 channels
+    assert _lib.lib().mpn_conv_bwd_data_bn_supported(128, 128, 3, _lib.MPN_F32) == 0

@@ -49,6 +49,37 @@ def test_resume_is_bit_identical_and_names_are_tensorflows(cuda, tmp_path):
         np.testing.assert_array_equal(got[k], want[k], err_msg=k)
 
 
+def test_resume_with_a_padded_stem_width_keeps_reference_shapes(cuda, tmp_path):
+    """depth_multiplier 0.75: the stem's 24 channels are 32 inside the arena (net.internal_shapes); the file holds the
+    reference shapes (variables AND Adam slots), and a resumed run continues bit for bit."""
+    from multiposenet_amd.net import KeypointNet
+    from multiposenet_amd.train import Trainer
+    from multiposenet_amd import checkpoint
+    from oracle import network as onet
+    _, img, lab, hp = _setup()
+    hp = dict(hp, depth_multiplier=0.75)
+    params = onet.randomize_bn(onet.init_params(5, depth_multiplier=0.75), 6)
+    net = KeypointNet(values=params, depth_multiplier=0.75, dtype=torch.bfloat16)
+    tr = Trainer(net, hp, use_graph=False)
+    for _ in range(2):
+        tr.step({"images": img}, lab)
+    path = str(tmp_path / "model.npz")
+    checkpoint.save_npz(path, net)
+    with np.load(path) as z:
+        for k in ("MobilenetV1/Conv2d_0/weights", "MobilenetV1/Conv2d_0/weights/Adam", "MobilenetV1/Conv2d_0/weights/Adam_1"):
+            assert z[k].shape == (3, 3, 3, 24), (k, z[k].shape)
+        assert z["MobilenetV1/Conv2d_1_depthwise/BatchNorm/moving_variance"].shape == (24,)
+        assert z["MobilenetV1/Conv2d_1_pointwise/weights/Adam"].shape == (1, 1, 24, 48)
+    third = tr.step({"images": img}, lab).cpu().numpy().copy()
+    net2 = KeypointNet(values=None, depth_multiplier=0.75, dtype=torch.bfloat16, seed=99)
+    checkpoint.load_npz(path, net2)
+    third2 = Trainer(net2, hp, use_graph=False).step({"images": img}, lab).cpu().numpy()
+    np.testing.assert_array_equal(third2, third)
+    a, b = net.state_dict(), net2.state_dict()
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
 def test_warm_start_restores_the_backbone_only(cuda, tmp_path):
     from multiposenet_amd.net import KeypointNet
     from multiposenet_amd import checkpoint

@@ -464,20 +464,23 @@ def test_train_loss_is_not_stale_after_eval_at_another_batch_size(cuda):
     assert not np.array_equal(out[True][1], out[True][2])      # the eval losses are another batch's
 
 
-def test_depth_multiplier_half_train_step(cuda):
-    """depth_multiplier = 0.5 (mobilenet_v1.py:25-27: 16 .. 512 backbone channels, the stem on one 16-row MFMA block, other
-    kernel geometries than the default): losses of an f32 train step against the f64 oracle, every gradient's direction,
-    and the bf16 build tracking the f32 one."""
+@pytest.mark.parametrize("dm,c0,c0_internal", [(0.5, 16, 16), (0.75, 24, 32), (0.25, 8, 16)], ids=["0.5", "0.75", "0.25"])
+def test_depth_multiplier_train_step(cuda, dm, c0, c0_internal):
+    """The reference takes any depth_multiplier (mobilenet_v1.py:25-27: max(int(x m), 8) channels). 0.5: 16 .. 512 backbone
+    channels. 0.75: 24 / 48 / 96 / 192 / 384 / 768 - the stem's 24 channels live padded to 32 inside the arena
+    (net.internal_shapes); 0.25: 8 (padded to 16) .. 256. Losses of an f32 train step against the f64 oracle, every
+    gradient's direction, the bf16 build tracking the f32 one; the pad stays exactly zero through the optimizer step and
+    state_dict / checkpoints carry the reference shapes."""
     from multiposenet_amd.net import KeypointNet
     from multiposenet_amd.train import Trainer
     rs = np.random.RandomState(8)
     B, H, W = 2, 128, 128
-    params = onet.randomize_bn(onet.init_params(5, depth_multiplier=0.5), 6)
+    params = onet.randomize_bn(onet.init_params(5, depth_multiplier=dm), 6)
     params["heatmaps/kernel"] = (rs.randn(1, 1, 64, 18) * 0.05).astype(np.float32)
-    assert params["MobilenetV1/Conv2d_0/weights"].shape == (3, 3, 3, 16)
+    assert params["MobilenetV1/Conv2d_0/weights"].shape == (3, 3, 3, c0)
     img = rs.rand(B, H, W, 3).astype(np.float32)
     lab = _labels(rs, B, H // 4, W // 4)
-    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 0.5}
+    hp = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": dm}
     ref = {k: v.astype(np.float64) for k, v in params.items()}
     m = {k: np.zeros_like(v) for k, v in ref.items()}
     v = {k: np.zeros_like(v) for k, v in ref.items()}
@@ -486,7 +489,8 @@ def test_depth_multiplier_half_train_step(cuda):
     dlab = {k: torch.tensor(val).cuda() for k, val in lab.items()}
     out = {}
     for dt in (torch.float32, torch.bfloat16):
-        net = KeypointNet(values=params, depth_multiplier=0.5, dtype=dt)
+        net = KeypointNet(values=params, depth_multiplier=dm, dtype=dt)
+        assert net.stem_w.shape[3] == c0_internal
         tr = Trainer(net, hp, use_graph=False)
         out[dt] = tr.step(feats, dlab).cpu().numpy().copy()
         assert bool(torch.isfinite(net.theta).all()) and bool(torch.isfinite(net.grad).all())
@@ -494,7 +498,16 @@ def test_depth_multiplier_half_train_step(cuda):
             np.testing.assert_allclose(out[dt][6], total, rtol=2e-4)
             np.testing.assert_allclose(out[dt][:6], list(losses.values()), rtol=2e-4, atol=1e-9)
             for k, g in grads.items():
-                got = net.grads[k].cpu().numpy().astype(np.float64).ravel()
+                got = net.unpad(k, net.grads[k]).cpu().numpy().astype(np.float64).ravel()
                 cos = float(got @ g.ravel() / (np.linalg.norm(got) * np.linalg.norm(g) + 1e-30))
                 assert cos > 0.99, (k, cos)
+        sd = net.state_dict()
+        for k, val in params.items():
+            assert sd[k].shape == val.shape, k
+        for k, (axis, n) in net._pads.items():       # the pad: zero variables, zero gradients, zero Adam slots after the step
+            for arena in (net.vars, net.grads, net._train_arena.views(net.adam_m), net._train_arena.views(net.adam_v)):
+                if k in arena:
+                    t = arena[k]
+                    assert float(t.narrow(axis, n, t.shape[axis] - n).abs().max()) == 0.0, k
+        assert bool(net._pads) == (c0 != c0_internal)
     np.testing.assert_allclose(out[torch.bfloat16][6], out[torch.float32][6], rtol=3e-2)
