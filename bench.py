@@ -158,7 +158,10 @@ def dry_run_cpu(args):
         red.start(split, None), red.start(0, split), red.finish()
     torch.distributed.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    fail_at = os.environ.get("MPN_BENCH_FAIL_AT_STEP")           # tests: "<rank>:<step>" - that rank raises inside its step loop,
+    for i in range(args.steps):                                   # after earlier collectives have completed; its peers block in theirs
+        if fail_at is not None and fail_at == f"{rank}:{i}":
+            raise RuntimeError(f"rank {rank}: injected failure in step {i}")
         grad.fill_(float(rank + 1))
         red.start(split, None)       # head end first (overlaps the backbone's backward on the GPU path)
         red.start(0, split)
@@ -257,8 +260,13 @@ def main():
 
     def pct(q):
         return round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 3)
+    per_rank_ms = [round(1e3 * dt_s / args.steps, 3)]
     if world > 1:
-        t = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+        mine = torch.tensor([dt_s], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(every, mine)                 # a straggler shows in the line, not only in the maximum
+        per_rank_ms = [round(1e3 * float(x.item()) / args.steps, 3) for x in every]
+        t = mine.clone()
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt_s = float(t.item())
     loss = float(trainer._losses[6])
@@ -272,7 +280,8 @@ def main():
         "config": {"workload": f"MobileNet-v1+FPN+keypoint_subnet fwd+bwd+Adam, {args.size}x{args.size}, per-GPU batch {args.batch}",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
                    "final_total_loss": loss,
-                   "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1},
+                   "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                   "ms_per_step_per_rank": per_rank_ms},
     }
     if trainer.reducer is not None and trainer.comm_events:
         # exposed (not overlapped) gradient exchange per step: from the end of the backbone's backward graph to the moment
@@ -285,6 +294,16 @@ def main():
         out["config"]["step_mfma_frac_of_peak"] = whole_step_mfma_fraction(args.batch, args.size, dt_s / args.steps)
         from bench_legs import conv_wgrad_roofline
         out["roofline_wgrad"] = conv_wgrad_roofline(net, args.batch, args.size, dt, b=trainer._static_bufs())   # the largest family by time
+        if dt == torch.bfloat16:
+            from bench_legs import in_step_families, mfma_achievable_peak
+            ceil = mfma_achievable_peak()     # what a hipcc-scheduled MFMA stream sustains on this box
+            if ceil is not None:
+                for r in (out["roofline"], out["roofline_wgrad"]):
+                    r["achievable_peak"] = ceil["with_lds_operand_reads_TFLOPs"]
+                    r["frac_of_achievable"] = round(r["achieved"] / ceil["with_lds_operand_reads_TFLOPs"], 4)
+                out["roofline"]["achievable_peak_detail"] = ceil
+            # the north star's kernel families inside the real step (per-launch HIP events over one eager step)
+            out["north_star_in_step"] = in_step_families(trainer, feats, labels, args.batch, args.size)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from bench_legs import cpu_baseline, decode_benchmark, render_benchmark, prn_benchmark
         from bench_legs import host_fed_rate

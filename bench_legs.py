@@ -97,61 +97,140 @@ def conv_wgrad_roofline(net, batch, size, dtype, iters=30, warmup=10, b=None):
             "frac": round(flops / sec / 1e12 / peak, 4), "launch_us": round(sec * 1e6, 2), "split_k_slabs": int(nparts)}
 
 
-def north_star_kernels(batch=32, iters=20):
+def north_star_kernels(batch=32, iters=24):
     """The two kernel families the north star sets targets for, at the bench shape (bs32 @ 512x512, bf16), each launch
-    timed alone with HIP events on the launch stream: the depthwise 3x3 path against the 8 TB/s HBM peak (algorithmic
-    bytes = input read once + output written once) and pointwise 1x1 layers against the 2.5 PFLOP/s bf16 MFMA peak."""
+    timed alone with HIP events on the launch stream - COLD: every launch works on another set of tensors, the sets together
+    far beyond the 256 MB memory-side cache, which is what the kernels see inside the train step (round 3 re-launched on one
+    set and read 0.49-0.63 where the step's own trace said 0.39-0.43: VERDICT r3 "weak" 7). `copy_frac` = a torch copy of the
+    same bytes under the same rotation: what this box gives a pure stream (0.65-0.67 of the 8 TB/s the fractions are quoted
+    against). Depthwise 3x3 against the HBM peak (algorithmic bytes = input read once + output written once), pointwise 1x1
+    against the 2.5 PFLOP/s bf16 MFMA peak and the HBM peak (only the 16x16 layers are matrix-bound)."""
     dt = torch.bfloat16
     stream = torch.cuda.current_stream()
 
-    def timed(fn):
-        for _ in range(3):
-            fn()
+    def timed(fn, nset):
+        for i in range(nset):
+            fn(i)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
-        for _ in range(iters):
-            fn()
+        for i in range(iters):
+            fn(i)
         e1.record(stream)
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / iters
 
-    out = {"depthwise": [], "pointwise": []}
+    out = {"timing": "cold: rotating tensor sets of >= 1 GB in all", "depthwise": [], "pointwise": []}
     for (H, C, s) in [(256, 32, 1), (256, 64, 2), (128, 128, 1), (128, 128, 2), (32, 512, 1)]:
-        x = torch.randn(batch, H, H, C, device="cuda").to(dt)
+        OH = H // s
+        byt = (batch * H * H * C + batch * OH * OH * C) * 2
+        nset = max(2, min(12, int(1.2e9 // byt)))
+        xs = [torch.randn(batch, H, H, C, device="cuda").to(dt) for _ in range(nset)]
+        ys = [torch.empty(batch, OH, OH, C, device="cuda", dtype=dt) for _ in range(nset)]
+        dys = [torch.randn(batch, OH, OH, C, device="cuda").to(dt) for _ in range(nset)]
+        dxs = [torch.empty(batch, H, H, C, device="cuda", dtype=dt) for _ in range(nset)]
         w = torch.randn(3, 3, C, device="cuda") * 0.2
         aff = ops.Affine(torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda") * 0.1, 2)
-        OH = H // s
-        y = torch.empty(batch, OH, OH, C, device="cuda", dtype=dt)
-        dy = torch.randn(batch, OH, OH, C, device="cuda").to(dt)
-        dx = torch.empty_like(x)
         dw = torch.empty(3, 3, C, device="cuda")
         part = torch.empty(ops.dwconv_num_parts(batch, H, H, C, s, dt) * 2 * C, device="cuda")
         slab = torch.empty(ops.dwconv_wgrad_num_parts(batch, H, H, C, s, dt) * 9 * C, device="cuda")
-        byt = (x.numel() + y.numel()) * 2
-        row = {"layer": f"{C}ch @{H}x{H} stride {s}"}
-        for name, fn in (("fwd", lambda: ops.dwconv_fwd(x, w, s, aff, out=y, stats_part=part)),
-                         ("dgrad", lambda: ops.dwconv_bwd_data(dy, w, (H, H), s, out=dx)),
-                         ("wgrad", lambda: ops.dwconv_bwd_weight(x, dy, s, aff, dw, slab, reduce=False))):
-            sec = timed(fn)
+        row = {"layer": f"{C}ch @{H}x{H} stride {s}", "sets": nset}
+        for name, fn in (("fwd", lambda i: ops.dwconv_fwd(xs[i % nset], w, s, aff, out=ys[i % nset], stats_part=part)),
+                         ("dgrad", lambda i: ops.dwconv_bwd_data(dys[i % nset], w, (H, H), s, out=dxs[i % nset])),
+                         ("wgrad", lambda i: ops.dwconv_bwd_weight(xs[i % nset], dys[i % nset], s, aff, dw, slab, reduce=False))):
+            sec = timed(fn, nset)
             row[name + "_GBps"] = round(byt / sec / 1e9, 0)
             row[name + "_frac_of_8TBps"] = round(byt / sec / 8e12, 3)
+        if s == 1:
+            sec = timed(lambda i: ys[i % nset].copy_(xs[i % nset]), nset)
+            row["copy_frac_of_8TBps"] = round(byt / sec / 8e12, 3)
         out["depthwise"].append(row)
-        del x, y, dy, dx
+        del xs, ys, dys, dxs
+        torch.cuda.empty_cache()
     for (H, Cin, Cout) in [(128, 128, 128), (64, 256, 256), (32, 512, 512), (16, 1024, 1024)]:
-        x = torch.randn(batch, H, H, Cin, device="cuda").to(dt)
+        byt = (batch * H * H * (Cin + Cout)) * 2
+        nset = max(2, min(12, int(1.2e9 // byt)))
+        xs = [torch.randn(batch, H, H, Cin, device="cuda").to(dt) for _ in range(nset)]
+        ys = [torch.empty(batch, H, H, Cout, device="cuda", dtype=dt) for _ in range(nset)]
         pc = ops.PackedConv(torch.randn(1, 1, Cin, Cout, device="cuda") * 0.05, dt)
         aff = ops.Affine(torch.rand(Cin, device="cuda") + 0.5, torch.randn(Cin, device="cuda") * 0.1, 2)
-        y = torch.empty(batch, H, H, Cout, device="cuda", dtype=dt)
         part = torch.empty(ops.conv_num_parts(batch, H, H, 1) * 2 * Cout, device="cuda")
-        sec = timed(lambda: ops.conv_fwd(x, pc.fwd, Cout, 1, aff, out=y, stats_part=part))
+        sec = timed(lambda i: ops.conv_fwd(xs[i % nset], pc.fwd, Cout, 1, aff, out=ys[i % nset], stats_part=part), nset)
         fl = 2.0 * batch * H * H * Cin * Cout
-        byt = (x.numel() + y.numel()) * 2
-        out["pointwise"].append({"layer": f"{Cin}->{Cout} @{H}x{H}", "TFLOPs": round(fl / sec / 1e12, 1),
+        out["pointwise"].append({"layer": f"{Cin}->{Cout} @{H}x{H}", "sets": nset, "TFLOPs": round(fl / sec / 1e12, 1),
                                  "frac_of_mfma_peak": round(fl / sec / 1e12 / PEAK_BF16_TFLOPS, 3),
                                  "GBps": round(byt / sec / 1e9, 0), "frac_of_8TBps": round(byt / sec / 8e12, 3),
                                  "arithmetic_intensity_flop_per_byte": round(fl / byt, 1)})
-        del x, y
+        del xs, ys
+        torch.cuda.empty_cache()
     return out
+
+
+def in_step_families(trainer, feats, labels, batch, size):
+    """The north-star families INSIDE the real train step: one eager step (the same launches the hipGraph replays) with every
+    launch bracketed by HIP events on the launch stream (multiposenet_amd._lib.PROFILE), summed per family and held against
+    SURVEY 8(d)'s algorithmic work: depthwise 3x3 (forward + data + weight gradients) against the 8 TB/s HBM peak; the
+    backbone's pointwise 1x1 layers (forward + data + weight gradients) against BOTH peaks - as a family they are
+    HBM-bound (144 FLOP per byte, machine balance 312). `frac` in `north_star_kernels` are the stand-alone cold launches."""
+    from multiposenet_amd import _lib
+    graph = trainer.use_graph
+    trainer.use_graph = False
+    try:
+        for _ in range(2):
+            trainer.step(feats, labels)          # eager warm-up
+        torch.cuda.synchronize()
+        _lib.PROFILE = []
+        trainer.step(feats, labels)
+        torch.cuda.synchronize()
+        rec, _lib.PROFILE = _lib.PROFILE, None
+    finally:
+        _lib.PROFILE = None
+        trainer.use_graph = graph
+    fam = {"depthwise": 0.0, "pointwise": 0.0}
+    n = {"depthwise": 0, "pointwise": 0}
+    total = 0.0
+    for tag, name, e0, e1 in rec:
+        us = e0.elapsed_time(e1) * 1e3
+        total += us
+        key = "depthwise" if name.startswith("mpn_dwconv") else ("pointwise" if tag == "pointwise" else None)
+        if key:
+            fam[key] += us
+            n[key] += 1
+    scale = batch / 32.0 * (size / 512.0) ** 2
+    dw_bytes, pw_bytes, pw_flop = 4.362e9 * scale, 3.750e9 * scale, 541e9 * scale       # SURVEY 8(d), bs32 @ 512x512
+    return {"source": "per-launch HIP events over one eager step (the launches the hipGraph replays)",
+            "launches": len(rec), "sum_of_launches_us": round(total, 1),
+            "depthwise": {"launches": n["depthwise"], "us": round(fam["depthwise"], 1), "algorithmic_GB": round(dw_bytes / 1e9, 3),
+                          "frac_of_8TBps": round(dw_bytes / (fam["depthwise"] * 1e-6) / 8e12, 3)},
+            "pointwise": {"launches": n["pointwise"], "us": round(fam["pointwise"], 1), "algorithmic_GFLOP": round(pw_flop / 1e9, 1),
+                          "algorithmic_GB": round(pw_bytes / 1e9, 3),
+                          "frac_of_mfma_peak": round(pw_flop / (fam["pointwise"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 3),
+                          "frac_of_8TBps": round(pw_bytes / (fam["pointwise"] * 1e-6) / 8e12, 3)}}
+
+
+def mfma_achievable_peak():
+    """What a hipcc-built v_mfma_f32_16x16x32_bf16 stream sustains on THIS box (tools/mfma_ceiling.hip --quick, a stand-alone
+    binary built by __graft_entry__.build(): random operands, all CUs, two waves per SIMD, 16 accumulator tiles per wave like
+    the shipped 3x3 kernel): bare (nothing but MFMAs) and with every operand fragment re-read from LDS at the shipped kernel's
+    0.375 ds_read_b128 per MFMA - the number the MFMA kernels' fractions should be read against next to the nominal 2.5 PF,
+    with the clock the chip holds under that load. None when the binary is missing."""
+    import json
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "build", "mfma_ceiling")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, "--quick"], capture_output=True, text=True, timeout=120)
+    except (OSError, subprocess.TimeoutExpired):
+        return None
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(rows) < 2:
+        return None
+    bare = next(x for x in rows if x["variant"] == "bare")
+    lds = next(x for x in rows if x["variant"].startswith("lds"))
+    return {"bare_mfma_TFLOPs": bare["TFLOPs"], "bare_clock_GHz": bare["clock_GHz"],
+            "with_lds_operand_reads_TFLOPs": lds["TFLOPs"], "with_lds_clock_GHz": lds["clock_GHz"],
+            "simd_cycles_per_mfma": [bare["simd_cycles_per_mfma"], lds["simd_cycles_per_mfma"]],
+            "source": "tools/mfma_ceiling.hip --quick (this run, this box)"}
 
 
 def cpu_baseline(size, budget_s=20.0):

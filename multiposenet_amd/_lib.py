@@ -178,8 +178,36 @@ def check(rc):
         raise MpnError(msg)
 
 
+# bench.py's in-step family timing: while PROFILE is a list every launch is bracketed by two events on the launch stream and
+# recorded as (tag, entry point, start, end); `tagged` names the call site's family where the entry point alone does not (a 1x1
+# convolution of the backbone and an FPN lateral are the same entry point). None (the default): one attribute test per call.
+PROFILE = None
+_TAG = ""
+
+
+class tagged:
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        global _TAG
+        self.prev, _TAG = _TAG, self.tag
+
+    def __exit__(self, *a):
+        global _TAG
+        _TAG = self.prev
+
+
 def call(name, *args):
+    if PROFILE is None:
+        check(getattr(lib(), name)(*args))
+        return
+    import torch
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     check(getattr(lib(), name)(*args))
+    e1.record()
+    PROFILE.append((_TAG, name, e0, e1))
 
 
 def ptr(t):

@@ -20,7 +20,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6
 
 NUM_KEYPOINTS = 17   # detector/constants.py:10
@@ -532,8 +532,9 @@ class KeypointNet:
             if is_training:
                 ops.bn_finalize(blk["dw_bn"], sp, ops.dwconv_num_parts(N, hin, win, ydw.shape[3], blk["stride"], self.dtype),
                                 ydw.numel() // ydw.shape[3])
-            ypw = ops.conv_fwd(ydw, blk["pw"].packed.fwd, blk["pw"].cout, 1, blk["dw_bn"].affine, out=b["pw"][i],
-                               stats_part=sp if is_training else None)
+            with _lib.tagged("pointwise"):
+                ypw = ops.conv_fwd(ydw, blk["pw"].packed.fwd, blk["pw"].cout, 1, blk["dw_bn"].affine, out=b["pw"][i],
+                                   stats_part=sp if is_training else None)
             if is_training:
                 ops.bn_finalize(blk["pw_bn"], sp, ops.conv_num_parts(N, h, w, 1), N * h * w)
             x, aff = ypw, blk["pw_bn"].affine
@@ -752,13 +753,16 @@ class KeypointNet:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
             ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced, raw=raw_sums and reduced > 0)
             raw_sums = False                                    # (depthwise data gradients sum g * xhat themselves)
-            W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
+            with _lib.tagged("pointwise"):
+                W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
             # the deep pointwise layers' data gradients also reduce for the depthwise batch-norm they feed
             if self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(blk["pw"].cout, blk["pw"].cin, 1, self.dtype):
-                rows = ops.conv_bwd_data_bn(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, blk["dw_bn"], b["dw"][i], g["dw"][i], sp)
+                with _lib.tagged("pointwise"):
+                    rows = ops.conv_bwd_data_bn(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, blk["dw_bn"], b["dw"][i], g["dw"][i], sp)
                 ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, reduced_parts=rows, raw=True)
             else:
-                ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
+                with _lib.tagged("pointwise"):
+                    ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
                 ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine

@@ -84,6 +84,19 @@ def test_a_dying_rank_ends_the_others_and_the_launcher_returns_its_code():
     assert r.stdout.strip() == ""
 
 
+def test_a_rank_raising_inside_its_step_loop_ends_its_peers_within_seconds():
+    """not before the first collective (above) but in the middle of the timed loop, when the peers are
+    already blocked in an all-reduce that will never complete: the launcher sees the exit code and ends them."""
+    import time
+    t0 = time.monotonic()
+    r = _run(["--gpus", "2", "--dry-run-cpu", "--steps", "6", "--warmup", "1"], env={"MPN_BENCH_FAIL_AT_STEP": "1:3"}, timeout=180)
+    took = time.monotonic() - t0
+    assert r.returncode not in (0, None) and r.returncode > 0
+    assert "injected failure in step 3" in r.stderr and "rank exit codes" in r.stderr
+    assert r.stdout.strip() == ""
+    assert took < 90, took            # (two interpreter + torch start-ups; the wait for the dead rank itself is the 50 ms poll)
+
+
 def test_ranks_started_by_an_outer_launcher_are_not_relaunched():
     """WORLD_SIZE in the environment (torch.distributed.run) = this process IS a rank: a mismatch with --gpus asserts."""
     r = _run(["--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "0"],

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 typedef __bf16 x8 __attribute__((ext_vector_type(8)));
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(TB) mfma_loop(const x8* __restrict__ in, float
 }
 
 template <int NACC, bool LDS, int TB>
-static void run(const char* name, int waves_per_simd, const x8* in, float* out, long long* stamps, int cus) {
+static void run(const char* name, int waves_per_simd, const x8* in, float* out, long long* stamps, int cus, float warm_ms = 1000.f) {
     const int threads = 256 * waves_per_simd, blocks = cus;
     const int iters = 20000;
     hipEvent_t e0, e1;
@@ -93,7 +94,7 @@ static void run(const char* name, int waves_per_simd, const x8* in, float* out, 
     // warm: >= 1 s of back-to-back launches on random data so the clock settles where a real run holds it
     float ms = 0.f;
     int reps = 0;
-    for (float total = 0.f; total < 1000.f; ++reps) {
+    for (float total = 0.f; total < warm_ms; ++reps) {
         CK(hipEventRecord(e0));
         mfma_loop<NACC, LDS, TB><<<blocks, threads>>>(in, out, iters, stamps);
         CK(hipEventRecord(e1));
@@ -128,7 +129,8 @@ static void run(const char* name, int waves_per_simd, const x8* in, float* out, 
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && std::string(argv[1]) == "--quick";      // bench.py: two variants, 0.4 s of warm-up each
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
@@ -136,13 +138,18 @@ int main() {
     std::vector<unsigned short> h(4096 * 8);
     srand(1);
     for (auto& v : h) {                      // uniform [-1, 1) as bf16 (full-range random operands: DVFS-honest)
-        float f = (float)rand() / RAND_MAX * 2.f - 1.f;
+        float f = (float)(rand() & 0xFFFFFF) / 16777216.f * 2.f - 1.f;
         unsigned u; memcpy(&u, &f, 4);
         v = (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16);
     }
     x8* in; float* out; long long* stamps;
     CK(hipMalloc(&in, h.size() * 2)); CK(hipMalloc(&out, sizeof(float) * cus * 512)); CK(hipMalloc(&stamps, sizeof(long long) * 2 * cus * 8));
     CK(hipMemcpy(in, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    if (quick) {
+        run<16, false, 512>("bare", 2, in, out, stamps, cus, 400.f);
+        run<16, true, 512>("lds_0.375_reads_per_mfma", 2, in, out, stamps, cus, 400.f);
+        return 0;
+    }
     // TB = 512: at most 256 registers per lane (two waves per SIMD fit); TB = 256: up to 512 (accumulators may sit in AGPRs)
     run<16, false, 512>("bare", 1, in, out, stamps, cus);
     run<16, false, 512>("bare", 2, in, out, stamps, cus);
