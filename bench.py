@@ -152,10 +152,10 @@ def dry_run_cpu(args):
     shapes = {k: v for k, v in mnet.variable_shapes(1.0).items() if mnet.is_trainable(k)}
     arena = mnet._Arena(shapes, "cpu")
     grad = arena.new()
-    split = mnet.backbone_grad_end_of(arena)
+    split, deep = mnet.backbone_grad_end_of(arena), mnet.backbone_deep_begin_of(arena)
     red = GradientAllReducer(grad)
     for _ in range(args.warmup):
-        red.start(split, None), red.start(0, split), red.finish()
+        red.start(split, None), red.start(deep, split), red.start(0, deep), red.finish()
     torch.distributed.barrier()
     t0 = time.perf_counter()
     fail_at = os.environ.get("MPN_BENCH_FAIL_AT_STEP")           # tests: "<rank>:<step>" - that rank raises inside its step loop,
@@ -164,7 +164,8 @@ def dry_run_cpu(args):
             raise RuntimeError(f"rank {rank}: injected failure in step {i}")
         grad.fill_(float(rank + 1))
         red.start(split, None)       # head end first (overlaps the backbone's backward on the GPU path)
-        red.start(0, split)
+        red.start(deep, split)       # the deep backbone blocks (overlaps the shallow blocks' backward)
+        red.start(0, deep)
         red.finish()
     torch.distributed.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)

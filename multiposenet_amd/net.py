@@ -129,6 +129,17 @@ def initial_values(seed=0, depth_multiplier=1.0):
     return out
 
 
+DP_DEEP_FROM_BLOCK = 7    # data-parallel exchange: backbone blocks 7..13 (2.9 M of the backbone's 3.2 M parameters, the SHORT end of
+                          # its backward pass: 32x32 and 16x16 maps) travel while blocks 6..1 and the stem (0.3 M parameters on the
+                          # large maps, most of the backward time) are still computed
+
+
+def backbone_deep_begin_of(arena, first_block=DP_DEEP_FROM_BLOCK):
+    """Offset in a flat arena of the trainable variables where backbone block `first_block` begins (the arena is laid out in
+    network order: Conv2d_0, Conv2d_1_depthwise, ... Conv2d_13_pointwise, then the head end)."""
+    return arena.offsets[f"MobilenetV1/Conv2d_{first_block}_depthwise/depthwise_weights"][0]
+
+
 class _Arena:
     """Flat f32 device arena with named, 16-byte aligned views."""
 
@@ -457,15 +468,19 @@ class KeypointNet:
                       self._head_grad.numel(), self._head_grad))
         total = sum(((np_ * n + 3) // 4) * 4 for _, np_, n, _ in sites)
         slab = torch.empty(total, dtype=torch.float32, device=dev)
-        backbone_keys = {id(blk["pw"].dw) for blk in self.blocks} | {id(blk["dw_dw"]) for blk in self.blocks} | {id(self.stem_dw)}
-        g["slab"], jobs, off = {}, ([], []), 0
+        deep_keys = {id(blk[k]) if k == "dw_dw" else id(blk[k].dw) for blk in self.blocks if blk["i"] >= DP_DEEP_FROM_BLOCK
+                     for k in ("pw", "dw_dw")}
+        shallow_keys = {id(blk[k]) if k == "dw_dw" else id(blk[k].dw) for blk in self.blocks if blk["i"] < DP_DEEP_FROM_BLOCK
+                        for k in ("pw", "dw_dw")} | {id(self.stem_dw)}
+        g["slab"], jobs, off = {}, ([], [], []), 0
         for key, np_, n, out in sites:
             view = slab[off:off + np_ * n]
             g["slab"][key] = view
-            jobs[1 if key in backbone_keys else 0].append((view, np_, n, out.view(-1)))
+            jobs[1 if key in deep_keys else (2 if key in shallow_keys else 0)].append((view, np_, n, out.view(-1)))
             off += ((np_ * n + 3) // 4) * 4
-        # two launches: the head / FPN gradients are complete (and can be all-reduced) while the backbone still runs
-        g["reducer"] = (ops.SlabReducer(jobs[0], dev), ops.SlabReducer(jobs[1], dev))
+        # three launches: the head / FPN gradients, then the deep backbone blocks', are complete (and can be all-reduced) while
+        # the rest of the backbone still runs
+        g["reducer"] = tuple(ops.SlabReducer(j, dev) for j in jobs)
         b["g"] = g
         return g
 
@@ -647,14 +662,20 @@ class KeypointNet:
             fn()
 
     @property
+    def backbone_deep_begin(self):
+        """Offset in the flat gradient arena where backbone block DP_DEEP_FROM_BLOCK begins (see backward)."""
+        return backbone_deep_begin_of(self._train_arena)
+
+    @property
     def backbone_grad_end(self):
         """Offset in the flat gradient arena where the backbone's variables end (the arena is laid out backbone first)."""
         return backbone_grad_end_of(self._train_arena)
 
     def backward(self, part=None):
         """Gradients of the total loss w.r.t. every trainable variable -> self.grad (call after compute_losses).
-        part=0: head + subnet + FPN only (their gradients are final when it returns); part=1: the backbone, after
-        part 0; None: both. Data-parallel training all-reduces the part-0 gradients while part 1 runs.
+        part=0: head + subnet + FPN only (their gradients are final when it returns); part=1: backbone blocks 13..7, after
+        part 0; part=2: blocks 6..1 and the stem, after part 1; None: all three. Data-parallel training all-reduces the
+        part-0 gradients while part 1 runs and the part-1 gradients (the bulk of the backbone's parameters) while part 2 runs.
         Two HIP streams: the main one carries the activation-gradient chain, the side one all weight gradients
         (MFMA split-K kernels + slab reductions), so HBM-bound batch-norm passes overlap MFMA-bound wgrad kernels."""
         b, feats, images = self._last
@@ -668,11 +689,12 @@ class KeypointNet:
             if self._wstream is not None:
                 torch.cuda.current_stream().wait_stream(self._wstream)
             g["reducer"][0].run()
-        if part in (None, 1):
-            self._backward_backbone(b, g, images, sp, slab, W)
-            if self._wstream is not None:
-                torch.cuda.current_stream().wait_stream(self._wstream)   # join: every slab is written
-            g["reducer"][1].run()   # every gradient is in the arena
+        for ph in (1, 2):
+            if part in (None, ph):
+                self._backward_backbone(b, g, images, sp, slab, W, ph)
+                if self._wstream is not None:
+                    torch.cuda.current_stream().wait_stream(self._wstream)   # join: every slab of this phase is written
+                g["reducer"][ph].run()   # (after phase 2: every gradient is in the arena)
 
     def _backward_head(self, b, g, feats, sp, slab, W):
         # ---- head + final conv
@@ -743,11 +765,20 @@ class KeypointNet:
             else:
                 ops.conv_fwd(g["x"][l], self.lateral[l].packed.bwd, raw.shape[3], 1, None, out=g["c"][f"c{l}"])
 
-    def _backward_backbone(self, b, g, images, sp, slab, W):
-        dA = g["c"]["c5"]
-        reduced, raw_sums = g.get("c5_reduced", 0), True       # (the lateral's data gradient may have reduced for the last batch-norm)
-        lateral_added = False
-        for i in range(len(self.blocks) - 1, -1, -1):
+    def _backward_backbone(self, b, g, images, sp, slab, W, phase):
+        """phase 1: blocks 13 .. DP_DEEP_FROM_BLOCK; phase 2: the blocks below and the stem. The chain's state between the two
+        (the gradient tensor, whether the last data gradient already reduced for the next batch-norm, whether a lateral's
+        gradient is already added) is Python state handed over through `g` - static per shape, so both phases capture."""
+        first = DP_DEEP_FROM_BLOCK - 1            # index of the first deep block
+        if phase == 1:
+            dA = g["c"]["c5"]
+            reduced, raw_sums = g.get("c5_reduced", 0), True   # (the lateral's data gradient may have reduced for the last batch-norm)
+            lateral_added = False
+            rng = range(len(self.blocks) - 1, first - 1, -1)
+        else:
+            dA, reduced, raw_sums, lateral_added = g["bb_chain"]
+            rng = range(first - 1, -1, -1)
+        for i in rng:
             blk = self.blocks[i]
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13 and not lateral_added:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
@@ -789,6 +820,9 @@ class KeypointNet:
             else:
                 ops.dwconv_bwd_data(g["dw"][i], blk["dw_w"], b["hw"][i], blk["stride"], out=dst, addend=addend)
             dA = dst
+        if phase == 1:
+            g["bb_chain"] = (dA, reduced, raw_sums, lateral_added)
+            return
         ops.bn_backward(self.stem_bn, g["stem"], b["stem"], sp, reduced_parts=reduced)
         W(lambda: ops.stem_conv_bwd_weight(images, g["stem"], self.stem_dw, slab[id(self.stem_dw)], reduce=False))
 

@@ -25,11 +25,13 @@ class Trainer:
         self._losses = None       # the f32[8] loss tensor of the buffer set the train step runs on
         self._graph_fb = None
         self._graph_bb = None
+        self._graph_bb2 = None
         self._graph_opt = None
 
     # ---- pieces
     def _fwd_bwd(self, part=None):
-        """part None: everything; 0: forward + losses + head/FPN backward; 1: backbone backward (+ weight decay)."""
+        """part None: everything; 0: forward + losses + head/FPN backward; 1: backward of the deep backbone blocks; 2: of the
+        shallow blocks and the stem (+ weight decay)."""
         s = self._static
         if part in (None, 0):
             self.net.forward(s["images"], True)
@@ -37,7 +39,7 @@ class Trainer:
             if self.weight_decay > 0.0:
                 self.net.add_weight_decay_loss(self.weight_decay)
         self.net.backward(part)
-        if part in (None, 1) and self.weight_decay > 0.0:
+        if part in (None, 2) and self.weight_decay > 0.0:
             self.net.add_weight_decay_gradients(self.weight_decay)
 
     def _opt(self):
@@ -56,7 +58,7 @@ class Trainer:
         s = self._static
         if s is None or s["images"].shape != imgs.shape or s["images"].dtype != imgs.dtype:
             self._static = {"images": imgs.clone(), "labels": {k: v.clone() for k, v in labels.items()}}
-            self._graph_fb = self._graph_bb = self._graph_opt = None
+            self._graph_fb = self._graph_bb = self._graph_bb2 = self._graph_opt = None
             # the loss tensor of THIS shape's buffer set: a graph replay does not touch net._last, which an eval_step at
             # another batch size rebinds in between
             N, H, W, _ = imgs.shape
@@ -82,13 +84,17 @@ class Trainer:
                 self._fwd_bwd()
                 self._opt()
         else:
-            # data parallel: three graphs around the two RCCL exchanges (head/FPN gradients travel while the backbone's
-            # backward still runs; weight decay touches every gradient, so with it the exchange waits for the end)
+            # data parallel: four graphs around the three RCCL exchanges (head/FPN gradients travel while the backbone's backward
+            # runs, the deep backbone blocks' - 2.9 M of its 3.2 M parameters - while the shallow blocks' backward runs: what stays
+            # exposed is the exchange of ~1.3 MB; weight decay touches every gradient, so with it the exchange waits for the end)
             with torch.cuda.graph(self._graph_fb):
                 self._fwd_bwd(0)
             self._graph_bb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_bb):
                 self._fwd_bwd(1)
+            self._graph_bb2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph_bb2):
+                self._fwd_bwd(2)
             self._graph_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph_opt):
                 self._opt()
@@ -113,15 +119,18 @@ class Trainer:
                 self.net.repack_weights()
             self._graph_fb.replay()
             if self.reducer is not None:
-                split = self.net.backbone_grad_end
+                split, deep = self.net.backbone_grad_end, self.net.backbone_deep_begin
                 early = self.weight_decay == 0.0
                 if early:
                     self.reducer.start(split, None)      # head + FPN gradients: overlapped with the backbone's backward
                 self._graph_bb.replay()
+                if early:
+                    self.reducer.start(deep, split)      # deep backbone blocks: overlapped with the shallow blocks' backward
+                self._graph_bb2.replay()
                 if self.measure_comm:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                self.reducer.start(0, split if early else None)
+                self.reducer.start(0, deep if early else None)
                 self.reducer.finish()
                 if self.measure_comm:
                     e1.record()

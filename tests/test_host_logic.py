@@ -67,11 +67,13 @@ def _worker(rank, world, port, out):
     flat = torch.randn(100003 * 4)           # rank-dependent "gradients"
     mine = flat.clone()
     red = GradientAllReducer(flat, bucket_bytes=64 << 10)
-    # the two-phase exchange of train.Trainer: the head end of the arena first (while the backbone's backward would
-    # still run), then the rest; every element exactly once
-    split = 123456
+    # the three-phase exchange of train.Trainer: the head end of the arena first (while the backbone's backward would
+    # still run), then the deep backbone blocks (while the shallow ones' backward runs), then the rest; every element
+    # exactly once
+    split, deep = 123456, 40000
     red.start(split, None)
-    red.start(0, split)
+    red.start(deep, split)
+    red.start(0, deep)
     red.finish()
     out[rank] = (mine.numpy(), flat.numpy().copy(), red.grad_scale, len(red.bounds))
     torch.distributed.destroy_process_group()
@@ -87,3 +89,22 @@ def test_two_rank_gloo_gradient_allreduce():
     assert nb > 1 and scale == 0.5
     np.testing.assert_array_equal(s0, s1)                           # every rank holds the same sum
     np.testing.assert_allclose(s0, g0 + g1, rtol=1e-6, atol=1e-6)   # = sum of the per-rank gradients
+
+
+def test_the_three_exchange_ranges_tile_the_arena_and_follow_the_backward_order():
+    """Data-parallel exchange: [head end | deep backbone blocks 7..13 | blocks 1..6 + stem] are contiguous
+    ranges of the flat arena in the order the three backward phases complete them; the deep range holds most of the backbone."""
+    from multiposenet_amd import net as mnet
+    shapes = {k: v for k, v in mnet.variable_shapes(1.0).items() if mnet.is_trainable(k)}
+    arena = mnet._Arena(shapes, "cpu")
+    end, deep = mnet.backbone_grad_end_of(arena), mnet.backbone_deep_begin_of(arena)
+    total = arena.new().numel()
+    assert 0 < deep < end < total and deep % 4 == 0 and end % 4 == 0
+    for k, (o, n, _) in arena.offsets.items():
+        if not k.startswith("MobilenetV1/"):
+            assert o >= end, k
+        else:
+            blk = int(k.split("Conv2d_")[1].split("_")[0].split("/")[0])
+            assert (o >= deep) == (blk >= mnet.DP_DEEP_FROM_BLOCK), k
+    assert (end - deep) > 8 * deep                      # 2.9 M of 3.2 M backbone parameters travel under the shallow blocks
+    assert deep * 4 < 1.5e6                             # what stays exposed: ~1.3 MB
