@@ -202,22 +202,27 @@ __device__ __forceinline__ void bn_finalize_block(
     float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ save_mean,
     float* __restrict__ save_invstd, int rstride = 1) {
     const int c = cblock * CPB + threadIdx.x;
+    // the per-channel parameters are requested BEFORE the slab reduction (behind its barrier the loads would start a second
+    // memory round trip of their own: a finalize is a 4 us launch made of two dependent round trips and little else)
+    const bool mine = (int)threadIdx.x < CPB && c < C;
+    const float g_c = mine ? gamma[c] : 0.f, b_c = mine ? beta[c] : 0.f;
+    const float mm_c = (mine && mov_mean) ? mov_mean[c] : 0.f, mv_c = (mine && mov_mean) ? mov_var[c] : 0.f;
     double s, q;
     reduce_parts<CPB>(part, nparts, C, cblock, red, s, q, rstride);
-    if ((int)threadIdx.x < CPB && c < C) {
+    if (mine) {
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-        const float sc = gamma[c] * invstd;
+        const float sc = g_c * invstd;
         scale[c] = sc;
-        shift[c] = beta[c] - (float)mean * sc;
+        shift[c] = b_c - (float)mean * sc;
         if (save_mean) save_mean[c] = (float)mean;
         if (save_invstd) save_invstd[c] = invstd;
         if (mov_mean) {
             const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
-            mov_mean[c] = mov_mean[c] * momentum + (float)mean * (1.f - momentum);
-            mov_var[c] = mov_var[c] * momentum + (float)unbiased * (1.f - momentum);
+            mov_mean[c] = mm_c * momentum + (float)mean * (1.f - momentum);
+            mov_var[c] = mv_c * momentum + (float)unbiased * (1.f - momentum);
         }
     }
 }
@@ -409,11 +414,13 @@ __device__ __forceinline__ void bn_bwd_finalize_block(int cblock, double (*red)[
                                                       float* __restrict__ k2, const float* __restrict__ mean = nullptr,
                                                       const float* __restrict__ invstd = nullptr, int rstride = 1) {
     const int c = cblock * CPB + threadIdx.x;
+    const bool mine = (int)threadIdx.x < CPB && c < C;
+    const float m_c = (mine && mean != nullptr) ? mean[c] : 0.f, i_c = (mine && mean != nullptr) ? invstd[c] : 0.f;   // (before the reduction: see bn_finalize_block)
     double s, q;
     reduce_parts<CPB>(part, nparts, C, cblock, red, s, q, rstride);
-    if ((int)threadIdx.x < CPB && c < C) {
+    if (mine) {
         // producers that reduce in their epilogue (mpn_conv_bwd_data_bn) sum g * x: sum g * xhat = invstd * (sum g x - mean * sum g)
-        if (mean != nullptr) q = (q - (double)mean[c] * s) * (double)invstd[c];
+        if (mean != nullptr) q = (q - (double)m_c * s) * (double)i_c;
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         k1[c] = (float)(s / count);
