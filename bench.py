@@ -319,6 +319,9 @@ def main():
             out["north_star_kernels"] = north_star_kernels(args.batch)
             out["f32_build"] = f32_build_rate(args.batch, args.size)          # the build that meets the 1e-3 parity bound
             out["bf16_vs_f32"] = bf16_vs_f32_argmax_agreement(args.batch, args.size)
+            from bench_legs import trained_bf16_parity
+            tp = trained_bf16_parity()                                         # ... and on TRAINED (sharp) heatmaps
+            out["bf16_vs_f32_trained"] = {k: v for k, v in tp.items() if not k.startswith("_")}
         out["prn"] = prn_benchmark(128)
         from bench_legs import retinanet_benchmark
         out["retinanet"] = retinanet_benchmark(16)               # BASELINE config 4

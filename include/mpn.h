@@ -193,7 +193,10 @@ int mpn_bn_bwd_apply_grouped(int njobs, void* const* dA, const void* const* x, c
  * keypoint_subnet.py:64-91, produce their statistics side by side). Descriptor tables as for the batched slab reduction:
  * mpn_bn_fin_desc_fill / mpn_bn_bwd_fin_desc_fill write one host-side descriptor each (mpn_*_desc_bytes() bytes; return the
  * number of blocks of the job, -1 on bad arguments; block_begin = running sum); the caller copies the array to the device
- * once. Same arithmetic, bit for bit, as mpn_bn_finalize / mpn_bn_bwd_finalize per layer. */
+ * once. Same arithmetic, bit for bit, as mpn_bn_finalize / mpn_bn_bwd_finalize per layer BELOW 4096 partial rows; from 4096 rows
+ * on the per-layer entry points first add groups of 32 rows in place (f64 inside a group, the group's sum rounded to f32: `part`
+ * is scratch and is DESTROYED - finalizing the same slab twice double-counts), which the batched kernels do not: the two then
+ * agree to f32 rounding of the group sums (tests/test_ops_bwd_gpu.py::test_batched_and_per_layer_finalize_from_4096_rows). */
 size_t mpn_bn_fin_desc_bytes(void);
 size_t mpn_bn_bwd_fin_desc_bytes(void);
 int mpn_bn_fin_desc_fill(void* desc_host, const float* part, int nparts, int C, long long count, const float* gamma,

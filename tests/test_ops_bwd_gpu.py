@@ -590,6 +590,36 @@ def test_finalizes_over_thousands_of_partial_rows(cuda, nparts, C):
     np.testing.assert_allclose(bn.dgamma.cpu().numpy(), want, atol=1e-5 * float(np.abs(want).max()) + tol * float(np.abs(m_ * i_).max() + i_.max()))
 
 
+def test_batched_and_per_layer_finalize_from_4096_rows(cuda):
+    """from 4096 partial rows on the per-layer finalizes compact the slab in place first (group sums rounded to
+    f32, the slab destroyed), the batched ones do not - include/mpn.h says so now. Here: exactly 4096 rows (the subnet's level-2
+    3x3 layers at batch 32 @ 512x512), both paths on copies of one slab: equal to f32 rounding of the group sums, the per-layer
+    call leaves its slab changed (compacted), the batched call leaves it untouched."""
+    ops = _ops()
+    rs = np.random.RandomState(77)
+    C, nparts = 128, 4096
+    count = nparts * 256
+    slab = (rs.rand(nparts, 2, C) * 50 + 5).astype(np.float32)
+    slab[:, 1] = slab[:, 0] ** 2 / 256 + rs.rand(nparts, C).astype(np.float32) * 20
+
+    def mk():
+        bn = ops.BNState(torch.full((C,), 1.25, device="cuda"), torch.full((C,), -0.5, device="cuda"), torch.zeros(C, device="cuda"),
+                         torch.ones(C, device="cuda"), 1)
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+    a, b = mk(), mk()
+    pa, pb = torch.tensor(slab).cuda().view(-1), torch.tensor(slab).cuda().view(-1)
+    ops.bn_finalize(a, pa, nparts, count, training=True)
+    ops.BnFinalizeBatch([(b, pb, nparts, count)], "cuda:0").run()
+    torch.cuda.synchronize()
+    assert torch.equal(pb.cpu(), torch.tensor(slab).view(-1))           # batched: the slab is read only
+    assert not torch.equal(pa.cpu(), torch.tensor(slab).view(-1))       # per layer: compacted in place (scratch)
+    for f in ("scale", "shift", "mean", "invstd", "moving_mean", "moving_var"):
+        np.testing.assert_allclose(getattr(a, f).cpu().numpy(), getattr(b, f).cpu().numpy(), rtol=3e-6, atol=1e-7, err_msg=f)
+    s64 = slab.astype(np.float64).sum(0)
+    np.testing.assert_allclose(b.mean.cpu().numpy(), s64[0] / count, rtol=1e-6)
+
+
 def test_axpy_batched_equals_per_tensor_axpy(cuda):
     """mpn_axpy_batched (the weight-decay gradient of every regularised variable in one launch, keypoints_model.py:129-138)
     on 70 tensors of ragged sizes (two launches of <= 64 jobs): bit for bit the per-tensor mpn_axpy, nothing outside."""
