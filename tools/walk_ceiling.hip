@@ -62,6 +62,81 @@ __global__ __launch_bounds__(256) void walk(const unsigned char* __restrict__ x,
     }
 }
 
+// Mixed piece sizes: which side's request size matters? A thread owns 16 bytes of channels of a column pair; LV / SV = bytes per load /
+// store instruction (8: two instructions per piece, 512-byte wave requests; 16: one, 1-KB requests).
+template <int LV, int SV>
+__global__ __launch_bounds__(256) void walk_mixed(const unsigned char* __restrict__ x, unsigned char* __restrict__ y, int H, int W, int C,
+                                                   int rows, int ncg, int cols, int xblocks, int yblocks, int cblocks) {
+    int b = blockIdx.x;
+    const int xb = b % xblocks; b /= xblocks;
+    const int yb = b % yblocks; b /= yblocks;
+    const int cgb = b % cblocks;
+    const int img = b / cblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;
+    const long long cbyte = (long long)(cgb * ncg + cgl) * 16;
+    const int ox = (xb * cols + col) * 2;
+    if (ox >= W || col >= cols) return;
+    const long long rowb = (long long)W * C * 2, pixb = (long long)C * 2;
+    const unsigned char* xi = x + (long long)img * H * rowb + cbyte;
+    unsigned char* yo = y + (long long)img * H * rowb + cbyte + (long long)ox * pixb;
+    long long xoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) xoff[k] = (long long)std::min(std::max(ox - 1 + k, 0), W - 1) * pixb;
+    const int oy0 = yb * rows, oy1 = std::min(oy0 + rows, H);
+    uint4 buf[2][4];
+    auto load = [&](uint4 (&r)[4], int iy) {
+        const unsigned char* rp = xi + (long long)std::min(std::max(iy, 0), H - 1) * rowb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (LV == 16) r[k] = *reinterpret_cast<const uint4*>(rp + xoff[k]);
+            else {
+                const uint2 a = *reinterpret_cast<const uint2*>(rp + xoff[k]), c = *reinterpret_cast<const uint2*>(rp + xoff[k] + 8);
+                r[k] = make_uint4(a.x, a.y, c.x, c.y);
+            }
+        }
+    };
+    load(buf[0], oy0 - 1); load(buf[1], oy0);
+    uint4 w0 = buf[0][0], w1 = buf[0][3];
+    for (int oy = oy0; oy < oy1; oy += 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (oy + j < oy1) {
+                uint4 a = buf[j][0], c = buf[j][2];
+                a.x += buf[j][1].x + w0.x; a.y ^= buf[j][1].y ^ w0.y; a.z += buf[j][1].z + w0.z; a.w ^= buf[j][1].w ^ w0.w;
+                c.x += buf[j][3].x + w1.x; c.y ^= buf[j][3].y ^ w1.y; c.z += buf[j][3].z + w1.z; c.w ^= buf[j][3].w ^ w1.w;
+                w0 = buf[j][1]; w1 = buf[j][2];
+                load(buf[j], oy + j + 1);
+                unsigned char* yp = yo + (long long)(oy + j) * rowb;
+                if (SV == 16) {
+                    *reinterpret_cast<uint4*>(yp) = a;
+                    if (ox + 1 < W) *reinterpret_cast<uint4*>(yp + pixb) = c;
+                } else {
+                    *reinterpret_cast<uint2*>(yp) = make_uint2(a.x, a.y); *reinterpret_cast<uint2*>(yp + 8) = make_uint2(a.z, a.w);
+                    if (ox + 1 < W) { *reinterpret_cast<uint2*>(yp + pixb) = make_uint2(c.x, c.y); *reinterpret_cast<uint2*>(yp + pixb + 8) = make_uint2(c.z, c.w); }
+                }
+            }
+        }
+    }
+}
+template <int LV, int SV>
+static double run_mixed(int N, int H, int W, int C, int rows, std::vector<unsigned char*>& xs, std::vector<unsigned char*>& ys, int iters) {
+    int ncg = C / 8; if (ncg > 16) ncg = 16;
+    const int cblocks = (C / 8) / ncg, cols = 256 / ncg;
+    const int xblocks = (W / 2 + cols - 1) / cols, yblocks = (H + rows - 1) / rows;
+    const int grid = N * yblocks * xblocks * cblocks;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int ns = (int)xs.size();
+    for (int i = 0; i < ns; ++i) walk_mixed<LV, SV><<<grid, 256>>>(xs[i], ys[i], H, W, C, rows, ncg, cols, xblocks, yblocks, cblocks);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) walk_mixed<LV, SV><<<grid, 256>>>(xs[i % ns], ys[i % ns], H, W, C, rows, ncg, cols, xblocks, yblocks, cblocks);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e-3 / iters;
+}
+
 // The same walk with the input rows staged by LDS-DMA into a WAVE-PRIVATE ring of D rows (no block barriers: a wave waits
 // for its own DMA with a counted vmcnt and reads only what it fetched): thread = 8 bytes of channels of one column pair as in
 // the shipped kernel, a wave = 64 / ncg column pairs, its ring row = (2 * pairs + 2) pixels x C x 2 bytes fetched by
@@ -210,6 +285,9 @@ int main() {
 #define RUNR(D) { const double t = run_ring<D>(N, H, W, C, rows, xs, ys, iters); \
             if (t > 0) printf("  rows/strip %2d  LDS-DMA ring of %d rows per wave, 8-byte window reads: %6.1f us  %.3f of 8 TB/s\n", rows, D, t * 1e6, tb / t / 8e12); fflush(stdout); }
             RUNR(3) RUNR(4) RUNR(6) RUNR(8)
+#define RUNM(L, S) { const double t = run_mixed<L, S>(N, H, W, C, rows, xs, ys, iters); \
+            printf("  rows/strip %2d  16-byte lanes, %2d-byte loads, %2d-byte stores: %6.1f us  %.3f of 8 TB/s\n", rows, L, S, t * 1e6, tb / t / 8e12); fflush(stdout); }
+            if (rows == 32) { RUNM(16, 16) RUNM(8, 16) RUNM(16, 8) RUNM(8, 8) }
         }
         for (int i = 0; i < ns; ++i) { CK(hipFree(xs[i])); CK(hipFree(ys[i])); }
     }
