@@ -8,6 +8,7 @@
 // each thread then produces 16 bytes of output channels for a few pixels out of LDS.
 // The following batch-norm's partial statistics come out of the same pass (wave shuffles over
 // the lanes that share a channel vector, then one LDS hop across the 4 waves).
+#include <type_traits>
 #include "common.h"
 #include <stdlib.h>
 
@@ -501,13 +502,20 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw2_kernel(const DwParams
         xok[k] = ok0 && ix >= 0 && ix < p.W;
         xoff[k] = (xok[k] ? ix : 0) * p.C;
     }
+    // every lane of the wave has its whole 4-column window inside the image (all but the waves that touch the left / right
+    // border): the twelve zero-selects per row are skipped - the walk is co-limited by its vector instruction stream (115 per row
+    // step: profiles/r04_dwconv_traffic.json) - on a wave-uniform branch around the whole walk
+    const bool interior = __all(xok[0] && xok[2] && xok[3]) != 0;
+    // (measured and not adopted: buffer loads with the image as a wave-uniform descriptor, the row as a scalar offset and a 32-bit
+    //  per-lane offset - seven 64-bit vector address instructions per row less, and 2-6 % SLOWER on cold tensors)
     auto row_load = [&](Raw4<T> (&r)[4], int iy) {
         const int iyc = min(max(iy, 0), p.H - 1);
         const T* rowp = ximg + (long long)iyc * p.W * p.C;
 #pragma unroll
         for (int k = 0; k < 4; ++k) raw_load(r[k], rowp + xoff[k]);
     };
-    auto row_act = [&](const Raw4<T> (&r)[4], int iy, f32x2_t (&a)[4][2]) {
+    auto row_act = [&](auto edge, const Raw4<T> (&r)[4], int iy, f32x2_t (&a)[4][2]) __attribute__((always_inline)) {
+        constexpr bool EDGE = decltype(edge)::value;
         if (iy < 0 || iy >= p.H) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) { a[k][0] = (f32x2_t){0.f, 0.f}; a[k][1] = (f32x2_t){0.f, 0.f}; }
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw2_kernel(const DwParams
 #pragma unroll
                 for (int j = 0; j < 4; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);
             }
-            if (k != 1) {   // (column 1 = the first output's own column: inside the image whenever the lane is)
+            if (k != 1 && EDGE) {   // (column 1 = the first output's own column: inside the image whenever the lane is)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) f[j] = xok[k] ? f[j] : 0.f;
             }
@@ -594,37 +602,42 @@ __global__ __launch_bounds__(kThreads) void dwconv_fwd_sw2_kernel(const DwParams
         }
         yp += ystep;
     };
-    Raw4<T> ra[4], rb[4], rc[4], ya[2], yb2[2], yc[2];
-    int iy = oy_begin - p.pad_t;
-    row_load(ra, iy);
-    row_load(rb, iy + 1);
-    row_load(rc, iy + 2);
-    bnr_load(ya, oy_begin);
-    bnr_load(yb2, oy_begin + 1);
-    bnr_load(yc, oy_begin + 2);
-    row_act(ra, iy, r0);
-    row_load(ra, iy + 3);
-    row_act(rb, iy + 1, r1);
-    row_load(rb, iy + 4);
-    iy += 2;
-    for (int oy = oy_begin; oy < oy_end; oy += 3, iy += 3) {
-        row_act(rc, iy, r2);
-        row_load(rc, iy + 3);
-        emit(r0, r1, r2, ya);
-        bnr_load(ya, oy + 3);
-        if (oy + 1 < oy_end) {
-            row_act(ra, iy + 1, r0);
-            row_load(ra, iy + 4);
-            emit(r1, r2, r0, yb2);
-            bnr_load(yb2, oy + 4);
+    // the walk, once per variant of the row activation (a wave-uniform branch around the whole loop: inside it hipcc turns the
+    // condition back into selects)
+    auto walk = [&](auto edge) __attribute__((always_inline)) {
+        Raw4<T> ra[4], rb[4], rc[4], ya[2], yb2[2], yc[2];
+        int iy = oy_begin - p.pad_t;
+        row_load(ra, iy);
+        row_load(rb, iy + 1);
+        row_load(rc, iy + 2);
+        bnr_load(ya, oy_begin);
+        bnr_load(yb2, oy_begin + 1);
+        bnr_load(yc, oy_begin + 2);
+        row_act(edge, ra, iy, r0);
+        row_load(ra, iy + 3);
+        row_act(edge, rb, iy + 1, r1);
+        row_load(rb, iy + 4);
+        iy += 2;
+        for (int oy = oy_begin; oy < oy_end; oy += 3, iy += 3) {
+            row_act(edge, rc, iy, r2);
+            row_load(rc, iy + 3);
+            emit(r0, r1, r2, ya);
+            bnr_load(ya, oy + 3);
+            if (oy + 1 < oy_end) {
+                row_act(edge, ra, iy + 1, r0);
+                row_load(ra, iy + 4);
+                emit(r1, r2, r0, yb2);
+                bnr_load(yb2, oy + 4);
+            }
+            if (oy + 2 < oy_end) {
+                row_act(edge, rb, iy + 2, r1);
+                row_load(rb, iy + 5);
+                emit(r2, r0, r1, yc);
+                bnr_load(yc, oy + 5);
+            }
         }
-        if (oy + 2 < oy_end) {
-            row_act(rb, iy + 2, r1);
-            row_load(rb, iy + 5);
-            emit(r2, r0, r1, yc);
-            bnr_load(yc, oy + 5);
-        }
-    }
+    };
+    if (interior) walk(std::false_type{}); else walk(std::true_type{});
     if (p.part != nullptr) {
         float st[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
 #pragma unroll
