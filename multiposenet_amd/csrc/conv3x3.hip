@@ -193,7 +193,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     Vec16<T> av[kAVec];
     auto a_load = [&](const Tile& t, int chunk) {
         const Job& p = g.job[t.job];
-        const T* xb = reinterpret_cast<const T*>(p.x) + slot * 8 + chunk * 64;
+        // Offsets in full-rate arithmetic (the ISA of the first version: 34 v_mul_lo_u32 + 12 v_mul_hi_i32 per chunk and thread - quarter
+        // rate, ~740 of the ~2 100 issue cycles this lambda cost a wave): the image base is scalar, row and column offsets are 24-bit
+        // multiplies (launch() checks W * xs < 2^24 and the tensor below 2^31 elements), pixel / 18 = pixel * 3641 >> 16 (exact below 1024)
+        const int wxs = p.W * p.xs;
+        const T* xb = reinterpret_cast<const T*>(p.x) + (long long)t.img * p.H * wxs + slot * 8 + chunk * 64;
         okmask = 0;
         int pr = prow;
         asm volatile("" : "+v"(pr));   // opaque: keeps the offset arithmetic here instead of hoisted (and spilled) across the tile loop
@@ -201,12 +205,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         for (int i = 0; i < kAVec; ++i) {
             const int pix = pr + i * 64;
             const int pc = pix < kNPix ? pix : kNPix - 1;
-            const int hy = pc / kHW, hx = pc - hy * kHW;
+            static_assert(kHW == 18, "hx = pc - 18 hy below");
+            const int hy = (int)(__umul24((unsigned)pc, 3641u) >> 16), hx = pc - ((hy << 4) + (hy << 1));
             const int iy = t.oy0 + hy - 1, ix = t.ox0 + hx - 1;
-            const bool ok = pix < kNPix && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            // (bitwise, unsigned compares: the short-circuit form compiles to exec-mask branches around every test)
+            const bool ok = (pix < kNPix) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             okmask |= (ok ? 1u : 0u) << i;
             const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-            av[i].load(xb + ((t.img * p.H + iyc) * p.W + ixc) * p.xs);      // (launch() checks that the offsets fit 31 bits)
+            av[i].load(xb + (int)(__umul24((unsigned)iyc, (unsigned)wxs) + __umul24((unsigned)ixc, (unsigned)p.xs)));
         }
     };
     auto a_commit = [&](int buf, int chunk) {
@@ -601,6 +607,8 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
         MPN_REQUIRE((jobs[j].in_scale != nullptr) == affine, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the affine / no affine variant");
         MPN_REQUIRE((long long)jobs[j].N * jobs[j].H * jobs[j].W * jobs[j].xs < (1ll << 31), MPN_ERR_BAD_SHAPE,
                     "conv3x3: the input tensor must span fewer than 2^31 elements");
+        MPN_REQUIRE((long long)jobs[j].W * jobs[j].xs < (1ll << 24) && jobs[j].H < (1 << 24), MPN_ERR_BAD_SHAPE,
+                    "conv3x3: a pixel row must span fewer than 2^24 elements (24-bit offset arithmetic)");
         g.job[j] = jobs[j];
         g.begin[j] = begin;
         begin += blocks_of(jobs[j]);
