@@ -82,6 +82,16 @@ template <> __device__ __forceinline__ float from_f32<float>(float x) { return x
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
 template <> __device__ __forceinline__ half_t from_f32<half_t>(float x) { return (half_t)x; }   // v_cvt_f16_f32: round to nearest even
 
+// Two f32 -> one dword of two bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32 (RNE, a NaN stays a NaN). Written as two scalar
+// casts + shift + or, hipcc emits two converts, a shift and a v_or_b32_sdwa - four instructions per pair in every staging and
+// epilogue path (found in the 3x3 kernel's commit: 48 converts + 24 merges for 24 pairs).
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
+}
+
 // 16-byte vector of T, unpacked to / packed from f32 registers.
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
@@ -121,10 +131,7 @@ template <> struct Vec16<bf16_t> {
         unsigned u[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            // plain casts: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
-            const bf16_t lo = (bf16_t)f[2 * i], hi = (bf16_t)f[2 * i + 1];
-            u[i] = (unsigned)__builtin_bit_cast(unsigned short, lo) |
-                   ((unsigned)__builtin_bit_cast(unsigned short, hi) << 16);
+            u[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
         }
         raw = make_uint4(u[0], u[1], u[2], u[3]);
     }

@@ -118,10 +118,9 @@ __device__ __forceinline__ void apply_affine_act(Vec16<T>& v, const float* sc, c
 // 4 consecutive channels of the storage type <-> f32
 __device__ __forceinline__ void store4(float* p, const f32x4_t& v) { *reinterpret_cast<f32x4_t*>(p) = v; }
 __device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) {
-    const bf16_t a = (bf16_t)v[0], b = (bf16_t)v[1], c = (bf16_t)v[2], d = (bf16_t)v[3];
     uint2 q;
-    q.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-    q.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    q.x = pack_bf16x2(v[0], v[1]);
+    q.y = pack_bf16x2(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = q;
 }
 __device__ __forceinline__ void store4(half_t* p, const f32x4_t& v) {

@@ -66,10 +66,9 @@ __device__ __forceinline__ void store4(float* p, const float (&f)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float (&f)[4]) {
-    const bf16_t a = (bf16_t)f[0], b = (bf16_t)f[1], c = (bf16_t)f[2], d = (bf16_t)f[3];
     uint2 q;
-    q.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-    q.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    q.x = pack_bf16x2(f[0], f[1]);
+    q.y = pack_bf16x2(f[2], f[3]);
     *reinterpret_cast<uint2*>(p) = q;
 }
 

@@ -174,10 +174,9 @@ __device__ __forceinline__ void store4(float* p, const float (&f)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(f[0], f[1], f[2], f[3]);
 }
 __device__ __forceinline__ void store4(bf16_t* p, const float (&f)[4]) {
-    const bf16_t a = (bf16_t)f[0], b = (bf16_t)f[1], c = (bf16_t)f[2], d = (bf16_t)f[3];
     uint2 q;
-    q.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-    q.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    q.x = pack_bf16x2(f[0], f[1]);
+    q.y = pack_bf16x2(f[2], f[3]);
     *reinterpret_cast<uint2*>(p) = q;
 }
 
@@ -440,11 +439,8 @@ __global__ __launch_bounds__(kThreads, 2) void head_bwd_mfma_kernel(const bf16_t
                 const bool live = m0 + px < M;
                 const float g0 = live ? dv[k].x : 0.f, g1 = live ? dv[k].y : 0.f;
                 const bf16_t h0 = (bf16_t)g0, h1 = (bf16_t)g1;
-                const bf16_t l0 = (bf16_t)(g0 - (float)h0), l1 = (bf16_t)(g1 - (float)h1);
-                *reinterpret_cast<unsigned*>(d_hi + px * DRS + pr * 4) =
-                    (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-                *reinterpret_cast<unsigned*>(d_lo + px * DRS + pr * 4) =
-                    (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+                *reinterpret_cast<unsigned*>(d_hi + px * DRS + pr * 4) = pack_bf16x2(g0, g1);
+                *reinterpret_cast<unsigned*>(d_lo + px * DRS + pr * 4) = pack_bf16x2(g0 - (float)h0, g1 - (float)h1);
             }
         }
     };

@@ -32,10 +32,15 @@ __global__ void adam_prepare_kernel(long long* __restrict__ step, float* __restr
 constexpr int kAdamCast = 4;
 struct AdamCast { long long begin4[kAdamCast], end4[kAdamCast]; void* dst[kAdamCast]; int count, dtype; };
 template <typename T> __device__ __forceinline__ void adam_cast_store(void* dst, long long i4, const float4& q) {
-    const T a = (T)q.x, b = (T)q.y, c = (T)q.z, d = (T)q.w;
     uint2 o;
-    o.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
-    o.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    if constexpr (sizeof(T) == 2 && !__is_same(T, half_t)) {      // bf16: one convert per pair (common.h)
+        o.x = pack_bf16x2(q.x, q.y);
+        o.y = pack_bf16x2(q.z, q.w);
+    } else {
+        const T a = (T)q.x, b = (T)q.y, c = (T)q.z, d = (T)q.w;
+        o.x = (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+        o.y = (unsigned)__builtin_bit_cast(unsigned short, c) | ((unsigned)__builtin_bit_cast(unsigned short, d) << 16);
+    }
     reinterpret_cast<uint2*>(dst)[i4] = o;
 }
 template <int U, bool CAST>

@@ -282,10 +282,9 @@ __global__ __launch_bounds__(kThreads) void stem_fwd_mfma_kernel(const void* __r
 #pragma unroll
         for (int mb = 0; mb < MB; ++mb) {
             const acc_t c = acc[gi][mb];
-            const bf16_t o0 = (bf16_t)c[0], o1 = (bf16_t)c[1], o2 = (bf16_t)c[2], o3 = (bf16_t)c[3];
             uint2 q;
-            q.x = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
-            q.y = (unsigned)__builtin_bit_cast(unsigned short, o2) | ((unsigned)__builtin_bit_cast(unsigned short, o3) << 16);
+            q.x = pack_bf16x2(c[0], c[1]);
+            q.y = pack_bf16x2(c[2], c[3]);
             *reinterpret_cast<uint2*>(dst + mb * 32) = q;
         }
     }
