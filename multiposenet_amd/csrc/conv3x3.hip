@@ -260,12 +260,13 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     auto bnr_load = [&](const Tile& t, int hp) {
         if constexpr (BNR) {
             const Job& p = g.job[t.job];
-            const T* xb = reinterpret_cast<const T*>(p.bnr_x) + t.ntile * BN + (N64 ? 0 : wn * 64) + (lane & 7) * 8;
+            const int wbs = p.W * p.bnr_xs;          // (scalar image base + 24-bit offsets: see a_load)
+            const T* xb = reinterpret_cast<const T*>(p.bnr_x) + (long long)t.img * p.H * wbs + t.ntile * BN + (N64 ? 0 : wn * 64) + (lane & 7) * 8;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = (lane >> 3) + 8 * k;
                 const int oy = min(t.oy0 + 4 * wm + hp * 2 + (row >> 4), p.H - 1), ox = min(t.ox0 + (row & 15), p.W - 1);
-                bx[(N64 ? 0 : hp * 4) + k] = *reinterpret_cast<const uint4*>(xb + (((long long)t.img * p.H + oy) * p.W + ox) * p.bnr_xs);
+                bx[(N64 ? 0 : hp * 4) + k] = *reinterpret_cast<const uint4*>(xb + (int)(__umul24((unsigned)oy, (unsigned)wbs) + __umul24((unsigned)ox, (unsigned)p.bnr_xs)));
             }
         }
     };
@@ -439,6 +440,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             for (int j = 0; j < 8; ++j) ones[j] = 1.0f;
             // copy-out lanes: lane j moves 16-byte piece j % 8 of image rows j / 8 + 8 k (8 lanes = the wave's 128 bytes of a pixel)
             const int cpiece = lane & 7, crow = lane >> 3;
+            const int wys = p.W * p.ys;
+            T* __restrict__ yimg = y + (long long)cur.img * p.H * wys + n0 + (N64 ? 0 : wn * 64);   // (wave-uniform)
 #pragma unroll
             for (int hpi = 0; hpi < (N64 ? 1 : 2); ++hpi) {
                 const int hp = N64 ? wn : hpi;                                // (N64: the rows this wave finishes; their sums sit in acc[0..1])
@@ -500,8 +503,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         }
                         o = make_uint4(du[0], du[1], du[2], du[3]);
                     }
+                    // (scalar image base + 24-bit row / column offsets, as in a_load: the 64-bit form was 36 v_mul_lo_u32 + 19
+                    //  v_mad_u64_u32 per tile and thread - quarter rate; launch() checks the output tensor below 2^31 elements)
                     if (oy < p.H && ox < p.W)
-                        *reinterpret_cast<uint4*>(y + (((long long)cur.img * p.H + oy) * p.W + ox) * p.ys + n0 + (N64 ? 0 : wn * 64) + cpiece * 8) = o;
+                        *reinterpret_cast<uint4*>(yimg + (int)(__umul24((unsigned)oy, (unsigned)wys) + __umul24((unsigned)ox, (unsigned)p.ys)) + cpiece * 8) = o;
                 }
             }
             if constexpr (BNR) {
@@ -607,8 +612,10 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
         MPN_REQUIRE((jobs[j].in_scale != nullptr) == affine, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the affine / no affine variant");
         MPN_REQUIRE((long long)jobs[j].N * jobs[j].H * jobs[j].W * jobs[j].xs < (1ll << 31), MPN_ERR_BAD_SHAPE,
                     "conv3x3: the input tensor must span fewer than 2^31 elements");
-        MPN_REQUIRE((long long)jobs[j].W * jobs[j].xs < (1ll << 24) && jobs[j].H < (1 << 24), MPN_ERR_BAD_SHAPE,
-                    "conv3x3: a pixel row must span fewer than 2^24 elements (24-bit offset arithmetic)");
+        MPN_REQUIRE((long long)jobs[j].W * jobs[j].xs < (1ll << 24) && (long long)jobs[j].W * jobs[j].ys < (1ll << 24) && jobs[j].H < (1 << 24),
+                    MPN_ERR_BAD_SHAPE, "conv3x3: a pixel row must span fewer than 2^24 elements (24-bit offset arithmetic)");
+        MPN_REQUIRE((long long)jobs[j].N * jobs[j].H * jobs[j].W * jobs[j].ys < (1ll << 31), MPN_ERR_BAD_SHAPE,
+                    "conv3x3: the output tensor must span fewer than 2^31 elements");
         g.job[j] = jobs[j];
         g.begin[j] = begin;
         begin += blocks_of(jobs[j]);
@@ -624,6 +631,8 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
     const bool bnr = jobs[0].bnr_x != nullptr;
     for (int j = 0; j < njobs; ++j) {
         MPN_REQUIRE((jobs[j].bnr_x != nullptr) == bnr, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the fused-reduction variant");
+        MPN_REQUIRE(!bnr || ((long long)jobs[j].W * jobs[j].bnr_xs < (1ll << 24) && (long long)jobs[j].N * jobs[j].H * jobs[j].W * jobs[j].bnr_xs < (1ll << 31)),
+                    MPN_ERR_BAD_SHAPE, "conv3x3: the fed batch-norm's raw tensor must span fewer than 2^31 elements, a pixel row fewer than 2^24");
         MPN_REQUIRE(!bnr || (!affine && jobs[j].stats_part && jobs[j].bnr_scale && jobs[j].bnr_shift && jobs[j].bnr_xs >= jobs[j].Cout &&
                              jobs[j].bnr_xs % 8 == 0 && jobs[j].Cout <= kMaxCin && mpn_aligned16(jobs[j].bnr_x)),
                     MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a data gradient (no producer affine), a partial slab and the layer's affine");
