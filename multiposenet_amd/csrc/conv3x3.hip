@@ -24,6 +24,7 @@
 // pair adds its two partial accumulators through LDS (each wave hands over the half of the rows it will not finish: 8 KB per
 // wave, one block barrier) and finishes 32 pixels x 64 channels each.
 #include "conv3x3.h"
+#include <type_traits>
 
 namespace {
 using namespace mpn_c3;
@@ -41,26 +42,65 @@ constexpr int kAVec = (kNPix * 8 + kThreads - 1) / kThreads;   // 16-byte pieces
 constexpr int kRedBytes = 4 * 2 * 128 * (int)sizeof(float);
 constexpr int kMaxCin = 512;                 // scale / shift table of the producer's batch-norm: [2][kMaxCin] floats
 constexpr int kTabBytes = 2 * kMaxCin * (int)sizeof(float);
-constexpr int kLds = kSmem + kRedBytes + kTabBytes;
+#ifdef MPN_DIAG
+constexpr int kDiagBytes = 8 * 13 * 3 * 8;   // per-wave stage stamps (below)
+#else
+constexpr int kDiagBytes = 0;
+#endif
+constexpr int kLds = kSmem + kRedBytes + kTabBytes + kDiagBytes;
 static_assert(8 * 32 * (64 * 2 + 8) <= kABytes, "the wave-private epilogue images fit in one halo buffer");
 static_assert(kLds <= 160 * 1024, "LDS budget");
 static_assert(kAVec == 6, "the counted wait of a chunk's first stage assumes six halo loads per thread");
 
 // diagnostic build (tools/stamp_c3.py): s_memtime of this block's THIRD tile at the loop top (0), after each chunk (1, 2, ...)
 // and after the epilogue (7)
+// knock-outs (tools/ko_c3.sh; never in the shipped library): MPN_KO & 1 = no epilogue, & 2 = no halo staging inside the tile loop,
+// & 8 = every halo load from image 0 / tile 0 (cache-hot), & 16 = epilogue without the global stores
+#ifndef MPN_KO
+#define MPN_KO 0
+#endif
+// and, per WAVE, three stamps around the end of each of that tile's first 12 stages (before the counted wait, after it, after the
+// barrier) plus the start and the end of its epilogue: kept in LDS (a global store inside the loop would change the vector-memory
+// counter the waits count), copied out behind the block's slots at the end: dbg[256 * 8 + ((block * 8 + wave) * 13 + stage) * 3 + k]
 #ifdef MPN_DIAG
 #define C3_STAMP(k) do { if (g.job[0].dbg && threadIdx.x == 0 && titer == 2) g.job[0].dbg[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define C3_WSTAMP(st, k) do { if (g.job[0].dbg && titer == 2 && (st) < 13 && (threadIdx.x & 63) == 0) \
+    wst[((threadIdx.x >> 6) * 13 + (st)) * 3 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define C3_STAMP(k) do { } while (0)
+#define C3_WSTAMP(st, k) do { } while (0)
 #endif
 
-template <typename T>
-__device__ __forceinline__ void affine_act(Vec16<T>& v, const float (&sc)[8], const float (&sh)[8], float lo, float hi) {
+// The producer's batch-norm affine + activation on eight 16-bit values: two elements per v_pk_fma_f32, rounded back to storage, and
+// the activation on the ROUNDED pairs as integers - sign-magnitude formats order like int16 on the non-negative side, so ReLU is
+// v_pk_max_i16(x, 0) and the upper clamp v_pk_min_i16(x, 6.0): one instruction per two elements instead of a v_med3_f32 per
+// element. Rounding is monotone and keeps 0 and 6 fixed, so act(round(v)) == round(act(v)) bit for bit (a -0.0 becomes +0.0).
+// lo2 = 0 (ReLU / ReLU6) or 0x80008000 (no activation: max with -32768 is the identity); RELU6 adds the upper clamp.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+__device__ __forceinline__ unsigned pk_min_i16(unsigned a, unsigned b) {
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+template <typename T> __device__ __forceinline__ constexpr unsigned six_pair() { return sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? 0x40C040C0u : 0x46004600u; }
+template <typename T, bool RELU6>
+__device__ __forceinline__ void affine_act(Vec16<T>& v, const f32x2_t (&sc)[4], const f32x2_t (&sh)[4], unsigned lo2) {
     float f[8];
     v.unpack(f);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) f[j] = __builtin_amdgcn_fmed3f(f[j] * sc[j] + sh[j], lo, hi);
+    for (int j = 0; j < 4; ++j) {
+        const f32x2_t r = __builtin_elementwise_fma((f32x2_t){f[2 * j], f[2 * j + 1]}, sc[j], sh[j]);
+        f[2 * j] = r[0]; f[2 * j + 1] = r[1];
+    }
     v.pack(f);
+    unsigned u[4] = {v.raw.x, v.raw.y, v.raw.z, v.raw.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        u[j] = pk_max_i16(u[j], lo2);
+        if (RELU6) u[j] = pk_min_i16(u[j], six_pair<T>());
+    }
+    v.raw = make_uint4(u[0], u[1], u[2], u[3]);
 }
 
 __device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) {
@@ -77,11 +117,13 @@ __device__ __forceinline__ void store4(half_t* p, const f32x4_t& v) {
 // A 16-byte LDS store the compiler does not see as one: in front of a C++ LDS store hipcc waits for every LDS-DMA in
 // flight (vmcnt(0): it cannot tell that the weight ring and the halo image do not overlap) - here that exposed the whole
 // latency of the weight stage requested at the top of the same stage, once per chunk.
+template <int OFF>
 __device__ __forceinline__ void lds_store16_raw(unsigned char* p, const uint4& v) {
+    static_assert(OFF >= 0 && OFF < 65536, "16-bit immediate offset");
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     const u32x4_t d = {v.x, v.y, v.z, v.w};
     const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)p;
-    asm volatile("ds_write_b128 %0, %1" :: "v"(a), "v"(d) : "memory");
+    asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(d), "n"(OFF) : "memory");
 }
 
 struct Group {
@@ -130,6 +172,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     unsigned char* Bs = smem + 2 * kABytes;        // [2][ky 3][128 co][64]
     float* red = reinterpret_cast<float*>(smem + kSmem);   // [4 wm][2][128] statistics of the tile that has just finished
     float* tab = reinterpret_cast<float*>(smem + kSmem + kRedBytes);   // [2][kMaxCin] scale, shift of the job in `tab_job`
+#ifdef MPN_DIAG
+    unsigned long long* wst = reinterpret_cast<unsigned long long*>(smem + kSmem + kRedBytes + kTabBytes);
+    for (int i = threadIdx.x; i < 8 * 13 * 3; i += kThreads) wst[i] = 0;
+#endif
 
     const int total = g.begin[g.njobs];
     // XCD-aware walk: the dispatcher deals consecutive block ids round-robin over the 8 XCDs (one L2 each); the blocks of one XCD
@@ -165,11 +211,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                                              (__attribute__((address_space(3))) void*)(dst + j * 8192), 16, 0, 0);
     };
 
-    // ---- halo staging: thread -> 16-byte slot tid % 8 of halo pixels tid / 8 + 64 i. Loads are unpredicated from clamped
-    // coordinates (a predicated load is waited for on the spot); pixels outside the image are zeroed at commit time.
-    const int slot = tid & 7, prow = tid >> 3;
-    const float act_lo = (AFFINE && g.job[0].in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;     // (in_act is shared by the jobs)
-    const float act_hi = (AFFINE && g.job[0].in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    // ---- halo staging: thread -> 16-byte slot tid % 8 of halo pixels q + 54 i, q = tid / 8 < 54, i = 0..5: three halo rows per
+    // step, so a thread's column hx = q % 18 is FIXED and its rows are hy = q / 18 + 3 i - the column terms of the address and of the
+    // range test are formed once per image, each load adds one row term (the first version walked pixels q + 64 i: a division by
+    // 18, two clamps and two multiplies per load, 111 vector instructions per image; now ~45). Threads with q >= 54 (two lanes of
+    // wave 6, all of wave 7) load clamped addresses and store nothing. Loads are unpredicated from clamped coordinates (a
+    // predicated load is waited for on the spot); pixels outside the image are zeroed at commit time.
+    const int slot = tid & 7, q54 = tid >> 3;
+    const int qy = (int)(__umul24((unsigned)q54, 3641u) >> 16), qx = q54 - ((qy << 4) + (qy << 1));
+    static_assert(kHW == 18 && kNPix == 6 * 54, "six steps of three halo rows");
+    const unsigned act_lo2 = (AFFINE && g.job[0].in_act != MPN_ACT_NONE) ? 0u : 0x80008000u;     // (in_act is shared by the jobs)
+    const bool act_relu6 = AFFINE && g.job[0].in_act == MPN_ACT_RELU6;
     int tab_job = -1;
     // the producer's scale / shift of a job, kept in LDS (16 registers per thread otherwise, live across two stages). Rewritten
     // only where no commit that reads the old table can follow before the next barrier.
@@ -187,55 +239,69 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             }
         }
     };
-    // The element offsets are recomputed per load (a few dozen scalar-ish VALU instructions per chunk) rather than kept: six more
-    // long-lived registers per thread spill.
     unsigned okmask = 0;        // of the tile whose halo was fetched last: pixel i of this thread lies inside the image
     Vec16<T> av[kAVec];
-    auto a_load = [&](const Tile& t, int chunk) {
+    // pieces I0 .. I0 + NP - 1 of the halo image of (tile, chunk) into av[]; a_load = all six
+    // (i0, np: constants once the stage loop is unrolled - the guards below fold away)
+    auto a_load_part = [&](const int i0, const int np, const Tile& t, int chunk) __attribute__((always_inline)) {
         const Job& p = g.job[t.job];
-        // Offsets in full-rate arithmetic (the ISA of the first version: 34 v_mul_lo_u32 + 12 v_mul_hi_i32 per chunk and thread - quarter
-        // rate, ~740 of the ~2 100 issue cycles this lambda cost a wave): the image base is scalar, row and column offsets are 24-bit
-        // multiplies (launch() checks W * xs < 2^24 and the tensor below 2^31 elements), pixel / 18 = pixel * 3641 >> 16 (exact below 1024)
-        const int wxs = p.W * p.xs;
-        const T* xb = reinterpret_cast<const T*>(p.x) + (long long)t.img * p.H * wxs + slot * 8 + chunk * 64;
-        okmask = 0;
-        int pr = prow;
-        asm volatile("" : "+v"(pr));   // opaque: keeps the offset arithmetic here instead of hoisted (and spilled) across the tile loop
+        // Offsets in full-rate arithmetic: the image base is scalar, row and column BYTE offsets are 24-bit multiplies added as an
+        // unsigned 32-bit offset to it (the load's scalar-base + vector-offset form: no 64-bit address arithmetic; launch() checks
+        // 2 W xs < 2^24 and the tensor below 2^31 elements)
+        const int wxb = p.W * p.xs * 2;
+#if (MPN_KO & 8)
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + (long long)chunk * 128;
+        const int ox0 = 0, oy0 = 0;
+#else
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + ((long long)t.img * p.H * (p.W * p.xs) + chunk * 64) * 2;
+        const int ox0 = t.ox0, oy0 = t.oy0;
+#endif
+        int hx = qx, hy = qy;
+        asm volatile("" : "+v"(hx), "+v"(hy));   // opaque: keeps the offset arithmetic here instead of hoisted (and spilled) across the tile loop
+        const int ix = ox0 + hx - 1;
+        const bool okx = (unsigned)ix < (unsigned)p.W;
+        const unsigned col = __umul24((unsigned)min(max(ix, 0), p.W - 1), (unsigned)(p.xs * 2)) + slot * 16;
+        if (i0 == 0) okmask = 0;
 #pragma unroll
         for (int i = 0; i < kAVec; ++i) {
-            const int pix = pr + i * 64;
-            const int pc = pix < kNPix ? pix : kNPix - 1;
-            static_assert(kHW == 18, "hx = pc - 18 hy below");
-            const int hy = (int)(__umul24((unsigned)pc, 3641u) >> 16), hx = pc - ((hy << 4) + (hy << 1));
-            const int iy = t.oy0 + hy - 1, ix = t.ox0 + hx - 1;
+            if (i < i0 || i >= i0 + np) continue;
+            const int iy = oy0 + (3 * i - 1) + hy;
             // (bitwise, unsigned compares: the short-circuit form compiles to exec-mask branches around every test)
-            const bool ok = (pix < kNPix) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const bool ok = okx & ((unsigned)iy < (unsigned)p.H);
             okmask |= (ok ? 1u : 0u) << i;
-            const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
-            av[i].load(xb + (int)(__umul24((unsigned)iyc, (unsigned)wxs) + __umul24((unsigned)ixc, (unsigned)p.xs)));
+            av[i].load(reinterpret_cast<const T*>(xb + (__umul24((unsigned)min(max(iy, 0), p.H - 1), (unsigned)wxb) + col)));
         }
     };
-    auto a_commit = [&](int buf, int chunk) {
-        unsigned char* dst = As + buf * kABytes + prow * kRS + slot * 16;
-        float sc[8], sh[8];
+    auto a_commit_t = [&](auto relu6, const int i0, const int np, int buf, int chunk) __attribute__((always_inline)) {
+        unsigned char* dst = As + buf * kABytes + q54 * kRS + slot * 16;
+        f32x2_t sc[4], sh[4];
         if constexpr (AFFINE) {
             const float* ts = tab + chunk * 64 + slot * 8;
             const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(ts), s1 = *reinterpret_cast<const f32x4_t*>(ts + 4);
             const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin), h1 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin + 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { sc[j] = s0[j]; sc[4 + j] = s1[j]; sh[j] = h0[j]; sh[4 + j] = h1[j]; }
+            sc[0] = (f32x2_t){s0[0], s0[1]}; sc[1] = (f32x2_t){s0[2], s0[3]}; sc[2] = (f32x2_t){s1[0], s1[1]}; sc[3] = (f32x2_t){s1[2], s1[3]};
+            sh[0] = (f32x2_t){h0[0], h0[1]}; sh[1] = (f32x2_t){h0[2], h0[3]}; sh[2] = (f32x2_t){h1[0], h1[1]}; sh[3] = (f32x2_t){h1[2], h1[3]};
         }
+        if (q54 < 54) {
 #pragma unroll
-        for (int i = 0; i < kAVec; ++i) {
-            if (prow + i * 64 < kNPix) {
-                if constexpr (AFFINE) affine_act<T>(av[i], sc, sh, act_lo, act_hi);
+            for (int i = 0; i < kAVec; ++i) {
+                if (i < i0 || i >= i0 + np) continue;
+                if constexpr (AFFINE) affine_act<T, decltype(relu6)::value>(av[i], sc, sh, act_lo2);
                 if (!((okmask >> i) & 1u)) av[i].zero();
-                lds_store16_raw(dst + i * 64 * kRS, av[i].raw);
+                if (i == 0) lds_store16_raw<0>(dst, av[i].raw);
+                if (i == 1) lds_store16_raw<1 * 54 * kRS>(dst, av[i].raw);
+                if (i == 2) lds_store16_raw<2 * 54 * kRS>(dst, av[i].raw);
+                if (i == 3) lds_store16_raw<3 * 54 * kRS>(dst, av[i].raw);
+                if (i == 4) lds_store16_raw<4 * 54 * kRS>(dst, av[i].raw);
+                if (i == 5) lds_store16_raw<5 * 54 * kRS>(dst, av[i].raw);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the compiler does not track the raw stores: complete before the barrier)
     };
-
+    auto a_commit_part = [&](const int i0, const int np, int buf, int chunk) __attribute__((always_inline)) {
+        // (a wave-uniform branch around the WHOLE commit: inside it hipcc would if-convert the clamp back into a select per element)
+        if (act_relu6) a_commit_t(std::true_type{}, i0, np, buf, chunk); else a_commit_t(std::false_type{}, i0, np, buf, chunk);
+    };
     // statistics rows of the tile that finished last, written after the next block barrier (red is complete by then)
     float* st_dst = nullptr;
     const int st_half = tid >> 8, st_which = (tid >> 7) & 1, st_c = tid & 127;
@@ -275,10 +341,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
     int cc = 0, ss = 0;        // running chunk / stage counters: halo buffer cc & 1, weight buffer ss & 1
     b_issue(wsrc, 0, 0);
-    a_load(cur, 0);
+    a_load_part(0, kAVec, cur, 0);
     tab_load(cur.job);
     __syncthreads();           // table visible
-    a_commit(0, 0);
+    a_commit_part(0, kAVec, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -312,13 +378,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 if (sl < NS - 1 || !last_chunk) b_issue(wsrc, chunk * NS + sl + 1, (ss + 1) & 1);
                 else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
                 if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, N64 ? wn : 0); }
+#if !(MPN_KO & 2)
                 if (sl == 0) {
                     // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
-                    // the six registers become PHIs, hipcc copies them right behind the loads - and waits for the loads there
-                    if (last_chunk) a_load(nxt, 0); else a_load(cur, chunk + 1);
+                    // the six registers become PHIs, hipcc copies them right behind the loads - and waits for the loads there.
+                    // (Spreading the six loads over the chunk's first three stages, two per stage behind that stage's weight pieces,
+                    //  with the commits two stages later, changes nothing: the counted waits are short - profiles/r04_c3_stage_stamps.txt)
+                    if (last_chunk) a_load_part(0, kAVec, nxt, 0); else a_load_part(0, kAVec, cur, chunk + 1);
                     // (last chunk: this tile's commits are all behind a barrier - the table may change for the next tile's job)
                     if (last_chunk && has_next) tab_load(nxt.job);
                 }
+#endif
                 X8 a[6], b0[4], b1[4];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) a[r] = *reinterpret_cast<const X8*>(ab + a_off + r * (kHW * kRS));
@@ -342,7 +412,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 // the halo image prepared under this chunk: its loads have had two stages to land, and the buffer was last read
                 // in the previous chunk (the wave-private epilogue images in it: before the barrier of this chunk's first stage)
                 // (N64: sl == 2 is the chunk's last stage - the commit still completes in front of its barrier)
-                if (sl == 2 && stage_more) a_commit((cc + 1) & 1, last_chunk ? 0 : chunk + 1);
+#if !(MPN_KO & 2)
+                if (sl == 2 && stage_more) a_commit_part(0, kAVec, (cc + 1) & 1, last_chunk ? 0 : chunk + 1);
+#endif
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -350,21 +422,37 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 // this wave's pieces of the next weight stage have landed. In a chunk's first stage the six halo loads issued BEHIND
                 // them stay in flight (the counter retires in order; they are committed two stages later) - behind a raw barrier:
                 // __syncthreads() would wait for them too
-                if (sl == 0) {
+                C3_WSTAMP(chunk * NS + sl, 0);
+                if (sl == 0 && !(MPN_KO & 2)) {
                     asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                    C3_WSTAMP(chunk * NS + sl, 1);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    C3_WSTAMP(chunk * NS + sl, 1);
                     __syncthreads();
                 }
+                C3_WSTAMP(chunk * NS + sl, 2);
                 if (sl == 0 && chunk == 0) stats_flush();          // (every wave's `red` rows of the previous tile are visible)
             }
             C3_STAMP(1 + (chunk < 5 ? chunk : 5));
         }
 
+#if (MPN_KO & 1)
+        {
+            f32x4_t s4 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s4 += acc[i][j];
+            if (s4[0] + s4[1] + s4[2] + s4[3] == 12345.678f) reinterpret_cast<float*>(g.job[cur.job].y)[tid] = s4[0];
+        }
+#else
         // ================= epilogue of tile `cur`, wave-local. Halo buffer (cc - 1) & 1 is free: every wave is past the last
         // stage's barrier, and the next halo image to be committed into it comes two barriers from now.
         {
+            C3_WSTAMP(12, 0);
             const Job& p = g.job[cur.job];
             T* __restrict__ y = reinterpret_cast<T*>(p.y);
             const int n0 = cur.ntile * BN;
@@ -442,17 +530,23 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             const int cpiece = lane & 7, crow = lane >> 3;
             const int wys = p.W * p.ys;
             T* __restrict__ yimg = y + (long long)cur.img * p.H * wys + n0 + (N64 ? 0 : wn * 64);   // (wave-uniform)
-#pragma unroll
-            for (int hpi = 0; hpi < (N64 ? 1 : 2); ++hpi) {
+            // Full tiles (block-uniform) skip the zeroing of pixels outside the image (64 selects per wave) and the store predicates:
+            // a branch around the whole pass - inside it hipcc if-converts the test back into the selects.
+            const bool full_tile = cur.oy0 + 16 <= p.H && cur.ox0 + 16 <= p.W;
+            // a lane's store offset inside its wave's 32 pixels is a constant (row = crow + 8 k -> image row k / 2, column crow + 8 (k & 1));
+            // the rest of the address is scalar: the stores take a scalar base + this 32-bit byte offset, no vector address arithmetic
+            const unsigned lane_off = (unsigned)(crow * p.ys + cpiece * 8) * 2u;
+            auto ep_pass = [&](auto edge, const int hpi) __attribute__((always_inline)) {
+                constexpr bool EDGE = decltype(edge)::value;
                 const int hp = N64 ? wn : hpi;                                // (N64: the rows this wave finishes; their sums sit in acc[0..1])
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml) {
                     const int mt = hp * 2 + ml;
-                    const bool ok = (cur.oy0 + 4 * wm + mt) < p.H && (cur.ox0 + l15) < p.W;
+                    const bool ok = !EDGE || ((cur.oy0 + 4 * wm + mt) < p.H && (cur.ox0 + l15) < p.W);
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
                         f32x4_t v = N64 ? acc[ml][nt] : acc[hpi * 2 + ml][nt];
-                        if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};           // pixels outside the image must not count in the statistics
+                        if (EDGE && !ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // pixels outside the image must not count in the statistics
                         store4(reinterpret_cast<T*>(Ow + (ml * 16 + l15) * RSW + (nt * 16 + lq * 4) * 2), v);
                     }
                 }
@@ -470,7 +564,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                     }
                 }
                 // whole 128-byte pieces of pixel rows to HBM (the other 64-channel wave writes the other half of the 256 bytes):
-                // all eight LDS reads first (unconditional), then the predicated stores - one LDS round trip per 32 pixels
+                // all eight LDS reads first (unconditional), then the stores - one LDS round trip per 32 pixels
                 uint2 ca[4], cb[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -480,7 +574,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int row = crow + 8 * k;                              // image row = (ml, l15)
-                    const int oy = cur.oy0 + 4 * wm + hp * 2 + (row >> 4), ox = cur.ox0 + (row & 15);
+                    const int oyb = cur.oy0 + 4 * wm + hp * 2 + (k >> 1), oxb = cur.ox0 + 8 * (k & 1);     // (scalar)
                     uint4 o = make_uint4(ca[k].x, ca[k].y, cb[k].x, cb[k].y);
                     if constexpr (BNR) {
                         // g = dy where the fed batch-norm's activation passes (lo < x * scale + shift < hi, the test of
@@ -503,11 +597,16 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         }
                         o = make_uint4(du[0], du[1], du[2], du[3]);
                     }
-                    // (scalar image base + 24-bit row / column offsets, as in a_load: the 64-bit form was 36 v_mul_lo_u32 + 19
-                    //  v_mad_u64_u32 per tile and thread - quarter rate; launch() checks the output tensor below 2^31 elements)
-                    if (oy < p.H && ox < p.W)
-                        *reinterpret_cast<uint4*>(yimg + (int)(__umul24((unsigned)oy, (unsigned)wys) + __umul24((unsigned)ox, (unsigned)p.ys)) + cpiece * 8) = o;
+                    // (launch() checks the output tensor below 2^31 elements)
+                    unsigned char* ybase = reinterpret_cast<unsigned char*>(yimg + ((long long)oyb * wys + (long long)oxb * p.ys));
+                    const bool inside = !EDGE || (oyb < p.H && cur.ox0 + (row & 15) < p.W);
+                    if (inside && (!(MPN_KO & 16) || o.x == 0x12345678u))
+                        *reinterpret_cast<uint4*>(ybase + lane_off) = o;
                 }
+            };
+#pragma unroll
+            for (int hpi = 0; hpi < (N64 ? 1 : 2); ++hpi) {
+                if (full_tile) ep_pass(std::false_type{}, hpi); else ep_pass(std::true_type{}, hpi);
             }
             if constexpr (BNR) {
                 // the lanes of one 16-byte piece (lane bits 3..5 = the 8 row lanes): fixed butterfly, then lanes 0..7 hold the wave's
@@ -567,6 +666,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 }
             }
         }
+#endif
+        C3_WSTAMP(12, 1);
         C3_STAMP(7);
 #ifdef MPN_DIAG
         ++titer;
@@ -580,6 +681,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     stats_flush();
 #ifdef MPN_DIAG
     if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+    if (g.job[0].dbg) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 8 * 13 * 3; i += kThreads) g.job[0].dbg[(size_t)gridDim.x * 8 + (size_t)blockIdx.x * (8 * 13 * 3) + i] = wst[i];
+    }
 #endif
 }
 
@@ -612,8 +717,8 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
         MPN_REQUIRE((jobs[j].in_scale != nullptr) == affine, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the affine / no affine variant");
         MPN_REQUIRE((long long)jobs[j].N * jobs[j].H * jobs[j].W * jobs[j].xs < (1ll << 31), MPN_ERR_BAD_SHAPE,
                     "conv3x3: the input tensor must span fewer than 2^31 elements");
-        MPN_REQUIRE((long long)jobs[j].W * jobs[j].xs < (1ll << 24) && (long long)jobs[j].W * jobs[j].ys < (1ll << 24) && jobs[j].H < (1 << 24),
-                    MPN_ERR_BAD_SHAPE, "conv3x3: a pixel row must span fewer than 2^24 elements (24-bit offset arithmetic)");
+        MPN_REQUIRE((long long)jobs[j].W * jobs[j].xs < (1ll << 23) && (long long)jobs[j].W * jobs[j].ys < (1ll << 24) && jobs[j].H < (1 << 24),
+                    MPN_ERR_BAD_SHAPE, "conv3x3: a pixel row must span fewer than 2^23 input / 2^24 output elements (24-bit offset arithmetic)");
         MPN_REQUIRE((long long)jobs[j].N * jobs[j].H * jobs[j].W * jobs[j].ys < (1ll << 31), MPN_ERR_BAD_SHAPE,
                     "conv3x3: the output tensor must span fewer than 2^31 elements");
         g.job[j] = jobs[j];
