@@ -374,26 +374,34 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 // (N64: stage sl = kx holds both k-steps, this wave multiplies k-step wn)
                 const int a_off = N64 ? sl * kRS + wn * 64 : (sl >> 1) * kRS + (sl & 1) * 64;
                 const unsigned char* bb = bbase + (ss & 1) * kStageBytes;
-                // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
-                if (sl < NS - 1 || !last_chunk) b_issue(wsrc, chunk * NS + sl + 1, (ss + 1) & 1);
-                else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
-                if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, N64 ? wn : 0); }
+                // The stage's requests (next weight stage, in a chunk's first stage the next halo image): BEHIND the stage's first fragment
+                // reads - in front of them every wave of the block spent its first ~200 cycles behind the barrier issuing LDS-DMA pieces
+                // while the matrix pipe had nothing to do (same box: 135.3 -> 132.9 us with affine + statistics). The fused-reduction
+                // variants keep them in front: with ten fragments live across the requests they spill.
+                auto requests = [&]() __attribute__((always_inline)) {
+                    // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
+                    if (sl < NS - 1 || !last_chunk) b_issue(wsrc, chunk * NS + sl + 1, (ss + 1) & 1);
+                    else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
+                    if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, N64 ? wn : 0); }
 #if !(MPN_KO & 2)
-                if (sl == 0) {
-                    // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
-                    // the six registers become PHIs, hipcc copies them right behind the loads - and waits for the loads there.
-                    // (Spreading the six loads over the chunk's first three stages, two per stage behind that stage's weight pieces,
-                    //  with the commits two stages later, changes nothing: the counted waits are short - profiles/r04_c3_stage_stamps.txt)
-                    if (last_chunk) a_load_part(0, kAVec, nxt, 0); else a_load_part(0, kAVec, cur, chunk + 1);
-                    // (last chunk: this tile's commits are all behind a barrier - the table may change for the next tile's job)
-                    if (last_chunk && has_next) tab_load(nxt.job);
-                }
+                    if (sl == 0) {
+                        // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
+                        // the six registers become PHIs, hipcc copies them right behind the loads - and waits for the loads there.
+                        // (Spreading the six loads over the chunk's first three stages, two per stage behind that stage's weight pieces,
+                        //  with the commits two stages later, changes nothing: the counted waits are short - profiles/r04_c3_stage_stamps.txt)
+                        if (last_chunk) a_load_part(0, kAVec, nxt, 0); else a_load_part(0, kAVec, cur, chunk + 1);
+                        // (last chunk: this tile's commits are all behind a barrier - the table may change for the next tile's job)
+                        if (last_chunk && has_next) tab_load(nxt.job);
+                    }
 #endif
+                };
+                if constexpr (BNR) requests();
                 X8 a[6], b0[4], b1[4];
 #pragma unroll
                 for (int r = 0; r < 6; ++r) a[r] = *reinterpret_cast<const X8*>(ab + a_off + r * (kHW * kRS));
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) b0[nt] = *reinterpret_cast<const X8*>(bb + nt * 1024);
+                if constexpr (!BNR) requests();
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) b1[nt] = *reinterpret_cast<const X8*>(bb + 8192 + nt * 1024);
