@@ -303,8 +303,10 @@ def main():
                     r["achievable_peak"] = ceil["with_lds_operand_reads_TFLOPs"]
                     r["frac_of_achievable"] = round(r["achieved"] / ceil["with_lds_operand_reads_TFLOPs"], 4)
                 out["roofline"]["achievable_peak_detail"] = ceil
-            # the north star's kernel families inside the real step (per-launch HIP events over one eager step)
-            out["north_star_in_step"] = in_step_families(trainer, feats, labels, args.batch, args.size)
+            # the north star's kernel families inside the real step (per-launch HIP events over one eager step). N = 1 only: it
+            # STEPS the trainer, and with more ranks a step contains the gradient exchange - rank 0 must not enter a collective alone
+            if world == 1:
+                out["north_star_in_step"] = in_step_families(trainer, feats, labels, args.batch, args.size)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from bench_legs import cpu_baseline, decode_benchmark, render_benchmark, prn_benchmark
         from bench_legs import host_fed_rate

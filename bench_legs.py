@@ -172,8 +172,10 @@ def in_step_families(trainer, feats, labels, batch, size):
     backbone's pointwise 1x1 layers (forward + data + weight gradients) against BOTH peaks - as a family they are
     HBM-bound (144 FLOP per byte, machine balance 312). `frac` in `north_star_kernels` are the stand-alone cold launches."""
     from multiposenet_amd import _lib
-    graph = trainer.use_graph
-    trainer.use_graph = False
+    # Rank 0 runs this AFTER the timed region, alone: the eager step must not reach the gradient exchange (a collective that only
+    # one rank enters hangs the job at the final barrier) - the reducer is detached for these steps. bench.py calls it at N = 1 only.
+    graph, reducer = trainer.use_graph, trainer.reducer
+    trainer.use_graph, trainer.reducer = False, None
     try:
         for _ in range(2):
             trainer.step(feats, labels)          # eager warm-up
@@ -184,7 +186,7 @@ def in_step_families(trainer, feats, labels, batch, size):
         rec, _lib.PROFILE = _lib.PROFILE, None
     finally:
         _lib.PROFILE = None
-        trainer.use_graph = graph
+        trainer.use_graph, trainer.reducer = graph, reducer
     fam = {"depthwise": 0.0, "pointwise": 0.0}
     n = {"depthwise": 0, "pointwise": 0}
     total = 0.0
@@ -200,11 +202,11 @@ def in_step_families(trainer, feats, labels, batch, size):
     return {"source": "per-launch HIP events over one eager step (the launches the hipGraph replays)",
             "launches": len(rec), "sum_of_launches_us": round(total, 1),
             "depthwise": {"launches": n["depthwise"], "us": round(fam["depthwise"], 1), "algorithmic_GB": round(dw_bytes / 1e9, 3),
-                          "frac_of_8TBps": round(dw_bytes / (fam["depthwise"] * 1e-6) / 8e12, 3)},
+                          "frac_of_8TBps": round(dw_bytes / (max(fam["depthwise"], 1e-3) * 1e-6) / 8e12, 3)},
             "pointwise": {"launches": n["pointwise"], "us": round(fam["pointwise"], 1), "algorithmic_GFLOP": round(pw_flop / 1e9, 1),
                           "algorithmic_GB": round(pw_bytes / 1e9, 3),
-                          "frac_of_mfma_peak": round(pw_flop / (fam["pointwise"] * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 3),
-                          "frac_of_8TBps": round(pw_bytes / (fam["pointwise"] * 1e-6) / 8e12, 3)}}
+                          "frac_of_mfma_peak": round(pw_flop / (max(fam["pointwise"], 1e-3) * 1e-6) / 1e12 / PEAK_BF16_TFLOPS, 3),
+                          "frac_of_8TBps": round(pw_bytes / (max(fam["pointwise"], 1e-3) * 1e-6) / 8e12, 3)}}
 
 
 def mfma_achievable_peak():

@@ -102,3 +102,37 @@ def test_ranks_started_by_an_outer_launcher_are_not_relaunched():
     r = _run(["--gpus", "2", "--dry-run-cpu", "--steps", "1", "--warmup", "0"],
              env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_rank0_only_legs_never_enter_the_gradient_exchange(monkeypatch):
+    """After the timed region rank 0 alone runs the roofline legs. `in_step_families` STEPS the trainer: with more than one
+    rank a step contains the all-reduce, and a collective entered by one rank hangs the job at the final barrier. The leg
+    detaches the reducer for its steps (and restores it), and bench.py runs it at N = 1 only."""
+    import inspect
+    import torch
+    import bench, bench_legs
+
+    class Reducer:
+        grad_scale = 0.5
+
+        def all_reduce(self):
+            raise AssertionError("a collective on one rank")
+        start = finish = all_reduce
+
+    class StubTrainer:
+        def __init__(self):
+            self.use_graph, self.reducer, self.seen = True, Reducer(), []
+
+        def step(self, feats, labels):
+            self.seen.append((self.use_graph, self.reducer))
+            if self.reducer is not None:
+                self.reducer.all_reduce()
+
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    tr = StubTrainer()
+    out = bench_legs.in_step_families(tr, None, None, 32, 512)
+    assert tr.seen == [(False, None)] * 3 and tr.use_graph is True and isinstance(tr.reducer, Reducer)
+    assert out["launches"] == 0
+    src = inspect.getsource(bench.main)
+    call = src.index("in_step_families(trainer")
+    assert "if world == 1:" in src[call - 200:call]
