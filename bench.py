@@ -42,13 +42,13 @@ def _free_port():
     return p
 
 
-def rank_commands(n, argv, port, base_env=None):
+def rank_commands(n, argv, port, base_env=None, shared_device=False):
     """[(argv, env)] of the N rank processes the launcher starts: this script again with the caller's arguments and the
-    rendezvous variables torch.distributed.run would set."""
+    rendezvous variables torch.distributed.run would set (shared_device: every rank on device 0 - the rehearsal mode)."""
     base_env = dict(os.environ if base_env is None else base_env)
     out = []
     for r in range(n):
-        env = dict(base_env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(base_env, RANK=str(r), LOCAL_RANK="0" if shared_device else str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         out.append(([sys.executable, os.path.abspath(__file__)] + list(argv), env))
     return out
@@ -79,16 +79,16 @@ def visible_gpu_count(kfd_root="/sys/class/kfd/kfd/topology/nodes", env=None):
     return have
 
 
-def launch_ranks(n, argv, dry_run=False, timeout_s=1500.0):
+def launch_ranks(n, argv, dry_run=False, timeout_s=1500.0, shared_device=False):
     """The launcher (parent of the ranks). Makes no GPU call: devices are counted from the kfd topology in sysfs, never
     through torch / HIP (torch's own count falls back to hipGetDeviceCount when amdsmi is missing, which would bring
     the runtime up in a process that forks)."""
     if not dry_run:
         have = visible_gpu_count()
-        if have < n:
+        if have < (1 if shared_device else n):
             sys.stderr.write(f"bench.py: --gpus {n} needs {n} devices, {have} visible\n")
             return 2
-    cmds = rank_commands(n, argv, _free_port())
+    cmds = rank_commands(n, argv, _free_port(), shared_device=shared_device)
     procs = []
     import tempfile
     out0 = tempfile.TemporaryFile()      # (a file, not a pipe: nobody reads while the ranks run, and a full pipe would block rank 0)
@@ -197,6 +197,9 @@ def main():
     ap.add_argument("--no-fuse-stem-stats", action="store_true", help="A/B: batch-norm statistics of the stem output as a separate pass")
     ap.add_argument("--no-fuse-conv-bn", action="store_true", help="A/B: batch-norm reductions behind the 3x3 data gradients as separate passes")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse launcher + exchange on CPU over gloo (tests)")
+    ap.add_argument("--rehearse-shared-device", action="store_true",
+                    help="REHEARSAL, not a measurement: the N ranks of the real GPU path (graphs, exchange, every rank-0 leg) all on "
+                         "device 0 with the gradient exchange over gloo - what a one-GPU box can run of the N > 1 control flow")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -208,13 +211,14 @@ def main():
             sys.stderr.write(f"bench.py: --gpus {args.gpus} but the environment says WORLD_SIZE={ws}\n")
             sys.exit(2)
         # a WORLD_SIZE some scheduler exported without RANK is not a rank's environment: launch our own ranks
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.dry_run_cpu))    # before anything touches the GPU
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.dry_run_cpu,
+                              shared_device=args.rehearse_shared_device))                # before anything touches the GPU
     if args.dry_run_cpu:
         sys.exit(dry_run_cpu(args))
 
     from multiposenet_amd import _lib
     from multiposenet_amd.parallel import init_distributed
-    rank, local_rank, world = init_distributed("nccl")
+    rank, local_rank, world = init_distributed("gloo" if args.rehearse_shared_device else "nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     _lib.lib()   # fail loudly if the HIP library is missing
@@ -329,6 +333,9 @@ def main():
         out["retinanet"] = retinanet_benchmark(16)               # BASELINE config 4
         from bench_legs import joint_inference_benchmark
         out["joint_inference"] = joint_inference_benchmark()     # create_pb.py's graph behind inference/detector.py
+    if args.rehearse_shared_device:
+        out["rehearsal"] = f"{world} ranks share ONE device, gradient exchange over gloo through the host: control flow only, not a measurement"
+        out["value"] = None
     if rank == 0:
         print(json.dumps(out))
     if torch.distributed.is_initialized():   # (also the 1-rank rehearsal, MPN_DP_FORCE_COLLECTIVE=1)

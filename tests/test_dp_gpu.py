@@ -160,3 +160,22 @@ def test_distributed_without_process_group_is_refused(cuda, monkeypatch):
 
 if __name__ == "__main__":
     _worker_main()
+
+
+def test_bench_two_rank_path_rehearsed_on_one_device(cuda):
+    """`bench.py --gpus 2 --rehearse-shared-device`: the launcher, both ranks of the REAL GPU path (four graphs around three
+    exchanges, barrier + max-over-ranks timing, per-rank step times) and every leg rank 0 runs alone after the timed region, with
+    both ranks on device 0 and the exchange over gloo. A leg that stepped the trainer on rank 0 alone once entered the all-reduce
+    there and would have hung the first real multi-rank run at the final barrier - this is the run that shows it."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-shared-device", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["rccl_ranks"] == 2 and out["value"] is None and "rehearsal" in out
+    assert len(out["config"]["ms_per_step_per_rank"]) == 2 and "exposed_allreduce_ms_per_step" in out["config"]
+    assert "roofline" in out and "north_star_in_step" not in out
+    assert np.isfinite(out["config"]["final_total_loss"])
