@@ -271,6 +271,17 @@ int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part, int N, int
                           int stride, int dtype, const float* in_scale, const float* in_shift,
                           int in_act, mpn_stream_t stream);
 
+/* Stride-1 depthwise backward in ONE pass over dy, x and dx - both gradients of tf.nn.depthwise_conv2d
+ * (/root/reference/detector/backbones/mobilenet_v1.py:101) and the batch-norm backward reduction of the layer that produced x
+ * (mobilenet_v1.py:29-38): dx [N,H,W,C] = data gradient; wpart [mpn_dwconv_wgrad_num_parts][9][C] = weight-gradient partials over
+ * act(x * in_scale + in_shift) (finish with mpn_reduce_partials); bn_part (NULL: no reduction) [mpn_dwconv_wgrad_num_parts][2][C] =
+ * sum(g), sum(g * xhat) with g = dx where in_act passes, xhat = (x - mean) * invstd (finish with mpn_bn_bwd_finalize). Replaces
+ * mpn_dwconv_bwd_weight + mpn_dwconv_bwd_data_bn (five tensor passes) by three. dx must not alias x or dy. */
+int mpn_dwconv_bwd_fused_supported(int N, int H, int W, int C, int stride, int dtype);
+int mpn_dwconv_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, int N, int H, int W, int C,
+                         int dtype, const float* in_scale, const float* in_shift, int in_act, const float* mean,
+                         const float* invstd, float* bn_part, mpn_stream_t stream);
+
 /* ------------------------------------------------------------------------------------
  * K1+K2  `2*x-1` + Conv2d_0 (3x3 stride 2 'SAME', 3 -> C0) fused
  * (detector/backbones/mobilenet_v1.py:41,53,56). images NHWC f32 in [0,1], or uint8

@@ -46,6 +46,7 @@ struct DwParams {
     int bnr_act;
     const void* addend; // stride-2 sliding-window data gradient: a tensor of dx's shape added before the store (and before BNR)
     int xcd_remap;      // sliding-window kernels: XCD-aware block -> strip map
+    float* wpart;       // fused backward (dwconv_bwd_sw2_kernel): the weight gradient's partial slab [units][9][C] (part: the fused reduction's)
     int swr;            // forward sliding window: output rows per strip (0: sw_rows(OH)); shorter strips where a launch without
                         // statistics would leave CUs idle (batch-1 inference: 13 launches of ~16 us each at 640 x 640)
 };
@@ -960,6 +961,231 @@ __global__ __launch_bounds__(kThreads) void dwconv_wgrad_sw2_kernel(const DwPara
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-1 BACKWARD in one walk: the data gradient (dwconv_fwd_sw2_kernel over dY with the flipped kernel), the batch-norm backward
+// reduction of the layer it feeds (BNR) and the weight gradient (dwconv_wgrad_sw2_kernel). As launches of their own the two
+// gradients read dY twice and the layer's raw input twice (once for the weight gradient's activated window, once for the
+// reduction's mask and xhat): 5 tensor passes; here dY, the raw input and dA move once each: 3. Same thread map (4 channels x 2
+// columns, walking down a strip), ONE window in registers: three rows x four columns of dY. The data gradient of row r gathers
+// from it as before; the weight gradient is organised by INPUT row - the activated input row r (four columns, transient) meets
+// dY rows r+1, r, r-1 (ky = 0, 1, 2) at this thread's two columns: acc[ky][kx] += in[r][c+j+kx-1] * dY[r-ky+1][c+j] - so the
+// second 3 x 4 window the weight-gradient kernel keeps is not needed; the strip's input rows are exactly its output rows, every
+// (input row, ky) pair is counted once over the grid. The reduction's raw input at the thread's own columns is the same row r.
+// p.x: raw input of the depthwise conv (= the fed layer's raw conv output) with its batch-norm affine in_scale / in_shift /
+// in_act (the mask test of the reduction is the same expression); p.dy: dY; p.y: dA; p.wpart: weight partials [units][9][C];
+// BNR: p.part [units][2][C] with p.bnr_mean / p.bnr_invstd.
+template <typename T, bool BNR>
+__global__ __launch_bounds__(kThreads) void dwconv_bwd_sw2_kernel(const DwParams p, int ncg, int cols, int xblocks, int yblocks, int rows) {
+    __shared__ __attribute__((aligned(16))) float red[9 * kThreads * 4];   // [tap][thread][4 channels]; afterwards [thread][8] of the reduction
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+    T* __restrict__ y = reinterpret_cast<T*>(p.y);
+    int b = xcd_work_id(p.xcd_remap);
+    const int cgb = b % p.cblocks; b /= p.cblocks;
+    const int unit = b;                                               // partial-slab row (both slabs)
+    const int xb = b % xblocks; b /= xblocks;
+    const int yb = b % yblocks;
+    const int img = b / yblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;       // column PAIR
+    const int c = (cgb * ncg + cgl) * 4;
+    const int ox = (xb * cols + col) * 2;
+    const bool ok0 = c < p.C && ox < p.W && col < cols;
+    const bool ok1 = ok0 && ox + 1 < p.W;
+    const int cc = ok0 ? c : 0;
+    f32x2_t sc01, sc23, sh01, sh23;
+    f32x2_t w01[9], w23[9];                                            // FLIPPED: the data gradient correlates dY with w[8 - t]
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 q = *reinterpret_cast<const float4*>(p.w + (8 - t) * p.C + cc);
+        w01[t] = (f32x2_t){q.x, q.y};
+        w23[t] = (f32x2_t){q.z, q.w};
+    }
+    {
+        const float4 s4 = *reinterpret_cast<const float4*>(p.in_scale + cc), h4 = *reinterpret_cast<const float4*>(p.in_shift + cc);
+        sc01 = (f32x2_t){s4.x, s4.y}; sc23 = (f32x2_t){s4.z, s4.w};
+        sh01 = (f32x2_t){h4.x, h4.y}; sh23 = (f32x2_t){h4.z, h4.w};
+    }
+    const float lo = (p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    f32x2_t bis01 = {0.f, 0.f}, bis23 = {0.f, 0.f}, bnm01 = {0.f, 0.f}, bnm23 = {0.f, 0.f};
+    if constexpr (BNR) {
+        const float4 m4 = *reinterpret_cast<const float4*>(p.bnr_mean + cc), i4 = *reinterpret_cast<const float4*>(p.bnr_invstd + cc);
+        bis01 = (f32x2_t){i4.x, i4.y}; bis23 = (f32x2_t){i4.z, i4.w};
+        bnm01 = (f32x2_t){-m4.x * i4.x, -m4.y * i4.y}; bnm23 = (f32x2_t){-m4.z * i4.z, -m4.w * i4.w};
+    }
+    const int oy_begin = yb * rows, oy_end = min(oy_begin + rows, p.H);
+    const int ix0 = ox - 1;                                           // leftmost column of the 4-column windows
+    const long long img_off = (long long)img * p.H * p.W * p.C + cc;
+    const T* ximg = x + img_off;
+    const T* dimg = dy + img_off;
+    bool xok[4];
+    int xoff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ix = ix0 + k;
+        xok[k] = ok0 && ix >= 0 && ix < p.W;
+        xoff[k] = (xok[k] ? ix : 0) * p.C;
+    }
+    const long long rstep = (long long)p.W * p.C;
+    auto row_load = [&](Raw4<T> (&r)[4], const T* base, int iy) {
+        const T* rowp = base + (long long)min(max(iy, 0), p.H - 1) * rstep;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) raw_load(r[k], rowp + xoff[k]);
+    };
+    // a dY row into the window (zeros outside the image)
+    auto dy_row = [&](const Raw4<T> (&r)[4], int iy, f32x2_t (&a)[4][2]) {
+        const bool rowok = iy >= 0 && iy < p.H;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[4];
+            raw_unpack(r[k], f);
+            const bool ok = rowok && xok[k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f[j] = ok ? f[j] : 0.f;
+            a[k][0] = (f32x2_t){f[0], f[1]};
+            a[k][1] = (f32x2_t){f[2], f[3]};
+        }
+    };
+    // the activated input row (always inside the image: the strip's own rows; columns outside are the activated tensor's zero padding)
+    auto in_row = [&](const Raw4<T> (&r)[4], f32x2_t (&a)[4][2]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float f[4];
+            raw_unpack(r[k], f);
+            f32x2_t v01 = (f32x2_t){f[0], f[1]} * sc01 + sh01, v23 = (f32x2_t){f[2], f[3]} * sc23 + sh23;
+            v01.x = __builtin_amdgcn_fmed3f(v01.x, lo, hi); v01.y = __builtin_amdgcn_fmed3f(v01.y, lo, hi);
+            v23.x = __builtin_amdgcn_fmed3f(v23.x, lo, hi); v23.y = __builtin_amdgcn_fmed3f(v23.y, lo, hi);
+            if (k != 1) {   // (column 1 = the thread's first own column: inside the image whenever the lane is)
+                v01.x = xok[k] ? v01.x : 0.f; v01.y = xok[k] ? v01.y : 0.f;
+                v23.x = xok[k] ? v23.x : 0.f; v23.y = xok[k] ? v23.y : 0.f;
+            }
+            a[k][0] = v01;
+            a[k][1] = v23;
+        }
+    };
+    f32x2_t a01[9], a23[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { a01[t] = (f32x2_t){0.f, 0.f}; a23[t] = (f32x2_t){0.f, 0.f}; }
+    f32x2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+    T* yp = y + img_off + ((long long)oy_begin * p.W + (ok0 ? ox : 0)) * p.C;
+    auto account = [&](f32x2_t d01, f32x2_t d23, const Raw4<T>& xr) {
+        if constexpr (BNR) {
+            float f[4];
+            raw_unpack(xr, f);
+            const f32x2_t x01 = {f[0], f[1]}, x23 = {f[2], f[3]};
+            const f32x2_t p01 = x01 * sc01 + sh01, p23 = x23 * sc23 + sh23;
+            const f32x2_t r01 = round_storage<T>(d01), r23 = round_storage<T>(d23);
+            f32x2_t g01, g23;
+            g01.x = (p01.x > lo && p01.x < hi) ? r01.x : 0.f; g01.y = (p01.y > lo && p01.y < hi) ? r01.y : 0.f;
+            g23.x = (p23.x > lo && p23.x < hi) ? r23.x : 0.f; g23.y = (p23.y > lo && p23.y < hi) ? r23.y : 0.f;
+            s01 += g01; s23 += g23;
+            q01 += g01 * (x01 * bis01 + bnm01); q23 += g23 * (x23 * bis23 + bnm23);
+        }
+    };
+    // one row r: window rows (r - 1, r, r + 1) = (d0, d1, d2) of dY, the input row `xin` (activated) with its raw pieces `xr`
+    auto step = [&](const f32x2_t (&d0)[4][2], const f32x2_t (&d1)[4][2], const f32x2_t (&d2)[4][2], const f32x2_t (&xin)[4][2],
+                    const Raw4<T> (&xr)[4]) {
+        // data gradient of the two columns (the forward kernel's emit over dY, flipped weights)
+        f32x2_t e01 = {0.f, 0.f}, e23 = {0.f, 0.f}, g01 = {0.f, 0.f}, g23 = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            e01 += d0[k][0] * w01[k];          e23 += d0[k][1] * w23[k];
+            e01 += d1[k][0] * w01[3 + k];      e23 += d1[k][1] * w23[3 + k];
+            e01 += d2[k][0] * w01[6 + k];      e23 += d2[k][1] * w23[6 + k];
+            g01 += d0[k + 1][0] * w01[k];      g23 += d0[k + 1][1] * w23[k];
+            g01 += d1[k + 1][0] * w01[3 + k];  g23 += d1[k + 1][1] * w23[3 + k];
+            g01 += d2[k + 1][0] * w01[6 + k];  g23 += d2[k + 1][1] * w23[6 + k];
+        }
+        if (ok0) {
+            account(e01, e23, xr[1]);
+            store4x2(yp, e01, e23);
+        }
+        if (ok1) {
+            account(g01, g23, xr[2]);
+            store4x2(yp + p.C, g01, g23);
+        }
+        yp += rstep;
+        // weight gradient: input row r against dY rows r + 1 (ky = 0), r (ky = 1), r - 1 (ky = 2) at the own columns (window 1, 2)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a01[k] += xin[k][0] * d2[1][0] + xin[k + 1][0] * d2[2][0];     a23[k] += xin[k][1] * d2[1][1] + xin[k + 1][1] * d2[2][1];
+            a01[3 + k] += xin[k][0] * d1[1][0] + xin[k + 1][0] * d1[2][0]; a23[3 + k] += xin[k][1] * d1[1][1] + xin[k + 1][1] * d1[2][1];
+            a01[6 + k] += xin[k][0] * d0[1][0] + xin[k + 1][0] * d0[2][0]; a23[6 + k] += xin[k][1] * d0[1][1] + xin[k + 1][1] * d0[2][1];
+        }
+    };
+    f32x2_t r0[4][2], r1[4][2], r2[4][2], xin[4][2];
+    Raw4<T> da[4], db[4], dc[4], xa[4], xb2[4], xc[4];
+    // dY rows oy_begin - 1, oy_begin, oy_begin + 1 and input rows oy_begin, +1, +2 are requested up front; afterwards every consumed
+    // buffer is re-requested three rows ahead (as in the forward walk)
+    row_load(da, dimg, oy_begin - 1);
+    row_load(db, dimg, oy_begin);
+    row_load(dc, dimg, oy_begin + 1);
+    row_load(xa, ximg, oy_begin);
+    row_load(xb2, ximg, oy_begin + 1);
+    row_load(xc, ximg, oy_begin + 2);
+    dy_row(da, oy_begin - 1, r0);
+    row_load(da, dimg, oy_begin + 2);
+    dy_row(db, oy_begin, r1);
+    row_load(db, dimg, oy_begin + 3);
+    for (int r = oy_begin; r < oy_end; r += 3) {
+        dy_row(dc, r + 1, r2);
+        row_load(dc, dimg, r + 4);
+        in_row(xa, xin);
+        step(r0, r1, r2, xin, xa);
+        row_load(xa, ximg, r + 3);
+        if (r + 1 < oy_end) {
+            dy_row(da, r + 2, r0);
+            row_load(da, dimg, r + 5);
+            in_row(xb2, xin);
+            step(r1, r2, r0, xin, xb2);
+            row_load(xb2, ximg, r + 4);
+        }
+        if (r + 2 < oy_end) {
+            dy_row(db, r + 3, r1);
+            row_load(db, dimg, r + 6);
+            in_row(xc, xin);
+            step(r2, r0, r1, xin, xc);
+            row_load(xc, ximg, r + 5);
+        }
+    }
+    // weight partials: the block's columns summed in a fixed order
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float4 v = make_float4(a01[t].x, a01[t].y, a23[t].x, a23[t].y);
+        if (!ok0) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&red[(t * kThreads + threadIdx.x) * 4]) = v;
+    }
+    __syncthreads();
+    const int nch = ncg * 4;
+    {
+        float* dst = p.wpart + (long long)unit * 9 * p.C + cgb * nch;
+        for (int o = threadIdx.x; o < 9 * nch; o += kThreads) {
+            const int t = o / nch, cj = o - t * nch;
+            if (cgb * nch + cj < p.C) {
+                float sum = 0.f;
+                for (int cidx = 0; cidx < cols; ++cidx) sum += red[(t * kThreads + cidx * ncg) * 4 + cj];
+                dst[t * p.C + cj] = sum;
+            }
+        }
+    }
+    if constexpr (BNR) {
+        __syncthreads();   // the weight partials have been read
+        float st[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = ok0 ? st[j] : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < ncg && (cgb * ncg + (int)threadIdx.x) * 4 < p.C) {
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int cidx = 0; cidx < cols; ++cidx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += red[(cidx * ncg + threadIdx.x) * 8 + j];
+            float* dst = p.part + (long long)unit * 2 * p.C + (cgb * ncg + threadIdx.x) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[j] = acc8[j]; dst[p.C + j] = acc8[4 + j]; }
+        }
+    }
+}
+
 // stride-2 data gradient (gather form): dx[iy,ix,c] = sum_{ky,kx} dy[(iy+pt-ky)/2,(ix+pl-kx)/2,c]*w[ky,kx,c]
 // over the taps for which the division is exact. One thread = one input pixel x 16 bytes of channels.
 template <typename T>
@@ -1592,6 +1818,45 @@ extern "C" int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part,
             dwconv_wgrad_kernel<T, 2><<<grid, kThreads, sm, st>>>(p, nsplit);
         });
     }
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* 1 when mpn_dwconv_bwd_fused takes this shape: stride 1, the sliding-window geometry of the weight gradient (its partial slab
+ * has mpn_dwconv_wgrad_num_parts rows, and so has the fused reduction's) */
+extern "C" int mpn_dwconv_bwd_fused_supported(int N, int H, int W, int C, int stride, int dtype) {
+    DwParams p = {};
+    if (stride != 1 || fill_params(p, N, H, W, C, stride, dtype)) return 0;
+    return (C % 4 == 0 && dw_wg_use_sw(p) && dw_wg_sw_geom(p).xt == 2) ? 1 : 0;
+}
+
+/* Stride-1 depthwise backward in ONE pass over dy, x and dx (tf.nn.depthwise_conv2d's two gradients, mobilenet_v1.py:101, + the
+ * batch-norm backward reduction of the layer that produced x): dx = data gradient [N,H,W,C]; wpart
+ * [mpn_dwconv_wgrad_num_parts][9][C] = weight-gradient partials over act(x * in_scale + in_shift) (finish with mpn_reduce_partials);
+ * bn_part (NULL: no reduction) [mpn_dwconv_wgrad_num_parts][2][C] = sum(g), sum(g * xhat) with g = dx where the activation passes,
+ * xhat = (x - mean) * invstd (finish with mpn_bn_bwd_finalize). Replaces mpn_dwconv_bwd_weight + mpn_dwconv_bwd_data_bn: three
+ * tensor passes instead of five. */
+extern "C" int mpn_dwconv_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, int N, int H, int W, int C,
+                                    int dtype, const float* in_scale, const float* in_shift, int in_act, const float* mean,
+                                    const float* invstd, float* bn_part, mpn_stream_t stream) {
+    MPN_REQUIRE(mpn_dwconv_bwd_fused_supported(N, H, W, C, 1, dtype), MPN_ERR_BAD_SHAPE,
+                "dwconv_bwd_fused: shape not supported (mpn_dwconv_bwd_fused_supported == 0)");
+    MPN_REQUIRE(x && dy && w && dx && wpart && in_scale && in_shift, MPN_ERR_BAD_ARG, "dwconv_bwd_fused: null pointer");
+    MPN_REQUIRE(bn_part == nullptr || (mean && invstd), MPN_ERR_BAD_ARG, "dwconv_bwd_fused: the reduction needs mean and invstd");
+    MPN_REQUIRE(dx != dy && dx != x, MPN_ERR_BAD_ARG, "dwconv_bwd_fused: dx must not alias an input");
+    DwParams p = {};
+    if (int rc = fill_params(p, N, H, W, C, 1, dtype)) return rc;
+    p.x = x; p.dy = dy; p.w = w; p.y = dx; p.wpart = wpart; p.part = bn_part;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.bnr_mean = mean; p.bnr_invstd = invstd;
+    const DwWgSwGeom g = dw_wg_sw_geom(p);
+    p.cblocks = g.cblocks;
+    const long long blocks = (long long)g.units * g.cblocks;
+    MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_fused: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, {
+        if (bn_part) dwconv_bwd_sw2_kernel<T, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+        else dwconv_bwd_sw2_kernel<T, false><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+    });
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

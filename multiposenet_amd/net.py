@@ -315,6 +315,7 @@ class KeypointNet:
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
+        self.fuse_dw_bwd = True   # stride-1 depthwise layers: data gradient + that reduction + weight gradient in ONE walk (mpn_dwconv_bwd_fused)
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
         self.fuse_conv_bn = True
@@ -409,7 +410,8 @@ class KeypointNet:
             stat_floats = max(stat_floats, ops.dwconv_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw,
                               nbn(rows(b["dw"][i])) * 2 * cdw,
                               ops.conv_num_parts(N, *b["hw"][i + 1], 1) * 2 * cpw, nbn(rows(b["pw"][i])) * 2 * cpw,
-                              ops.dwconv_bwd_data_bn_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw)
+                              ops.dwconv_bwd_data_bn_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw,
+                              ops.dwconv_wgrad_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw)   # (the fused backward's rows)
         for l in lv:
             stat_floats = max(stat_floats, ops.conv_num_parts(N, *lv[l], 3) * 2 * DEPTH, nbn(N * lv[l][0] * lv[l][1]) * 2 * DEPTH)
         b["stat_part"] = torch.empty(stat_floats, dtype=torch.float32, device=dev)
@@ -797,8 +799,19 @@ class KeypointNet:
                 ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
-            W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))
             dst = g["pw"][i - 1] if i > 0 else g["stem"]
+            prev_feature = i > 0 and self.blocks[i - 1]["i"] in FEATURE_BLOCKS
+            # stride-1 layers whose input is not an FPN feature: both gradients and the reduction for the batch-norm below in one
+            # walk over dY, the raw input and dA (three tensor passes instead of five)
+            if self.fuse_dw_bwd and self.fuse_dw_bn and blk["stride"] == 1 and not prev_feature and \
+                    ops.dwconv_bwd_fused_supported(dst.shape[0], *b["hw"][i], dst.shape[3], 1, dst.dtype):
+                prev_bn = self.blocks[i - 1]["pw_bn"] if i > 0 else self.stem_bn
+                _, reduced = ops.dwconv_bwd_fused(xin, g["dw"][i], blk["dw_w"], prev_bn, None, out=dst, wpart=slab[id(blk["dw_dw"])],
+                                                  bn_part=sp, reduce=False)
+                lateral_added = False
+                dA = dst
+                continue
+            W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))
             # the data gradient also reduces for the batch-norm it feeds (one read of dA and one launch less), unless a
             # lateral's gradient still has to be added to dA first
             prev_bn = self.blocks[i - 1]["pw_bn"] if i > 0 else self.stem_bn

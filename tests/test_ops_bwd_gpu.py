@@ -709,3 +709,54 @@ def test_adam_step_with_operand_casts(cuda, dtype):
     for (o, c), d in zip(ranges, dsts):
         assert torch.equal(d[:c], p2[o:o + c].to(dtype))
         assert bool((d[c:] == 7.0).all())
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 16, 64), (1, 32, 32, 512), (1, 37, 29, 32), (2, 64, 64, 128), (1, 130, 70, 32),
+                                       (1, 9, 11, 1024), (3, 24, 24, 256)])
+def test_dwconv_bwd_fused_equals_the_separate_launches(cuda, dtype, N, H, W, C):
+    """mpn_dwconv_bwd_fused (stride 1): ONE walk gives the data gradient of mpn_dwconv_bwd_data_bn bit for bit, the weight gradient
+    of mpn_dwconv_bwd_weight (another summation order: f32 rounding of the partial sums), and partial rows that finalize to the
+    dgamma / dbeta of the separate reduction - odd sizes (strips and column pairs that end inside the map), one to many
+    channel blocks."""
+    ops = _ops()
+    rs = np.random.RandomState(C + H + W)
+    assert ops.dwconv_bwd_fused_supported(N, H, W, C, 1, dtype) and not ops.dwconv_bwd_fused_supported(N, H, W, C, 2, dtype)
+    x = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)                 # raw input of the depthwise conv = raw output of the fed layer
+    dy = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)
+    w = dev((rs.randn(3, 3, C) / 3).astype(np.float32))
+
+    def mkbn():
+        one = lambda: torch.tensor((0.5 + rs.rand(C)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), 2)
+        bn.scale.copy_(one()); bn.invstd.copy_(one())
+        bn.shift.copy_(torch.tensor((rs.randn(C) * 0.5).astype(np.float32)).cuda()); bn.mean.copy_(torch.tensor((rs.randn(C) * 0.3).astype(np.float32)).cuda())
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+    st = rs.get_state()
+    bn_a = mkbn(); rs.set_state(st); bn_b = mkbn()
+    # the separate launches
+    dw_want = torch.zeros(3, 3, C, device="cuda")
+    ops.dwconv_bwd_weight(x, dy, 1, bn_b.affine, dw_want)
+    dA_want, rows_b = ops.dwconv_bwd_data(dy, w, (H, W), 1, bn=bn_b, x_bn=x)
+    part_b = torch.empty(rows_b * 2 * C, device="cuda")
+    dA_b, _ = ops.dwconv_bwd_data(dy, w, (H, W), 1, bn=bn_b, x_bn=x, part=part_b)
+    # the fused launch
+    dw_got = torch.zeros(3, 3, C, device="cuda")
+    dA_got, rows = ops.dwconv_bwd_fused(x, dy, w, bn_a, dw_got)
+    assert rows == ops.dwconv_wgrad_num_parts(N, H, W, C, 1, dtype)
+    assert torch.equal(dA_got, dA_want)
+    scale = float(dw_want.abs().max()) + 1e-6
+    assert float((dw_got - dw_want).abs().max()) <= 3e-5 * scale * max(1.0, (N * H * W) ** 0.5 / 16)
+    part_a = torch.empty(rows * 2 * C, device="cuda")
+    dA_a, _ = ops.dwconv_bwd_fused(x, dy, w, bn_a, dw_got, bn_part=part_a)
+    ops.bn_backward(bn_a, dA_a, x, part_a, reduced_parts=rows)
+    ops.bn_backward(bn_b, dA_b, x, part_b, reduced_parts=rows_b)
+    M = N * H * W
+    assert float((bn_a.dgamma - bn_b.dgamma).abs().max()) <= 2e-5 * (float(bn_b.dgamma.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
+    assert float((bn_a.dbeta - bn_b.dbeta).abs().max()) <= 2e-5 * (float(bn_b.dbeta.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
+    assert_close(dA_a, dA_b.float().cpu(), dtype, 4)       # (after the apply pass: k1 / k2 come from differently grouped partial sums)
+    # without the reduction: the same gradients
+    dw_n = torch.zeros(3, 3, C, device="cuda")
+    dA_n, r0 = ops.dwconv_bwd_fused(x, dy, w, bn_a, dw_n, reduce_bn=False)
+    assert r0 == 0 and torch.equal(dA_n, dA_want) and torch.equal(dw_n, dw_got)
