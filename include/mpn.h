@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 400   /* r4: see INTEGRATION.md "ABI revisions" */
+#define MPN_VERSION 401   /* r4: see INTEGRATION.md "ABI revisions" */
 
 enum { MPN_F32 = 0, MPN_BF16 = 1, MPN_F16 = 2 /* dense 1x1 / 3x3 convolutions (forward, weight gradient, pack), the PRN entry points and the decode input; the BN / depthwise / loss kernels of the keypoint step take F32 and BF16 only */ };
 

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPN_LIB: an alternative build of the same library (diagnostic A/B of compile-time variants, tools/build_variant.sh)
 LIB_PATH = os.environ.get("MPN_LIB") or os.path.join(_HERE, "libmpn_hip.so")
 
-MPN_VERSION = 400     # the ABI revision this binding was written against (include/mpn.h); lib() refuses another
+MPN_VERSION = 401     # the ABI revision this binding was written against (include/mpn.h); lib() refuses another
 MPN_F32, MPN_BF16, MPN_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
