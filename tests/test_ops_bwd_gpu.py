@@ -21,7 +21,9 @@ WGRAD_CASES = [
     (1, 12, 20, 128, 128, 3, 0),     # partial tiles
     (2, 16, 16, 512, 64, 3, 0),      # final_conv3x3
     (1, 4, 4, 128, 128, 3, 1),
-    (2, 16, 16, 32, 64, 1, 2),       # pointwise 1
+    (2, 16, 16, 32, 64, 1, 2),       # pointwise 1 (the thin 32 x 64 block tile)
+    (1, 37, 29, 32, 64, 1, 1),       # ... ragged M, many tiles per split
+    (2, 10, 6, 16, 32, 1, 2),        # ... at depth_multiplier 0.5
     (2, 16, 16, 256, 128, 1, 2),     # lateral
     (3, 16, 16, 1024, 1024, 1, 2),   # pointwise 13
     (1, 10, 6, 64, 128, 1, 2),       # ragged M
