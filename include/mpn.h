@@ -144,6 +144,18 @@ int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, int ksize, 
 int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int Cin,
                         int Cout, int x_stride, int dy_stride, int ksize, int dtype, const float* in_scale,
                         const float* in_shift, int in_act, mpn_stream_t stream);
+
+/* A thin 1x1 convolution's backward in ONE pass over x and dy (Conv2d_1_pointwise / Conv2d_2_pointwise,
+ * /root/reference/detector/backbones/mobilenet_v1.py:66-74: tf.gradients of slim.conv2d w.r.t. its kernel and its input, and the
+ * reduction of the batch-norm below, mobilenet_v1.py:29-38): wpart [mpn_conv_wgrad_num_parts(N,H,W,Cin,Cout,1,dtype)][Cin][Cout] =
+ * weight-gradient partials over act(x * in_scale + in_shift) (finish with mpn_reduce_partials); dx [N,H,W,Cin] = dy . w^T MASKED by that
+ * activation (lo < x * in_scale + in_shift < hi on the raw x); bn_part [same rows][2][Cin] = partial sums of the masked gradient g and
+ * of g * x with the RAW x (finish with mpn_bn_bwd_finalize_raw). What mpn_conv_bwd_weight + mpn_conv_bwd_data_bn give in two passes over
+ * both tensors. w: the layer's f32 kernel [Cin][Cout] (HWIO of a 1x1). Strides in elements, 0 = dense. dx must not alias x or dy. */
+int mpn_conv1x1_bwd_fused_supported(int Cin, int Cout, int dtype);
+int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, float* bn_part, int N, int H, int W,
+                          int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype, const float* in_scale,
+                          const float* in_shift, int in_act, mpn_stream_t stream);
 /* The weight gradients of njobs independent layers of one (Cin, Cout, ksize, dtype) in ONE grid - the pyramid levels of a
  * subnet stage (keypoint_subnet.py:66-79: one phi_subnet per level; fpn.py:38-52: one 3x3 per level). The 256 blocks are
  * divided among the jobs by their pixel counts, so a stage leaves 128 partial slabs in all instead of 128 per level, and the

@@ -41,6 +41,13 @@ struct WgradParams {
     int nsplit;
     int n_cg, n_cb;
     int xcd_remap;    // XCD-aware block -> work map inside the job (needs the job's first block on XCD 0)
+    // fused thin pointwise backward (mpn_conv1x1_bwd_fused; the DG variant of the kernel): the layer's f32 kernel [Cin][Cout], the
+    // data gradient [M][Cin] (pixel stride dxs, written MASKED by the activation of the batch-norm that produced x) and the partial
+    // rows [nsplit][2][Cin] of that batch-norm's backward reduction (sums of g and of g * x with the RAW x)
+    const float* wf;
+    void* dx;
+    int dxs;
+    float* bn_part;
 #ifdef MPN_DIAG
     unsigned long long* dbg;   // diagnostic build only (mpn_diag_set_wgrad_stamps): per-wave phase times, else NULL
 #endif
@@ -57,6 +64,30 @@ __device__ __forceinline__ int fsw128(int r) { return ((r >> 1) & 1) | (((r >> 3
 template <int RB> __device__ __forceinline__ int lds_off(int row, int seg, int within) {
     const int f = (RB == 64) ? fsw64(row) : (RB == 128 ? fsw128(row) : fsw256(row));
     return row * RB + ((seg ^ f) << 5) + within;
+}
+
+// four storage elements <-> f32 (the fused data gradient's 8-byte pieces)
+template <typename T> struct Raw4h { uint2 v; };
+__device__ __forceinline__ void raw4_unpack(const Raw4h<bf16_t>& r, float (&f)[4]) {
+    f[0] = __uint_as_float(r.v.x << 16); f[1] = __uint_as_float(r.v.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.v.y << 16); f[3] = __uint_as_float(r.v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void raw4_unpack(const Raw4h<half_t>& r, float (&f)[4]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t a = __builtin_bit_cast(h2_t, r.v.x), b = __builtin_bit_cast(h2_t, r.v.y);
+    f[0] = (float)a[0]; f[1] = (float)a[1]; f[2] = (float)b[0]; f[3] = (float)b[1];
+}
+template <typename T> __device__ __forceinline__ float round_to_storage(float v);
+template <> __device__ __forceinline__ float round_to_storage<bf16_t>(float v) { return to_f32((bf16_t)v); }
+template <> __device__ __forceinline__ float round_to_storage<half_t>(float v) { return (float)(_Float16)v; }
+template <typename T> __device__ __forceinline__ uint2 pack4_storage(const float (&g)[4]);
+template <> __device__ __forceinline__ uint2 pack4_storage<bf16_t>(const float (&g)[4]) {
+    return make_uint2(pack_bf16x2(g[0], g[1]), pack_bf16x2(g[2], g[3]));
+}
+template <> __device__ __forceinline__ uint2 pack4_storage<half_t>(const float (&g)[4]) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    const h2_t a = {(_Float16)g[0], (_Float16)g[1]}, b = {(_Float16)g[2], (_Float16)g[3]};
+    return make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
 }
 
 template <typename H> __device__ __forceinline__ typename H::x4 tr_read(const unsigned char* base, int off) {
@@ -313,7 +344,12 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
 //   1x1:              (256, 256, 4x2) = 128 ci x 128 co
 // (a device function: the plain kernel and the grouped kernel - several independent layers of one channel geometry, e.g. the
 //  four pyramid levels of a subnet stage, in ONE grid of one block per CU - share it; blk / nblk = this job's block index and count)
-template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+// DG (thin 1x1 layers, one block = all input and output channels): the DATA gradient of the same tile rides along. Both of the weight
+// gradient's LDS images are what it needs - dA^T[ci][px] = W[ci][:] . dY[px][:] takes the dY rows as they lie (plain 16-byte reads, no
+// transpose) and the layer's kernel from registers (bf16 fragments, loaded once) - plus the RAW input rows for the mask and the
+// sums of the batch-norm reduction (a third image, written by the same commit). Separately the two gradients read dY twice and x
+// twice; here once each: 536 -> 402... MB on Conv2d_1_pointwise. A wave owns 16 of the tile's 128 pixels for this part.
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER, bool DG = false>
 __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const int blk, const int nblk) {
     using H = H16<T>;
     using X8 = typename H::x8;
@@ -336,10 +372,16 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     // cycles - the MFMA phase was VALU-bound.)
     constexpr int SA = RBA + 32, SD = RBD + 32;
     constexpr int ABYTES = NPIXA * SA, DBYTES = 128 * SD;
+    static_assert(!DG || (TAPS == 1 && !STAGGER), "the fused data gradient: 1x1, waves in step");
+    constexpr int OS = RBA + 16;                       // DG: pixel-row stride of the output image
+    constexpr int RBYTES = DG ? 128 * SA : 0, OBYTES = DG ? 128 * OS : 0;
+    constexpr int KS2 = BNW / 32;                      // DG: k-steps of the data gradient (over the output channels)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [2][ABYTES] A images, [2][DBYTES] dY images, [2][CG] f32 scale / shift
+    // [2][ABYTES] A images, [2][DBYTES] dY images, [2][CG] f32 scale / shift; DG: + raw input image, output image, [8][2][CG] sums
     float* aff = reinterpret_cast<float*>(smem + 2 * ABYTES + 2 * DBYTES);
+    unsigned char* Rs = smem + 2 * ABYTES + 2 * DBYTES + 2 * CG * (int)sizeof(float);
+    unsigned char* Os = Rs + RBYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -490,6 +532,11 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
                 }
                 if (!((inb >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
                 *reinterpret_cast<uint4*>(As + pix * SA + aslot * 16) = q;
+                if constexpr (DG) {   // (single-buffered: read in front of the tile's second barrier, rewritten behind it)
+                    uint4 r = *reinterpret_cast<const uint4*>(&v[i].raw);
+                    if (!((inb >> i) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
+                    *reinterpret_cast<uint4*>(Rs + pix * SA + aslot * 16) = r;
+                }
             }
         }
 #pragma unroll
@@ -521,6 +568,28 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     const int grp = STAGGER ? wave >> 2 : 0;   // !STAGGER: all waves in step (one group, two barriers per tile)
     const int ntl = p.ntiles > split ? (p.ntiles - split + p.nsplit - 1) / p.nsplit : 0;   // tiles of this block
     const int ahead = 1 + grp;
+    // DG: the layer's kernel as bf16 fragments W[ci = mt * 16 + l15][co = ks * 32 + lq * 8 ..] (the rounding of the packed weights the
+    // separate data gradient multiplies with), zero beyond the layer's channels; running sums of the reduction per lane:
+    // channels mt * 16 + lq * 4 + r over the lane's pixel column l15 of every tile
+    X8 wfr[DG ? MT_TOTAL : 1][DG ? KS2 : 1];
+    float bsum[DG ? MT_TOTAL : 1][4], bsq[DG ? MT_TOTAL : 1][4];
+    if constexpr (DG) {
+#pragma unroll
+        for (int mt = 0; mt < MT_TOTAL; ++mt) {
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const int ci = ci0 + mt * 16 + l15, co = co0 + ks * 32 + lq * 8;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = (ci < p.Cin && co + j < p.Cout) ? p.wf[(long long)ci * p.Cout + co + j] : 0.f;
+                Vec16<T> o;
+                o.pack(f);
+                wfr[mt][ks] = __builtin_bit_cast(X8, o.raw);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bsum[mt][r] = 0.f; bsq[mt][r] = 0.f; }
+        }
+    }
     if (ntl > 0) load_tile(split);
     __syncthreads();   // scale / shift table visible
     if (ntl > 0) commit_tile(smem, smem + 2 * ABYTES);
@@ -593,12 +662,60 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
             // lgkmcnt(0) before each MFMA group) and the ring degenerates to distance 0
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (DG) {
+            // dA^T[ci][px] of this wave's 16 pixels: A operand = the kernel's fragment (rows = ci), B operand = the dY rows as they
+            // lie (k = co, columns = px); a lane ends up with channels mt * 16 + lq * 4 .. + 3 of pixel wave * 16 + l15
+            const int px = wave * 16 + l15;
+            f32x4_t dacc[MT_TOTAL];
+#pragma unroll
+            for (int mt = 0; mt < MT_TOTAL; ++mt) dacc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS2; ++ks) {
+                const X8 dfr = *reinterpret_cast<const X8*>(Ds + px * SD + ks * 64 + lq * 16);
+#pragma unroll
+                for (int mt = 0; mt < MT_TOTAL; ++mt) dacc[mt] = H::mfma(wfr[mt][ks], dfr, dacc[mt]);
+            }
+            // mask by the activation of the batch-norm that produced x (lo < x * scale + shift < hi on the RAW x), round to
+            // storage, sums of g and g * x, the tile's image for whole-row stores
+#pragma unroll
+            for (int mt = 0; mt < MT_TOTAL; ++mt) {
+                const int cl = mt * 16 + lq * 4;
+                const uint2 xr = *reinterpret_cast<const uint2*>(Rs + px * SA + cl * 2);
+                float xf[4];
+                {
+                    Raw4h<T> r4; r4.v = xr;
+                    raw4_unpack(r4, xf);
+                }
+                const f32x4_t sc4 = *reinterpret_cast<const f32x4_t*>(aff + cl), sh4 = *reinterpret_cast<const f32x4_t*>(aff + CG + cl);
+                float g[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pre = xf[r] * sc4[r] + sh4[r];
+                    const float d = round_to_storage<T>(dacc[mt][r]);
+                    g[r] = (pre > lo && pre < hi) ? d : 0.f;
+                    bsum[mt][r] += g[r];
+                    bsq[mt][r] += g[r] * xf[r];
+                }
+                *reinterpret_cast<uint2*>(Os + px * OS + cl * 2) = pack4_storage<T>(g);
+            }
+        }
         MPN_WG_STAMP(3);
         __syncthreads();
         MPN_WG_STAMP(2);
         if (more) {
             const int nb = (it + ahead) & 1;
             commit_tile(smem + nb * ABYTES, smem + 2 * ABYTES + nb * DBYTES);
+        }
+        if constexpr (DG) {
+            // the tile's 128 x Cin gradients leave as 16-byte pieces of whole pixel rows (rows past the end / channels past Cin: skipped)
+            const int tile = split + it * p.nsplit;
+            const int mleft = (int)(p.M - (long long)tile * 128);
+            T* __restrict__ dxp = reinterpret_cast<T*>(p.dx) + (long long)tile * 128 * p.dxs + ci0;
+            for (int v0 = tid; v0 < 128 * ASLOTS; v0 += NT) {
+                const int pr = v0 / ASLOTS, sl = v0 - pr * ASLOTS;
+                if (pr < mleft && ci0 + sl * 8 < p.Cin)
+                    *reinterpret_cast<uint4*>(dxp + (long long)pr * p.dxs + sl * 8) = *reinterpret_cast<const uint4*>(Os + pr * OS + sl * 16);
+            }
         }
         MPN_WG_STAMP(0);
     }
@@ -611,6 +728,33 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
 #endif
 #undef MPN_WG_STAMP
 
+    if constexpr (DG) {
+        // sums over the 16 pixel lanes of a (mt, lq) group (fixed butterfly), then over the 8 waves through LDS in wave order
+        float* red = reinterpret_cast<float*>(Os + OBYTES);       // [8 waves][2][CG]
+        __syncthreads();                                           // (the last tile's copy-out has read the output image)
+#pragma unroll
+        for (int mt = 0; mt < MT_TOTAL; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = bsum[mt][r], b = bsq[mt][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+                if (l15 == 0) {
+                    red[(wave * 2 + 0) * CG + mt * 16 + lq * 4 + r] = a;
+                    red[(wave * 2 + 1) * CG + mt * 16 + lq * 4 + r] = b;
+                }
+            }
+        __syncthreads();
+        for (int o = tid; o < 2 * CG; o += NT) {
+            const int which = o / CG, c = o - which * CG;
+            if (ci0 + c < p.Cin) {
+                float a = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) a += red[(w8 * 2 + which) * CG + c];
+                p.bn_part[((long long)split * 2 + which) * p.Cin + ci0 + c] = a;
+            }
+        }
+    }
     float* __restrict__ dst = p.part + (long long)split * TAPS * p.Cin * p.Cout;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
@@ -632,6 +776,11 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
 template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
 __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradParams p) {
     conv_wgrad_bf16_body<T, TAPS, RBA, RBD, WM, STAGGER>(p, blockIdx.x, gridDim.x);
+}
+
+template <typename T, int RBA, int RBD, int WM>
+__global__ __launch_bounds__(512, 1) void conv1x1_bwd_fused_kernel(const WgradParams p) {
+    conv_wgrad_bf16_body<T, 1, RBA, RBD, WM, false, true>(p, blockIdx.x, gridDim.x);
 }
 
 // up to five independent layers of one (Cin, Cout, ksize) in one grid: as launches of their own the small pyramid levels are
@@ -898,4 +1047,59 @@ extern "C" int mpn_conv_bwd_weight_grouped(int njobs, const void* const* x, cons
     if (ksize == 1) return launch_wgrad_bf16_grouped<bf16_t, 1, 256, 256, 4, false>(grp, begin, st);
     if (Cout <= 64) return launch_wgrad_bf16_grouped<bf16_t, 9, 256, 128, 4, true>(grp, begin, st);
     return launch_wgrad_bf16_grouped<bf16_t, 9, 128, 256, 2, true>(grp, begin, st);
+}
+
+namespace {
+template <typename T, int RBA, int RBD, int WM>
+int launch_conv1x1_bwd_fused(const WgradParams& p, hipStream_t st) {
+    constexpr int CG = RBA / 2;
+    constexpr int smem = 2 * 128 * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * CG * (int)sizeof(float) + 128 * (RBA + 32) + 128 * (RBA + 16) +
+                         8 * 2 * CG * (int)sizeof(float);
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static mpn_attr_mask_t attr_mask{0};
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv1x1_bwd_fused_kernel<T, RBA, RBD, WM>, smem, &attr_mask));
+    conv1x1_bwd_fused_kernel<T, RBA, RBD, WM><<<dim3((unsigned)p.nsplit), dim3(512), smem, st>>>(p);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+}  // namespace
+
+/* 1 when mpn_conv1x1_bwd_fused takes this layer: bf16 storage (the batch-norm kernels that finish the reduction take f32 / bf16), a thin pointwise layer whose channels fit ONE block tile
+ * (Cin <= 64, Cout <= 128: Conv2d_1_pointwise and Conv2d_2_pointwise of mobilenet_v1.py:66-74 at depth_multiplier 1) */
+extern "C" int mpn_conv1x1_bwd_fused_supported(int Cin, int Cout, int dtype) {
+    return (dtype == MPN_BF16 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin <= 64 && Cout <= 128) ? 1 : 0;
+}
+
+/* A thin 1x1 convolution's backward in ONE pass over x and dy: wpart [mpn_conv_wgrad_num_parts(.., 1, ..)][Cin][Cout] = weight-gradient
+ * partials over act(x * in_scale + in_shift) (finish with mpn_reduce_partials), dx [N,H,W,Cin] = dy . w^T MASKED by that activation
+ * (lo < x * in_scale + in_shift < hi on the raw x) and bn_part [same rows][2][Cin] = partial sums of the masked gradient g and of
+ * g * x with the RAW x (finish with mpn_bn_bwd_finalize_raw) - what mpn_conv_bwd_weight + mpn_conv_bwd_data_bn produce in two passes
+ * over both tensors. w: the layer's f32 kernel [Cin][Cout] (HWIO of a 1x1), rounded to the storage type as the packed weights are. */
+extern "C" int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, float* bn_part, int N, int H,
+                                     int W, int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype,
+                                     const float* in_scale, const float* in_shift, int in_act, mpn_stream_t stream) {
+    MPN_REQUIRE(mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype), MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused: layer not covered (Cin %d, Cout %d)", Cin, Cout);
+    MPN_REQUIRE(x && dy && w && dx && wpart && bn_part && in_scale && in_shift && N > 0 && H > 0 && W > 0, MPN_ERR_BAD_ARG, "conv1x1_bwd_fused: bad arguments");
+    MPN_REQUIRE(mpn_aligned16(x) && mpn_aligned16(dy) && mpn_aligned16(dx), MPN_ERR_BAD_ALIGN, "conv1x1_bwd_fused: pointers must be 16-byte aligned");
+    MPN_REQUIRE(dx != x && dx != dy, MPN_ERR_BAD_ARG, "conv1x1_bwd_fused: dx must not alias an input");
+    WgradParams p = {};
+    p.x = x; p.dy = dy; p.part = wpart; p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act;
+    p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.xs = x_stride > 0 ? x_stride : Cin; p.dys = dy_stride > 0 ? dy_stride : Cout; p.dxs = dx_stride > 0 ? dx_stride : Cin;
+    MPN_REQUIRE(p.xs >= Cin && p.dys >= Cout && p.dxs >= Cin && p.xs % 8 == 0 && p.dys % 8 == 0 && p.dxs % 8 == 0, MPN_ERR_BAD_SHAPE,
+                "conv1x1_bwd_fused: pixel strides must be multiples of 8 not below the channel counts");
+    MPN_REQUIRE((long long)N * H * W * p.xs < (1ll << 31) && (long long)N * H * W * p.dys < (1ll << 31), MPN_ERR_BAD_SHAPE,
+                "conv1x1_bwd_fused: tensors must span fewer than 2^31 elements");
+    const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout, 1, 2);
+    MPN_REQUIRE(g.n_cg == 1 && g.n_cb == 1, MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused: one block tile must hold the layer");
+    p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
+    p.M = (long long)N * H * W;
+    p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = 1; p.n_cb = 1; p.xcd_remap = 1;
+    p.wf = w; p.dx = dx; p.bn_part = bn_part;
+#ifdef MPN_DIAG
+    p.dbg = nullptr;
+#endif
+    hipStream_t st = (hipStream_t)stream;
+    const bool thin32 = Cin <= 32 && Cout <= 64;
+    return thin32 ? launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2>(p, st) : launch_conv1x1_bwd_fused<bf16_t, 128, 256, 2>(p, st);
 }

@@ -315,6 +315,7 @@ class KeypointNet:
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
+        self.fuse_pw_bwd = True   # thin pointwise layers (Cin <= 64, Cout <= 128): weight + data gradient + reduction in one pass (mpn_conv1x1_bwd_fused)
         self.fuse_dw_bwd = True   # stride-1 depthwise layers: data gradient + that reduction + weight gradient in ONE walk (mpn_dwconv_bwd_fused)
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
@@ -786,17 +787,24 @@ class KeypointNet:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
             ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced, raw=raw_sums and reduced > 0)
             raw_sums = False                                    # (depthwise data gradients sum g * xhat themselves)
-            with _lib.tagged("pointwise"):
-                W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
-            # the deep pointwise layers' data gradients also reduce for the depthwise batch-norm they feed
-            if self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(blk["pw"].cout, blk["pw"].cin, 1, self.dtype):
+            # the thin pointwise layers: weight gradient, data gradient and the reduction for the depthwise batch-norm below in ONE
+            # pass over the layer's input and dY (each tensor once instead of twice)
+            if self.fuse_pw_bwd and self.fuse_conv_bn and ops.conv1x1_bwd_fused_supported(blk["pw"].cin, blk["pw"].cout, self.dtype):
                 with _lib.tagged("pointwise"):
-                    rows = ops.conv_bwd_data_bn(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, blk["dw_bn"], b["dw"][i], g["dw"][i], sp)
+                    rows = ops.conv1x1_bwd_fused(b["dw"][i], dA, blk["pw"].w, blk["dw_bn"], g["dw"][i], slab[id(blk["pw"].dw)], sp)
                 ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, reduced_parts=rows, raw=True)
             else:
                 with _lib.tagged("pointwise"):
-                    ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
-                ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
+                    W(lambda: ops.conv_bwd_weight(b["dw"][i], dA, 1, blk["dw_bn"].affine, blk["pw"].dw, slab[id(blk["pw"].dw)], reduce=False))
+                # the deep pointwise layers' data gradients also reduce for the depthwise batch-norm they feed
+                if self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(blk["pw"].cout, blk["pw"].cin, 1, self.dtype):
+                    with _lib.tagged("pointwise"):
+                        rows = ops.conv_bwd_data_bn(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, blk["dw_bn"], b["dw"][i], g["dw"][i], sp)
+                    ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, reduced_parts=rows, raw=True)
+                else:
+                    with _lib.tagged("pointwise"):
+                        ops.conv_fwd(dA, blk["pw"].packed.bwd, blk["pw"].cin, 1, None, out=g["dw"][i])
+                    ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp)
             xin = b["pw"][i - 1] if i > 0 else b["stem"]
             ain = self.blocks[i - 1]["pw_bn"].affine if i > 0 else self.stem_bn.affine
             dst = g["pw"][i - 1] if i > 0 else g["stem"]

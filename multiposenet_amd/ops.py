@@ -152,6 +152,26 @@ def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
     return [conv_num_parts(N, t.shape[1], t.shape[2], 3) for t in dys]
 
 
+def conv1x1_bwd_fused_supported(cin, cout, dtype):
+    """True when conv1x1_bwd_fused takes this pointwise layer (bf16 storage, Cin <= 64, Cout <= 128)."""
+    return _lib.lib().mpn_conv1x1_bwd_fused_supported(int(cin), int(cout), _lib.dtype_code(dtype)) == 1
+
+
+def conv1x1_bwd_fused(x, dy, w, bn, out, wpart, bn_part):
+    """A thin 1x1 convolution's backward in one pass over x and dy: x = the layer's RAW input (raw output of the layer with batch-norm
+    state `bn`), dy = gradient w.r.t. the layer's output, w = its f32 kernel [1,1,Cin,Cout]. out <- the data gradient masked by bn's
+    activation, wpart <- the weight gradient's split-K slab (conv_wgrad_num_parts rows; reduce later), bn_part <- partial sums of g
+    and g * x (raw x). Returns the rows both slabs hold - pass them to bn_backward(..., reduced_parts=rows, raw=True)."""
+    N, H, W, cin = x.shape
+    cout = dy.shape[3]
+    rows = conv_wgrad_num_parts(N, H, W, cin, cout, 1, x.dtype)
+    if wpart.numel() < rows * cin * cout or bn_part.numel() < rows * 2 * cin:
+        raise ValueError("conv1x1_bwd_fused: partial slab too small")
+    call("mpn_conv1x1_bwd_fused", ptr(x), ptr(dy), ptr(w), ptr(out), ptr(wpart), ptr(bn_part), N, H, W, cin, cout, _slice_stride(x, cin),
+         _slice_stride(dy, cout), _slice_stride(out, cin), _lib.dtype_code(x.dtype), ptr(bn.scale), ptr(bn.shift), int(bn.act), stream_ptr())
+    return rows
+
+
 def conv_wgrad_num_parts(N, H, W, cin, cout, ksize, dtype):
     return _lib.lib().mpn_conv_wgrad_num_parts(N, H, W, cin, cout, ksize, _lib.dtype_code(dtype))
 

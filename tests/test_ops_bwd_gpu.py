@@ -762,3 +762,58 @@ def test_dwconv_bwd_fused_equals_the_separate_launches(cuda, dtype, N, H, W, C):
     dw_n = torch.zeros(3, 3, C, device="cuda")
     dA_n, r0 = ops.dwconv_bwd_fused(x, dy, w, bn_a, dw_n, reduce_bn=False)
     assert r0 == 0 and torch.equal(dA_n, dA_want) and torch.equal(dw_n, dw_got)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16], ids=["bf16"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,act", [(2, 16, 16, 32, 64, 2), (1, 37, 29, 32, 64, 1), (2, 24, 24, 64, 128, 2), (1, 10, 6, 16, 32, 2),
+                                                 (3, 40, 40, 64, 128, 1), (1, 9, 7, 48, 96, 2)])
+def test_conv1x1_bwd_fused_equals_the_two_pass_backward(cuda, dtype, N, H, W, Cin, Cout, act):
+    """mpn_conv1x1_bwd_fused: ONE pass over x and dy gives the weight-gradient slab of mpn_conv_bwd_weight (bit for bit: the same
+    tiles, the same MFMA order), the masked data gradient of mpn_conv_bwd_data_bn (same products, the accumulation order of another
+    kernel: within a storage ulp) and partial rows that finalize like that kernel's - ragged pixel counts, channels below the tile."""
+    ops = _ops()
+    rs = np.random.RandomState(Cin + Cout + H)
+    x = dev(rnd(rs.randn(N, H, W, Cin), dtype), dtype)
+    dy = dev(rnd(rs.randn(N, H, W, Cout), dtype), dtype)
+    w = dev((rs.randn(1, 1, Cin, Cout) / np.sqrt(Cout)).astype(np.float32))
+    assert ops.conv1x1_bwd_fused_supported(Cin, Cout, dtype) and not ops.conv1x1_bwd_fused_supported(128, 128, dtype)
+    assert not ops.conv1x1_bwd_fused_supported(Cin, Cout, torch.float32) and not ops.conv1x1_bwd_fused_supported(Cin, Cout, torch.float16)
+
+    def mkbn(seed):
+        r2 = np.random.RandomState(seed)
+        one = lambda: torch.tensor((0.5 + r2.rand(Cin)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), act)
+        bn.scale.copy_(one()); bn.invstd.copy_(one())
+        bn.shift.copy_(torch.tensor((r2.randn(Cin) * 0.5).astype(np.float32)).cuda()); bn.mean.copy_(torch.tensor((r2.randn(Cin) * 0.3).astype(np.float32)).cuda())
+        bn.dgamma, bn.dbeta = torch.zeros(Cin, device="cuda"), torch.zeros(Cin, device="cuda")
+        return bn
+    bn_a, bn_b = mkbn(5), mkbn(5)
+    rows = ops.conv_wgrad_num_parts(N, H, W, Cin, Cout, 1, dtype)
+    M = N * H * W
+    # two passes
+    wp_b = torch.zeros(rows * Cin * Cout, device="cuda")
+    dW_b = torch.zeros(1, 1, Cin, Cout, device="cuda")
+    ops.conv_bwd_weight(x, dy, 1, bn_b.affine, dW_b, wp_b, reduce=True)
+    pc = ops.PackedConv(w, dtype)
+    g_b = torch.empty_like(x)
+    if ops.conv_bwd_data_bn_supported(Cout, Cin, 1, dtype):
+        sp_b = torch.zeros(max(ops.conv_num_parts(N, H, W, 1), rows) * 2 * Cin, device="cuda")
+        rows_b = ops.conv_bwd_data_bn(dy, pc.bwd, Cin, 1, bn_b, x, g_b, sp_b)
+        ops.bn_backward(bn_b, g_b, x, sp_b, reduced_parts=rows_b, raw=True)
+    else:   # (shapes the two-pass fused reduction does not take: plain data gradient + separate reduction)
+        ops.conv_fwd(dy, pc.bwd, Cin, 1, None, out=g_b)
+        ops.bn_backward(bn_b, g_b, x, torch.zeros(ops._lib.lib().mpn_bn_stats_num_parts(M) * 2 * Cin, device="cuda"))
+    # one pass
+    wp_a = torch.zeros(rows * Cin * Cout, device="cuda")
+    sp_a = torch.zeros(rows * 2 * Cin, device="cuda")
+    g_a = torch.empty_like(x)
+    r = ops.conv1x1_bwd_fused(x, dy, w, bn_a, g_a, wp_a, sp_a)
+    assert r == rows
+    dW_a = torch.zeros(1, 1, Cin, Cout, device="cuda")
+    ops.call("mpn_reduce_partials", ops.ptr(wp_a), rows, Cin * Cout, ops.ptr(dW_a), 0, 1.0, ops.stream_ptr())
+    scale = float(dW_b.abs().max()) + 1e-6
+    assert float((dW_a - dW_b).abs().max()) <= 2e-6 * scale * max(1.0, M ** 0.5 / 8)
+    ops.bn_backward(bn_a, g_a, x, sp_a, reduced_parts=rows, raw=True)
+    assert float((bn_a.dgamma - bn_b.dgamma).abs().max()) <= 3e-5 * (float(bn_b.dgamma.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
+    assert float((bn_a.dbeta - bn_b.dbeta).abs().max()) <= 3e-5 * (float(bn_b.dbeta.abs().max()) + 1e-6) * max(1.0, M ** 0.5 / 16)
+    assert_close(g_a, g_b.float().cpu(), dtype, 4)
