@@ -156,6 +156,16 @@ int mpn_conv1x1_bwd_fused_supported(int Cin, int Cout, int dtype);
 int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, float* bn_part, int N, int H, int W,
                           int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype, const float* in_scale,
                           const float* in_shift, int in_act, mpn_stream_t stream);
+/* ... with the batch-norm backward APPLY pass of the layer's OWN batch-norm folded into the staging of dY (the 32 x 64 block tile only:
+ * Cin <= 32, Cout <= 64): g = the gradient w.r.t. the layer's activated output (what mpn_bn_bwd_apply would turn into dy in place),
+ * y_raw = the layer's raw output, ap_* that batch-norm's affine, saved statistics and the k1 / k2 of mpn_bn_bwd_finalize. The slabs and dx of
+ * mpn_bn_bwd_apply followed by mpn_conv1x1_bwd_fused (to the storage rounding of a rare staged element); g and y_raw are not written. */
+int mpn_conv1x1_bwd_fused_apply_supported(int Cin, int Cout, int dtype);
+int mpn_conv1x1_bwd_fused_apply(const void* x, const void* g, const void* y_raw, const float* w, void* dx, float* wpart, float* bn_part,
+                                int N, int H, int W, int Cin, int Cout, int x_stride, int g_stride, int y_stride, int dx_stride,
+                                int dtype, const float* in_scale, const float* in_shift, int in_act, const float* ap_scale,
+                                const float* ap_shift, const float* ap_mean, const float* ap_invstd, const float* ap_k1,
+                                const float* ap_k2, int ap_act, mpn_stream_t stream);
 /* The weight gradients of njobs independent layers of one (Cin, Cout, ksize, dtype) in ONE grid - the pyramid levels of a
  * subnet stage (keypoint_subnet.py:66-79: one phi_subnet per level; fpn.py:38-52: one 3x3 per level). The 256 blocks are
  * divided among the jobs by their pixel counts, so a stage leaves 128 partial slabs in all instead of 128 per level, and the

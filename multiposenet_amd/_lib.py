@@ -42,6 +42,8 @@ SIGNATURES = {
     "mpn_conv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_conv1x1_bwd_fused_supported": (_I, [_I, _I, _I]),
     "mpn_conv1x1_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
+    "mpn_conv1x1_bwd_fused_apply_supported": (_I, [_I, _I, _I]),
+    "mpn_conv1x1_bwd_fused_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "mpn_conv_wgrad_grouped_num_parts": (_I, [_I, _I, _P, _P, _I, _I, _I, _I, _P]),
     "mpn_conv_bwd_weight_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P]),
     "mpn_bn_stats_num_parts": (_I, [_L]),

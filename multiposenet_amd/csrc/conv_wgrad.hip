@@ -48,6 +48,13 @@ struct WgradParams {
     void* dx;
     int dxs;
     float* bn_part;
+    // ... with the batch-norm backward APPLY pass of the layer's OWN batch-norm folded into the dY staging (DAPPLY): dy is then the
+    // gradient w.r.t. the layer's activated output, ap_x the layer's raw output (pixel stride ap_xs), ap_* that batch-norm's affine,
+    // saved statistics and the k1 / k2 of mpn_bn_bwd_finalize
+    const void* ap_x;
+    int ap_xs;
+    const float* ap_scale; const float* ap_shift; const float* ap_mean; const float* ap_invstd; const float* ap_k1; const float* ap_k2;
+    int ap_act;
 #ifdef MPN_DIAG
     unsigned long long* dbg;   // diagnostic build only (mpn_diag_set_wgrad_stamps): per-wave phase times, else NULL
 #endif
@@ -349,7 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
 // transpose) and the layer's kernel from registers (bf16 fragments, loaded once) - plus the RAW input rows for the mask and the
 // sums of the batch-norm reduction (a third image, written by the same commit). Separately the two gradients read dY twice and x
 // twice; here once each: 536 -> 402... MB on Conv2d_1_pointwise. A wave owns 16 of the tile's 128 pixels for this part.
-template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER, bool DG = false>
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER, bool DG = false, bool DAPPLY = false>
 __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const int blk, const int nblk) {
     using H = H16<T>;
     using X8 = typename H::x8;
@@ -421,7 +428,27 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     const int dslot = tid % DSLOTS;
 
     Vec16<T> v[AVEC], dv[DVEC];
+    Vec16<T> ev[DAPPLY ? DVEC : 1];            // DAPPLY: the layer's raw output at the dY pieces
     unsigned inb = 0u, inbd = 0u;
+    static_assert(!DAPPLY || DG, "the apply pass folds into the fused thin backward");
+    // DAPPLY: dY = sc * g + (cb * y + cc), g = the incoming gradient where lo < y * sc + sh < hi, rounded to storage - the expression
+    // and the rounding of bn_bwd_apply_body (bn.hip); a thread's channels (its 16-byte slot) are fixed, the constants fold once
+    float asc[DAPPLY ? VE : 1], ash[DAPPLY ? VE : 1], acb[DAPPLY ? VE : 1], acc_[DAPPLY ? VE : 1];
+    float alo = -INFINITY, ahi = INFINITY;
+    if constexpr (DAPPLY) {
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            const int c = co0 + dslot * VE + j;
+            const bool ok = c < p.Cout;
+            const float s_ = ok ? p.ap_scale[c] : 0.f, h_ = ok ? p.ap_shift[c] : 0.f, m_ = ok ? p.ap_mean[c] : 0.f;
+            const float i_ = ok ? p.ap_invstd[c] : 0.f, a_ = ok ? p.ap_k1[c] : 0.f, b_ = ok ? p.ap_k2[c] : 0.f;
+            asc[j] = s_; ash[j] = h_;
+            acb[j] = -s_ * b_ * i_;
+            acc_[j] = -s_ * (a_ - m_ * i_ * b_);
+        }
+        alo = (p.ap_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+        ahi = (p.ap_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    }
 
     // Per-thread invariants of the staging (32-bit element offsets relative to the tile origin; the host checks that
     // both tensors have < 2^31 elements). Halo position packed as hy << 8 | hx.
@@ -501,6 +528,16 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
         for (int i = 0; i < AVEC; ++i) v[i].load(x + oa[i]);
 #pragma unroll
         for (int i = 0; i < DVEC; ++i) dv[i].load(dy + od[i]);
+        if constexpr (DAPPLY) {
+            // (dense layers: dy and the raw output share the pixel stride when ap_xs == dys; else the offset is rescaled per piece)
+            const T* __restrict__ ax = reinterpret_cast<const T*>(p.ap_x);
+#pragma unroll
+            for (int i = 0; i < DVEC; ++i) {
+                const int r = drow0 + i * (NT / DSLOTS);
+                const bool ok = (inbd >> i) & 1u;
+                ev[i].load(ax + (ok ? (long long)(tile * 128 + r) * p.ap_xs + co0 + dslot * VE : 0));
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -543,6 +580,20 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
         for (int i = 0; i < DVEC; ++i) {
             const int r = (tid / DSLOTS) + i * (NT / DSLOTS);
             uint4 q = *reinterpret_cast<const uint4*>(&dv[i].raw);
+            if constexpr (DAPPLY) {
+                float d[VE], f[VE];
+                dv[i].unpack(d);
+                ev[i].unpack(f);
+#pragma unroll
+                for (int j = 0; j < VE; ++j) {
+                    const float pre = f[j] * asc[j] + ash[j];
+                    const float gg = (pre > alo && pre < ahi) ? d[j] : 0.f;
+                    d[j] = asc[j] * gg + (acb[j] * f[j] + acc_[j]);
+                }
+                Vec16<T> o;
+                o.pack(d);
+                q = *reinterpret_cast<const uint4*>(&o.raw);
+            }
             if (!((inbd >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(Ds + r * SD + dslot * 16) = q;
         }
@@ -778,9 +829,9 @@ __global__ __launch_bounds__(512, 1) void conv_wgrad_bf16_kernel(const WgradPara
     conv_wgrad_bf16_body<T, TAPS, RBA, RBD, WM, STAGGER>(p, blockIdx.x, gridDim.x);
 }
 
-template <typename T, int RBA, int RBD, int WM>
+template <typename T, int RBA, int RBD, int WM, bool DAPPLY>
 __global__ __launch_bounds__(512, 1) void conv1x1_bwd_fused_kernel(const WgradParams p) {
-    conv_wgrad_bf16_body<T, 1, RBA, RBD, WM, false, true>(p, blockIdx.x, gridDim.x);
+    conv_wgrad_bf16_body<T, 1, RBA, RBD, WM, false, true, DAPPLY>(p, blockIdx.x, gridDim.x);
 }
 
 // up to five independent layers of one (Cin, Cout, ksize) in one grid: as launches of their own the small pyramid levels are
@@ -1050,15 +1101,15 @@ extern "C" int mpn_conv_bwd_weight_grouped(int njobs, const void* const* x, cons
 }
 
 namespace {
-template <typename T, int RBA, int RBD, int WM>
+template <typename T, int RBA, int RBD, int WM, bool DAPPLY = false>
 int launch_conv1x1_bwd_fused(const WgradParams& p, hipStream_t st) {
     constexpr int CG = RBA / 2;
     constexpr int smem = 2 * 128 * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * CG * (int)sizeof(float) + 128 * (RBA + 32) + 128 * (RBA + 16) +
                          8 * 2 * CG * (int)sizeof(float);
     static_assert(smem <= 160 * 1024, "LDS budget");
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv1x1_bwd_fused_kernel<T, RBA, RBD, WM>, smem, &attr_mask));
-    conv1x1_bwd_fused_kernel<T, RBA, RBD, WM><<<dim3((unsigned)p.nsplit), dim3(512), smem, st>>>(p);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv1x1_bwd_fused_kernel<T, RBA, RBD, WM, DAPPLY>, smem, &attr_mask));
+    conv1x1_bwd_fused_kernel<T, RBA, RBD, WM, DAPPLY><<<dim3((unsigned)p.nsplit), dim3(512), smem, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
@@ -1075,9 +1126,11 @@ extern "C" int mpn_conv1x1_bwd_fused_supported(int Cin, int Cout, int dtype) {
  * (lo < x * in_scale + in_shift < hi on the raw x) and bn_part [same rows][2][Cin] = partial sums of the masked gradient g and of
  * g * x with the RAW x (finish with mpn_bn_bwd_finalize_raw) - what mpn_conv_bwd_weight + mpn_conv_bwd_data_bn produce in two passes
  * over both tensors. w: the layer's f32 kernel [Cin][Cout] (HWIO of a 1x1), rounded to the storage type as the packed weights are. */
-extern "C" int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, float* bn_part, int N, int H,
-                                     int W, int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype,
-                                     const float* in_scale, const float* in_shift, int in_act, mpn_stream_t stream) {
+namespace {
+struct Conv1x1Apply { const void* y_raw; int y_stride; const float *scale, *shift, *mean, *invstd, *k1, *k2; int act; };
+int conv1x1_bwd_fused_impl(const void* x, const void* dy, const float* w, void* dx, float* wpart, float* bn_part, int N, int H,
+                           int W, int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype,
+                           const float* in_scale, const float* in_shift, int in_act, const Conv1x1Apply* ap, mpn_stream_t stream) {
     MPN_REQUIRE(mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype), MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused: layer not covered (Cin %d, Cout %d)", Cin, Cout);
     MPN_REQUIRE(x && dy && w && dx && wpart && bn_part && in_scale && in_shift && N > 0 && H > 0 && W > 0, MPN_ERR_BAD_ARG, "conv1x1_bwd_fused: bad arguments");
     MPN_REQUIRE(mpn_aligned16(x) && mpn_aligned16(dy) && mpn_aligned16(dx), MPN_ERR_BAD_ALIGN, "conv1x1_bwd_fused: pointers must be 16-byte aligned");
@@ -1101,5 +1154,42 @@ extern "C" int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float*
 #endif
     hipStream_t st = (hipStream_t)stream;
     const bool thin32 = Cin <= 32 && Cout <= 64;
+    if (ap != nullptr) {
+        MPN_REQUIRE(thin32, MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: layer not covered (Cin %d, Cout %d)", Cin, Cout);
+        MPN_REQUIRE(ap->y_raw && ap->scale && ap->shift && ap->mean && ap->invstd && ap->k1 && ap->k2 && mpn_aligned16(ap->y_raw), MPN_ERR_BAD_ARG,
+                    "conv1x1_bwd_fused_apply: bad batch-norm arguments");
+        p.ap_x = ap->y_raw; p.ap_xs = ap->y_stride > 0 ? ap->y_stride : Cout;
+        MPN_REQUIRE(p.ap_xs >= Cout && p.ap_xs % 8 == 0 && (long long)N * H * W * p.ap_xs < (1ll << 31), MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: bad raw-output stride");
+        p.ap_scale = ap->scale; p.ap_shift = ap->shift; p.ap_mean = ap->mean; p.ap_invstd = ap->invstd; p.ap_k1 = ap->k1; p.ap_k2 = ap->k2; p.ap_act = ap->act;
+        return launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2, true>(p, st);
+    }
     return thin32 ? launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2>(p, st) : launch_conv1x1_bwd_fused<bf16_t, 128, 256, 2>(p, st);
+}
+}  // namespace
+
+extern "C" int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, float* bn_part, int N, int H,
+                                     int W, int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype,
+                                     const float* in_scale, const float* in_shift, int in_act, mpn_stream_t stream) {
+    return conv1x1_bwd_fused_impl(x, dy, w, dx, wpart, bn_part, N, H, W, Cin, Cout, x_stride, dy_stride, dx_stride, dtype, in_scale, in_shift,
+                                  in_act, nullptr, stream);
+}
+
+/* 1 when mpn_conv1x1_bwd_fused_apply takes this layer (the 32 x 64 block tile: Cin <= 32, Cout <= 64, bf16) */
+extern "C" int mpn_conv1x1_bwd_fused_apply_supported(int Cin, int Cout, int dtype) {
+    return (mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype) && Cin <= 32 && Cout <= 64) ? 1 : 0;
+}
+
+/* mpn_conv1x1_bwd_fused with the batch-norm backward APPLY pass of the layer's OWN batch-norm folded into the staging of dY: g = the
+ * gradient w.r.t. the layer's activated output (what mpn_bn_bwd_apply would turn into dy in place), y_raw = the layer's raw output,
+ * ap_* that batch-norm's affine, saved statistics and the k1 / k2 of mpn_bn_bwd_finalize. The slabs and dx of mpn_bn_bwd_apply
+ * followed by mpn_conv1x1_bwd_fused (to the storage rounding of a rare staged element); g and y_raw are not written (two passes over the
+ * layer's output tensor less). */
+extern "C" int mpn_conv1x1_bwd_fused_apply(const void* x, const void* g, const void* y_raw, const float* w, void* dx, float* wpart,
+                                           float* bn_part, int N, int H, int W, int Cin, int Cout, int x_stride, int g_stride, int y_stride,
+                                           int dx_stride, int dtype, const float* in_scale, const float* in_shift, int in_act,
+                                           const float* ap_scale, const float* ap_shift, const float* ap_mean, const float* ap_invstd,
+                                           const float* ap_k1, const float* ap_k2, int ap_act, mpn_stream_t stream) {
+    const Conv1x1Apply ap = {y_raw, y_stride, ap_scale, ap_shift, ap_mean, ap_invstd, ap_k1, ap_k2, ap_act};
+    return conv1x1_bwd_fused_impl(x, g, w, dx, wpart, bn_part, N, H, W, Cin, Cout, x_stride, g_stride, dx_stride, dtype, in_scale, in_shift,
+                                  in_act, &ap, stream);
 }

@@ -315,6 +315,7 @@ class KeypointNet:
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
+        self.fuse_pw_apply = True # ... with the layer's own batch-norm apply pass folded in where the kernel takes it (Cin <= 32, Cout <= 64)
         self.fuse_pw_bwd = True   # thin pointwise layers (Cin <= 64, Cout <= 128): weight + data gradient + reduction in one pass (mpn_conv1x1_bwd_fused)
         self.fuse_dw_bwd = True   # stride-1 depthwise layers: data gradient + that reduction + weight gradient in ONE walk (mpn_dwconv_bwd_fused)
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
@@ -785,13 +786,17 @@ class KeypointNet:
             blk = self.blocks[i]
             if blk["i"] in FEATURE_BLOCKS and blk["i"] != 13 and not lateral_added:
                 ops.add_inplace(dA, g["c"][FEATURE_BLOCKS[blk["i"]]])
-            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced, raw=raw_sums and reduced > 0)
-            raw_sums = False                                    # (depthwise data gradients sum g * xhat themselves)
             # the thin pointwise layers: weight gradient, data gradient and the reduction for the depthwise batch-norm below in ONE
-            # pass over the layer's input and dY (each tensor once instead of twice)
-            if self.fuse_pw_bwd and self.fuse_conv_bn and ops.conv1x1_bwd_fused_supported(blk["pw"].cin, blk["pw"].cout, self.dtype):
+            # pass over the layer's input and dY (each tensor once instead of twice); on the thinnest one the layer's own batch-norm
+            # apply pass happens while dY is staged (two more passes over its output tensor less)
+            pw_fused = self.fuse_pw_bwd and self.fuse_conv_bn and ops.conv1x1_bwd_fused_supported(blk["pw"].cin, blk["pw"].cout, self.dtype)
+            pw_apply = pw_fused and self.fuse_pw_apply and ops.conv1x1_bwd_fused_apply_supported(blk["pw"].cin, blk["pw"].cout, self.dtype)
+            ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced, raw=raw_sums and reduced > 0, apply=not pw_apply)
+            raw_sums = False                                    # (depthwise data gradients sum g * xhat themselves)
+            if pw_fused:
                 with _lib.tagged("pointwise"):
-                    rows = ops.conv1x1_bwd_fused(b["dw"][i], dA, blk["pw"].w, blk["dw_bn"], g["dw"][i], slab[id(blk["pw"].dw)], sp)
+                    rows = ops.conv1x1_bwd_fused(b["dw"][i], dA, blk["pw"].w, blk["dw_bn"], g["dw"][i], slab[id(blk["pw"].dw)], sp,
+                                                 apply_bn=blk["pw_bn"] if pw_apply else None, y_raw=b["pw"][i] if pw_apply else None)
                 ops.bn_backward(blk["dw_bn"], g["dw"][i], b["dw"][i], sp, reduced_parts=rows, raw=True)
             else:
                 with _lib.tagged("pointwise"):

@@ -157,7 +157,12 @@ def conv1x1_bwd_fused_supported(cin, cout, dtype):
     return _lib.lib().mpn_conv1x1_bwd_fused_supported(int(cin), int(cout), _lib.dtype_code(dtype)) == 1
 
 
-def conv1x1_bwd_fused(x, dy, w, bn, out, wpart, bn_part):
+def conv1x1_bwd_fused_apply_supported(cin, cout, dtype):
+    """True when conv1x1_bwd_fused(apply_bn=...) takes this layer (Cin <= 32, Cout <= 64, bf16)."""
+    return _lib.lib().mpn_conv1x1_bwd_fused_apply_supported(int(cin), int(cout), _lib.dtype_code(dtype)) == 1
+
+
+def conv1x1_bwd_fused(x, dy, w, bn, out, wpart, bn_part, apply_bn=None, y_raw=None):
     """A thin 1x1 convolution's backward in one pass over x and dy: x = the layer's RAW input (raw output of the layer with batch-norm
     state `bn`), dy = gradient w.r.t. the layer's output, w = its f32 kernel [1,1,Cin,Cout]. out <- the data gradient masked by bn's
     activation, wpart <- the weight gradient's split-K slab (conv_wgrad_num_parts rows; reduce later), bn_part <- partial sums of g
@@ -167,6 +172,15 @@ def conv1x1_bwd_fused(x, dy, w, bn, out, wpart, bn_part):
     rows = conv_wgrad_num_parts(N, H, W, cin, cout, 1, x.dtype)
     if wpart.numel() < rows * cin * cout or bn_part.numel() < rows * 2 * cin:
         raise ValueError("conv1x1_bwd_fused: partial slab too small")
+    if apply_bn is not None:
+        # dy is the gradient w.r.t. the ACTIVATED output of the layer's own batch-norm `apply_bn` (finalized: k1 / k2 set), y_raw the
+        # layer's raw output: that batch-norm's apply pass happens while dY is staged
+        a = apply_bn
+        call("mpn_conv1x1_bwd_fused_apply", ptr(x), ptr(dy), ptr(y_raw), ptr(w), ptr(out), ptr(wpart), ptr(bn_part), N, H, W, cin, cout,
+             _slice_stride(x, cin), _slice_stride(dy, cout), _slice_stride(y_raw, cout), _slice_stride(out, cin), _lib.dtype_code(x.dtype),
+             ptr(bn.scale), ptr(bn.shift), int(bn.act), ptr(a.scale), ptr(a.shift), ptr(a.mean), ptr(a.invstd), ptr(a.k1), ptr(a.k2),
+             int(a.act), stream_ptr())
+        return rows
     call("mpn_conv1x1_bwd_fused", ptr(x), ptr(dy), ptr(w), ptr(out), ptr(wpart), ptr(bn_part), N, H, W, cin, cout, _slice_stride(x, cin),
          _slice_stride(dy, cout), _slice_stride(out, cin), _lib.dtype_code(x.dtype), ptr(bn.scale), ptr(bn.shift), int(bn.act), stream_ptr())
     return rows
@@ -385,7 +399,7 @@ def bn_act_apply(x, affine, out=None):
     return out
 
 
-def bn_backward(bn, dA, x, part, add_ch0=None, reduced_parts=0, raw=False):
+def bn_backward(bn, dA, x, part, add_ch0=None, reduced_parts=0, raw=False, apply=True):
     """In place: dA (gradient w.r.t. act(bn(x))) -> gradient w.r.t. the raw conv output x.
     Writes bn.dgamma / bn.dbeta. `part` must hold mpn_bn_stats_num_parts(M)*2*C floats.
     reduced_parts > 0: the producer of dA already wrote that many partial rows into `part` (dwconv_bwd_data(..., bn=...);
@@ -402,8 +416,9 @@ def bn_backward(bn, dA, x, part, add_ch0=None, reduced_parts=0, raw=False):
         call("mpn_bn_bwd_reduce", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
              int(bn.act), ptr(part), stream_ptr())
         call("mpn_bn_bwd_finalize", ptr(part), nparts, C, M, ptr(bn.dgamma), ptr(bn.dbeta), ptr(bn.k1), ptr(bn.k2), stream_ptr())
-    call("mpn_bn_bwd_apply", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
-         ptr(bn.k1), ptr(bn.k2), int(bn.act), ptr(add_ch0), stream_ptr())
+    if apply:       # (apply=False: reduce + finalize only - the consumer applies on load, conv1x1_bwd_fused(apply_bn=...))
+        call("mpn_bn_bwd_apply", ptr(dA), ptr(x), M, C, dc, ptr(bn.scale), ptr(bn.shift), ptr(bn.mean), ptr(bn.invstd),
+             ptr(bn.k1), ptr(bn.k2), int(bn.act), ptr(add_ch0), stream_ptr())
     return dA
 
 
