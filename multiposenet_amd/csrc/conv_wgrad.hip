@@ -433,18 +433,17 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     static_assert(!DAPPLY || DG, "the apply pass folds into the fused thin backward");
     // DAPPLY: dY = sc * g + (cb * y + cc), g = the incoming gradient where lo < y * sc + sh < hi, rounded to storage - the expression
     // and the rounding of bn_bwd_apply_body (bn.hip); a thread's channels (its 16-byte slot) are fixed, the constants fold once
-    float asc[DAPPLY ? VE : 1], ash[DAPPLY ? VE : 1], acb[DAPPLY ? VE : 1], acc_[DAPPLY ? VE : 1];
+    // (kept in LDS, [4][BNW] floats behind the sums' scratch, and read per piece: as 32 registers per thread they spill on the 64 x 128 tile)
+    float* apc = reinterpret_cast<float*>(Os + OBYTES + (DG ? 8 * 2 * CG * (int)sizeof(float) : 0));
     float alo = -INFINITY, ahi = INFINITY;
     if constexpr (DAPPLY) {
-#pragma unroll
-        for (int j = 0; j < VE; ++j) {
-            const int c = co0 + dslot * VE + j;
-            const bool ok = c < p.Cout;
-            const float s_ = ok ? p.ap_scale[c] : 0.f, h_ = ok ? p.ap_shift[c] : 0.f, m_ = ok ? p.ap_mean[c] : 0.f;
-            const float i_ = ok ? p.ap_invstd[c] : 0.f, a_ = ok ? p.ap_k1[c] : 0.f, b_ = ok ? p.ap_k2[c] : 0.f;
-            asc[j] = s_; ash[j] = h_;
-            acb[j] = -s_ * b_ * i_;
-            acc_[j] = -s_ * (a_ - m_ * i_ * b_);
+        for (int c = tid; c < BNW; c += NT) {
+            const bool ok = co0 + c < p.Cout;
+            const float s_ = ok ? p.ap_scale[co0 + c] : 0.f, h_ = ok ? p.ap_shift[co0 + c] : 0.f, m_ = ok ? p.ap_mean[co0 + c] : 0.f;
+            const float i_ = ok ? p.ap_invstd[co0 + c] : 0.f, a_ = ok ? p.ap_k1[co0 + c] : 0.f, b_ = ok ? p.ap_k2[co0 + c] : 0.f;
+            apc[c] = s_; apc[BNW + c] = h_;
+            apc[2 * BNW + c] = -s_ * b_ * i_;
+            apc[3 * BNW + c] = -s_ * (a_ - m_ * i_ * b_);
         }
         alo = (p.ap_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
         ahi = (p.ap_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
@@ -581,9 +580,16 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
             const int r = (tid / DSLOTS) + i * (NT / DSLOTS);
             uint4 q = *reinterpret_cast<const uint4*>(&dv[i].raw);
             if constexpr (DAPPLY) {
-                float d[VE], f[VE];
+                float d[VE], f[VE], asc[VE], ash[VE], acb[VE], acc_[VE];
                 dv[i].unpack(d);
                 ev[i].unpack(f);
+#pragma unroll
+                for (int j4 = 0; j4 < VE; j4 += 4) {
+                    const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(apc + dslot * VE + j4), q1 = *reinterpret_cast<const f32x4_t*>(apc + BNW + dslot * VE + j4);
+                    const f32x4_t q2 = *reinterpret_cast<const f32x4_t*>(apc + 2 * BNW + dslot * VE + j4), q3 = *reinterpret_cast<const f32x4_t*>(apc + 3 * BNW + dslot * VE + j4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { asc[j4 + j] = q0[j]; ash[j4 + j] = q1[j]; acb[j4 + j] = q2[j]; acc_[j4 + j] = q3[j]; }
+                }
 #pragma unroll
                 for (int j = 0; j < VE; ++j) {
                     const float pre = f[j] * asc[j] + ash[j];
@@ -1105,7 +1111,7 @@ template <typename T, int RBA, int RBD, int WM, bool DAPPLY = false>
 int launch_conv1x1_bwd_fused(const WgradParams& p, hipStream_t st) {
     constexpr int CG = RBA / 2;
     constexpr int smem = 2 * 128 * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * CG * (int)sizeof(float) + 128 * (RBA + 32) + 128 * (RBA + 16) +
-                         8 * 2 * CG * (int)sizeof(float);
+                         8 * 2 * CG * (int)sizeof(float) + (DAPPLY ? 4 * (RBD / 2) * (int)sizeof(float) : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
     static mpn_attr_mask_t attr_mask{0};
     MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv1x1_bwd_fused_kernel<T, RBA, RBD, WM, DAPPLY>, smem, &attr_mask));
@@ -1155,12 +1161,12 @@ int conv1x1_bwd_fused_impl(const void* x, const void* dy, const float* w, void* 
     hipStream_t st = (hipStream_t)stream;
     const bool thin32 = Cin <= 32 && Cout <= 64;
     if (ap != nullptr) {
-        MPN_REQUIRE(thin32, MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: layer not covered (Cin %d, Cout %d)", Cin, Cout);
         MPN_REQUIRE(ap->y_raw && ap->scale && ap->shift && ap->mean && ap->invstd && ap->k1 && ap->k2 && mpn_aligned16(ap->y_raw), MPN_ERR_BAD_ARG,
                     "conv1x1_bwd_fused_apply: bad batch-norm arguments");
         p.ap_x = ap->y_raw; p.ap_xs = ap->y_stride > 0 ? ap->y_stride : Cout;
         MPN_REQUIRE(p.ap_xs >= Cout && p.ap_xs % 8 == 0 && (long long)N * H * W * p.ap_xs < (1ll << 31), MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: bad raw-output stride");
         p.ap_scale = ap->scale; p.ap_shift = ap->shift; p.ap_mean = ap->mean; p.ap_invstd = ap->invstd; p.ap_k1 = ap->k1; p.ap_k2 = ap->k2; p.ap_act = ap->act;
+        MPN_REQUIRE(thin32, MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: layer not covered (Cin %d, Cout %d)", Cin, Cout);
         return launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2, true>(p, st);
     }
     return thin32 ? launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2>(p, st) : launch_conv1x1_bwd_fused<bf16_t, 128, 256, 2>(p, st);
@@ -1176,6 +1182,7 @@ extern "C" int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float*
 
 /* 1 when mpn_conv1x1_bwd_fused_apply takes this layer (the 32 x 64 block tile: Cin <= 32, Cout <= 64, bf16) */
 extern "C" int mpn_conv1x1_bwd_fused_apply_supported(int Cin, int Cout, int dtype) {
+    // (the 64 x 128 tile with the apply pass folded in needs 49 spilled registers and is slower than the separate pass: not offered)
     return (mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype) && Cin <= 32 && Cout <= 64) ? 1 : 0;
 }
 
