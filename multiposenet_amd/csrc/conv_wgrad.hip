@@ -628,14 +628,17 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     // DG: the layer's kernel as bf16 fragments W[ci = mt * 16 + l15][co = ks * 32 + lq * 8 ..] (the rounding of the packed weights the
     // separate data gradient multiplies with), zero beyond the layer's channels; running sums of the reduction per lane:
     // channels mt * 16 + lq * 4 + r over the lane's pixel column l15 of every tile
-    X8 wfr[DG ? MT_TOTAL : 1][DG ? KS2 : 1];
-    float bsum[DG ? MT_TOTAL : 1][4], bsq[DG ? MT_TOTAL : 1][4];
+    // (from four channel tiles on, two waves share two pixel tiles and split the channel tiles: half the fragment registers per wave)
+    constexpr int DGS = MT_TOTAL >= 4 ? 2 : 1, MTH = MT_TOTAL / DGS;
+    const int dg_mt0 = DG ? (wave % DGS) * MTH : 0, dg_pt0 = DG ? (wave / DGS) * DGS : 0;
+    X8 wfr[DG ? MTH : 1][DG ? KS2 : 1];
+    float bsum[DG ? MTH : 1][4], bsq[DG ? MTH : 1][4];
     if constexpr (DG) {
 #pragma unroll
-        for (int mt = 0; mt < MT_TOTAL; ++mt) {
+        for (int mt = 0; mt < MTH; ++mt) {
 #pragma unroll
             for (int ks = 0; ks < KS2; ++ks) {
-                const int ci = ci0 + mt * 16 + l15, co = co0 + ks * 32 + lq * 8;
+                const int ci = ci0 + (dg_mt0 + mt) * 16 + l15, co = co0 + ks * 32 + lq * 8;
                 float f[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) f[j] = (ci < p.Cin && co + j < p.Cout) ? p.wf[(long long)ci * p.Cout + co + j] : 0.f;
@@ -720,40 +723,41 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (DG) {
-            // dA^T[ci][px] of this wave's 16 pixels: A operand = the kernel's fragment (rows = ci), B operand = the dY rows as they
-            // lie (k = co, columns = px); a lane ends up with channels mt * 16 + lq * 4 .. + 3 of pixel wave * 16 + l15
-            const int px = wave * 16 + l15;
-            f32x4_t dacc[MT_TOTAL];
+            // dA^T[ci][px] of this wave's pixel tiles: A operand = the kernel's fragment (rows = ci), B operand = the dY rows as they
+            // lie (k = co, columns = px); a lane ends up with channels (dg_mt0 + mt) * 16 + lq * 4 .. + 3 of pixel (dg_pt0 + j) * 16 + l15
 #pragma unroll
-            for (int mt = 0; mt < MT_TOTAL; ++mt) dacc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < DGS; ++j) {
+                const int px = (dg_pt0 + j) * 16 + l15;
+                f32x4_t dacc[MTH];
 #pragma unroll
-            for (int ks = 0; ks < KS2; ++ks) {
-                const X8 dfr = *reinterpret_cast<const X8*>(Ds + px * SD + ks * 64 + lq * 16);
+                for (int mt = 0; mt < MTH; ++mt) dacc[mt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int mt = 0; mt < MT_TOTAL; ++mt) dacc[mt] = H::mfma(wfr[mt][ks], dfr, dacc[mt]);
-            }
-            // mask by the activation of the batch-norm that produced x (lo < x * scale + shift < hi on the RAW x), round to
-            // storage, sums of g and g * x, the tile's image for whole-row stores
+                for (int ks = 0; ks < KS2; ++ks) {
+                    const X8 dfr = *reinterpret_cast<const X8*>(Ds + px * SD + ks * 64 + lq * 16);
 #pragma unroll
-            for (int mt = 0; mt < MT_TOTAL; ++mt) {
-                const int cl = mt * 16 + lq * 4;
-                const uint2 xr = *reinterpret_cast<const uint2*>(Rs + px * SA + cl * 2);
-                float xf[4];
-                {
-                    Raw4h<T> r4; r4.v = xr;
+                    for (int mt = 0; mt < MTH; ++mt) dacc[mt] = H::mfma(wfr[mt][ks], dfr, dacc[mt]);
+                }
+                // mask by the activation of the batch-norm that produced x (lo < x * scale + shift < hi on the RAW x), round to
+                // storage, sums of g and g * x, the tile's image for whole-row stores
+#pragma unroll
+                for (int mt = 0; mt < MTH; ++mt) {
+                    const int cl = (dg_mt0 + mt) * 16 + lq * 4;
+                    Raw4h<T> r4;
+                    r4.v = *reinterpret_cast<const uint2*>(Rs + px * SA + cl * 2);
+                    float xf[4];
                     raw4_unpack(r4, xf);
-                }
-                const f32x4_t sc4 = *reinterpret_cast<const f32x4_t*>(aff + cl), sh4 = *reinterpret_cast<const f32x4_t*>(aff + CG + cl);
-                float g[4];
+                    const f32x4_t sc4 = *reinterpret_cast<const f32x4_t*>(aff + cl), sh4 = *reinterpret_cast<const f32x4_t*>(aff + CG + cl);
+                    float g[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pre = xf[r] * sc4[r] + sh4[r];
-                    const float d = round_to_storage<T>(dacc[mt][r]);
-                    g[r] = (pre > lo && pre < hi) ? d : 0.f;
-                    bsum[mt][r] += g[r];
-                    bsq[mt][r] += g[r] * xf[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const float pre = xf[r] * sc4[r] + sh4[r];
+                        const float d = round_to_storage<T>(dacc[mt][r]);
+                        g[r] = (pre > lo && pre < hi) ? d : 0.f;
+                        bsum[mt][r] += g[r];
+                        bsq[mt][r] += g[r] * xf[r];
+                    }
+                    *reinterpret_cast<uint2*>(Os + px * OS + cl * 2) = pack4_storage<T>(g);
                 }
-                *reinterpret_cast<uint2*>(Os + px * OS + cl * 2) = pack4_storage<T>(g);
             }
         }
         MPN_WG_STAMP(3);
@@ -787,18 +791,20 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
 
     if constexpr (DG) {
         // sums over the 16 pixel lanes of a (mt, lq) group (fixed butterfly), then over the 8 waves through LDS in wave order
-        float* red = reinterpret_cast<float*>(Os + OBYTES);       // [8 waves][2][CG]
+        float* red = reinterpret_cast<float*>(Os + OBYTES);       // [8 waves][2][CG] (a wave fills its own channel tiles, the rest stays 0)
         __syncthreads();                                           // (the last tile's copy-out has read the output image)
+        for (int o = tid; o < 8 * 2 * CG; o += NT) red[o] = 0.f;
+        __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < MT_TOTAL; ++mt)
+        for (int mt = 0; mt < MTH; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = bsum[mt][r], b = bsq[mt][r];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
                 if (l15 == 0) {
-                    red[(wave * 2 + 0) * CG + mt * 16 + lq * 4 + r] = a;
-                    red[(wave * 2 + 1) * CG + mt * 16 + lq * 4 + r] = b;
+                    red[(wave * 2 + 0) * CG + (dg_mt0 + mt) * 16 + lq * 4 + r] = a;
+                    red[(wave * 2 + 1) * CG + (dg_mt0 + mt) * 16 + lq * 4 + r] = b;
                 }
             }
         __syncthreads();
@@ -1166,8 +1172,7 @@ int conv1x1_bwd_fused_impl(const void* x, const void* dy, const float* w, void* 
         p.ap_x = ap->y_raw; p.ap_xs = ap->y_stride > 0 ? ap->y_stride : Cout;
         MPN_REQUIRE(p.ap_xs >= Cout && p.ap_xs % 8 == 0 && (long long)N * H * W * p.ap_xs < (1ll << 31), MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: bad raw-output stride");
         p.ap_scale = ap->scale; p.ap_shift = ap->shift; p.ap_mean = ap->mean; p.ap_invstd = ap->invstd; p.ap_k1 = ap->k1; p.ap_k2 = ap->k2; p.ap_act = ap->act;
-        MPN_REQUIRE(thin32, MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: layer not covered (Cin %d, Cout %d)", Cin, Cout);
-        return launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2, true>(p, st);
+        return thin32 ? launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2, true>(p, st) : launch_conv1x1_bwd_fused<bf16_t, 128, 256, 2, true>(p, st);
     }
     return thin32 ? launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2>(p, st) : launch_conv1x1_bwd_fused<bf16_t, 128, 256, 2>(p, st);
 }
@@ -1182,8 +1187,7 @@ extern "C" int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float*
 
 /* 1 when mpn_conv1x1_bwd_fused_apply takes this layer (the 32 x 64 block tile: Cin <= 32, Cout <= 64, bf16) */
 extern "C" int mpn_conv1x1_bwd_fused_apply_supported(int Cin, int Cout, int dtype) {
-    // (the 64 x 128 tile with the apply pass folded in needs 49 spilled registers and is slower than the separate pass: not offered)
-    return (mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype) && Cin <= 32 && Cout <= 64) ? 1 : 0;
+    return mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype);
 }
 
 /* mpn_conv1x1_bwd_fused with the batch-norm backward APPLY pass of the layer's OWN batch-norm folded into the staging of dY: g = the

@@ -819,7 +819,8 @@ def test_conv1x1_bwd_fused_equals_the_two_pass_backward(cuda, dtype, N, H, W, Ci
     assert_close(g_a, g_b.float().cpu(), dtype, 4)
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 64), (1, 37, 29, 32, 64), (2, 10, 6, 16, 32), (1, 64, 64, 24, 48)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 32, 64), (1, 37, 29, 32, 64), (2, 10, 6, 16, 32), (1, 64, 64, 24, 48), (2, 24, 24, 64, 128),
+                                           (1, 19, 23, 48, 96)])
 def test_conv1x1_bwd_fused_with_the_apply_pass_folded_in(cuda, N, H, W, Cin, Cout):
     """mpn_conv1x1_bwd_fused_apply: the layer's own batch-norm backward apply happens while dY is staged - the weight slab, the data
     gradient and the reduction partials of mpn_bn_bwd_apply followed by mpn_conv1x1_bwd_fused (to the rounding of a rare staged
@@ -831,7 +832,7 @@ def test_conv1x1_bwd_fused_with_the_apply_pass_folded_in(cuda, N, H, W, Cin, Cou
     g = dev(rnd(rs.randn(N, H, W, Cout), dtype), dtype)
     yraw = dev(rnd(rs.randn(N, H, W, Cout), dtype), dtype)
     w = dev((rs.randn(1, 1, Cin, Cout) / np.sqrt(Cout)).astype(np.float32))
-    assert ops.conv1x1_bwd_fused_apply_supported(Cin, Cout, dtype) and not ops.conv1x1_bwd_fused_apply_supported(64, 128, dtype)
+    assert ops.conv1x1_bwd_fused_apply_supported(Cin, Cout, dtype) and not ops.conv1x1_bwd_fused_apply_supported(128, 128, dtype)
 
     def mkbn(C, seed, act):
         r2 = np.random.RandomState(seed)
