@@ -145,19 +145,20 @@ int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H
                         int Cout, int x_stride, int dy_stride, int ksize, int dtype, const float* in_scale,
                         const float* in_shift, int in_act, mpn_stream_t stream);
 
-/* A thin 1x1 convolution's backward in ONE pass over x and dy (Conv2d_1_pointwise / Conv2d_2_pointwise,
+/* A thin 1x1 convolution's backward in ONE pass over x and dy (Cin <= 128, Cout <= 128, bf16: Conv2d_1..3_pointwise,
  * /root/reference/detector/backbones/mobilenet_v1.py:66-74: tf.gradients of slim.conv2d w.r.t. its kernel and its input, and the
  * reduction of the batch-norm below, mobilenet_v1.py:29-38): wpart [mpn_conv_wgrad_num_parts(N,H,W,Cin,Cout,1,dtype)][Cin][Cout] =
  * weight-gradient partials over act(x * in_scale + in_shift) (finish with mpn_reduce_partials); dx [N,H,W,Cin] = dy . w^T MASKED by that
  * activation (lo < x * in_scale + in_shift < hi on the raw x); bn_part [same rows][2][Cin] = partial sums of the masked gradient g and
  * of g * x with the RAW x (finish with mpn_bn_bwd_finalize_raw). What mpn_conv_bwd_weight + mpn_conv_bwd_data_bn give in two passes over
- * both tensors. w: the layer's f32 kernel [Cin][Cout] (HWIO of a 1x1). Strides in elements, 0 = dense. dx must not alias x or dy. */
+ * both tensors. bn_part == NULL: no reduction and dx is the plain, unmasked data gradient (an FPN lateral, /root/reference/detector/fpn.py:36-47).
+ * w: the layer's f32 kernel [Cin][Cout] (HWIO of a 1x1). Strides in elements, 0 = dense. dx must not alias x or dy. */
 int mpn_conv1x1_bwd_fused_supported(int Cin, int Cout, int dtype);
 int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, float* bn_part, int N, int H, int W,
                           int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype, const float* in_scale,
                           const float* in_shift, int in_act, mpn_stream_t stream);
-/* ... with the batch-norm backward APPLY pass of the layer's OWN batch-norm folded into the staging of dY (the 32 x 64 block tile only:
- * Cin <= 32, Cout <= 64): g = the gradient w.r.t. the layer's activated output (what mpn_bn_bwd_apply would turn into dy in place),
+/* ... with the batch-norm backward APPLY pass of the layer's OWN batch-norm folded into the staging of dY (Cin <= 64, Cout <= 128):
+ * g = the gradient w.r.t. the layer's activated output (what mpn_bn_bwd_apply would turn into dy in place),
  * y_raw = the layer's raw output, ap_* that batch-norm's affine, saved statistics and the k1 / k2 of mpn_bn_bwd_finalize. The slabs and dx of
  * mpn_bn_bwd_apply followed by mpn_conv1x1_bwd_fused (to the storage rounding of a rare staged element); g and y_raw are not written. */
 int mpn_conv1x1_bwd_fused_apply_supported(int Cin, int Cout, int dtype);

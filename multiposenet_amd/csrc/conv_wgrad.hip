@@ -384,10 +384,13 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     constexpr int RBYTES = DG ? 128 * SA : 0, OBYTES = DG ? 128 * OS : 0;
     constexpr int KS2 = BNW / 32;                      // DG: k-steps of the data gradient (over the output channels)
 
+    // Waves in step (no STAGGER) commit the next tile only behind the barrier that ends this tile's reads: ONE image of each operand
+    // would do. The weight-gradient launches keep two (nothing else wants the LDS); DG needs the room for its two extra images.
+    constexpr int NBUF = DG ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // [2][ABYTES] A images, [2][DBYTES] dY images, [2][CG] f32 scale / shift; DG: + raw input image, output image, [8][2][CG] sums
-    float* aff = reinterpret_cast<float*>(smem + 2 * ABYTES + 2 * DBYTES);
-    unsigned char* Rs = smem + 2 * ABYTES + 2 * DBYTES + 2 * CG * (int)sizeof(float);
+    // [NBUF][ABYTES] A images, [NBUF][DBYTES] dY images, [2][CG] f32 scale / shift; DG: + raw input image, output image, [8][2][CG] sums
+    float* aff = reinterpret_cast<float*>(smem + NBUF * ABYTES + NBUF * DBYTES);
+    unsigned char* Rs = smem + NBUF * ABYTES + NBUF * DBYTES + 2 * CG * (int)sizeof(float);
     unsigned char* Os = Rs + RBYTES;
 
     const int tid = threadIdx.x;
@@ -628,8 +631,9 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     // DG: the layer's kernel as bf16 fragments W[ci = mt * 16 + l15][co = ks * 32 + lq * 8 ..] (the rounding of the packed weights the
     // separate data gradient multiplies with), zero beyond the layer's channels; running sums of the reduction per lane:
     // channels mt * 16 + lq * 4 + r over the lane's pixel column l15 of every tile
-    // (from four channel tiles on, two waves share two pixel tiles and split the channel tiles: half the fragment registers per wave)
-    constexpr int DGS = MT_TOTAL >= 4 ? 2 : 1, MTH = MT_TOTAL / DGS;
+    // (from four channel tiles on, two waves share two pixel tiles and split the channel tiles - four waves and four pixel tiles from
+    //  eight on: a half / a quarter of the fragment registers per wave)
+    constexpr int DGS = MT_TOTAL >= 8 ? 4 : (MT_TOTAL >= 4 ? 2 : 1), MTH = MT_TOTAL / DGS;
     const int dg_mt0 = DG ? (wave % DGS) * MTH : 0, dg_pt0 = DG ? (wave / DGS) * DGS : 0;
     X8 wfr[DG ? MTH : 1][DG ? KS2 : 1];
     float bsum[DG ? MTH : 1][4], bsq[DG ? MTH : 1][4];
@@ -652,20 +656,20 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     }
     if (ntl > 0) load_tile(split);
     __syncthreads();   // scale / shift table visible
-    if (ntl > 0) commit_tile(smem, smem + 2 * ABYTES);
+    if (ntl > 0) commit_tile(smem, smem + NBUF * ABYTES);
     if (grp == 1) {
         if (ntl > 1) load_tile(split + p.nsplit);
         __syncthreads();
-        if (ntl > 1) commit_tile(smem + ABYTES, smem + 2 * ABYTES + DBYTES);
+        if (ntl > 1) commit_tile(smem + ABYTES, smem + NBUF * ABYTES + DBYTES);
     }
 #ifdef MPN_DIAG
     if (p.dbg) t_prev = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll 1
     for (int it = 0; it < ntl; ++it) {
-        const int buf = it & 1;
+        const int buf = NBUF == 2 ? (it & 1) : 0;
         unsigned char* As = smem + buf * ABYTES;
-        unsigned char* Ds = smem + 2 * ABYTES + buf * DBYTES;
+        unsigned char* Ds = smem + NBUF * ABYTES + buf * DBYTES;
         const bool more = it + ahead < ntl;
         if (more) load_tile(split + (it + ahead) * p.nsplit);   // flies under this tile's MFMAs
         MPN_WG_STAMP(1);
@@ -723,9 +727,11 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (DG) {
+            const bool bnr = p.bn_part != nullptr;
             // dA^T[ci][px] of this wave's pixel tiles: A operand = the kernel's fragment (rows = ci), B operand = the dY rows as they
             // lie (k = co, columns = px); a lane ends up with channels (dg_mt0 + mt) * 16 + lq * 4 .. + 3 of pixel (dg_pt0 + j) * 16 + l15
-#pragma unroll
+            // (a real loop over the pixel tiles: unrolled, hipcc hoists every tile's fragment reads and spills on the 128-channel tile)
+#pragma unroll 1
             for (int j = 0; j < DGS; ++j) {
                 const int px = (dg_pt0 + j) * 16 + l15;
                 f32x4_t dacc[MTH];
@@ -752,7 +758,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
                     for (int r = 0; r < 4; ++r) {
                         const float pre = xf[r] * sc4[r] + sh4[r];
                         const float d = round_to_storage<T>(dacc[mt][r]);
-                        g[r] = (pre > lo && pre < hi) ? d : 0.f;
+                        g[r] = (!bnr || (pre > lo && pre < hi)) ? d : 0.f;      // (no reduction asked for: the plain data gradient)
                         bsum[mt][r] += g[r];
                         bsq[mt][r] += g[r] * xf[r];
                     }
@@ -764,8 +770,8 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
         __syncthreads();
         MPN_WG_STAMP(2);
         if (more) {
-            const int nb = (it + ahead) & 1;
-            commit_tile(smem + nb * ABYTES, smem + 2 * ABYTES + nb * DBYTES);
+            const int nb = NBUF == 2 ? ((it + ahead) & 1) : 0;
+            commit_tile(smem + nb * ABYTES, smem + NBUF * ABYTES + nb * DBYTES);
         }
         if constexpr (DG) {
             // the tile's 128 x Cin gradients leave as 16-byte pieces of whole pixel rows (rows past the end / channels past Cin: skipped)
@@ -810,7 +816,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
         __syncthreads();
         for (int o = tid; o < 2 * CG; o += NT) {
             const int which = o / CG, c = o - which * CG;
-            if (ci0 + c < p.Cin) {
+            if (p.bn_part != nullptr && ci0 + c < p.Cin) {
                 float a = 0.f;
 #pragma unroll
                 for (int w8 = 0; w8 < 8; ++w8) a += red[(w8 * 2 + which) * CG + c];
@@ -1116,7 +1122,7 @@ namespace {
 template <typename T, int RBA, int RBD, int WM, bool DAPPLY = false>
 int launch_conv1x1_bwd_fused(const WgradParams& p, hipStream_t st) {
     constexpr int CG = RBA / 2;
-    constexpr int smem = 2 * 128 * (RBA + 32) + 2 * 128 * (RBD + 32) + 2 * CG * (int)sizeof(float) + 128 * (RBA + 32) + 128 * (RBA + 16) +
+    constexpr int smem = 128 * (RBA + 32) + 128 * (RBD + 32) + 2 * CG * (int)sizeof(float) + 128 * (RBA + 32) + 128 * (RBA + 16) +
                          8 * 2 * CG * (int)sizeof(float) + (DAPPLY ? 4 * (RBD / 2) * (int)sizeof(float) : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
     static mpn_attr_mask_t attr_mask{0};
@@ -1128,9 +1134,9 @@ int launch_conv1x1_bwd_fused(const WgradParams& p, hipStream_t st) {
 }  // namespace
 
 /* 1 when mpn_conv1x1_bwd_fused takes this layer: bf16 storage (the batch-norm kernels that finish the reduction take f32 / bf16), a thin pointwise layer whose channels fit ONE block tile
- * (Cin <= 64, Cout <= 128: Conv2d_1_pointwise and Conv2d_2_pointwise of mobilenet_v1.py:66-74 at depth_multiplier 1) */
+ * (Cin <= 128, Cout <= 128: Conv2d_1..3_pointwise of mobilenet_v1.py:66-74 at depth_multiplier 1, the FPN's lateral2) */
 extern "C" int mpn_conv1x1_bwd_fused_supported(int Cin, int Cout, int dtype) {
-    return (dtype == MPN_BF16 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin <= 64 && Cout <= 128) ? 1 : 0;
+    return (dtype == MPN_BF16 && Cin > 0 && Cout > 0 && Cin % 8 == 0 && Cout % 8 == 0 && Cin <= 128 && Cout <= 128) ? 1 : 0;
 }
 
 /* A thin 1x1 convolution's backward in ONE pass over x and dy: wpart [mpn_conv_wgrad_num_parts(.., 1, ..)][Cin][Cout] = weight-gradient
@@ -1144,7 +1150,8 @@ int conv1x1_bwd_fused_impl(const void* x, const void* dy, const float* w, void* 
                            int W, int Cin, int Cout, int x_stride, int dy_stride, int dx_stride, int dtype,
                            const float* in_scale, const float* in_shift, int in_act, const Conv1x1Apply* ap, mpn_stream_t stream) {
     MPN_REQUIRE(mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype), MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused: layer not covered (Cin %d, Cout %d)", Cin, Cout);
-    MPN_REQUIRE(x && dy && w && dx && wpart && bn_part && in_scale && in_shift && N > 0 && H > 0 && W > 0, MPN_ERR_BAD_ARG, "conv1x1_bwd_fused: bad arguments");
+    MPN_REQUIRE(x && dy && w && dx && wpart && in_scale && in_shift && N > 0 && H > 0 && W > 0, MPN_ERR_BAD_ARG, "conv1x1_bwd_fused: bad arguments");
+    MPN_REQUIRE(bn_part != nullptr || ap == nullptr, MPN_ERR_BAD_ARG, "conv1x1_bwd_fused_apply: needs the reduction's slab");
     MPN_REQUIRE(mpn_aligned16(x) && mpn_aligned16(dy) && mpn_aligned16(dx), MPN_ERR_BAD_ALIGN, "conv1x1_bwd_fused: pointers must be 16-byte aligned");
     MPN_REQUIRE(dx != x && dx != dy, MPN_ERR_BAD_ARG, "conv1x1_bwd_fused: dx must not alias an input");
     WgradParams p = {};
@@ -1165,8 +1172,9 @@ int conv1x1_bwd_fused_impl(const void* x, const void* dy, const float* w, void* 
     p.dbg = nullptr;
 #endif
     hipStream_t st = (hipStream_t)stream;
-    const bool thin32 = Cin <= 32 && Cout <= 64;
+    const bool thin32 = Cin <= 32 && Cout <= 64, wide = Cin > 64;
     if (ap != nullptr) {
+        MPN_REQUIRE(!wide, MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused_apply: layer not covered (Cin %d, Cout %d)", Cin, Cout);
         MPN_REQUIRE(ap->y_raw && ap->scale && ap->shift && ap->mean && ap->invstd && ap->k1 && ap->k2 && mpn_aligned16(ap->y_raw), MPN_ERR_BAD_ARG,
                     "conv1x1_bwd_fused_apply: bad batch-norm arguments");
         p.ap_x = ap->y_raw; p.ap_xs = ap->y_stride > 0 ? ap->y_stride : Cout;
@@ -1174,6 +1182,7 @@ int conv1x1_bwd_fused_impl(const void* x, const void* dy, const float* w, void* 
         p.ap_scale = ap->scale; p.ap_shift = ap->shift; p.ap_mean = ap->mean; p.ap_invstd = ap->invstd; p.ap_k1 = ap->k1; p.ap_k2 = ap->k2; p.ap_act = ap->act;
         return thin32 ? launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2, true>(p, st) : launch_conv1x1_bwd_fused<bf16_t, 128, 256, 2, true>(p, st);
     }
+    if (wide) return launch_conv1x1_bwd_fused<bf16_t, 256, 256, 4>(p, st);
     return thin32 ? launch_conv1x1_bwd_fused<bf16_t, 64, 128, 2>(p, st) : launch_conv1x1_bwd_fused<bf16_t, 128, 256, 2>(p, st);
 }
 }  // namespace
@@ -1185,9 +1194,10 @@ extern "C" int mpn_conv1x1_bwd_fused(const void* x, const void* dy, const float*
                                   in_act, nullptr, stream);
 }
 
-/* 1 when mpn_conv1x1_bwd_fused_apply takes this layer (the 32 x 64 block tile: Cin <= 32, Cout <= 64, bf16) */
+/* 1 when mpn_conv1x1_bwd_fused_apply takes this layer (Cin <= 64, Cout <= 128, bf16) */
 extern "C" int mpn_conv1x1_bwd_fused_apply_supported(int Cin, int Cout, int dtype) {
-    return mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype);
+    // (the 128-channel tile with the apply pass folded in spills 31 registers and is slower than the separate pass: 234 vs 179 us)
+    return (mpn_conv1x1_bwd_fused_supported(Cin, Cout, dtype) && Cin <= 64) ? 1 : 0;
 }
 
 /* mpn_conv1x1_bwd_fused with the batch-norm backward APPLY pass of the layer's OWN batch-norm folded into the staging of dY: g = the

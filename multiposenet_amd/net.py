@@ -759,6 +759,11 @@ class KeypointNet:
             if l > 2:
                 ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample
             raw, aff = feats[f"c{l}"]
+            if self.fuse_pw_bwd and l < 5 and aff is not None and ops.conv1x1_bwd_fused_supported(raw.shape[3], DEPTH, self.dtype):
+                # (lateral2: both gradients in one pass over c2 and its gradient; no batch-norm below this one to reduce for here -
+                #  c2 has a second consumer, the sum is reduced by the backbone's backward)
+                ops.conv1x1_bwd_fused(raw, g["x"][l], self.lateral[l].w, aff, g["c"][f"c{l}"], slab[id(self.lateral[l].dw)], None)
+                continue
             W(lambda: ops.conv_bwd_weight(raw, g["x"][l], 1, aff, self.lateral[l].dw, slab[id(self.lateral[l].dw)], reduce=False))
             # c5 has one consumer (lateral5): its data gradient also reduces for Conv2d_13_pointwise's batch-norm - the backbone's
             # backward pass starts from that finalize (`sp` is not touched in between)

@@ -153,12 +153,12 @@ def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
 
 
 def conv1x1_bwd_fused_supported(cin, cout, dtype):
-    """True when conv1x1_bwd_fused takes this pointwise layer (bf16 storage, Cin <= 64, Cout <= 128)."""
+    """True when conv1x1_bwd_fused takes this pointwise layer (bf16 storage, Cin <= 128, Cout <= 128)."""
     return _lib.lib().mpn_conv1x1_bwd_fused_supported(int(cin), int(cout), _lib.dtype_code(dtype)) == 1
 
 
 def conv1x1_bwd_fused_apply_supported(cin, cout, dtype):
-    """True when conv1x1_bwd_fused(apply_bn=...) takes this layer (Cin <= 32, Cout <= 64, bf16)."""
+    """True when conv1x1_bwd_fused(apply_bn=...) takes this layer (Cin <= 64, Cout <= 128, bf16)."""
     return _lib.lib().mpn_conv1x1_bwd_fused_apply_supported(int(cin), int(cout), _lib.dtype_code(dtype)) == 1
 
 
@@ -166,11 +166,12 @@ def conv1x1_bwd_fused(x, dy, w, bn, out, wpart, bn_part, apply_bn=None, y_raw=No
     """A thin 1x1 convolution's backward in one pass over x and dy: x = the layer's RAW input (raw output of the layer with batch-norm
     state `bn`), dy = gradient w.r.t. the layer's output, w = its f32 kernel [1,1,Cin,Cout]. out <- the data gradient masked by bn's
     activation, wpart <- the weight gradient's split-K slab (conv_wgrad_num_parts rows; reduce later), bn_part <- partial sums of g
-    and g * x (raw x). Returns the rows both slabs hold - pass them to bn_backward(..., reduced_parts=rows, raw=True)."""
+    and g * x (raw x). Returns the rows both slabs hold - pass them to bn_backward(..., reduced_parts=rows, raw=True).
+    bn_part=None: no reduction, out is the plain (unmasked) data gradient; `bn` then only supplies the affine of x (an ops.Affine does)."""
     N, H, W, cin = x.shape
     cout = dy.shape[3]
     rows = conv_wgrad_num_parts(N, H, W, cin, cout, 1, x.dtype)
-    if wpart.numel() < rows * cin * cout or bn_part.numel() < rows * 2 * cin:
+    if wpart.numel() < rows * cin * cout or (bn_part is not None and bn_part.numel() < rows * 2 * cin):
         raise ValueError("conv1x1_bwd_fused: partial slab too small")
     if apply_bn is not None:
         # dy is the gradient w.r.t. the ACTIVATED output of the layer's own batch-norm `apply_bn` (finalized: k1 / k2 set), y_raw the

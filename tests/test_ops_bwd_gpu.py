@@ -766,7 +766,8 @@ def test_dwconv_bwd_fused_equals_the_separate_launches(cuda, dtype, N, H, W, C):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16], ids=["bf16"])
 @pytest.mark.parametrize("N,H,W,Cin,Cout,act", [(2, 16, 16, 32, 64, 2), (1, 37, 29, 32, 64, 1), (2, 24, 24, 64, 128, 2), (1, 10, 6, 16, 32, 2),
-                                                 (3, 40, 40, 64, 128, 1), (1, 9, 7, 48, 96, 2)])
+                                                 (3, 40, 40, 64, 128, 1), (1, 9, 7, 48, 96, 2), (2, 24, 24, 128, 128, 2), (1, 37, 29, 96, 128, 1),
+                                                 (1, 20, 20, 128, 64, 2)])
 def test_conv1x1_bwd_fused_equals_the_two_pass_backward(cuda, dtype, N, H, W, Cin, Cout, act):
     """mpn_conv1x1_bwd_fused: ONE pass over x and dy gives the weight-gradient slab of mpn_conv_bwd_weight (bit for bit: the same
     tiles, the same MFMA order), the masked data gradient of mpn_conv_bwd_data_bn (same products, the accumulation order of another
@@ -776,7 +777,7 @@ def test_conv1x1_bwd_fused_equals_the_two_pass_backward(cuda, dtype, N, H, W, Ci
     x = dev(rnd(rs.randn(N, H, W, Cin), dtype), dtype)
     dy = dev(rnd(rs.randn(N, H, W, Cout), dtype), dtype)
     w = dev((rs.randn(1, 1, Cin, Cout) / np.sqrt(Cout)).astype(np.float32))
-    assert ops.conv1x1_bwd_fused_supported(Cin, Cout, dtype) and not ops.conv1x1_bwd_fused_supported(128, 128, dtype)
+    assert ops.conv1x1_bwd_fused_supported(Cin, Cout, dtype) and not ops.conv1x1_bwd_fused_supported(128, 256, dtype)
     assert not ops.conv1x1_bwd_fused_supported(Cin, Cout, torch.float32) and not ops.conv1x1_bwd_fused_supported(Cin, Cout, torch.float16)
 
     def mkbn(seed):
@@ -832,7 +833,7 @@ def test_conv1x1_bwd_fused_with_the_apply_pass_folded_in(cuda, N, H, W, Cin, Cou
     g = dev(rnd(rs.randn(N, H, W, Cout), dtype), dtype)
     yraw = dev(rnd(rs.randn(N, H, W, Cout), dtype), dtype)
     w = dev((rs.randn(1, 1, Cin, Cout) / np.sqrt(Cout)).astype(np.float32))
-    assert ops.conv1x1_bwd_fused_apply_supported(Cin, Cout, dtype) and not ops.conv1x1_bwd_fused_apply_supported(128, 128, dtype)
+    assert ops.conv1x1_bwd_fused_apply_supported(Cin, Cout, dtype) and not ops.conv1x1_bwd_fused_apply_supported(128, 128, dtype) and ops.conv1x1_bwd_fused_apply_supported(64, 128, dtype)
 
     def mkbn(C, seed, act):
         r2 = np.random.RandomState(seed)
@@ -859,3 +860,27 @@ def test_conv1x1_bwd_fused_with_the_apply_pass_folded_in(cuda, N, H, W, Cin, Cou
     assert float((sp_a - sp_b).abs().max()) <= 2e-5 * (float(sp_b.abs().max()) + 1e-6)
     assert float((wp_a != wp_b).float().mean()) < 0.05
     assert torch.equal(g, g0) and torch.equal(yraw, y0)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 128, 128), (1, 37, 29, 64, 128), (1, 10, 6, 32, 64)])
+def test_conv1x1_bwd_fused_without_a_reduction_is_the_plain_backward(cuda, N, H, W, Cin, Cout):
+    """bn_part = NULL (an FPN lateral): the weight slab of mpn_conv_bwd_weight bit for bit and the UNMASKED data gradient of mpn_conv_fwd
+    over the transposed kernel (another kernel's accumulation order: within a storage ulp)."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(Cin + Cout + H + 7)
+    x = dev(rnd(rs.randn(N, H, W, Cin), dtype), dtype)
+    dy = dev(rnd(rs.randn(N, H, W, Cout), dtype), dtype)
+    w = dev((rs.randn(1, 1, Cin, Cout) / np.sqrt(Cout)).astype(np.float32))
+    aff = ops.Affine(dev((0.5 + rs.rand(Cin)).astype(np.float32)), dev((rs.randn(Cin) * 0.5).astype(np.float32)), 2)
+    rows = ops.conv_wgrad_num_parts(N, H, W, Cin, Cout, 1, dtype)
+    wp_b, wp_a = torch.zeros(rows * Cin * Cout, device="cuda"), torch.zeros(rows * Cin * Cout, device="cuda")
+    dW = torch.zeros(1, 1, Cin, Cout, device="cuda")
+    ops.conv_bwd_weight(x, dy, 1, aff, dW, wp_b, reduce=False)
+    pc = ops.PackedConv(w, dtype)
+    dx_b = torch.empty_like(x)
+    ops.conv_fwd(dy, pc.bwd, Cin, 1, None, out=dx_b)
+    dx_a = torch.empty_like(x)
+    assert ops.conv1x1_bwd_fused(x, dy, w, aff, dx_a, wp_a, None) == rows
+    assert torch.equal(wp_a, wp_b)
+    assert_close(dx_a, dx_b.float().cpu(), dtype, Cout)
