@@ -315,6 +315,7 @@ class KeypointNet:
         assert ob == ok + nk, "heatmaps/kernel and heatmaps/bias must be adjacent in the arena"
         self._head_grad = self.grad[ok:ob + nb]
         self.fuse_dw_bn = True    # depthwise data gradients also reduce for the batch-norm they feed (mpn_dwconv_bwd_data_bn)
+        self.fuse_pw_wide = False # ... also on 128-channel layers (Conv2d_3_pointwise, lateral2): measured equal to the two-pass backward in the step
         self.fuse_pw_apply = True # ... with the layer's own batch-norm apply pass folded in where the kernel takes it (Cin <= 32, Cout <= 64)
         self.fuse_pw_bwd = True   # thin pointwise layers (Cin <= 64, Cout <= 128): weight + data gradient + reduction in one pass (mpn_conv1x1_bwd_fused)
         self.fuse_dw_bwd = True   # stride-1 depthwise layers: data gradient + that reduction + weight gradient in ONE walk (mpn_dwconv_bwd_fused)
@@ -759,7 +760,7 @@ class KeypointNet:
             if l > 2:
                 ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample
             raw, aff = feats[f"c{l}"]
-            if self.fuse_pw_bwd and l < 5 and aff is not None and ops.conv1x1_bwd_fused_supported(raw.shape[3], DEPTH, self.dtype):
+            if self.fuse_pw_bwd and self.fuse_pw_wide and l < 5 and aff is not None and ops.conv1x1_bwd_fused_supported(raw.shape[3], DEPTH, self.dtype):
                 # (lateral2: both gradients in one pass over c2 and its gradient; no batch-norm below this one to reduce for here -
                 #  c2 has a second consumer, the sum is reduced by the backbone's backward)
                 ops.conv1x1_bwd_fused(raw, g["x"][l], self.lateral[l].w, aff, g["c"][f"c{l}"], slab[id(self.lateral[l].dw)], None)
@@ -794,7 +795,8 @@ class KeypointNet:
             # the thin pointwise layers: weight gradient, data gradient and the reduction for the depthwise batch-norm below in ONE
             # pass over the layer's input and dY (each tensor once instead of twice); on the thinnest one the layer's own batch-norm
             # apply pass happens while dY is staged (two more passes over its output tensor less)
-            pw_fused = self.fuse_pw_bwd and self.fuse_conv_bn and ops.conv1x1_bwd_fused_supported(blk["pw"].cin, blk["pw"].cout, self.dtype)
+            pw_fused = self.fuse_pw_bwd and self.fuse_conv_bn and ops.conv1x1_bwd_fused_supported(blk["pw"].cin, blk["pw"].cout, self.dtype) and \
+                (blk["pw"].cin <= 64 or self.fuse_pw_wide)
             pw_apply = pw_fused and self.fuse_pw_apply and ops.conv1x1_bwd_fused_apply_supported(blk["pw"].cin, blk["pw"].cout, self.dtype)
             ops.bn_backward(blk["pw_bn"], dA, b["pw"][i], sp, reduced_parts=reduced, raw=raw_sums and reduced > 0, apply=not pw_apply)
             raw_sums = False                                    # (depthwise data gradients sum g * xhat themselves)
