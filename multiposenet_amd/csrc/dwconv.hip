@@ -1546,6 +1546,32 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
 // reduction alike), stride 2 the one-column kernel
 static int dw_xt(const DwParams& p) { return (p.H == p.OH && p.W == p.OW) ? 2 : 1; }
 struct DwSwGeom { int ncg, cols, xblocks, yblocks, cblocks; };
+static int dw_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return cus;
+}
+// Strip height of the stride-1 forward walk WITH statistics (the training forward). The kernel holds three 256-thread blocks per
+// CU; with the fixed 32-row strips the two largest layers made 1 024 blocks for 768 slots - a second round a third full, i.e. a
+// third of the launch at a third of the chip. Pick the height whose block count costs the fewest rounds x (rows + 2 primed rows):
+// 43-row strips = 768 blocks on those layers (Conv2d_1_depthwise 85 -> 64 us in the step).
+static int dw_fwd_rows(const DwParams& p, int blocks_per_row_strip) {
+    const int def = sw_rows(p.OH, 1);
+    if (!(p.H == p.OH && p.W == p.OW) || p.part == nullptr || p.bnr_x != nullptr) return def;
+    const long long slots = 3ll * dw_cu_count();
+    int best = def;
+    long long best_cost = -1;
+    for (int yb = (p.OH + 63) / 64; yb <= (p.OH + 15) / 16; ++yb) {
+        const int rows = (p.OH + yb - 1) / yb;
+        const long long blocks = (long long)blocks_per_row_strip * ((p.OH + rows - 1) / rows);
+        const long long cost = ((blocks + slots - 1) / slots) * (rows + 2);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = rows; }
+    }
+    return best;
+}
 static DwSwGeom dw_sw_geom(const DwParams& p) {
     DwSwGeom g;
     const int cg_total = p.C / 4;
@@ -1554,7 +1580,7 @@ static DwSwGeom dw_sw_geom(const DwParams& p) {
     g.cols = kThreads / g.ncg;
     g.cblocks = (cg_total + g.ncg - 1) / g.ncg;
     g.xblocks = (p.OW + g.cols * dw_xt(p) - 1) / (g.cols * dw_xt(p));
-    const int swr = p.swr > 0 ? p.swr : sw_rows(p.OH, p.H == p.OH ? 1 : 2);
+    const int swr = p.swr > 0 ? p.swr : dw_fwd_rows(p, p.N * g.cblocks * g.xblocks);
     g.yblocks = (p.OH + swr - 1) / swr;
     return g;
 }
@@ -1581,6 +1607,7 @@ extern "C" int mpn_dwconv_fwd(const void* x, const float* w, void* y, int N, int
     p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.flip = flip;
     hipStream_t st = (hipStream_t)stream;
     DwSwGeom g = dw_sw_geom(p);
+    if (stats_part != nullptr && stride == 1 && dw_xt(p) == 2) p.swr = (p.OH + g.yblocks - 1) / g.yblocks;   // (the height dw_sw_geom chose)
     if (stats_part == nullptr) {   // (with statistics the strip height fixes the slab rows: mpn_dwconv_num_parts)
         int swr = sw_rows(p.OH, stride);
         while (swr > 4 && (long long)p.N * g.cblocks * g.yblocks * g.xblocks < 512) {
