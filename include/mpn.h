@@ -304,6 +304,13 @@ int mpn_dwconv_bwd_fused_supported(int N, int H, int W, int C, int stride, int d
 int mpn_dwconv_bwd_fused(const void* x, const void* dy, const float* w, void* dx, float* wpart, int N, int H, int W, int C,
                          int dtype, const float* in_scale, const float* in_shift, int in_act, const float* mean,
                          const float* invstd, float* bn_part, mpn_stream_t stream);
+/* The stride-2 counterpart (even H and W; mpn_dwconv_bwd_fused_supported(.., 2, ..) == 1): dy [N,H/2,W/2,C]; dx [N,H,W,C] = data gradient
+ * (+ addend when not NULL: a tensor of dx's shape - the FPN lateral's gradient into the same backbone feature map - added before
+ * the store and before the reduction, as mpn_dwconv_bwd_data_add does); wpart [mpn_dwconv_wgrad_num_parts(.., 2, ..)][9][C]; bn_part
+ * (NULL: no reduction) [same rows][2][C]. The input and dy are read once instead of twice. dx must not alias x, dy or addend. */
+int mpn_dwconv_bwd_fused_s2(const void* x, const void* dy, const float* w, void* dx, float* wpart, int N, int H, int W, int C,
+                            int dtype, const float* in_scale, const float* in_shift, int in_act, const float* mean,
+                            const float* invstd, float* bn_part, const void* addend, mpn_stream_t stream);
 
 /* ------------------------------------------------------------------------------------
  * K1+K2  `2*x-1` + Conv2d_0 (3x3 stride 2 'SAME', 3 -> C0) fused

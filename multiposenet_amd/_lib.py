@@ -66,6 +66,7 @@ SIGNATURES = {
     "mpn_dwconv_bwd_weight": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     "mpn_dwconv_bwd_fused_supported": (_I, [_I, _I, _I, _I, _I, _I]),
     "mpn_dwconv_bwd_fused": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "mpn_dwconv_bwd_fused_s2": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
     "mpn_stem_conv_fwd": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mpn_stem_conv_fwd_num_parts": (_I, [_I, _I, _I, _I, _I]),
     "mpn_stem_conv_fwd_stats": (_I, [_P, _I, _P, _P, _I, _I, _I, _I, _I, _P, _P]),

@@ -1540,6 +1540,253 @@ __global__ __launch_bounds__(kThreads) void dwconv_dgrad_s2_sw_kernel(const T* _
         }
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stride-2 BACKWARD in one walk (even H, W: pad 0), the counterpart of dwconv_bwd_sw2_kernel: dwconv_dgrad_s2_sw_kernel's walk (a
+// thread = 4 channels of one dY column b, rows a down a strip; dY[a-1..a][b-1..b] gives the 2 x 2 block dA[2a..2a+1][2b..2b+1], the
+// addend and the reduction of the batch-norm below ride on it) that ALSO keeps the activated input rows 2a, 2a+1, 2a+2 at columns
+// 2b..2b+2 - the weight gradient's window for dY[a][b]: acc[ky][kx] += in[2a+ky][2b+kx] * dY[a][b]. Row 2a+2 is the next step's row
+// 2a, so a step loads two new input rows (six pieces). The reduction's raw x at the 2 x 2 block are four of those pieces: the
+// separate launches read the input once for the weight gradient and once more for the reduction, and dY twice.
+// p.x: raw input with its batch-norm affine in_scale / in_shift / in_act; p.dy: dY [N,OH,OW,C]; p.y: dA [N,H,W,C]; p.wpart: weight
+// partials [units][9][C]; BNR: p.part [units][2][C] with p.bnr_mean / p.bnr_invstd; ADD: p.addend (dA's shape).
+template <typename T, bool BNR, bool ADD>
+__global__ __launch_bounds__(kThreads) void dwconv_bwd_s2_kernel(const DwParams p, int ncg, int cols, int xblocks, int yblocks, int rows) {
+    __shared__ __attribute__((aligned(16))) float red[9 * kThreads * 4];   // [tap][thread][4 channels]; afterwards [thread][8] of the reduction
+    const T* __restrict__ x = reinterpret_cast<const T*>(p.x);
+    const T* __restrict__ dy = reinterpret_cast<const T*>(p.dy);
+    T* __restrict__ dxo = reinterpret_cast<T*>(p.y);
+    const int H = p.H, W = p.W, C = p.C, OH = p.OH, OW = p.OW;
+    int bi = xcd_work_id(p.xcd_remap);
+    const int cgb = bi % p.cblocks; bi /= p.cblocks;
+    const int unit = bi;                                              // partial-slab row (both slabs)
+    const int xb = bi % xblocks; bi /= xblocks;
+    const int yb = bi % yblocks;
+    const int img = bi / yblocks;
+    const int cgl = threadIdx.x % ncg, col = threadIdx.x / ncg;
+    const int c = (cgb * ncg + cgl) * 4;
+    const int b = xb * cols + col;
+    const bool lane_ok = c < C && b < OW && col < cols;
+    const int cc = lane_ok ? c : 0, bc = lane_ok ? b : 0;
+    f32x2_t w01[9], w23[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const float4 q = *reinterpret_cast<const float4*>(p.w + t * C + cc);
+        w01[t] = (f32x2_t){q.x, q.y};
+        w23[t] = (f32x2_t){q.z, q.w};
+    }
+    f32x2_t sc01, sc23, sh01, sh23;
+    {
+        const float4 s4 = *reinterpret_cast<const float4*>(p.in_scale + cc), h4 = *reinterpret_cast<const float4*>(p.in_shift + cc);
+        sc01 = (f32x2_t){s4.x, s4.y}; sc23 = (f32x2_t){s4.z, s4.w};
+        sh01 = (f32x2_t){h4.x, h4.y}; sh23 = (f32x2_t){h4.z, h4.w};
+    }
+    const float lo = (p.in_act != MPN_ACT_NONE) ? 0.f : -INFINITY;
+    const float hi = (p.in_act == MPN_ACT_RELU6) ? 6.f : INFINITY;
+    f32x2_t bis01 = {0.f, 0.f}, bis23 = {0.f, 0.f}, bnm01 = {0.f, 0.f}, bnm23 = {0.f, 0.f};
+    if constexpr (BNR) {
+        const float4 m4 = *reinterpret_cast<const float4*>(p.bnr_mean + cc), i4 = *reinterpret_cast<const float4*>(p.bnr_invstd + cc);
+        bis01 = (f32x2_t){i4.x, i4.y}; bis23 = (f32x2_t){i4.z, i4.w};
+        bnm01 = (f32x2_t){-m4.x * i4.x, -m4.y * i4.y}; bnm23 = (f32x2_t){-m4.z * i4.z, -m4.w * i4.w};
+    }
+    const int a_begin = yb * rows, a_end = min(a_begin + rows, OH);
+    const bool left_ok = bc > 0, right_ok = lane_ok && 2 * bc + 2 < W;
+    const T* dyimg = dy + ((long long)img * OH * OW) * C + cc;
+    const int off_c = bc * C, off_l = (left_ok ? bc - 1 : 0) * C;
+    const T* ximg = x + (long long)img * H * W * C + cc;
+    const int xo0 = 2 * bc * C, xo1 = xo0 + C, xo2 = right_ok ? xo0 + 2 * C : xo0;
+    const long long xrow = (long long)W * C;
+    auto dy_load = [&](Raw4<T> (&r)[2], int a) {
+        const T* rowp = dyimg + (long long)min(max(a, 0), OH - 1) * OW * C;
+        raw_load(r[0], rowp + off_l);
+        raw_load(r[1], rowp + off_c);
+    };
+    auto dy_cvt = [&](const Raw4<T> (&r)[2], int a, f32x2_t (&v)[2][2]) {   // [left, centre][channel pair]; zero outside
+        if (a < 0) {
+            v[0][0] = v[0][1] = v[1][0] = v[1][1] = (f32x2_t){0.f, 0.f};
+            return;
+        }
+        float f[4];
+        raw_unpack(r[0], f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = left_ok ? f[j] : 0.f;
+        v[0][0] = (f32x2_t){f[0], f[1]}; v[0][1] = (f32x2_t){f[2], f[3]};
+        raw_unpack(r[1], f);
+        v[1][0] = (f32x2_t){f[0], f[1]}; v[1][1] = (f32x2_t){f[2], f[3]};
+    };
+    auto x_load = [&](Raw4<T> (&r)[3], int iy) {
+        const T* rowp = ximg + (long long)min(iy, H - 1) * xrow;
+        raw_load(r[0], rowp + xo0);
+        raw_load(r[1], rowp + xo1);
+        raw_load(r[2], rowp + xo2);
+    };
+    // an input row, activated (zeros below the image / right of it: the activated tensor's padding)
+    auto x_act = [&](const Raw4<T> (&r)[3], int iy, f32x2_t (&a)[3][2]) {
+        const bool rowok = iy < H;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float f[4];
+            raw_unpack(r[k], f);
+            f32x2_t v01 = (f32x2_t){f[0], f[1]} * sc01 + sh01, v23 = (f32x2_t){f[2], f[3]} * sc23 + sh23;
+            v01.x = __builtin_amdgcn_fmed3f(v01.x, lo, hi); v01.y = __builtin_amdgcn_fmed3f(v01.y, lo, hi);
+            v23.x = __builtin_amdgcn_fmed3f(v23.x, lo, hi); v23.y = __builtin_amdgcn_fmed3f(v23.y, lo, hi);
+            const bool ok = rowok && (k < 2 || right_ok);
+            v01.x = ok ? v01.x : 0.f; v01.y = ok ? v01.y : 0.f;
+            v23.x = ok ? v23.x : 0.f; v23.y = ok ? v23.y : 0.f;
+            a[k][0] = v01;
+            a[k][1] = v23;
+        }
+    };
+    T* xp = dxo + (((long long)img * H + 2 * a_begin) * W + 2 * bc) * C + cc;
+    f32x2_t s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+    auto bnr_acc = [&](const Raw4<T>& yr, f32x2_t o01, f32x2_t o23) {
+        float f[4];
+        raw_unpack(yr, f);
+        const f32x2_t x01 = {f[0], f[1]}, x23 = {f[2], f[3]};
+        const f32x2_t p01 = x01 * sc01 + sh01, p23 = x23 * sc23 + sh23;
+        const f32x2_t d01 = round_storage<T>(o01), d23 = round_storage<T>(o23);
+        f32x2_t g01, g23;
+        g01.x = (p01.x > lo && p01.x < hi) ? d01.x : 0.f; g01.y = (p01.y > lo && p01.y < hi) ? d01.y : 0.f;
+        g23.x = (p23.x > lo && p23.x < hi) ? d23.x : 0.f; g23.y = (p23.y > lo && p23.y < hi) ? d23.y : 0.f;
+        s01 += g01; s23 += g23;
+        q01 += g01 * (x01 * bis01 + bnm01); q23 += g23 * (x23 * bis23 + bnm23);
+    };
+    const T* adp = nullptr;
+    if constexpr (ADD) adp = reinterpret_cast<const T*>(p.addend) + (((long long)img * H + 2 * a_begin) * W + 2 * bc) * C + cc;
+    Raw4<T> aq[ADD ? 4 : 1];   // the addend at the 2x2 block of the NEXT emit (requested one step ahead)
+    auto add_load = [&](int a) {
+        if constexpr (ADD) {
+            const T* q = adp + (long long)(2 * (min(a, OH - 1) - a_begin)) * xrow;
+            raw_load(aq[0], q); raw_load(aq[1], q + C); raw_load(aq[2], q + xrow); raw_load(aq[3], q + xrow + C);
+        }
+    };
+    auto add_acc = [&](const Raw4<T>& r, f32x2_t& o01, f32x2_t& o23) {
+        float f[4];
+        raw_unpack(r, f);
+        o01 += (f32x2_t){f[0], f[1]};
+        o23 += (f32x2_t){f[2], f[3]};
+    };
+    f32x2_t a01[9], a23[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { a01[t] = (f32x2_t){0.f, 0.f}; a23[t] = (f32x2_t){0.f, 0.f}; }
+    int a_cur = a_begin;
+    // the 2 x 2 block of dA from dY rows a - 1 (pv) and a (cv); e0 / e1: the raw input pieces of rows 2a / 2a + 1 at columns 2b, 2b + 1
+    auto emit = [&](const f32x2_t (&pv)[2][2], const f32x2_t (&cv)[2][2], const Raw4<T> (&e0)[2], const Raw4<T> (&e1)[2]) {
+        f32x2_t e01 = cv[1][0] * w01[0] + pv[1][0] * w01[6] + cv[0][0] * w01[2] + pv[0][0] * w01[8];
+        f32x2_t e23 = cv[1][1] * w23[0] + pv[1][1] * w23[6] + cv[0][1] * w23[2] + pv[0][1] * w23[8];
+        f32x2_t f01 = cv[1][0] * w01[1] + pv[1][0] * w01[7];
+        f32x2_t f23 = cv[1][1] * w23[1] + pv[1][1] * w23[7];
+        f32x2_t g01 = cv[1][0] * w01[3] + cv[0][0] * w01[5];
+        f32x2_t g23 = cv[1][1] * w23[3] + cv[0][1] * w23[5];
+        f32x2_t h01 = cv[1][0] * w01[4];
+        f32x2_t h23 = cv[1][1] * w23[4];
+        if constexpr (ADD) {
+            add_acc(aq[0], e01, e23);
+            add_acc(aq[1], f01, f23);
+            add_acc(aq[2], g01, g23);
+            add_acc(aq[3], h01, h23);
+        }
+        if (lane_ok) {
+            store4x2(xp, e01, e23);
+            store4x2(xp + C, f01, f23);
+            store4x2(xp + xrow, g01, g23);
+            store4x2(xp + xrow + C, h01, h23);
+            if constexpr (BNR) {
+                bnr_acc(e0[0], e01, e23);
+                bnr_acc(e0[1], f01, f23);
+                bnr_acc(e1[0], g01, g23);
+                bnr_acc(e1[1], h01, h23);
+            }
+        }
+        xp += 2 * xrow;
+        ++a_cur;
+        add_load(a_cur);
+    };
+    // weight gradient of dY[a][b] against the activated input rows 2a (r0), 2a + 1 (r1), 2a + 2 (r2) at columns 2b .. 2b + 2
+    auto wacc = [&](const f32x2_t (&r0)[3][2], const f32x2_t (&r1)[3][2], const f32x2_t (&r2)[3][2], const f32x2_t (&cv)[2][2]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a01[k] += r0[k][0] * cv[1][0];     a23[k] += r0[k][1] * cv[1][1];
+            a01[3 + k] += r1[k][0] * cv[1][0]; a23[3 + k] += r1[k][1] * cv[1][1];
+            a01[6 + k] += r2[k][0] * cv[1][0]; a23[6 + k] += r2[k][1] * cv[1][1];
+        }
+    };
+    add_load(a_begin);
+    Raw4<T> ra[2], rb[2], rc[2];       // dY rows in flight (three rotate)
+    Raw4<T> xa[3], xb2[3];             // the two new input rows of the next step
+    Raw4<T> ke[2], ko[2], k1[2];       // raw pieces (columns 2b, 2b + 1) of the even row carried over / the odd row
+    f32x2_t v0[2][2], v1[2][2];
+    f32x2_t E0[3][2], E1[3][2], E2[3][2];
+    dy_load(ra, a_begin - 1);
+    dy_load(rb, a_begin);
+    dy_load(rc, a_begin + 1);
+    x_load(xa, 2 * a_begin);
+    dy_cvt(ra, a_begin - 1, v0);
+    dy_load(ra, a_begin + 2);
+    x_act(xa, 2 * a_begin, E0);
+    ke[0] = xa[0]; ke[1] = xa[1];
+    x_load(xa, 2 * a_begin + 1);
+    x_load(xb2, 2 * a_begin + 2);
+    // one step: dY row a from `rd` (then re-requested three rows ahead) into `cv`; input rows 2a + 1, 2a + 2 from xa / xb2 (then
+    // re-requested for the next step); even rows alternate between (Ein, kin) and (Eout, kout)
+    auto step = [&](int a, Raw4<T> (&rd)[2], const f32x2_t (&pv)[2][2], f32x2_t (&cv)[2][2], const f32x2_t (&Ein)[3][2], const Raw4<T> (&kin)[2],
+                    f32x2_t (&Eout)[3][2], Raw4<T> (&kout)[2]) __attribute__((always_inline)) {
+        dy_cvt(rd, a, cv);
+        dy_load(rd, a + 3);
+        x_act(xa, 2 * a + 1, E1);
+        k1[0] = xa[0]; k1[1] = xa[1];
+        x_act(xb2, 2 * a + 2, Eout);
+        kout[0] = xb2[0]; kout[1] = xb2[1];
+        x_load(xa, 2 * a + 3);
+        x_load(xb2, 2 * a + 4);
+        emit(pv, cv, kin, k1);
+        wacc(Ein, E1, Eout, cv);
+    };
+    for (int a = a_begin; a < a_end; a += 6) {
+        step(a, rb, v0, v1, E0, ke, E2, ko);
+        if (a + 1 < a_end) step(a + 1, rc, v1, v0, E2, ko, E0, ke);
+        if (a + 2 < a_end) step(a + 2, ra, v0, v1, E0, ke, E2, ko);
+        if (a + 3 < a_end) step(a + 3, rb, v1, v0, E2, ko, E0, ke);
+        if (a + 4 < a_end) step(a + 4, rc, v0, v1, E0, ke, E2, ko);
+        if (a + 5 < a_end) step(a + 5, ra, v1, v0, E2, ko, E0, ke);
+    }
+    // weight partials: the block's columns summed in a fixed order
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float4 v = make_float4(a01[t].x, a01[t].y, a23[t].x, a23[t].y);
+        if (!lane_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&red[(t * kThreads + threadIdx.x) * 4]) = v;
+    }
+    __syncthreads();
+    const int nch = ncg * 4;
+    {
+        float* dst = p.wpart + (long long)unit * 9 * C + cgb * nch;
+        for (int o = threadIdx.x; o < 9 * nch; o += kThreads) {
+            const int t = o / nch, cj = o - t * nch;
+            if (cgb * nch + cj < C) {
+                float sum = 0.f;
+                for (int cidx = 0; cidx < cols; ++cidx) sum += red[(t * kThreads + cidx * ncg) * 4 + cj];
+                dst[t * C + cj] = sum;
+            }
+        }
+    }
+    if constexpr (BNR) {
+        __syncthreads();   // the weight partials have been read
+        float st[8] = {s01.x, s01.y, s23.x, s23.y, q01.x, q01.y, q23.x, q23.y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = lane_ok ? st[j] : 0.f;
+        __syncthreads();
+        if ((int)threadIdx.x < ncg && (cgb * ncg + (int)threadIdx.x) * 4 < C) {
+            float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int cidx = 0; cidx < cols; ++cidx)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc8[j] += red[(cidx * ncg + threadIdx.x) * 8 + j];
+            float* dst = p.part + (long long)unit * 2 * C + (cgb * ncg + threadIdx.x) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dst[j] = acc8[j]; dst[C + j] = acc8[4 + j]; }
+        }
+    }
+}
 }  // namespace
 
 // stride-1 launches use the two-column kernel (forward, plain data gradient and data gradient with the fused batch-norm
@@ -1853,8 +2100,13 @@ extern "C" int mpn_dwconv_bwd_weight(const void* x, const void* dy, float* part,
  * has mpn_dwconv_wgrad_num_parts rows, and so has the fused reduction's) */
 extern "C" int mpn_dwconv_bwd_fused_supported(int N, int H, int W, int C, int stride, int dtype) {
     DwParams p = {};
-    if (stride != 1 || fill_params(p, N, H, W, C, stride, dtype)) return 0;
-    return (C % 4 == 0 && dw_wg_use_sw(p) && dw_wg_sw_geom(p).xt == 2) ? 1 : 0;
+    if ((stride != 1 && stride != 2) || fill_params(p, N, H, W, C, stride, dtype)) return 0;
+    if (C % 4 != 0 || !dw_wg_use_sw(p)) return 0;
+    if (stride == 1) return dw_wg_sw_geom(p).xt == 2 ? 1 : 0;
+    // stride 2 (mpn_dwconv_bwd_fused_s2): even H and W, and the two separate walks' strips coincide (they do by construction)
+    const DwDgS2Geom d = dw_dg_s2_geom(p);
+    const DwWgSwGeom g = dw_wg_sw_geom(p);
+    return (d.ok && d.ncg == g.ncg && d.cols == g.cols && d.xblocks == g.xblocks && d.yblocks == g.yblocks && dg_rows(p.OH) == g.rows) ? 1 : 0;
 }
 
 /* Stride-1 depthwise backward in ONE pass over dy, x and dx (tf.nn.depthwise_conv2d's two gradients, mobilenet_v1.py:101, + the
@@ -1883,6 +2135,38 @@ extern "C" int mpn_dwconv_bwd_fused(const void* x, const void* dy, const float* 
     MPN_DISPATCH_DTYPE(dtype, {
         if (bn_part) dwconv_bwd_sw2_kernel<T, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
         else dwconv_bwd_sw2_kernel<T, false><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+    });
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+
+/* The stride-2 counterpart of mpn_dwconv_bwd_fused (even H and W; mpn_dwconv_bwd_fused_supported(.., stride 2, ..) == 1): x [N,H,W,C] the
+ * conv's raw input, dy [N,H/2,W/2,C]; dx [N,H,W,C] = data gradient (+ addend when not NULL: the FPN lateral's gradient into the same
+ * feature map, added before the store and before the reduction, as mpn_dwconv_bwd_data_add does); wpart
+ * [mpn_dwconv_wgrad_num_parts(.., 2, ..)][9][C]; bn_part (NULL: no reduction) [same rows][2][C]. Replaces mpn_dwconv_bwd_weight +
+ * mpn_dwconv_bwd_data_add / _bn: the input and dy are read once instead of twice. dx must not alias x, dy or addend. */
+extern "C" int mpn_dwconv_bwd_fused_s2(const void* x, const void* dy, const float* w, void* dx, float* wpart, int N, int H, int W, int C,
+                                       int dtype, const float* in_scale, const float* in_shift, int in_act, const float* mean,
+                                       const float* invstd, float* bn_part, const void* addend, mpn_stream_t stream) {
+    MPN_REQUIRE(mpn_dwconv_bwd_fused_supported(N, H, W, C, 2, dtype), MPN_ERR_BAD_SHAPE,
+                "dwconv_bwd_fused_s2: shape not supported (mpn_dwconv_bwd_fused_supported == 0)");
+    MPN_REQUIRE(x && dy && w && dx && wpart && in_scale && in_shift, MPN_ERR_BAD_ARG, "dwconv_bwd_fused_s2: null pointer");
+    MPN_REQUIRE(bn_part == nullptr || (mean && invstd), MPN_ERR_BAD_ARG, "dwconv_bwd_fused_s2: the reduction needs mean and invstd");
+    MPN_REQUIRE(dx != dy && dx != x && dx != addend, MPN_ERR_BAD_ARG, "dwconv_bwd_fused_s2: dx must not alias an input");
+    DwParams p = {};
+    if (int rc = fill_params(p, N, H, W, C, 2, dtype)) return rc;
+    p.x = x; p.dy = dy; p.w = w; p.y = dx; p.wpart = wpart; p.part = bn_part; p.addend = addend;
+    p.in_scale = in_scale; p.in_shift = in_shift; p.in_act = in_act; p.bnr_mean = mean; p.bnr_invstd = invstd;
+    const DwWgSwGeom g = dw_wg_sw_geom(p);
+    p.cblocks = g.cblocks;
+    const long long blocks = (long long)g.units * g.cblocks;
+    MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "dwconv_bwd_fused_s2: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    MPN_DISPATCH_DTYPE(dtype, {
+        if (bn_part && addend) dwconv_bwd_s2_kernel<T, true, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+        else if (bn_part) dwconv_bwd_s2_kernel<T, true, false><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+        else if (addend) dwconv_bwd_s2_kernel<T, false, true><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
+        else dwconv_bwd_s2_kernel<T, false, false><<<(unsigned)blocks, kThreads, 0, st>>>(p, g.ncg, g.cols, g.xblocks, g.yblocks, g.rows);
     });
     MPN_LAUNCH_CHECK();
     return MPN_OK;

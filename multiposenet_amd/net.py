@@ -318,6 +318,7 @@ class KeypointNet:
         self.fuse_pw_wide = False # ... also on 128-channel layers (Conv2d_3_pointwise, lateral2): measured equal to the two-pass backward in the step
         self.fuse_pw_apply = True # ... with the layer's own batch-norm apply pass folded in where the kernel takes it (Cin <= 32, Cout <= 64)
         self.fuse_pw_bwd = True   # thin pointwise layers (Cin <= 64, Cout <= 128): weight + data gradient + reduction in one pass (mpn_conv1x1_bwd_fused)
+        self.fuse_dw_bwd_s2 = True  # ... and the stride-2 ones (even maps; the FPN lateral's gradient added inside: mpn_dwconv_bwd_fused_s2)
         self.fuse_dw_bwd = True   # stride-1 depthwise layers: data gradient + that reduction + weight gradient in ONE walk (mpn_dwconv_bwd_fused)
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
@@ -831,12 +832,20 @@ class KeypointNet:
                 lateral_added = False
                 dA = dst
                 continue
+            prev_bn = self.blocks[i - 1]["pw_bn"] if i > 0 else self.stem_bn
+            # stride-2 layers (even maps): the same in one walk, the FPN lateral's gradient into the feature map below added inside it
+            if self.fuse_dw_bwd and self.fuse_dw_bwd_s2 and self.fuse_dw_bn and self.fuse_lateral_add and blk["stride"] == 2 and \
+                    ops.dwconv_bwd_fused_supported(dst.shape[0], *b["hw"][i], dst.shape[3], 2, dst.dtype):
+                addend = g["c"][FEATURE_BLOCKS[self.blocks[i - 1]["i"]]] if prev_feature else None
+                _, reduced = ops.dwconv_bwd_fused(xin, g["dw"][i], blk["dw_w"], prev_bn, None, out=dst, wpart=slab[id(blk["dw_dw"])],
+                                                  bn_part=sp, reduce=False, stride=2, addend=addend)
+                lateral_added = addend is not None
+                dA = dst
+                continue
             W(lambda: ops.dwconv_bwd_weight(xin, g["dw"][i], blk["stride"], ain, blk["dw_dw"], slab[id(blk["dw_dw"])], reduce=False))
             # the data gradient also reduces for the batch-norm it feeds (one read of dA and one launch less), unless a
             # lateral's gradient still has to be added to dA first
-            prev_bn = self.blocks[i - 1]["pw_bn"] if i > 0 else self.stem_bn
             prev_x = b["pw"][i - 1] if i > 0 else b["stem"]
-            prev_feature = i > 0 and self.blocks[i - 1]["i"] in FEATURE_BLOCKS
             # c2..c4 have two consumers (the next depthwise conv and an FPN lateral, mobilenet_v1.py:76-79): the lateral's
             # gradient is added inside the data-gradient kernel where it can be (stride-2 layers with even maps - all three
             # at the reference's input sizes), otherwise by add_inplace at the top of the next iteration

@@ -514,30 +514,36 @@ def dwconv_bwd_weight(x, dy, stride, affine, dw_out, part=None, reduce=True):
 
 
 def dwconv_bwd_fused_supported(N, H, W, C, stride, dtype):
-    """True when dwconv_bwd_fused takes this layer (stride 1, sliding-window geometry)."""
+    """True when dwconv_bwd_fused takes this layer (stride 1; stride 2 with even H and W)."""
     return _lib.lib().mpn_dwconv_bwd_fused_supported(N, H, W, C, stride, _lib.dtype_code(dtype)) == 1
 
 
-def dwconv_bwd_fused(x, dy, w, bn, dw_out, out=None, wpart=None, bn_part=None, reduce=True, reduce_bn=True):
+def dwconv_bwd_fused(x, dy, w, bn, dw_out, out=None, wpart=None, bn_part=None, reduce=True, reduce_bn=True, stride=1, addend=None):
     """Stride-1 depthwise backward in one pass: x = the conv's RAW input (the raw output of the layer with batch-norm state `bn`,
     whose affine + activation the forward applied on load), dy = gradient w.r.t. the conv's output. Writes the data gradient to
     `out`, the weight-gradient partials to `wpart` (reduced into dw_out when reduce) and, when reduce_bn, the partial sums of
     that batch-norm's backward reduction to `bn_part`; returns (out, rows) - pass rows to bn_backward(reduced_parts=rows)."""
     N, H, W, C = x.shape
     dc = _lib.dtype_code(x.dtype)
-    if not dwconv_bwd_fused_supported(N, H, W, C, 1, x.dtype):
+    if not dwconv_bwd_fused_supported(N, H, W, C, stride, x.dtype):
         raise ValueError("dwconv_bwd_fused: shape not supported")
+    if addend is not None and (stride != 2 or addend.shape != x.shape or addend.dtype != x.dtype or not addend.is_contiguous()):
+        raise ValueError("dwconv_bwd_fused: addend needs stride 2 and the result's shape and dtype")
     if out is None:
         out = torch.empty_like(x)
-    rows = _lib.lib().mpn_dwconv_wgrad_num_parts(N, H, W, C, 1, dc)
+    rows = _lib.lib().mpn_dwconv_wgrad_num_parts(N, H, W, C, stride, dc)
     if wpart is None:
         wpart = _f32(rows * 9 * C, x.device)
     if reduce_bn and bn_part is None:
         bn_part = _f32(rows * 2 * C, x.device)
     if wpart.numel() < rows * 9 * C or (reduce_bn and bn_part.numel() < rows * 2 * C):
         raise ValueError("dwconv_bwd_fused: partial slab too small")
-    call("mpn_dwconv_bwd_fused", ptr(x), ptr(dy), ptr(w), ptr(out), ptr(wpart), N, H, W, C, dc, ptr(bn.scale), ptr(bn.shift),
-         int(bn.act), ptr(bn.mean), ptr(bn.invstd), ptr(bn_part) if reduce_bn else None, stream_ptr())
+    if stride == 2:
+        call("mpn_dwconv_bwd_fused_s2", ptr(x), ptr(dy), ptr(w), ptr(out), ptr(wpart), N, H, W, C, dc, ptr(bn.scale), ptr(bn.shift),
+             int(bn.act), ptr(bn.mean), ptr(bn.invstd), ptr(bn_part) if reduce_bn else None, ptr(addend), stream_ptr())
+    else:
+        call("mpn_dwconv_bwd_fused", ptr(x), ptr(dy), ptr(w), ptr(out), ptr(wpart), N, H, W, C, dc, ptr(bn.scale), ptr(bn.shift),
+             int(bn.act), ptr(bn.mean), ptr(bn.invstd), ptr(bn_part) if reduce_bn else None, stream_ptr())
     if reduce:
         call("mpn_reduce_partials", ptr(wpart), rows, 9 * C, ptr(dw_out), 0, 1.0, stream_ptr())
     return out, (rows if reduce_bn else 0)

@@ -723,7 +723,7 @@ def test_dwconv_bwd_fused_equals_the_separate_launches(cuda, dtype, N, H, W, C):
     channel blocks."""
     ops = _ops()
     rs = np.random.RandomState(C + H + W)
-    assert ops.dwconv_bwd_fused_supported(N, H, W, C, 1, dtype) and not ops.dwconv_bwd_fused_supported(N, H, W, C, 2, dtype)
+    assert ops.dwconv_bwd_fused_supported(N, H, W, C, 1, dtype)
     x = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)                 # raw input of the depthwise conv = raw output of the fed layer
     dy = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)
     w = dev((rs.randn(3, 3, C) / 3).astype(np.float32))
@@ -884,3 +884,48 @@ def test_conv1x1_bwd_fused_without_a_reduction_is_the_plain_backward(cuda, N, H,
     assert ops.conv1x1_bwd_fused(x, dy, w, aff, dx_a, wp_a, None) == rows
     assert torch.equal(wp_a, wp_b)
     assert_close(dx_a, dx_b.float().cpu(), dtype, Cout)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("N,H,W,C,add", [(2, 16, 16, 64, True), (1, 32, 32, 512, False), (1, 48, 40, 256, True), (2, 64, 64, 128, False),
+                                           (1, 6, 10, 1024, True), (1, 130, 70, 32, False)])
+def test_dwconv_bwd_fused_stride2_equals_the_separate_launches(cuda, dtype, N, H, W, C, add):
+    """mpn_dwconv_bwd_fused_s2: one walk gives the data gradient (+ addend) of mpn_dwconv_bwd_data[_add] with the fused reduction bit
+    for bit (same expressions), the weight gradient of mpn_dwconv_bwd_weight (the same per-thread products in the same order: equal)
+    and the same partial rows - with and without the FPN lateral's addend, strips and columns that end inside the map."""
+    ops = _ops()
+    rs = np.random.RandomState(C + H + W + 11)
+    assert ops.dwconv_bwd_fused_supported(N, H, W, C, 2, dtype) and not ops.dwconv_bwd_fused_supported(N, H + 1, W, C, 2, dtype)
+    OH, OW = ops.dwconv_out_hw(H, W, 2)
+    x = dev(rnd(rs.randn(N, H, W, C), dtype), dtype)
+    dy = dev(rnd(rs.randn(N, OH, OW, C), dtype), dtype)
+    w = dev((rs.randn(3, 3, C) / 3).astype(np.float32))
+    addend = dev(rnd(rs.randn(N, H, W, C), dtype), dtype) if add else None
+
+    def mkbn(seed):
+        r2 = np.random.RandomState(seed)
+        one = lambda: torch.tensor((0.5 + r2.rand(C)).astype(np.float32)).cuda()
+        bn = ops.BNState(one(), one(), one(), one(), 2)
+        bn.scale.copy_(one()); bn.invstd.copy_(one())
+        bn.shift.copy_(torch.tensor((r2.randn(C) * 0.5).astype(np.float32)).cuda()); bn.mean.copy_(torch.tensor((r2.randn(C) * 0.3).astype(np.float32)).cuda())
+        bn.dgamma, bn.dbeta = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+        return bn
+    bn = mkbn(3)
+    rows = ops.dwconv_wgrad_num_parts(N, H, W, C, 2, dtype)
+    assert rows == ops.dwconv_bwd_data_bn_num_parts(N, H, W, C, 2, dtype)
+    # the separate launches
+    wp_b = torch.zeros(rows * 9 * C, device="cuda")
+    ops.dwconv_bwd_weight(x, dy, 2, bn.affine, None, wp_b, reduce=False)
+    sp_b = torch.zeros(rows * 2 * C, device="cuda")
+    dA_b, r_b = ops.dwconv_bwd_data(dy, w, (H, W), 2, bn=bn, x_bn=x, part=sp_b, addend=addend)
+    # the fused walk
+    wp_a, sp_a = torch.zeros(rows * 9 * C, device="cuda"), torch.zeros(rows * 2 * C, device="cuda")
+    dA_a, r_a = ops.dwconv_bwd_fused(x, dy, w, bn, None, wpart=wp_a, bn_part=sp_a, reduce=False, stride=2, addend=addend)
+    assert r_a == r_b == rows
+    assert torch.equal(dA_a, dA_b)
+    assert float((wp_a - wp_b).abs().max()) <= 1e-6 * (float(wp_b.abs().max()) + 1e-6)
+    assert float((sp_a - sp_b).abs().max()) <= 1e-6 * (float(sp_b.abs().max()) + 1e-6)
+    # without the reduction
+    wp_n = torch.zeros(rows * 9 * C, device="cuda")
+    dA_n, r0 = ops.dwconv_bwd_fused(x, dy, w, bn, None, wpart=wp_n, reduce=False, reduce_bn=False, stride=2, addend=addend)
+    assert r0 == 0 and torch.equal(dA_n, dA_b) and torch.equal(wp_n, wp_a)
