@@ -344,20 +344,46 @@ __device__ __forceinline__ void conv_mfma_body(const ConvParams& p, const int bl
     // windows; (3) after one barrier, whole 16-byte pieces of pixel rows go to global memory, 256 contiguous bytes per
     // 16 lanes. The statistics are those of the ROUNDED outputs - exactly the tensor the consumer normalises.
     if constexpr (sizeof(T) == 2) {
-        if (res == nullptr) {
+        // The upsample-add variant (FPN laterals, fpn.py:42-47: y = conv(x) + nearest-2x(res)) takes the same route: the residual
+        // is added to the f32 accumulators on the way INTO the image (one rounding, as in the direct epilogue). Its 1x1 tile is 128
+        // consecutive pixels: the tile origin's (image, row, column) come from one scalar division, a lane's pixel from compares
+        // (the direct epilogue's two 64-bit divisions per pixel and its 32-byte-segment stores cost lateral2 a third of its time).
+        // Maps narrower than 32 columns or smaller than a tile keep the direct epilogue.
+        const bool res_tiled = res != nullptr && TAPS == 1 && p.W >= 32 && (long long)p.H * p.W >= 128;
+        if (res == nullptr || res_tiled) {
             constexpr int RSO = BN * 2 + 8;
             constexpr int ROWS = MT * 32;
             unsigned char* O = smem;
             float* red = reinterpret_cast<float*>(smem + ROWS * RSO);   // [2 wm][2][BN]
+            int rn0 = 0, roy0 = 0, rox0 = 0;                             // (scalar) image / row / column of the tile's first pixel
+            if (res_tiled) {
+                rox0 = (int)(m0 % p.W);
+                const long long t_ = m0 / p.W;
+                roy0 = (int)(t_ % p.H);
+                rn0 = (int)(t_ / p.H);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int row = wm * (MT * 16) + mt * 16 + l15;
                 bool ok;
                 if (TAPS == 9) ok = (oy0 + (row >> 4)) < p.H && (ox0 + (row & 15)) < p.W;
                 else ok = (m0 + row) < p.M;
+                long long roff = 0;
+                if (res_tiled) {
+                    const int v_ = rox0 + row;                                               // < W + 128
+                    const int q_ = (v_ >= p.W) + (v_ >= 2 * p.W) + (v_ >= 3 * p.W) + (v_ >= 4 * p.W);   // (W >= 32: at most four wraps)
+                    const int ox_ = v_ - q_ * p.W;
+                    int oy_ = roy0 + q_, n_ = rn0;
+                    if (oy_ >= p.H) { oy_ -= p.H; ++n_; }                                    // (H * W >= 128: at most one image boundary)
+                    roff = ok ? (((long long)n_ * (p.H >> 1) + (oy_ >> 1)) * (p.W >> 1) + (ox_ >> 1)) * p.Cout : 0;
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     f32x4_t v = acc[mt][nt];
+                    if (res_tiled) {
+                        const int c_ = n0 + wn * (BN / 2) + nt * 16 + lq * 4;
+                        if (c_ < p.Cout) v += load4(res + roff + c_);
+                    }
                     if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // out-of-image pixels must not count in the statistics
                     store4(reinterpret_cast<T*>(O + row * RSO + (wn * (BN / 2) + nt * 16 + lq * 4) * 2), v);
                 }

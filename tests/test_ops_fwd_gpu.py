@@ -25,7 +25,11 @@ CONV_CASES = [
     (1, 4, 4, 128, 128, 3, 1, True, False),      # map smaller than a tile
     (2, 16, 16, 64, 256, 1, 2, True, False),
     (1, 8, 8, 1024, 128, 1, 2, False, False),    # lateral5 shape
-    (2, 16, 16, 256, 128, 1, 2, False, True),    # lateral + upsample-add
+    (2, 16, 16, 256, 128, 1, 2, False, True),    # lateral + upsample-add (narrow map: the direct epilogue)
+    (1, 32, 32, 128, 128, 1, 2, False, True),    # ... through the tile image: a tile = four map rows
+    (2, 64, 48, 256, 128, 1, 2, False, True),    # ... tiles that start inside a row and wrap twice
+    (3, 10, 40, 64, 128, 1, 1, False, True),     # ... tiles that cross an image boundary, ragged last tile
+    (1, 128, 128, 128, 128, 1, 2, False, True),  # ... lateral2's map: a tile = one row
     (1, 10, 6, 32, 64, 1, 2, True, False),       # ragged M
     (3, 16, 16, 1024, 1024, 1, 2, True, False),  # pointwise 13 shape
     (1, 10, 14, 40, 72, 3, 1, True, False),      # channel counts off the tile grid: partial K chunk, partial last n-tile
