@@ -479,11 +479,67 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
     }
     const bool dvalid = co0 + dslot * VE < p.Cout;
     const int drow0 = tid / DSLOTS;
+    // 1x1: the tile's pieces as buffer loads. A piece's byte offset is a per-thread constant + the tile's base, and rows past the end
+    // of the tensor (the ragged last tile) or channels past the layer's (offset 2^31: the host keeps both tensors below 2^31 bytes)
+    // fail the descriptor's range check and arrive as zeros: no compare / select / 64-bit address per load, no zeroing at commit.
+    // (A zero row of x may become act(shift) under the affine - it meets a zero row of dY. Under DAPPLY a zero dY row would become the
+    //  apply's constant term: those pieces keep their mask.)
+    constexpr bool BUF = TAPS == 1;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    unsigned relAb[BUF ? AVEC : 1], relDb[BUF ? DVEC : 1], relEb[(BUF && DAPPLY) ? DVEC : 1];
+    __amdgpu_buffer_rsrc_t rsx, rsd, rse;
+    if constexpr (BUF) {
+        constexpr unsigned kOut = 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < AVEC; ++i) relAb[i] = hyx[i] == 0x7fffffff ? kOut : (unsigned)relA[i] * (unsigned)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < DVEC; ++i) relDb[i] = dvalid ? (unsigned)relD[i] * (unsigned)sizeof(T) : kOut;
+        rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)(((p.M - 1) * p.xs + p.Cin) * (long long)sizeof(T)), 0x00020000);
+        rsd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy), 0, (int)(((p.M - 1) * p.dys + p.Cout) * (long long)sizeof(T)), 0x00020000);
+        if constexpr (DAPPLY) {
+#pragma unroll
+            for (int i = 0; i < DVEC; ++i)
+                relEb[i] = dvalid ? (unsigned)((drow0 + i * (NT / DSLOTS)) * p.ap_xs + co0 + dslot * VE) * (unsigned)sizeof(T) : kOut;
+            rse = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.ap_x), 0, (int)(((p.M - 1) * p.ap_xs + p.Cout) * (long long)sizeof(T)), 0x00020000);
+        }
+    }
 
     // Loads are UNCONDITIONAL (out-of-image lanes read element 0 of the tensor and are zeroed at commit time): a
     // predicated load is lowered to load + select, which waits for the data right here and defeats the prefetch.
     // Addresses and masks first, then the loads back to back.
     auto load_tile = [&](int tile) {
+        if constexpr (BUF) {
+            const unsigned tbA = (unsigned)tile * 128u * (unsigned)p.xs * (unsigned)sizeof(T);
+            const unsigned tbD = (unsigned)tile * 128u * (unsigned)p.dys * (unsigned)sizeof(T);
+            if constexpr (DAPPLY) {
+                const int mleft = (int)(p.M - (long long)tile * 128);
+                unsigned md = 0u;
+#pragma unroll
+                for (int i = 0; i < DVEC; ++i) md |= ((dvalid && drow0 + i * (NT / DSLOTS) < mleft) ? 1u : 0u) << i;
+                inbd = md;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < AVEC; ++i) {
+                const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)(relAb[i] + tbA), 0, 0);
+                v[i].raw = make_uint4(q.x, q.y, q.z, q.w);
+            }
+#pragma unroll
+            for (int i = 0; i < DVEC; ++i) {
+                const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rsd, (int)(relDb[i] + tbD), 0, 0);
+                dv[i].raw = make_uint4(q.x, q.y, q.z, q.w);
+            }
+            if constexpr (DAPPLY) {
+                const unsigned tbE = (unsigned)tile * 128u * (unsigned)p.ap_xs * (unsigned)sizeof(T);
+#pragma unroll
+                for (int i = 0; i < DVEC; ++i) {
+                    const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rse, (int)(relEb[i] + tbE), 0, 0);
+                    ev[i].raw = make_uint4(q.x, q.y, q.z, q.w);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
         int oy0 = 0, ox0 = 0, baseA, baseD, mleft = 0;
         if (TAPS == 9) {
             const int tx = tile % p.tiles_x;
@@ -569,11 +625,11 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
                     o.pack(f);
                     q = *reinterpret_cast<const uint4*>(&o.raw);
                 }
-                if (!((inb >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
+                if (!BUF && !((inb >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
                 *reinterpret_cast<uint4*>(As + pix * SA + aslot * 16) = q;
                 if constexpr (DG) {   // (single-buffered: read in front of the tile's second barrier, rewritten behind it)
                     uint4 r = *reinterpret_cast<const uint4*>(&v[i].raw);
-                    if (!((inb >> i) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
+                    if (!BUF && !((inb >> i) & 1u)) r = make_uint4(0u, 0u, 0u, 0u);
                     *reinterpret_cast<uint4*>(Rs + pix * SA + aslot * 16) = r;
                 }
             }
@@ -603,7 +659,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
                 o.pack(d);
                 q = *reinterpret_cast<const uint4*>(&o.raw);
             }
-            if (!((inbd >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
+            if ((!BUF || DAPPLY) && !((inbd >> i) & 1u)) q = make_uint4(0u, 0u, 0u, 0u);
             *reinterpret_cast<uint4*>(Ds + r * SD + dslot * 16) = q;
         }
     };
@@ -976,6 +1032,9 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
                 "conv wgrad: pixel strides (%d, %d) must be multiples of %d not below the channel counts", x_stride, dy_stride, ve);
     MPN_REQUIRE((long long)N * H * W * p.xs < (1ll << 31) && (long long)N * H * W * p.dys < (1ll << 31), MPN_ERR_BAD_SHAPE,
                 "conv wgrad: strided tensors must span fewer than 2^31 elements");
+    // (the 16-bit 1x1 kernel addresses its tiles with 32-bit byte offsets and keeps 2^31 as the out-of-range offset)
+    MPN_REQUIRE(ksize != 1 || es != 2 || ((long long)N * H * W * p.xs < (1ll << 30) && (long long)N * H * W * p.dys < (1ll << 30)),
+                MPN_ERR_BAD_SHAPE, "conv wgrad: 16-bit 1x1 tensors must span fewer than 2^31 bytes");
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
     p.M = (long long)N * H * W;
     p.ntiles = g.ntiles; p.nsplit = g.nsplit; p.n_cg = g.n_cg; p.n_cb = g.n_cb; p.xcd_remap = 1;
@@ -1092,6 +1151,8 @@ extern "C" int mpn_conv_bwd_weight_grouped(int njobs, const void* const* x, cons
         MPN_REQUIRE(p.xs >= Cin && p.dys >= Cout && p.xs % 8 == 0 && p.dys % 8 == 0, MPN_ERR_BAD_SHAPE, "conv wgrad grouped: bad pixel strides");
         MPN_REQUIRE((long long)N * H[j] * W[j] * p.xs < (1ll << 31) && (long long)N * H[j] * W[j] * p.dys < (1ll << 31), MPN_ERR_BAD_SHAPE,
                     "conv wgrad grouped: tensors must span fewer than 2^31 elements");
+        MPN_REQUIRE(ksize != 1 || ((long long)N * H[j] * W[j] * p.xs < (1ll << 30) && (long long)N * H[j] * W[j] * p.dys < (1ll << 30)),
+                    MPN_ERR_BAD_SHAPE, "conv wgrad grouped: 1x1 tensors must span fewer than 2^31 bytes");
         p.tiles_x = (W[j] + 15) / 16; p.tiles_y = (H[j] + 7) / 8;
         p.M = (long long)N * H[j] * W[j];
         p.ntiles = geoms[j].ntiles; p.nsplit = nsplit[j]; p.n_cg = geoms[j].n_cg; p.n_cb = geoms[j].n_cb;
@@ -1162,6 +1223,8 @@ int conv1x1_bwd_fused_impl(const void* x, const void* dy, const float* w, void* 
                 "conv1x1_bwd_fused: pixel strides must be multiples of 8 not below the channel counts");
     MPN_REQUIRE((long long)N * H * W * p.xs < (1ll << 31) && (long long)N * H * W * p.dys < (1ll << 31), MPN_ERR_BAD_SHAPE,
                 "conv1x1_bwd_fused: tensors must span fewer than 2^31 elements");
+    MPN_REQUIRE((long long)N * H * W * p.xs < (1ll << 30) && (long long)N * H * W * p.dys < (1ll << 30), MPN_ERR_BAD_SHAPE,
+                "conv1x1_bwd_fused: tensors must span fewer than 2^31 bytes");
     const WgradGeom g = wgrad_geom(N, H, W, Cin, Cout, 1, 2);
     MPN_REQUIRE(g.n_cg == 1 && g.n_cb == 1, MPN_ERR_BAD_SHAPE, "conv1x1_bwd_fused: one block tile must hold the layer");
     p.tiles_x = (W + 15) / 16; p.tiles_y = (H + 7) / 8;
