@@ -346,7 +346,8 @@ __global__ __launch_bounds__(kThreads, 2) void conv_wgrad_kernel(const WgradPara
 // current tile's MFMAs start and are committed (batch-norm affine + activation) into the OTHER half of a
 // double-buffered LDS image afterwards, so that one barrier per tile remains and the round trip hides under
 // ~4.6k MFMA cycles per SIMD.  Geometries (RBA, RBD bytes per LDS pixel row; WM x WN waves over m/n tiles):
-//   3x3:              (128, 256, 2x4) = 64 ci x 9 taps x 128 co, 144 accumulator registers per lane
+//   3x3:              (128, 256, 4x2) = 64 ci x 9 taps x 128 co, 144 accumulator registers per lane (a wave: one m-tile x four n-tiles,
+//                     0.72 fragment reads per MFMA; as 2 x 2 tiles 1.11 and 0.3 % of the step slower)
 //   3x3, Cout <= 64:  (256, 128, 4x2) = 128 ci x 9 taps x 64 co
 //   1x1:              (256, 256, 4x2) = 128 ci x 128 co
 // (a device function: the plain kernel and the grouped kernel - several independent layers of one channel geometry, e.g. the
@@ -1048,12 +1049,12 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
         if (wgrad_thin1x1(Cin, Cout, ksize)) return launch_wgrad_bf16<half_t, 1, 64, 128, 2, false>(p, st);
         if (ksize == 1) return launch_wgrad_bf16<half_t, 1, 256, 256, 4, false>(p, st);
         if (Cout <= 64) return launch_wgrad_bf16<half_t, 9, 256, 128, 4, true>(p, st);
-        return launch_wgrad_bf16<half_t, 9, 128, 256, 2, true>(p, st);
+        return launch_wgrad_bf16<half_t, 9, 128, 256, 4, true>(p, st);
     }
     if (wgrad_thin1x1(Cin, Cout, ksize)) return launch_wgrad_bf16<bf16_t, 1, 64, 128, 2, false>(p, st);
     if (ksize == 1) return launch_wgrad_bf16<bf16_t, 1, 256, 256, 4, false>(p, st);
     if (Cout <= 64) return launch_wgrad_bf16<bf16_t, 9, 256, 128, 4, true>(p, st);
-    return launch_wgrad_bf16<bf16_t, 9, 128, 256, 2, true>(p, st);
+    return launch_wgrad_bf16<bf16_t, 9, 128, 256, 4, true>(p, st);
 }
 
 namespace {
@@ -1171,12 +1172,12 @@ extern "C" int mpn_conv_bwd_weight_grouped(int njobs, const void* const* x, cons
         if (wgrad_thin1x1(Cin, Cout, ksize)) return launch_wgrad_bf16_grouped<half_t, 1, 64, 128, 2, false>(grp, begin, st);
         if (ksize == 1) return launch_wgrad_bf16_grouped<half_t, 1, 256, 256, 4, false>(grp, begin, st);
         if (Cout <= 64) return launch_wgrad_bf16_grouped<half_t, 9, 256, 128, 4, true>(grp, begin, st);
-        return launch_wgrad_bf16_grouped<half_t, 9, 128, 256, 2, true>(grp, begin, st);
+        return launch_wgrad_bf16_grouped<half_t, 9, 128, 256, 4, true>(grp, begin, st);
     }
     if (wgrad_thin1x1(Cin, Cout, ksize)) return launch_wgrad_bf16_grouped<bf16_t, 1, 64, 128, 2, false>(grp, begin, st);
     if (ksize == 1) return launch_wgrad_bf16_grouped<bf16_t, 1, 256, 256, 4, false>(grp, begin, st);
     if (Cout <= 64) return launch_wgrad_bf16_grouped<bf16_t, 9, 256, 128, 4, true>(grp, begin, st);
-    return launch_wgrad_bf16_grouped<bf16_t, 9, 128, 256, 2, true>(grp, begin, st);
+    return launch_wgrad_bf16_grouped<bf16_t, 9, 128, 256, 4, true>(grp, begin, st);
 }
 
 namespace {
