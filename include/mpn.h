@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 401   /* r4: see INTEGRATION.md "ABI revisions" */
+#define MPN_VERSION 402   /* r4: see INTEGRATION.md "ABI revisions" */
 
 enum { MPN_F32 = 0, MPN_BF16 = 1, MPN_F16 = 2 /* dense 1x1 / 3x3 convolutions (forward, weight gradient, pack), the PRN entry points and the decode input; the BN / depthwise / loss kernels of the keypoint step take F32 and BF16 only */ };
 
@@ -82,8 +82,8 @@ int mpn_heatmap_decode(const void* heatmaps, int dtype, int B, int h, int w, int
  *            together with in_act (MPN_ACT_*), so normalised activations never touch HBM
  *   w_packed weights from mpn_conv_pack_weights (same dtype as x)
  *   y        [N,H,W,Cout]
- *   stats_part NULL or [mpn_conv_num_parts()][2][Cout] f32: per-tile sum and sum of squares
- *            of y for the following batch-norm (mpn_bn_finalize reduces them)
+ *   stats_part NULL or [mpn_conv_num_parts()][2][Cout] f32: partial sums and sums of squares of y for the
+ *            following batch-norm; mpn_conv_stats_rows() rows are written (mpn_bn_finalize reduces them)
  *   up_res   NULL or [N,H/2,W/2,Cout]: y += nearest-2x-upsample(up_res)  (detector/fpn.py:51,58-76)
  */
 size_t mpn_conv_packed_bytes(int Cin, int Cout, int ksize, int transpose, int dtype);
@@ -98,7 +98,12 @@ int mpn_conv_pack_desc_fill(void* desc_host, const float* w_hwio, int Cin, int C
                             int dtype, void* out, int block_begin);
 int mpn_conv_pack_weights_batched(const void* descs_device, int ndesc, int total_blocks, int dtype,
                                   mpn_stream_t stream);
+/* rows to SIZE a statistics slab with: one per 8 x 16-pixel tile (3x3) / per 128 pixels (1x1) */
 int mpn_conv_num_parts(int N, int H, int W, int ksize);
+/* rows a convolution of this shape WRITES (what mpn_bn_finalize / the finalize descriptors must be given as nparts): the persistent
+ * 3x3 kernel (16-bit storage, Cin % 64 == 0, Cout % 64 == 0) sums the rows of a block's tiles and writes one row per block - the same
+ * count alone and inside a group -, every other kernel mpn_conv_num_parts rows. Never more than mpn_conv_num_parts; < 0 without a device. */
+int mpn_conv_stats_rows(int N, int H, int W, int Cin, int Cout, int ksize, int dtype);
 /* x_stride / y_stride: elements between consecutive pixels of x / y; 0 = dense (Cin / Cout). A larger stride reads /
  * writes a channel slice of a wider NHWC tensor in place - phi_subnet_2's second conv writes straight into the first 128
  * channels of the 512-channel concat tensor (keypoint_subnet.py:37: tf.concat with upsample factor 1 is a copy). */
@@ -119,14 +124,14 @@ int mpn_conv_fwd_grouped(int njobs, const void* const* x, const void* const* w_p
  * weights) that ALSO do the first pass of the batch-norm backward of the layer they feed (keypoint_subnet.py:75-78: conv ->
  * bn -> relu -> conv; layer_utils.py:9-16): dx[j] is written MASKED - g = dx where lo < bn_x[j] * bn_scale[j] + bn_shift[j] < hi
  * (the activation bn_act passed), else 0, so mpn_bn_bwd_apply's own mask is a no-op on it - and part[j]
- * ([mpn_conv_num_parts(N,H[j],W[j],3)][2][C] floats) receives the partial sums of g and of g * bn_x with the RAW x: finish
+ * ([mpn_conv_num_parts(N,H[j],W[j],3)][2][C] floats, mpn_conv_stats_rows of them written) receives the partial sums of g and of g * bn_x with the RAW x: finish
  * with a finalize built by mpn_bn_bwd_fin_desc_fill_raw. One tensor read and one launch less than mpn_bn_bwd_reduce behind
  * the data gradient. dy [N,H,W,K], dx / bn_x [N,H,W,C] (pixel strides as arrays or NULL = dense); 16-bit storage,
  * K % 64 == 0, K <= 512, C % 64 == 0, C <= 512: mpn_conv_bwd_data_bn_supported(K, C, ksize, dtype) != 0. */
 int mpn_conv_bwd_data_bn_supported(int K, int C, int ksize, int dtype);
 /* One layer: 3x3 as above, or a 1x1 layer (bf16, K and C multiples of 8: the data gradients of Conv2d_1..13_pointwise, which
  * feed the depthwise layers' batch-norms, mobilenet_v1.py:66-74, and of the FPN's lateral of c5, fpn.py:38) - through the GEMM
- * kernel where mpn_conv_fwd routes the geometry there, else the tiled kernel. part: [mpn_conv_num_parts(N,H,W,ksize)][2][C];
+ * kernel where mpn_conv_fwd routes the geometry there, else the tiled kernel. part: [mpn_conv_num_parts(N,H,W,ksize)][2][C] (mpn_conv_stats_rows written);
  * finish with mpn_bn_bwd_finalize_raw. */
 int mpn_conv_bwd_data_bn(const void* dy, const void* w_packed_t, void* dx, int N, int H, int W, int K, int C, int dy_stride,
                          int dx_stride, int ksize, int dtype, const void* bn_x, int bn_x_stride, const float* bn_scale,

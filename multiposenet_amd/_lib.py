@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPN_LIB: an alternative build of the same library (diagnostic A/B of compile-time variants, tools/build_variant.sh)
 LIB_PATH = os.environ.get("MPN_LIB") or os.path.join(_HERE, "libmpn_hip.so")
 
-MPN_VERSION = 401     # the ABI revision this binding was written against (include/mpn.h); lib() refuses another
+MPN_VERSION = 402     # the ABI revision this binding was written against (include/mpn.h); lib() refuses another
 MPN_F32, MPN_BF16, MPN_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
@@ -36,6 +36,7 @@ SIGNATURES = {
     "mpn_conv_pack_desc_fill": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I]),
     "mpn_conv_pack_weights_batched": (_I, [_P, _I, _I, _I, _P]),
     "mpn_conv_num_parts": (_I, [_I, _I, _I, _I]),
+    "mpn_conv_stats_rows": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "mpn_conv_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P, _P, _P]),
     "mpn_conv_fwd_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     "mpn_conv_wgrad_num_parts": (_I, [_I, _I, _I, _I, _I, _I, _I]),

@@ -32,8 +32,8 @@ struct Job {
     void* y;              // [N,H,W,*] pixel stride ys
     const float* in_scale;   // producer's batch-norm affine applied on load (NULL: none)
     const float* in_shift;
-    float* stats_part;    // [N * ceil(H/8) * ceil(W/16)][2][Cout] partial sums of the rounded outputs (rows of the 8 x 16 tiling
-                          // the tiled kernel writes: mpn_conv_num_parts), or NULL
+    float* stats_part;    // [stats_rows(N, H, W, Cout)][2][Cout] partial sums of the rounded outputs (one row per block that has a
+                          // tile of the job: mpn_conv_stats_rows), or NULL
     int in_act;
     int N, H, W, Cin, Cout, xs, ys;
     // Data-gradient launches that also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn): y is the gradient w.r.t. the
@@ -54,5 +54,7 @@ inline int blocks_of(const Job& j) {
 
 // one grid over up to kMaxJobs independent layers of the same (Cin, Cout, dtype) - e.g. the pyramid levels of a subnet stage
 int launch(const Job* jobs, int njobs, int dtype, hipStream_t st);
+// rows of the statistics slab a job of this shape writes (the same alone and in a group); < 0: no device
+int stats_rows(int N, int H, int W, int Cout);
 
 }  // namespace mpn_c3

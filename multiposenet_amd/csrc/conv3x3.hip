@@ -14,7 +14,7 @@
 // LDS: 2 x 51 840 (halo images, 160-byte rows: conflict-free ds_read_b128) + 2 x 24 576 (weight stages, LDS-DMA) = 152 832 B.
 // Epilogue as in the tiled kernel: the tile leaves through a bf16 LDS image (whole 256-byte pixel rows to HBM), the
 // batch-norm partial sums come from the matrix unit (ones x F and F^T x F over transposed reads of that image) and are
-// written as the two 8 x 16-pixel rows of the partial slab that the tiled kernel would have written.
+// summed over a block's tiles of a layer: one row of the partial slab per block (mpn_conv_stats_rows).
 //
 // N64 variant (64 output channels per tile: final_conv3x3 512 -> 64, keypoint_subnet.py:38, and the detector's tower convolutions,
 // box_predictor.py:101-103): the same 16 x 16 pixel tile, the same stage bytes and the same 48 MFMAs per wave and stage - the two
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     int w = blockIdx.x;
     if ((gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (w >= total) return;
+    const int w_first = w;
 #ifdef MPN_DIAG
     if (g.job[0].dbg && threadIdx.x == 0) g.job[0].dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -302,19 +303,26 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         // (a wave-uniform branch around the WHOLE commit: inside it hipcc would if-convert the clamp back into a select per element)
         if (act_relu6) a_commit_t(std::true_type{}, i0, np, buf, chunk); else a_commit_t(std::false_type{}, i0, np, buf, chunk);
     };
-    // statistics rows of the tile that finished last, written after the next block barrier (red is complete by then)
+    // Statistics: a block SUMS the rows of its tiles of one job (threads 0..255: one of the two sums, one channel; f32, in the order of
+    // its walk) and writes them once, behind its last tile of that job: one slab row per block instead of two per tile (the four
+    // pyramid levels at batch 32: 256 rows for the finalize instead of 5 440). The sums of the tile that finished last are taken from
+    // `red` after the next block barrier (complete by then).
     float* st_dst = nullptr;
-    const int st_half = tid >> 8, st_which = (tid >> 7) & 1, st_c = tid & 127;
+    float st_acc = 0.f;
+    bool st_pending = false, st_store = false;
+    const int st_which = (tid >> 7) & 1, st_c = tid & 127;
     auto stats_flush = [&]() {
-        if (st_dst != nullptr) {
-            if constexpr (N64) {   // red [8 waves][2][64]: the four waves of a tile half, fixed order
-                const float* r = red + ((4 * st_half) * 2 + st_which) * 64 + st_c;
-                *st_dst = (r[0] + r[128]) + (r[256] + r[384]);
-            } else {
-                *st_dst = red[((2 * st_half) * 2 + st_which) * 128 + st_c] + red[((2 * st_half + 1) * 2 + st_which) * 128 + st_c];
+        if (st_pending) {
+            if constexpr (N64) {   // red [8 waves][2][64], fixed order: the four waves of the upper half, then of the lower half
+                const float* r = red + st_which * 64 + st_c;
+                st_acc += ((r[0] + r[128]) + (r[256] + r[384])) + ((r[512] + r[640]) + (r[768] + r[896]));
+            } else {               // red [4 wm][2][128]
+                const float* r = red + st_which * 128 + st_c;
+                st_acc += (r[0] + r[256]) + (r[512] + r[768]);
             }
+            if (st_store) { *st_dst = st_acc; st_acc = 0.f; }
         }
-        st_dst = nullptr;
+        st_pending = false;
     };
 
     // BNR: the raw tensor of the fed batch-norm at this wave's 64 pixels x 64 channels, in the copy-out layout of the epilogue
@@ -658,11 +666,16 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         }
                     }
                 }
-                // two rows of the 8 x 16-pixel partial slab: the tile's upper half (waves wm 0, 1) and lower half (wm 2, 3)
-                const int tiles_y8 = (p.H + 7) >> 3, tiles_x = (p.W + 15) >> 4, ty8 = cur.ty * 2 + st_half;
-                if (ty8 < tiles_y8 && (!N64 || st_c < 64)) {
-                    const long long prow8 = ((long long)cur.img * tiles_y8 + ty8) * tiles_x + cur.tx;
-                    st_dst = p.stats_part + (prow8 * 2 + st_which) * Cout + n0 + st_c;
+                // the block's row of this job's slab (pixels outside the image count as zeros): row = the position of the block's
+                // FIRST tile of the job among the job's first gridDim.x tiles, i.e. rows 0 .. min(grid, tiles) / n_tiles - 1
+                // (mpn_conv_stats_rows; the grid is a multiple of n_tiles, so a block keeps its channel tile within a job)
+                {
+                    const int n_tiles = N64 ? (Cout >> 6) : (Cout >> 7), grid = (int)gridDim.x;
+                    int off = (w_first - g.begin[cur.job]) % grid;
+                    if (off < 0) off += grid;
+                    st_pending = tid < 256 && (!N64 || st_c < 64);
+                    st_store = !has_next || nxt.job != cur.job;
+                    st_dst = p.stats_part + ((long long)(off / n_tiles) * 2 + st_which) * Cout + n0 + st_c;
                 }
             }
             // N64: the next tile's first weight stage is requested into the weight buffer that held slots 6 and 7
@@ -739,8 +752,12 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
     int dev = 0, cus = 0;
     MPN_HIP(hipGetDevice(&dev));
     MPN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (begin > cus) begin = cus;   // `begin` is the grid size from here on
     const bool n64 = (jobs[0].Cout & 127) != 0;     // (the jobs of a group share Cin and Cout)
+    {   // `begin` is the grid size from here on: a multiple of the channel tiles per pixel tile (see the statistics rows)
+        const int n_tiles = n64 ? jobs[0].Cout / 64 : jobs[0].Cout / 128;
+        if (begin > cus) begin = cus - cus % n_tiles;
+        MPN_REQUIRE(begin > 0, MPN_ERR_BAD_SHAPE, "conv3x3: %d channel tiles on %d compute units", n_tiles, cus);
+    }
     const bool bnr = jobs[0].bnr_x != nullptr;
     for (int j = 0; j < njobs; ++j) {
         MPN_REQUIRE((jobs[j].bnr_x != nullptr) == bnr, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the fused-reduction variant");
@@ -753,6 +770,18 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
     if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, bnr, st);
     if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, bnr, st);
     MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");
+}
+
+/* rows of a job's statistics slab: one per block that has a tile of the job (see the kernel) */
+int stats_rows(int N, int H, int W, int Cout) {
+    const bool n64 = (Cout & 127) != 0;
+    const int n_tiles = n64 ? Cout / 64 : Cout / 128;
+    const long long tiles = (long long)N * ((H + 15) / 16) * ((W + 15) / 16) * n_tiles;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    const long long grid = cus - cus % n_tiles;
+    if (grid <= 0) return -1;
+    return (int)((tiles < grid ? tiles : grid) / n_tiles);
 }
 
 }  // namespace mpn_c3

@@ -848,6 +848,19 @@ extern "C" int mpn_conv_num_parts(int N, int H, int W, int ksize) {
     return (int)(((long long)N * H * W + 127) / 128);
 }
 
+/* Rows of the statistics slab that mpn_conv_fwd[_grouped] / mpn_conv_bwd_data_bn[_grouped] WRITE for one layer of this shape (what
+ * the finalize must be told): the persistent 3x3 kernel (16-bit storage, Cin % 64 == 0, Cout % 64 == 0) writes one row per block
+ * that has a tile of the layer - the same alone and inside a group -, every other kernel one row per tile (mpn_conv_num_parts, which
+ * stays the upper bound to size the slab with). < 0: no device to ask for its compute-unit count. */
+extern "C" int mpn_conv_stats_rows(int N, int H, int W, int Cin, int Cout, int ksize, int dtype) {
+    MPN_REQUIRE(ksize == 1 || ksize == 3, MPN_ERR_BAD_SHAPE, "conv: ksize must be 1 or 3 (got %d)", ksize);
+    MPN_REQUIRE(N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, MPN_ERR_BAD_SHAPE, "conv: bad shape");
+    MPN_REQUIRE(dtype == MPN_F32 || dtype == MPN_BF16 || dtype == MPN_F16, MPN_ERR_BAD_DTYPE, "conv: dtype %d", dtype);
+    const int es = dtype == MPN_F32 ? 4 : 2;
+    if (ksize == 3 && pack_geom(Cin, Cout, 9, es, dtype).row_bytes < 0) return mpn_c3::stats_rows(N, H, W, Cout);
+    return mpn_conv_num_parts(N, H, W, ksize);
+}
+
 template <int TAPS, int BN, int RB> constexpr int conv_smem_bytes() {
     return (TAPS == 9 ? kHaloW * kHaloH : 128) * a_row_stride(RB) + 2 * (2 * BN * 64);
 }

@@ -601,7 +601,7 @@ class KeypointNet:
         h, w = b["lv"][2]
         ops.conv_fwd(b["concat"], self.final_conv.packed.fwd, 64, 3, self.concat_affine, out=b["final"], stats_part=sp)   # :38
         if sep:
-            ops.bn_finalize(self.final_bn, sp, ops.conv_num_parts(N, h, w, 3), N * h * w)
+            ops.bn_finalize(self.final_bn, sp, ops.conv_stats_rows(N, h, w, b["concat"].shape[3], 64, 3, self.dtype), N * h * w)
         if inference_outputs:
             return ops.heatmap_head_fwd(b["final"], self.heat_w, self.heat_b, self.final_bn.affine, inference=True)
         return ops.heatmap_head_fwd(b["final"], self.heat_w, self.heat_b, self.final_bn.affine, out=b["logits"])
@@ -616,10 +616,11 @@ class KeypointNet:
             h, w = b["lv"][l]
             cnt = N * h * w
             for k, bn in (("p", self.p_bn[l]), ("bn1", self.phi[l]["bn1"]), ("bn2", self.phi[l]["bn2"])):
-                fwd[k].append((bn, b["stat_lv"][l], ops.conv_num_parts(N, h, w, 3), cnt))
+                rows3 = ops.conv_stats_rows(N, h, w, DEPTH, DEPTH, 3, self.dtype)     # (every 3x3 layer of the subnet: DEPTH -> DEPTH)
+                fwd[k].append((bn, b["stat_lv"][l], rows3, cnt))
                 # p / bn1: reduced inside the data gradient that produces their gradient (conv rows, sum g * x with the raw x)
                 if k != "bn2" and self._fused_conv_bn():
-                    bwd[k].append((bn, b["stat_lv"][l], ops.conv_num_parts(N, h, w, 3), cnt, True))
+                    bwd[k].append((bn, b["stat_lv"][l], rows3, cnt, True))
                 else:
                     bwd[k].append((bn, b["stat_lv"][l], nbn(cnt), cnt))
         out = {k: ops.BnFinalizeBatch(v, self.device) for k, v in fwd.items()}

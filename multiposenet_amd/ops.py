@@ -60,7 +60,18 @@ class PackedConv:
 
 
 def conv_num_parts(N, H, W, ksize):
+    """Rows to SIZE a convolution's statistics slab with (one per tile: an upper bound of what any kernel writes)."""
     return _lib.lib().mpn_conv_num_parts(N, H, W, ksize)
+
+
+def conv_stats_rows(N, H, W, cin, cout, ksize, dtype):
+    """Rows of its statistics slab a convolution [N,H,W,cin] -> cout WRITES (conv_fwd[_grouped]; conv_bwd_data_bn[_grouped] with
+    cin = the gradient's channels, cout = the fed batch-norm's): the nparts of the finalize behind it. The persistent 3x3 kernel
+    writes one row per block, every other kernel conv_num_parts rows (mpn_conv_stats_rows)."""
+    rows = _lib.lib().mpn_conv_stats_rows(int(N), int(H), int(W), int(cin), int(cout), int(ksize), _lib.dtype_code(dtype))
+    if rows <= 0:
+        raise _lib.MpnError(f"mpn_conv_stats_rows({N}, {H}, {W}, {cin}, {cout}, {ksize}) = {rows}: {_lib.last_error()}")
+    return rows
 
 
 def _slice_stride(t, channels):
@@ -133,13 +144,13 @@ def conv_bwd_data_bn(dy, packed_t, c, ksize, bn, x_bn, out, part):
     N, H, W, k = dy.shape
     call("mpn_conv_bwd_data_bn", ptr(dy), ptr(packed_t), ptr(out), N, H, W, k, int(c), _slice_stride(dy, k), _slice_stride(out, c), int(ksize),
          _lib.dtype_code(dy.dtype), ptr(x_bn), _slice_stride(x_bn, c), ptr(bn.scale), ptr(bn.shift), int(bn.act), ptr(part), stream_ptr())
-    return conv_num_parts(N, H, W, ksize)
+    return conv_stats_rows(N, H, W, k, c, ksize, dy.dtype)
 
 
 def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
     """Data gradients of several independent 3x3 convolutions in one grid that also reduce for the batch-norm layers `bns`
     they feed (raw tensors xs_bn): outs[j] <- masked gradient, parts[j] <- partial sums of g and g * x (RAW x: finalize with a
-    BnBwdFinalizeBatch job marked raw). Returns the rows each slab holds (conv_num_parts)."""
+    BnBwdFinalizeBatch job marked raw). Returns the rows each slab holds (conv_stats_rows)."""
     import ctypes
     n = len(dys)
     N, _, _, k = dys[0].shape
@@ -149,7 +160,7 @@ def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
          IA(*[_slice_stride(o, c) for o in outs]), _lib.dtype_code(dys[0].dtype), PA(*[ptr(x) for x in xs_bn]),
          IA(*[_slice_stride(x, c) for x in xs_bn]), PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]), int(bns[0].act),
          PA(*[ptr(t) for t in parts]), stream_ptr())
-    return [conv_num_parts(N, t.shape[1], t.shape[2], 3) for t in dys]
+    return [conv_stats_rows(N, t.shape[1], t.shape[2], k, c, 3, t.dtype) for t in dys]
 
 
 def conv1x1_bwd_fused_supported(cin, cout, dtype):

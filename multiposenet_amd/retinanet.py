@@ -296,20 +296,24 @@ class PersonDetectorNet:
         b["stat_pre7"] = torch.empty(nbn(N * lv[6][0] * lv[6][1]) * 2 * DEPTH, dtype=torch.float32, device=dev)
         # batched finalizes: one table per stage
         cnt = {l: N * lv[l][0] * lv[l][1] for l in LEVELS}
-        fwd3 = {l: ops.conv_num_parts(N, *lv[l], 3) for l in LEVELS}
+        # rows the producing kernel writes (ops.conv_stats_rows: one per block for the persistent 3x3 kernel, one per tile otherwise)
+        def rows3(l, cin, cout):
+            return ops.conv_stats_rows(N, lv[l][0], lv[l][1], cin, cout, 3, self.dtype)
         fin = {}
         rows1 = {l: ops.conv_num_parts(N, *lv[l], 1) for l in (6, 7)}     # p6 / p7 come out of the 1x1 kernel
-        fin["p345"] = ops.BnFinalizeBatch([(self.p_bn[l], b["stat_lv"][l], fwd3[l], cnt[l]) for l in (3, 4, 5)], dev)
+        fin["p345"] = ops.BnFinalizeBatch([(self.p_bn[l], b["stat_lv"][l], rows3(l, DEPTH, DEPTH), cnt[l]) for l in (3, 4, 5)], dev)
         # the raw p6 feeds TWO batch-norms (p6_batch_norm and fpn/pre_p7_bn): the same partial sums, two finalizes
         fin["p6"] = ops.BnFinalizeBatch([(bn, b["stat_lv"][6], rows1[6], cnt[6]) for bn in (self.p_bn[6], self.pre_p7_bn)], dev)
         fin["p7"] = ops.BnFinalizeBatch([(self.p_bn[7], b["stat_lv"][7], rows1[7], cnt[7])], dev)
         for net, _, _ in NETS:
             for i in range(4):
-                fin[(net, i)] = ops.BnFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], fwd3[l], cnt[l]) for l in LEVELS], dev)
+                cin_i = DEPTH if i == 0 else TOWER_DEPTH
+                fin[(net, i)] = ops.BnFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], rows3(l, cin_i, TOWER_DEPTH), cnt[l]) for l in LEVELS], dev)
                 # batch_norm_0..2 are reduced inside the data gradient of the tower convolution above them (conv rows, raw x),
                 # batch_norm_3 inside the data gradient of the output convolution (the tiled kernel: 8 / 24 -> 64 channels)
                 if (i < 3 and self._fused_conv_bn()) or (i == 3 and self._fused_out_bn(net)):
-                    fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], fwd3[l], cnt[l], True) for l in LEVELS], dev)
+                    k_i = TOWER_DEPTH if i < 3 else self.out_conv[net].cout      # channels of the gradient that data gradient reads
+                    fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], rows3(l, k_i, TOWER_DEPTH), cnt[l], True) for l in LEVELS], dev)
                 else:
                     fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
         fin["dp"] = ops.BnBwdFinalizeBatch([(self.p_bn[l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
