@@ -762,9 +762,7 @@ PackGeom pack_geom(int Kin, int Nout, int taps, int es, int dtype) {
         g.tile_bytes = mpn_c3::tile_bytes64(Kin); g.total_bytes = mpn_c3::packed_bytes(Kin, Nout);
         return g;
     }
-    // (a deep-K 1x1 layer with 128 outputs - the lateral of c5, 1024 -> 128 on the 16 x 16 maps: 64 pixel tiles at batch 32 - takes
-    //  64-channel tiles: twice the blocks for its sixteen sequential chunks)
-    g.BN = (Nout % 128 == 0 && !(taps == 1 && Kin >= 1024 && Nout == 128)) ? 128 : 64;
+    g.BN = (Nout % 128 == 0) ? 128 : 64;
     g.n_tiles = (Nout + g.BN - 1) / g.BN;
     const int kbytes = Kin * es;
     // chunk (= LDS pixel row) width: 128 bytes of K for 3x3 (a 28.8 KB halo image: the two co-resident blocks of a CU

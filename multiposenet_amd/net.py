@@ -213,8 +213,6 @@ class KeypointNet:
         self.load_state_dict(values if values is not None else initial_values(seed, depth_multiplier))
         self._build_layers()
         self._bufs = {}
-        self.overlap_reduce = False   # opt-in: the slab reductions of the first two backward phases on a second HIP stream (see backward)
-        self._rstream = None
         self.overlap_wgrad = False    # opt-in: weight gradients on a second HIP stream (measured 4% SLOWER at bs32: the
                                       # kernels already fill the chip, concurrent ones only contend; see backward)
         self._wstream = None
@@ -693,32 +691,17 @@ class KeypointNet:
         if self.overlap_wgrad and self._wstream is None:
             self._wstream = torch.cuda.Stream(device=self.device)
         W = self._wgrad
-        # overlap_reduce (whole backward in one call only): the reductions of the head / FPN slabs and of the deep blocks' slabs - pure
-        # streaming reads, every layer owns its slab region - run on a second stream under the backbone's backward, joined at the end
-        side = self.overlap_reduce and part is None
-        if side and self._rstream is None:
-            self._rstream = torch.cuda.Stream(device=self.device)
-
-        def reduce(ph):
-            if not side or ph == 2:
-                if side:
-                    torch.cuda.current_stream().wait_stream(self._rstream)
-                g["reducer"][ph].run()
-                return
-            self._rstream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._rstream):
-                g["reducer"][ph].run()
         if part in (None, 0):
             self._backward_head(b, g, feats, sp, slab, W)
             if self._wstream is not None:
                 torch.cuda.current_stream().wait_stream(self._wstream)
-            reduce(0)
+            g["reducer"][0].run()
         for ph in (1, 2):
             if part in (None, ph):
                 self._backward_backbone(b, g, images, sp, slab, W, ph)
                 if self._wstream is not None:
                     torch.cuda.current_stream().wait_stream(self._wstream)   # join: every slab of this phase is written
-                reduce(ph)   # (after phase 2: every gradient is in the arena)
+                g["reducer"][ph].run()   # (after phase 2: every gradient is in the arena)
 
     def _backward_head(self, b, g, feats, sp, slab, W):
         # ---- head + final conv
