@@ -52,6 +52,25 @@ def test_version_and_error_string():
     assert isinstance(_lib.last_error(), str)
 
 
+def test_statistics_row_counts_are_host_arithmetic():
+    """mpn_conv_stats_rows: the rows a convolution writes never exceed the rows its slab is sized with; the tiled / GEMM kernels
+    (1x1, thin or f32 3x3) write one per tile; the persistent 3x3 kernel's count needs the device's compute-unit count - without a
+    device the binding raises instead of guessing."""
+    import pytest
+    import torch
+    from multiposenet_amd import ops
+    assert ops.conv_stats_rows(2, 16, 24, 256, 256, 1, torch.bfloat16) == ops.conv_num_parts(2, 16, 24, 1)
+    assert ops.conv_stats_rows(2, 16, 24, 24, 64, 3, torch.bfloat16) == ops.conv_num_parts(2, 16, 24, 3)       # thin K: tiled kernel
+    assert ops.conv_stats_rows(2, 16, 24, 128, 128, 3, torch.float32) == ops.conv_num_parts(2, 16, 24, 3)     # f32: tiled kernel
+    if torch.cuda.is_available():
+        rows = ops.conv_stats_rows(32, 128, 128, 128, 128, 3, torch.bfloat16)
+        assert 0 < rows <= 256 < ops.conv_num_parts(32, 128, 128, 3)
+        assert ops.conv_stats_rows(1, 4, 4, 128, 128, 3, torch.bfloat16) == 1
+    else:
+        with pytest.raises(_lib.MpnError):
+            ops.conv_stats_rows(32, 128, 128, 128, 128, 3, torch.bfloat16)
+
+
 def test_host_side_validation_needs_no_gpu():
     # argument checks run before any HIP call
     import ctypes
