@@ -125,6 +125,10 @@ def test_launchers_refuse_channel_counts_their_lds_buffers_do_not_cover():
     # dense convolution: channel counts in vectors of the storage type, kernel size 1 or 3
     with pytest.raises(ValueError):
         call("mpn_conv_fwd", P, P, P, 1, 16, 16, 20, 64, 0, 0, 1, _lib.MPN_BF16, None, None, 0, None, None, None)
+    # 16-bit 1x1 weight gradient: its tiles are buffer loads with 32-bit byte offsets (2^31 = the out-of-range offset), so both
+    # tensors must span fewer than 2^31 bytes; the 3x3 geometries keep the 2^31-element bound
+    with pytest.raises(ValueError, match="2\\^31 bytes"):
+        call("mpn_conv_bwd_weight", P, P, P, 32, 2048, 2048, 8, 8, 0, 0, 1, _lib.MPN_BF16, None, None, 0, None)   # 2^31 bytes of x
     # fused batch-norm reduction behind a data gradient: only the geometries mpn_conv_bwd_data_bn_supported lists
     assert _lib.lib().mpn_conv_bwd_data_bn_supported(128, 128, 3, _lib.MPN_BF16) == 1
     assert _lib.lib().mpn_conv_bwd_data_bn_supported(128, 1024, 3, _lib.MPN_BF16) == 0        # the affine table holds 512 channels
