@@ -348,6 +348,34 @@ def test_conv_fwd_grouped_equals_separate_launches(cuda, dtype):
         assert torch.equal(a, b)
 
 
+def test_conv_fwd_grouped_statistics_rows_with_two_channel_tiles(cuda):
+    """The persistent kernel's one-row-per-block statistics when a pixel tile has TWO channel tiles (Cout = 256) and the group has
+    more tiles (368) than the device has compute units: blocks walk several tiles of a job and cross from one job into the next;
+    every row mpn_conv_stats_rows promises is written whole (both channel tiles), nothing behind it, and the sums are those of
+    the outputs."""
+    ops = _ops()
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(23)
+    N, Cin, Cout = 4, 64, 256
+    sizes = [(96, 96), (48, 48), (16, 16)]
+    xs, pcs, affs, outs, parts = [], [], [], [], []
+    for (h, w) in sizes:
+        xs.append(dev(rnd(rs.randn(N, h, w, Cin), dtype), dtype))
+        pcs.append(ops.PackedConv(dev((rs.randn(3, 3, Cin, Cout) / np.sqrt(9 * Cin)).astype(np.float32)), dtype))
+        affs.append(ops.Affine(dev(torch.tensor(0.5 + rs.rand(Cin), dtype=torch.float32)), dev(torch.tensor(rs.randn(Cin) * 0.5, dtype=torch.float32)), 1))
+        outs.append(torch.full((N, h, w, Cout), float("nan"), device="cuda", dtype=dtype))
+        parts.append(torch.full((ops.conv_num_parts(N, h, w, 3), 2, Cout), float("nan"), device="cuda"))
+    ops.conv_fwd_grouped(xs, [pc.fwd for pc in pcs], Cout, 3, affs, outs, parts)
+    for x, pc, a, y, part, (h, w) in zip(xs, pcs, affs, outs, parts, sizes):
+        assert torch.equal(y, ops.conv_fwd(x, pc.fwd, Cout, 3, a))
+        rows = ops.conv_stats_rows(N, h, w, Cin, Cout, 3, dtype)
+        assert 0 < rows <= part.shape[0] and bool(torch.isfinite(part[:rows]).all()) and bool(torch.isnan(part[rows:]).all())
+        s = part[:rows].double().sum(0).cpu()
+        yd = y.double().reshape(-1, Cout).cpu()
+        np.testing.assert_allclose(s[0].numpy(), yd.sum(0).numpy(), rtol=1e-5, atol=1e-2)
+        np.testing.assert_allclose(s[1].numpy(), (yd * yd).sum(0).numpy(), rtol=1e-5, atol=1e-2)
+
+
 def test_conv_fwd_channel_slices_of_wider_tensors(cuda):
     """x / y pixel strides: a conv reads a channel slice of a wider NHWC tensor and writes into a slice of another one
     (phi_subnet_2/conv2 -> the first 128 channels of the 512-channel concat tensor), 3x3 tiled kernel and 1x1 GEMM kernel."""
