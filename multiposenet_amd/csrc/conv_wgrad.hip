@@ -742,7 +742,7 @@ __device__ __forceinline__ void conv_wgrad_bf16_body(const WgradParams& p, const
         // buffered dY fragments run ACROSS k-step boundaries (a rolled k-step loop drains the LDS pipeline 4x per tile).
         constexpr int STEPS = TAPS * MTW;
         constexpr int TOTAL = 4 * STEPS;
-        constexpr int RING0 = NTW >= 4 ? 4 : 6;
+        constexpr int RING0 = NTW >= 4 ? 4 : ((TAPS == 9 && RBA == 256) ? 4 : 6);   // (the 64-output 3x3 geometry: six spill three registers)
         constexpr int RING = RING0 < STEPS ? RING0 : STEPS;
         constexpr int KSA = (TAPS == 9 ? 2 * kHaloW : 32) * SA, KSD = 32 * SD;
         auto a_load = [&](int gs) -> X8 {
