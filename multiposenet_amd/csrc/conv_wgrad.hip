@@ -1008,6 +1008,23 @@ extern "C" int mpn_conv_wgrad_num_parts(int N, int H, int W, int Cin, int Cout, 
     return wgrad_geom(N, H, W, Cin, Cout, ksize, dtype == MPN_F32 ? 4 : 2).nsplit;
 }
 
+namespace {
+template <typename T, int TAPS, int RBA, int RBD, int WM, bool STAGGER>
+int launch_wgrad_bf16_grouped(const WgradGroup& g, int blocks, hipStream_t st);
+// A single 3x3 layer with more than 64 outputs runs as a group of one: as a kernel of its own (the parameters in the kernel's
+// arguments instead of behind the job index) hipcc spills four registers of this 256-register geometry.
+template <typename T>
+int launch_wgrad_single_as_group(const WgradParams& p, hipStream_t st) {
+    WgradGroup grp = {};
+    grp.p[0] = p;
+    const int blocks = p.n_cg * p.n_cb * p.nsplit;
+    grp.begin[0] = 0;
+    for (int j = 1; j <= kMaxWgradGroup; ++j) grp.begin[j] = blocks;
+    grp.njobs = 1;
+    return launch_wgrad_bf16_grouped<T, 9, 128, 256, 4, true>(grp, blocks, st);
+}
+}  // namespace
+
 /* part: [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (HWIO per split); finish with mpn_reduce_partials */
 extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, int N, int H, int W, int Cin, int Cout,
                                    int x_stride, int dy_stride, int ksize, int dtype, const float* in_scale,
@@ -1049,12 +1066,12 @@ extern "C" int mpn_conv_bwd_weight(const void* x, const void* dy, float* part, i
         if (wgrad_thin1x1(Cin, Cout, ksize)) return launch_wgrad_bf16<half_t, 1, 64, 128, 2, false>(p, st);
         if (ksize == 1) return launch_wgrad_bf16<half_t, 1, 256, 256, 4, false>(p, st);
         if (Cout <= 64) return launch_wgrad_bf16<half_t, 9, 256, 128, 4, true>(p, st);
-        return launch_wgrad_bf16<half_t, 9, 128, 256, 4, true>(p, st);
+        return launch_wgrad_single_as_group<half_t>(p, st);
     }
     if (wgrad_thin1x1(Cin, Cout, ksize)) return launch_wgrad_bf16<bf16_t, 1, 64, 128, 2, false>(p, st);
     if (ksize == 1) return launch_wgrad_bf16<bf16_t, 1, 256, 256, 4, false>(p, st);
     if (Cout <= 64) return launch_wgrad_bf16<bf16_t, 9, 256, 128, 4, true>(p, st);
-    return launch_wgrad_bf16<bf16_t, 9, 128, 256, 4, true>(p, st);
+    return launch_wgrad_single_as_group<bf16_t>(p, st);
 }
 
 namespace {
