@@ -29,10 +29,6 @@
 namespace {
 using namespace mpn_c3;
 
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-constexpr int kThreads = 512;
 constexpr int kHW = 18;                      // halo width = height
 constexpr int kNPix = kHW * kHW;             // 324
 constexpr int kRS = 160;                     // LDS bytes per halo pixel: 128 bytes of K + 32 of padding
@@ -71,49 +67,6 @@ static_assert(kAVec == 6, "the counted wait of a chunk's first stage assumes six
 #define C3_WSTAMP(st, k) do { } while (0)
 #endif
 
-// The producer's batch-norm affine + activation on eight 16-bit values: two elements per v_pk_fma_f32, rounded back to storage, and
-// the activation on the ROUNDED pairs as integers - sign-magnitude formats order like int16 on the non-negative side, so ReLU is
-// v_pk_max_i16(x, 0) and the upper clamp v_pk_min_i16(x, 6.0): one instruction per two elements instead of a v_med3_f32 per
-// element. Rounding is monotone and keeps 0 and 6 fixed, so act(round(v)) == round(act(v)) bit for bit (a -0.0 becomes +0.0).
-// lo2 = 0 (ReLU / ReLU6) or 0x80008000 (no activation: max with -32768 is the identity); RELU6 adds the upper clamp.
-typedef short s16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
-}
-__device__ __forceinline__ unsigned pk_min_i16(unsigned a, unsigned b) {
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
-}
-template <typename T> __device__ __forceinline__ constexpr unsigned six_pair() { return sizeof(T) == 2 && std::is_same<T, bf16_t>::value ? 0x40C040C0u : 0x46004600u; }
-template <typename T, bool RELU6>
-__device__ __forceinline__ void affine_act(Vec16<T>& v, const f32x2_t (&sc)[4], const f32x2_t (&sh)[4], unsigned lo2) {
-    float f[8];
-    v.unpack(f);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const f32x2_t r = __builtin_elementwise_fma((f32x2_t){f[2 * j], f[2 * j + 1]}, sc[j], sh[j]);
-        f[2 * j] = r[0]; f[2 * j + 1] = r[1];
-    }
-    v.pack(f);
-    unsigned u[4] = {v.raw.x, v.raw.y, v.raw.z, v.raw.w};
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        u[j] = pk_max_i16(u[j], lo2);
-        if (RELU6) u[j] = pk_min_i16(u[j], six_pair<T>());
-    }
-    v.raw = make_uint4(u[0], u[1], u[2], u[3]);
-}
-
-__device__ __forceinline__ void store4(bf16_t* p, const f32x4_t& v) {
-    typedef __bf16 b4_t __attribute__((ext_vector_type(4)));
-    const b4_t h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
-}
-__device__ __forceinline__ void store4(half_t* p, const f32x4_t& v) {
-    typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
-    const h4_t h = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, h);
-}
-
 // A 16-byte LDS store the compiler does not see as one: in front of a C++ LDS store hipcc waits for every LDS-DMA in
 // flight (vmcnt(0): it cannot tell that the weight ring and the halo image do not overlap) - here that exposed the whole
 // latency of the weight stage requested at the top of the same stage, once per chunk.
@@ -124,34 +77,6 @@ __device__ __forceinline__ void lds_store16_raw(unsigned char* p, const uint4& v
     const u32x4_t d = {v.x, v.y, v.z, v.w};
     const unsigned a = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)p;
     asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(a), "v"(d), "n"(OFF) : "memory");
-}
-
-struct Group {
-    Job job[kMaxJobs];
-    int begin[kMaxJobs + 1];   // first tile of each job; begin[njobs] = number of tiles
-    int njobs;
-};
-
-// where a tile lives (wave-uniform)
-struct Tile {
-    int job, ntile, img, oy0, ox0, ty, tx;
-};
-template <bool N64>
-__device__ __forceinline__ Tile tile_of(const Group& g, int w) {
-    Tile t;
-    t.job = 0;
-#pragma unroll
-    for (int k = 1; k < kMaxJobs; ++k)
-        if (k < g.njobs && w >= g.begin[k]) t.job = k;
-    const Job& p = g.job[t.job];
-    int b = w - g.begin[t.job];
-    const int n_tiles = N64 ? (p.Cout >> 6) : (p.Cout >> 7), tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
-    t.ntile = b % n_tiles; b /= n_tiles;
-    t.tx = b % tiles_x; b /= tiles_x;
-    t.ty = b % tiles_y;
-    t.img = b / tiles_y;
-    t.oy0 = t.ty * 16; t.ox0 = t.tx * 16;
-    return t;
 }
 
 // PERSISTENT: block b walks tiles b, b + gridDim.x, ... of the group. Across tiles nothing drains: the weight stream and
@@ -767,6 +692,10 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
                              jobs[j].bnr_xs % 8 == 0 && jobs[j].Cout <= kMaxCin && mpn_aligned16(jobs[j].bnr_x)),
                     MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a data gradient (no producer affine), a partial slab and the layer's affine");
     }
+#ifndef MPN_C3_OLD
+    // 128-channel tiles: the channel-split kernel (conv3x3_cs.hip); -DMPN_C3_OLD builds keep this file's kernel for A/B runs
+    if (!n64) return launch_cs(g, begin, dtype, affine, bnr, st);
+#endif
     if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, bnr, st);
     if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, bnr, st);
     MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");

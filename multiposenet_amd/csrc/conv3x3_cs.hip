@@ -1,0 +1,642 @@
+// 3x3 convolution (forward and data gradient), 16-bit storage, 128 output channels per tile: the CHANNEL-SPLIT kernel (round 5).
+//
+// Same tile as conv3x3.hip - one persistent 8-wave block per CU, 16 x 16 pixels x 128 output channels, 64-channel chunks of an
+// 18 x 18 halo image in LDS - but the eight waves split the OUTPUT CHANNELS (16 each) and every wave multiplies all 256 pixels:
+//   * a wave's weight fragments are its own: three 16 x 32 fragments per stage (the taps ky = 0..2 of one kernel column for one
+//     32-channel k-step) come STRAIGHT FROM L2 INTO REGISTERS (one coalesced 1 KB load each, requested a stage ahead) - no LDS
+//     image of the weights, no LDS-DMA, and therefore no block barrier per stage: the block meets once per 64-channel chunk (the
+//     halo image changes) instead of six times. conv3x3.hip's stamps showed where its time went: eight waves leave
+//     every stage barrier together, read, wait and multiply at the same times, and every vector instruction of the halo commit and
+//     the epilogue added its issue time to a stage that 96 MFMAs already fill by half. Here the waves drift apart between two chunk
+//     barriers, so one wave's commit or wait runs beside its SIMD partner's MFMAs.
+//   * the LDS traffic per MFMA is unchanged: halo row h (16 pixels x 32 channels, one ds_read_b128 per lane) feeds output rows
+//     h, h - 1, h - 2 at ky = 0, 1, 2 - 18 fragment reads per 48 MFMAs, streamed through a ring of six - and the weight image in
+//     global memory is the one conv3x3.hip streams by LDS-DMA (its 64-byte rows of one output channel: a wave's fragment (ky, its
+//     16 channels) is one contiguous KB of it), so mpn_conv_pack_weights is unchanged.
+//   * 48 KB of LDS are free: the tile leaves through ONE block-wide bf16 image [256 px][128 co] (the released halo buffer + a spare
+//     region between the two halo buffers), written from the accumulators (a lane holds 4 channels of one pixel), read back by
+//     transposing reads for the batch-norm statistics (ones x F, F^T x F on the matrix unit, as before) and as whole 256-byte pixel
+//     rows for the stores: every store instruction writes four complete pixels.
+// A stand-alone model of this stage (tools/stage2_ceiling.hip, profiles/r05_stage2_ceiling.txt) runs at 0.65 of the nominal MFMA
+// peak WITH the halo staging work, where the model of conv3x3.hip's stage reaches 0.66 without it.
+// LDS: [halo 0: 51 840][spare 17 792][halo 1: 51 840][statistics 8 192][scale / shift table 4 096] = 133 760 bytes.
+#include "conv3x3.h"
+
+namespace {
+using namespace mpn_c3;
+
+// every LDS access of this kernel goes through an explicit address-space-3 pointer: inside the kernel's inlined lambdas hipcc lost
+// track of generic pointers into the dynamic LDS array and emitted flat_load + spilled 64-bit addresses for the fragment reads
+#define LDS __attribute__((address_space(3)))
+typedef LDS unsigned char* lds_p;
+typedef LDS float* lds_f;
+template <typename V> __device__ __forceinline__ V lds_ld(lds_p p) { return *(const LDS V*)p; }
+template <typename V> __device__ __forceinline__ void lds_st(lds_p p, const V& v) { *(LDS V*)p = v; }
+
+constexpr int kHW = 18;                      // halo width = height
+constexpr int kNPix = kHW * kHW;             // 324
+constexpr int kRS = 160;                     // LDS bytes per halo pixel: 128 bytes of K + 32 of padding (conflict-free ds_read_b128)
+constexpr int kABytes = kNPix * kRS;         // 51 840
+constexpr int kRSO = 272;                    // output image: bytes per pixel (256 + 16)
+constexpr int kImg = 256 * kRSO;             // 69 632
+constexpr int kSpare = kImg - kABytes;       // 17 792
+constexpr int kHaloArea = 2 * kABytes + kSpare;   // [halo 0][spare][halo 1]; the image of a tile = the released buffer + the spare
+constexpr int kRedBytes = (8 * 2 * 128 + 192) * (int)sizeof(float);   // [8 waves][2][128] + 192 dummy words (lanes off the Gram diagonal: 2048 + lane + 16 nt)
+constexpr int kMaxCin = 512;
+constexpr int kTabBytes = 2 * kMaxCin * (int)sizeof(float);
+#ifdef MPN_DIAG
+constexpr int kDiagBytes = 8 * 32 * 8;       // per-wave stamps (below)
+#else
+constexpr int kDiagBytes = 0;
+#endif
+constexpr int kProgBytes = 64;               // per wave: the number of stages it has started (priority feedback, below)
+constexpr int kLds = kHaloArea + kRedBytes + kTabBytes + kProgBytes + kDiagBytes;
+constexpr int kAVec = 6;                     // 16-byte pieces of a halo image per thread
+constexpr int kRingDefault = 6;              // halo fragments in flight
+static_assert(kLds <= 160 * 1024, "LDS budget");
+static_assert(kSpare >= 0 && kHaloArea - kImg == kABytes, "the image over halo buffer 1 starts where halo buffer 0 ends");
+
+__device__ __forceinline__ int halo_off(int buf) { return buf ? kABytes + kSpare : 0; }
+__device__ __forceinline__ int image_off(int buf) { return buf ? kABytes : 0; }
+
+// diagnostic build (tools/stamp_c3cs.py; never in the shipped library): per WAVE, s_memtime of the block's THIRD tile at the loop top
+// (0), behind each chunk's barrier (1..8), behind the image's barrier (9); 10 = behind the barrier that ends the PREVIOUS tile's
+// epilogue (in this tile's first chunk); 12 = s_memrealtime at kernel entry, 13 at its end. Kept in LDS, copied out at the end:
+// dbg[(block * 8 + wave) * 32 + k]; 16 + 6 c + s = the end of stage s of chunk c (c < 2)
+#ifdef MPN_DIAG
+#define CS_STAMP(k) do { if (g.job[0].dbg && titer == 2 && (threadIdx.x & 63) == 0) wst[(threadIdx.x >> 6) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define CS_STAMP(k) do { } while (0)
+#endif
+
+// a / b for 0 <= a < 2^22, b > 0 (tile counts): one v_rcp_f32 and a correction instead of the ~25 scalar instructions of an integer
+// division - three divisions per tile stood in front of every tile's first MFMA, in all eight waves at once
+__device__ __forceinline__ int qdiv(int a, int b) {
+    int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+    const int r = a - q * b;
+    q += (r >= b) ? 1 : 0;
+    q -= (r < 0) ? 1 : 0;
+    return q;
+}
+__device__ __forceinline__ Tile tile_fast(const Group& g, int w) {
+    Tile t;
+    t.job = 0;
+#pragma unroll
+    for (int k = 1; k < kMaxJobs; ++k)
+        if (k < g.njobs && w >= g.begin[k]) t.job = k;
+    const Job& p = g.job[t.job];
+    int b = w - g.begin[t.job];
+    const int n_tiles = p.Cout >> 7, tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
+    int q = qdiv(b, n_tiles); t.ntile = b - q * n_tiles; b = q;
+    q = qdiv(b, tiles_x); t.tx = b - q * tiles_x; b = q;
+    q = qdiv(b, tiles_y); t.ty = b - q * tiles_y;
+    t.img = q;
+    t.oy0 = t.ty * 16; t.ox0 = t.tx * 16;
+    return t;
+}
+
+// ACT: 0 = no producer affine, 1 = affine + (ReLU or none, by in_act), 2 = affine + ReLU6
+// MODE: 0 = plain, 1 = batch-norm statistics of the output, 2 = data gradient that also reduces for the batch-norm it feeds (BNR)
+template <typename T, int ACT, int MODE>
+__global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) {
+    constexpr bool AFFINE = ACT != 0, STATS = MODE == 1, BNR = MODE == 2;
+    constexpr int kRing = kRingDefault;
+    // the fused-reduction variant finishes a tile BEHIND its last chunk instead of under the next tile's first stages: its epilogue
+    // (the raw tensor of the fed batch-norm, the masks, sixteen running sums) does not fit beside the accumulators - 43 spilled registers
+    constexpr bool PIPE = !BNR;
+    static_assert(!BNR || ACT == 0, "the fused batch-norm backward reduction rides on a data gradient (no producer affine)");
+    using H = H16<T>;
+    using X8 = typename H::x8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const lds_p L = (lds_p)smem;
+    const lds_f red = (lds_f)(L + kHaloArea);                 // [8 waves][2][128] statistics of the tile that has just finished
+    const lds_f tab = (lds_f)(L + kHaloArea + kRedBytes);     // [2][kMaxCin] scale, shift of the job in `tab_job`
+
+#ifdef MPN_DIAG
+    LDS unsigned long long* wst = (LDS unsigned long long*)(L + kHaloArea + kRedBytes + kTabBytes + kProgBytes);
+    if (threadIdx.x < 256) wst[threadIdx.x] = 0;
+    int titer = 0;
+#endif
+    const int total = g.begin[g.njobs];
+    // XCD-aware walk (conv3x3.hip): the blocks of one XCD take consecutive tiles of every round
+    int w = blockIdx.x;
+    if ((gridDim.x & 7) == 0) w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (w >= total) return;
+    const int w_first = w;
+#ifdef MPN_DIAG
+    const unsigned long long rt_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Priority feedback between the two waves of a SIMD (waves w and w ^ 4). Left alone the OLDER wave of a pair wins every
+    // arbitration: it ran a chunk's six stages in 7.4 k cycles at almost the speed it has alone, its partner got the issue slots it
+    // left (2.6 stages in that time) and then finished ALONE - 4 k cycles at 65 % of the matrix pipe - while the older wave waited
+    // at the chunk's barrier (tools/stamp_c3cs.py, profiles/r05_c3cs_stamps.txt). Each wave publishes the number of stages it has
+    // started and reads its partner's; the one that is behind raises its priority, so the pair stays within a stage of each other.
+    const lds_p prog_mine = L + kHaloArea + kRedBytes + kTabBytes + wave * 4, prog_other = L + kHaloArea + kRedBytes + kTabBytes + (wave ^ 4) * 4;
+    int pcount = 0, pseen = 0;
+    if (tid < 16) lds_st<int>(L + kHaloArea + kRedBytes + kTabBytes + tid * 4, 0);
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int Cin = g.job[0].Cin, Cout = g.job[0].Cout;    // (shared by the jobs of a group)
+    const int nchunk = Cin >> 6;
+    const long long wtile = 9ll * Cin * 128 * 2;
+
+    // per-lane fragment bases; everything added later is a compile-time or wave-uniform offset
+    const lds_p abase = L + l15 * kRS + lq * 16;
+    // a wave's weight fragment (ky, channels 16 wave .. + 15) inside a stage of the packed image [ky 3][co 128][64 bytes]: rows of
+    // 64 bytes = 32 input channels, their four 16-byte slots swizzled with swz(co) (the LDS image of conv3x3.hip)
+    const unsigned lane_w = (unsigned)(wave * 1024 + l15 * 64 + ((lq ^ swz(l15)) << 4));
+    // buffer loads: the per-lane offset is a constant of the thread, the stage and tap offsets are scalar (no 64-bit vector address
+    // arithmetic per load - plain pointer arithmetic cost two VALU per load and kept address pairs live across the loop, which
+    // spilled). The descriptor is built AT the load from the readfirstlane'd halves of the tile's weight pointer: carried across
+    // the loop (or picked by a select) it lives in vector registers and every load gets a waterfall loop.
+    auto b_load = [&](X8 (&dst)[3], const unsigned char* wp, int soff) __attribute__((always_inline)) {
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const unsigned long long a = (unsigned long long)wp;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)wtile, 0x00020000);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+            dst[ky] = __builtin_bit_cast(X8, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rs, lane_w, soff + ky * 8192, 0));
+    };
+
+    // ---- halo staging (conv3x3.hip): thread -> 16-byte slot tid % 8 of halo pixels q + 54 i, q < 54, i = 0..5 (three halo rows per
+    // step: the column hx = q % 18 is fixed, rows hy = q / 18 + 3 i). Threads 432..511 REPEAT the work of threads 352..431 (the same
+    // values to the same addresses): no predicate, no branch inside a stage.
+    const int slot = tid & 7, q64 = tid >> 3;
+    const int q54 = q64 < 54 ? q64 : q64 - 10;
+    const int qy = (int)(__umul24((unsigned)q54, 3641u) >> 16), qx = q54 - ((qy << 4) + (qy << 1));
+    static_assert(kHW == 18 && kNPix == 6 * 54, "six steps of three halo rows");
+    const unsigned act_lo2 = (AFFINE && g.job[0].in_act != MPN_ACT_NONE) ? 0u : 0x80008000u;     // (in_act is shared by the jobs)
+    int tab_job = -1;
+    auto tab_load = [&](int job) {
+        if constexpr (AFFINE) {
+            for (int i = tid; i < Cin; i += kThreads) { tab[i] = g.job[job].in_scale[i]; tab[kMaxCin + i] = g.job[job].in_shift[i]; }
+        }
+        if constexpr (BNR) {   // (no producer affine in a data gradient: the table holds the fed batch-norm's scale / shift)
+            for (int i = tid; i < Cout; i += kThreads) { tab[i] = g.job[job].bnr_scale[i]; tab[kMaxCin + i] = g.job[job].bnr_shift[i]; }
+        }
+        tab_job = job;
+    };
+    unsigned okmask = 0;        // of the image fetched last: piece i of this thread lies inside the image
+    Vec16<T> av[kAVec];
+    auto a_load = [&](const Tile& t, int chunk) __attribute__((always_inline)) {
+        const Job& p = g.job[t.job];
+        // the image base is scalar, row and column BYTE offsets are 24-bit multiplies added as an unsigned 32-bit offset
+        // (launch() checks 2 W xs < 2^24 and the tensor below 2^31 elements)
+        const int wxb = p.W * p.xs * 2;
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x) + ((long long)t.img * p.H * (p.W * p.xs) + chunk * 64) * 2;
+        int hx = qx, hy = qy;
+        asm volatile("" : "+v"(hx), "+v"(hy));   // opaque: keeps the offset arithmetic here instead of hoisted (and spilled) across the tile loop
+        const int ix = t.ox0 + hx - 1;
+        const bool okx = (unsigned)ix < (unsigned)p.W;
+        const unsigned col = __umul24((unsigned)min(max(ix, 0), p.W - 1), (unsigned)(p.xs * 2)) + slot * 16;
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < kAVec; ++i) {
+            const int iy = t.oy0 + (3 * i - 1) + hy;
+            const bool ok = okx & ((unsigned)iy < (unsigned)p.H);
+            okmask |= (ok ? 1u : 0u) << i;
+            av[i].load(reinterpret_cast<const T*>(xb + (__umul24((unsigned)min(max(iy, 0), p.H - 1), (unsigned)wxb) + col)));
+        }
+    };
+    // The commit of piece i of the fetched image into halo buffer `buf`, in five steps that a stage spreads over its MFMA groups:
+    // j = 0..3: dword j (two channels: affine + activation + zero padding), j = 4: the 16-byte LDS store. The scale / shift of the
+    // chunk's channels at this thread's slot are read from the table first (tab_read).
+    f32x2_t sc[4], sh[4];
+    auto tab_read = [&](int chunk) __attribute__((always_inline)) {
+        if constexpr (AFFINE) {
+            const lds_p ts = (lds_p)(tab + chunk * 64 + slot * 8);
+            const f32x4_t s0 = lds_ld<f32x4_t>(ts), s1 = lds_ld<f32x4_t>(ts + 16);
+            const f32x4_t h0 = lds_ld<f32x4_t>(ts + kMaxCin * 4), h1 = lds_ld<f32x4_t>(ts + kMaxCin * 4 + 16);
+            sc[0] = (f32x2_t){s0[0], s0[1]}; sc[1] = (f32x2_t){s0[2], s0[3]}; sc[2] = (f32x2_t){s1[0], s1[1]}; sc[3] = (f32x2_t){s1[2], s1[3]};
+            sh[0] = (f32x2_t){h0[0], h0[1]}; sh[1] = (f32x2_t){h0[2], h0[3]}; sh[2] = (f32x2_t){h1[0], h1[1]}; sh[3] = (f32x2_t){h1[2], h1[3]};
+        }
+    };
+    auto commit_step = [&](const int i, const int j, int buf) __attribute__((always_inline)) {
+        if (j < 4) {
+            unsigned u = j == 0 ? av[i].raw.x : (j == 1 ? av[i].raw.y : (j == 2 ? av[i].raw.z : av[i].raw.w));
+            if constexpr (AFFINE) {
+                f32x2_t f;
+                if constexpr (std::is_same<T, bf16_t>::value) {
+                    f = (f32x2_t){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+                } else {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    const h2_t hh = __builtin_bit_cast(h2_t, u);
+                    f = (f32x2_t){(float)hh[0], (float)hh[1]};
+                }
+                f = __builtin_elementwise_fma(f, sc[j], sh[j]);
+                if constexpr (std::is_same<T, bf16_t>::value) {
+                    u = pack_bf16x2(f[0], f[1]);
+                } else {
+                    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                    const h2_t hh = {(_Float16)f[0], (_Float16)f[1]};
+                    u = __builtin_bit_cast(unsigned, hh);
+                }
+                u = pk_max_i16(u, act_lo2);
+                if constexpr (ACT == 2) u = pk_min_i16(u, six_pair<T>());
+            }
+            if (!((okmask >> i) & 1u)) u = 0u;
+            if (j == 0) av[i].raw.x = u; else if (j == 1) av[i].raw.y = u; else if (j == 2) av[i].raw.z = u; else av[i].raw.w = u;
+        } else {
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            lds_st<u32x4_t>(L + halo_off(buf) + q54 * kRS + slot * 16 + i * (54 * kRS), (u32x4_t){av[i].raw.x, av[i].raw.y, av[i].raw.z, av[i].raw.w});
+        }
+    };
+
+    // Statistics: a block SUMS the rows of its tiles of one job (threads 0..255: one of the two sums, one channel; f32, in the order of
+    // its walk) and writes them once, behind its last tile of that job: one slab row per block (mpn_conv_stats_rows).
+    float* st_dst = nullptr;
+    float st_acc = 0.f;
+    bool st_pending = false, st_store = false;
+    const int st_which = (tid >> 7) & 1, st_c = tid & 127;
+    auto stats_flush = [&]() {
+        if (st_pending) {
+            const lds_f r = red + st_which * 128 + st_c;    // red [8 waves][2][128], fixed order
+            st_acc += ((r[0] + r[256]) + (r[512] + r[768])) + ((r[1024] + r[1280]) + (r[1536] + r[1792]));
+            if (st_store) { *st_dst = st_acc; st_acc = 0.f; }
+        }
+        st_pending = false;
+    };
+
+    // ---- the epilogue of a tile runs UNDER THE NEXT TILE'S FIRST THREE STAGES (its image lies over the halo buffer that the next
+    // tile's first chunk does not read, and is released - one block barrier - before the commits of that chunk's stages 3..5 write
+    // there): the state of the tile whose image is waiting
+    // (a block's FIRST tile runs the same stages over an image that does not exist yet: prev_real = false masks its stores)
+    Tile prev = {};
+    bool prev_real = false;
+    int prev_img = 0;
+    // everything its stores need, as scalars fixed when the image was written (a job field read inside a stage is an s_load whose
+    // wait - lgkmcnt(0) - also drains the fragment reads in flight: 250-300 cycles per store in the first version):
+    // the tile's first output element, bytes per image row / per pixel, rows and columns of the tile inside the image
+    unsigned char* e_y = nullptr;
+    int e_rowb = 0, e_pxb = 0, e_h = 0, e_w = 0;
+    const unsigned char* e_bx = nullptr;       // BNR: the same for the raw tensor of the fed batch-norm
+    int e_bx_rowb = 0, e_bx_pxb = 0, e_bx_hmax = 0, e_bx_wmax = 0, e_ntile = 0;
+    float e_blo = 0.f, e_bhi = 0.f;
+    // wave `wave` finishes pixels 32 wave .. + 31 (output rows 2 wave, 2 wave + 1), all 128 channels.
+    // transposing reads (ds_read_b64_tr_b16): lane 4q+pp of a 16-lane group supplies the address of block row q, channels 4pp..4pp+3;
+    // lane group lq covers pixels {2 (lq >> 1) + 16 (lq & 1) + 4 q + {0, 1}}: 8 of the 32 (the k order of a sum is free)
+    const int t_off = (wave * 32 + (lq >> 1) * 2 + 4 * ((lq & 1) * 4 + (l15 >> 2))) * kRSO + (4 * (l15 & 3)) * 2;
+    const int piece = lane & 15, prow = lane >> 4;       // copy-out lanes: 16-byte piece of pixel rows prow + 4 k of the wave's 32
+    const int c_off = (wave * 32 + prow) * kRSO + piece * 16;
+    const int red_s = wave * 256 + l15, red_q = (lq == (l15 >> 2)) ? wave * 256 + 128 + l15 : 2048 + lane;   // (+ nt * 16; the dummy words: 2048..2223)
+    X8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = 1.0f;
+    float dsel[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dsel[j] = (l15 & 3) == j ? 1.f : 0.f;
+    auto tr_read_lds = [&](lds_p p) __attribute__((always_inline)) -> typename H::x4 {
+        if constexpr (std::is_same<T, bf16_t>::value) return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((LDS typename H::x4*)p);
+        else {
+            typedef __fp16 fp4_t __attribute__((ext_vector_type(4)));
+            return __builtin_bit_cast(typename H::x4, __builtin_amdgcn_ds_read_tr16_b64_v4f16((LDS fp4_t*)p));
+        }
+    };
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    auto pack4 = [&](const f32x4_t& v) __attribute__((always_inline)) -> u32x2_t {
+        if constexpr (std::is_same<T, bf16_t>::value) return (u32x2_t){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        else {
+            typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+            const h4_t hh = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            return __builtin_bit_cast(u32x2_t, hh);
+        }
+    };
+    typename H::x4 tlo, thi;
+    uint4 co[2], bx[BNR ? 4 : 1];
+    f32x2_t bs[4], bq[4];
+    auto bnr_ld = [&](const int k) __attribute__((always_inline)) -> uint4 {
+        // (rows / columns past the image: clamped - their dy is 0)
+        const int oy = min(2 * wave + (k >> 2), e_bx_hmax), ox = min(prow + 4 * (k & 3), e_bx_wmax);
+        return *reinterpret_cast<const uint4*>(e_bx + (unsigned)(oy * e_bx_rowb + ox * e_bx_pxb + piece * 16));
+    };
+    // step (sl, h) of the waiting epilogue: sl = 0: statistics (two transposing reads at even h, the two MFMAs + the sums' rows at
+    // odd h; BNR: the raw tensor of the fed batch-norm at the first copy-out positions); sl = 1, 2: the copy-out of pixel rows
+    // prow + 4 k, k = 4 (sl - 1) .. + 3 (LDS reads at h = 0..3, stores at h = 6, 8, 10, 12); BNR: the sums at the end of sl = 2
+    auto e2_step = [&](const int sl, const int h) __attribute__((always_inline)) {
+        const lds_p im = L + prev_img;
+        if constexpr (STATS) {
+            if (sl == 0 && h < 16) {
+                const int nt = h >> 1;
+                if ((h & 1) == 0) {
+                    tlo = tr_read_lds(im + t_off + nt * 32);
+                    thi = tr_read_lds(im + t_off + kRSO + nt * 32);
+                } else {
+                    const X8 f = __builtin_shufflevector(tlo, thi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const f32x4_t sa = H::mfma(ones, f, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                    const f32x4_t ga = H::mfma(f, f, (f32x4_t){0.f, 0.f, 0.f, 0.f});
+                    // the Gram diagonal sits in element l15 & 3 of the lanes lq == l15 >> 2: picked by a 0 / 1 weight per element (exact:
+                    // the others add + 0; written as a select chain hipcc made three branches of it)
+                    const float q = __builtin_fmaf(ga[3], dsel[3], __builtin_fmaf(ga[2], dsel[2], __builtin_fmaf(ga[1], dsel[1], ga[0] * dsel[0])));
+                    red[red_s + nt * 16] = sa[0];        // (every row of ones x F is the column sum: the four lane groups write the same value)
+                    red[red_q + nt * 16] = q;            // (the Gram diagonal; the other lanes into the dummy words)
+                }
+            }
+        }
+        if constexpr (BNR) {
+            if (sl == 0 && h == 10) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { bs[j] = (f32x2_t){0.f, 0.f}; bq[j] = (f32x2_t){0.f, 0.f}; }
+            }
+            if (sl == 0 && h >= 12 && h < 16) bx[h - 12] = bnr_ld(h - 12);
+        }
+        if (sl == 1 || sl == 2) {
+            // pixel rows prow + 4 k, k = 4 (sl - 1) + kk: the LDS read of row kk at h = 3 kk + 1, its store at h = 3 kk + 6 (two rows in
+            // flight); BNR: the mask and the sums of its dwords 0, 1 at h = 3 kk + 4, of dwords 2, 3 at h = 3 kk + 5
+            const int half = sl - 1;
+            const int kk = h >= 6 ? (h - 6) / 3 : -1, ph = h >= 4 ? (h - 4) % 3 : -1;     // (of the row whose math / store falls on this h)
+            if (h >= 1 && h <= 10 && (h - 1) % 3 == 0) {
+                typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                const int kr = (h - 1) / 3;
+                const u32x4_t v = lds_ld<u32x4_t>(im + c_off + (4 * (half * 4 + kr)) * kRSO);
+                co[kr & 1] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
+            if constexpr (BNR) {
+                // g = dy where the fed batch-norm's activation passes (lo < x * scale + shift < hi, the test of bn_bwd_reduce /
+                // bn_bwd_apply, fused multiply-add), else 0; sums of g and g * x (pixels outside the image hold dy = 0).
+                // The batch-norm's scale / shift of this lane's channels come from the table at every use (held in registers
+                // they spill; the opaque offset keeps hipcc from hoisting the reads back out).
+                if (h >= 4 && h <= 14 && (ph == 0 || ph == 1)) {
+                    const int km = (h - 4) / 3;
+                    int toff = (e_ntile * 128 + piece * 8 + ph * 4) * 4;
+                    asm volatile("" : "+v"(toff));
+                    const f32x4_t s4 = lds_ld<f32x4_t>((lds_p)tab + toff), h4 = lds_ld<f32x4_t>((lds_p)tab + toff + kMaxCin * 4);
+                    const uint4 xv = bx[km];
+                    unsigned du[2] = {ph == 0 ? co[km & 1].x : co[km & 1].z, ph == 0 ? co[km & 1].y : co[km & 1].w};
+                    const unsigned xu[2] = {ph == 0 ? xv.x : xv.z, ph == 0 ? xv.y : xv.w};
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int j = ph * 2 + jj;
+                        const f32x2_t bsc = {s4[2 * jj], s4[2 * jj + 1]}, bsh = {h4[2 * jj], h4[2 * jj + 1]};
+                        const f32x2_t xf = {to_f32(__builtin_bit_cast(T, (unsigned short)(xu[jj] & 0xffffu))),
+                                            to_f32(__builtin_bit_cast(T, (unsigned short)(xu[jj] >> 16)))};
+                        const f32x2_t pre = xf * bsc + bsh;
+                        const unsigned m = ((pre[0] > e_blo && pre[0] < e_bhi) ? 0x0000ffffu : 0u) | ((pre[1] > e_blo && pre[1] < e_bhi) ? 0xffff0000u : 0u);
+                        du[jj] &= m;
+                        const f32x2_t gf = {to_f32(__builtin_bit_cast(T, (unsigned short)(du[jj] & 0xffffu))),
+                                            to_f32(__builtin_bit_cast(T, (unsigned short)(du[jj] >> 16)))};
+                        bs[j] += gf;
+                        bq[j] += gf * xf;
+                    }
+                    if (ph == 0) { co[km & 1].x = du[0]; co[km & 1].y = du[1]; } else { co[km & 1].z = du[0]; co[km & 1].w = du[1]; }
+                    if (ph == 1 && half == 0) bx[km] = bnr_ld(km + 4);
+                }
+            }
+            if (h >= 6 && h <= 15 && (h - 6) % 3 == 0) {
+                // whole 256-byte pixel rows to HBM (four complete pixels per instruction): scalar base + a 32-bit lane offset.
+                // Edge tiles: pixels outside the image are not stored (one compare per store, every lane passes on full tiles);
+                // a block's first tile has no image yet (prev_real).
+                const int k = half * 4 + kk;
+                const uint4 o = co[kk & 1];
+                const int row = 2 * wave + (k >> 2), col = 4 * (k & 3);
+                unsigned char* yb = e_y + ((long long)row * e_rowb + col * e_pxb);       // (scalar)
+                const unsigned lane_off = (unsigned)(prow * e_pxb + piece * 16);
+                if (prev_real && row < e_h && col + prow < e_w) *reinterpret_cast<uint4*>(yb + lane_off) = o;
+            }
+        }
+        if constexpr (BNR) {
+            if (sl == 2 && h >= 14 && h < 18) {
+                // the four lanes of one 16-byte piece (lane bits 4, 5): fixed butterfly, one channel pair per step (all four at once
+                // spill), then all four lane groups hold the wave's sums of their channels and write the same values to the same words
+                const int j = h - 14;
+#pragma unroll
+                for (int o = 16; o < 64; o <<= 1) {
+                    bs[j][0] += __shfl_xor(bs[j][0], o, 64); bs[j][1] += __shfl_xor(bs[j][1], o, 64);
+                    bq[j][0] += __shfl_xor(bq[j][0], o, 64); bq[j][1] += __shfl_xor(bq[j][1], o, 64);
+                }
+                const int cl = piece * 8 + 2 * j;
+                lds_st<f32x2_t>((lds_p)(red + wave * 256 + cl), bs[j]);
+                lds_st<f32x2_t>((lds_p)(red + wave * 256 + 128 + cl), bq[j]);
+            }
+        }
+    };
+    // behind the barrier that ends an epilogue: its sums into the block's running sums, another job's batch-norm table
+    auto e2_done = [&](int next_job) __attribute__((always_inline)) {
+        stats_flush();
+        if constexpr (BNR) { if (next_job != tab_job) tab_load(next_job); }
+    };
+
+    Tile cur = tile_of<false>(g, w);
+    prev = cur;
+    if constexpr (BNR) { e_bx = reinterpret_cast<const unsigned char*>(g.job[cur.job].bnr_x); }     // (a block's first tile: loads that nothing uses, from a valid address)
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
+    X8 b[2][3];
+    int cc = 0;                // running chunk counter: the chunk reads halo buffer cc & 1
+    b_load(b[0], wsrc, 0);
+    a_load(cur, 0);
+    if constexpr (AFFINE || BNR) tab_load(cur.job);
+    __syncthreads();           // table visible
+    tab_read(0);
+#pragma unroll
+    for (int i = 0; i < kAVec; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) commit_step(i, j, 0);
+    __syncthreads();
+
+    for (;;) {
+        CS_STAMP(0);
+        const int wnext = w + (int)gridDim.x;
+        const bool has_next = wnext < total;
+        const Tile nxt = tile_fast(g, has_next ? wnext : w);
+        const unsigned char* wsrc_next = reinterpret_cast<const unsigned char*>(g.job[nxt.job].wp) + nxt.ntile * wtile;
+
+        f32x4_t acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        // ONE chunk: six stages = (kx, k-step); per stage 48 MFMAs in 18 groups (halo row h feeds output rows h, h - 1, h - 2), each
+        // followed by the read of row h + kRing and by whatever else the stage carries (sched_barrier pins every group: the order
+        // below IS the instruction order): stage 0 the fetch of the next halo image, stages 3..5 its commit (two pieces per stage),
+        // stages 0..2 of a tile's FIRST chunk the previous tile's epilogue. (The two variants run one after the other, never as the
+        // two sides of a branch: hipcc hoists what both sides share in front of the branch - 74 more live registers.)
+        // (the weight pointers by value: captured by reference they stayed in scratch memory, one flat load + vmcnt(0) per stage)
+        auto chunk_body = [&](const int chunk, const unsigned char* const ws, const unsigned char* const ws_next, auto epi_tag) __attribute__((always_inline)) {
+            constexpr bool EPI = decltype(epi_tag)::value;
+            const lds_p ab = abase + halo_off(cc & 1);
+            const bool last_chunk = chunk + 1 == nchunk;
+            // the image to prepare under this chunk: the tile's next chunk, or the first chunk of the next tile (without a next tile
+            // this tile's first chunk once more, never read: the staging stays unconditional)
+            const Tile& st_tile = last_chunk ? nxt : cur;
+            const int st_chunk = last_chunk ? 0 : chunk + 1;
+            if constexpr (AFFINE) {
+                // another job's table (a few times per launch): no wave commits between a chunk's barrier and its stage 3
+                if (last_chunk && nxt.job != tab_job) {
+                    tab_load(nxt.job);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+#pragma unroll
+            for (int sl = 0; sl < 6; ++sl) {
+                const int a_off = (sl >> 1) * kRS + (sl & 1) * 64;
+                // the next stage's weight fragments (of this tile, or the first ones of the next tile) into the other register set
+                if (sl < 5) b_load(b[(sl + 1) & 1], ws, (chunk * 6 + sl + 1) * kStageBytes);
+                else b_load(b[0], last_chunk ? ws_next : ws, last_chunk ? 0 : (chunk * 6 + 6) * kStageBytes);
+                if (sl == 0) a_load(st_tile, st_chunk);
+                X8 a[18];
+#pragma unroll
+                for (int h = 0; h < kRing; ++h) a[h] = lds_ld<X8>(ab + a_off + h * (kHW * kRS));
+                if (sl == 3) tab_read(st_chunk);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int h = 0; h < 18; ++h) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int r = h - ky;
+                        if (r >= 0 && r < 16) acc[r] = H::mfma(b[sl & 1][ky], a[h], acc[r]);       // D^T = W^T x A^T
+                    }
+                    if (h + kRing < 18) a[h + kRing] = lds_ld<X8>(ab + a_off + (h + kRing) * (kHW * kRS));
+                    if (sl >= 3) {
+                        // pieces 2 (sl - 3) at h = 1..5 and 2 (sl - 3) + 1 at h = 9..13
+                        if (h >= 1 && h <= 5) commit_step(2 * (sl - 3), h - 1, (cc + 1) & 1);
+                        if (h >= 9 && h <= 13) commit_step(2 * (sl - 3) + 1, h - 9, (cc + 1) & 1);
+                    }
+                    if (EPI && sl < 3) e2_step(sl, h);
+#ifdef MPN_C3_PRIO    // (measured: the pair then runs stage by stage together, and the chunk takes the same time - off)
+                    if (h == 0) { ++pcount; lds_st<int>(prog_mine, pcount); pseen = lds_ld<int>(prog_other); }
+                    if (h == 8) {
+                        const int ps = __builtin_amdgcn_readfirstlane(pseen);
+                        if (ps > pcount) __builtin_amdgcn_s_setprio(2);
+                        else if (ps < pcount) __builtin_amdgcn_s_setprio(0);
+                        else __builtin_amdgcn_s_setprio(1);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                CS_STAMP(16 + (chunk < 1 ? chunk : 1) * 6 + sl);
+                if (EPI && sl == 2) {
+                    // every wave has read the waiting image and written its sums: the commits of stages 3..5 may write there
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    CS_STAMP(10);
+                    e2_done(cur.job);
+                }
+            }
+            // the chunk's barrier: every wave has read this halo image for the last time and committed its pieces of the next one
+            // (raw: only LDS traffic is ordered - the weight fragments in flight and the tile's output stores stay in flight)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            CS_STAMP(1 + (chunk < 7 ? chunk : 7));
+            ++cc;
+        };
+        if constexpr (PIPE) chunk_body(0, wsrc, wsrc_next, std::true_type{});
+        for (int chunk = PIPE ? 1 : 0; chunk < nchunk; ++chunk) chunk_body(chunk, wsrc, wsrc_next, std::false_type{});
+
+        // ================= tile `cur` into its image. Halo buffer (cc - 1) & 1 is free (the barrier above); the other one holds the
+        // next tile's first chunk. The image [256 px][kRSO] lies over the free buffer and the spare region: output row r, pixel l15,
+        // this wave's channels lq * 4 .. + 3. Pixels outside the image must not count in the statistics: zeroed on edge tiles.
+        {
+            const Job& p = g.job[cur.job];
+            const bool full_tile = cur.oy0 + 16 <= p.H && cur.ox0 + 16 <= p.W;
+            const lds_p iw = L + image_off((cc - 1) & 1) + l15 * kRSO + wave * 32 + lq * 8;
+            if (full_tile) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(acc[r]));
+            } else {
+                const bool okx = cur.ox0 + l15 < p.W;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = okx && cur.oy0 + r < p.H;
+                    lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(ok ? acc[r] : (f32x4_t){0.f, 0.f, 0.f, 0.f}));
+                }
+            }
+            prev = cur; prev_real = true; prev_img = image_off((cc - 1) & 1);
+            {
+                const int wys = p.W * p.ys;
+                e_y = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(p.y) + ((long long)cur.img * p.H + cur.oy0) * wys + (long long)cur.ox0 * p.ys + cur.ntile * 128);
+                e_rowb = wys * 2; e_pxb = p.ys * 2; e_h = p.H - cur.oy0; e_w = p.W - cur.ox0; e_ntile = cur.ntile;
+                if constexpr (BNR) {
+                    const int wbs = p.W * p.bnr_xs;
+                    e_bx = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.bnr_x) + ((long long)cur.img * p.H + cur.oy0) * wbs + (long long)cur.ox0 * p.bnr_xs + cur.ntile * 128);
+                    e_bx_rowb = wbs * 2; e_bx_pxb = p.bnr_xs * 2; e_bx_hmax = p.H - 1 - cur.oy0; e_bx_wmax = p.W - 1 - cur.ox0;
+                    e_blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
+                    e_bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
+                }
+            }
+            if (STATS || BNR) {
+                // the block's row of this job's slab: row = the position of the block's FIRST tile of the job among the job's first
+                // gridDim.x tiles (mpn_conv_stats_rows; the grid is a multiple of n_tiles, so a block keeps its channel tile within a job)
+                const int n_tiles = Cout >> 7, grid = (int)gridDim.x;
+                int off = (w_first - g.begin[cur.job]) % grid;
+                if (off < 0) off += grid;
+                st_pending = tid < 256;
+                st_store = !has_next || nxt.job != cur.job;
+                st_dst = p.stats_part + ((long long)(off / n_tiles) * 2 + st_which) * Cout + cur.ntile * 128 + st_c;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            CS_STAMP(9);
+            if constexpr (!PIPE) {
+#pragma unroll
+                for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+                    for (int h = 0; h < 18; ++h) { e2_step(sl, h); __builtin_amdgcn_sched_barrier(0); }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                e2_done(nxt.job);
+            }
+        }
+#ifdef MPN_DIAG
+        ++titer;
+#endif
+        if (!has_next) break;
+        cur = nxt;
+        wsrc = wsrc_next;
+        w = wnext;
+    }
+    // the last tile's epilogue, on its own
+    if constexpr (PIPE) {
+#pragma unroll
+        for (int sl = 0; sl < 3; ++sl)
+#pragma unroll
+            for (int h = 0; h < 18; ++h) { e2_step(sl, h); __builtin_amdgcn_sched_barrier(0); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        stats_flush();
+    }
+#ifdef MPN_DIAG
+    if (g.job[0].dbg) {
+        if ((threadIdx.x & 63) == 0) { wst[(threadIdx.x >> 6) * 32 + 12] = rt_begin; wst[(threadIdx.x >> 6) * 32 + 13] = __builtin_amdgcn_s_memrealtime(); }
+        __syncthreads();
+        if (threadIdx.x < 256) g.job[0].dbg[(size_t)blockIdx.x * 256 + threadIdx.x] = wst[threadIdx.x];
+    }
+#endif
+}
+
+template <typename T, int ACT, int MODE>
+int launch_t(const Group& g, int blocks, hipStream_t st) {
+    static mpn_attr_mask_t attr_mask{0};
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_cs_kernel<T, ACT, MODE>, kLds, &attr_mask));
+    conv3x3_cs_kernel<T, ACT, MODE><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
+    MPN_LAUNCH_CHECK();
+    return MPN_OK;
+}
+template <typename T, int ACT>
+int launch_m(const Group& g, int blocks, bool stats, hipStream_t st) {
+    return stats ? launch_t<T, ACT, 1>(g, blocks, st) : launch_t<T, ACT, 0>(g, blocks, st);
+}
+template <typename T>
+int launch_v(const Group& g, int blocks, bool affine, bool bnr, hipStream_t st) {
+    if (bnr) return launch_t<T, 0, 2>(g, blocks, st);
+    const bool stats = g.job[0].stats_part != nullptr;
+    if (!affine) return launch_m<T, 0>(g, blocks, stats, st);
+    return g.job[0].in_act == MPN_ACT_RELU6 ? launch_m<T, 2>(g, blocks, stats, st) : launch_m<T, 1>(g, blocks, stats, st);
+}
+
+}  // namespace
+
+namespace mpn_c3 {
+
+int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, hipStream_t st) {
+    MPN_REQUIRE(g.job[0].Cin <= kMaxCin && g.job[0].Cout <= kMaxCin, MPN_ERR_BAD_SHAPE, "conv3x3: at most %d channels", kMaxCin);
+    for (int j = 1; j < g.njobs; ++j)
+        MPN_REQUIRE((g.job[j].stats_part != nullptr) == (g.job[0].stats_part != nullptr), MPN_ERR_BAD_ARG,
+                    "conv3x3: the jobs of a group share the statistics / no statistics variant");
+    if (dtype == MPN_BF16) return launch_v<bf16_t>(g, blocks, affine, bnr, st);
+    if (dtype == MPN_F16) return launch_v<half_t>(g, blocks, affine, bnr, st);
+    MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");
+}
+
+}  // namespace mpn_c3
