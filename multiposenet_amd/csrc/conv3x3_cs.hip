@@ -52,7 +52,10 @@ constexpr int kDiagBytes = 0;
 constexpr int kProgBytes = 64;               // per wave: the number of stages it has started (priority feedback, below)
 constexpr int kLds = kHaloArea + kRedBytes + kTabBytes + kProgBytes + kDiagBytes;
 constexpr int kAVec = 6;                     // 16-byte pieces of a halo image per thread
-constexpr int kRingDefault = 6;              // halo fragments in flight
+#ifndef MPN_C3_RING
+#define MPN_C3_RING 6
+#endif
+constexpr int kRingDefault = MPN_C3_RING;              // halo fragments in flight
 static_assert(kLds <= 160 * 1024, "LDS budget");
 static_assert(kSpare >= 0 && kHaloArea - kImg == kABytes, "the image over halo buffer 1 starts where halo buffer 0 ends");
 
@@ -422,9 +425,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     prev = cur;
     if constexpr (BNR) { e_bx = reinterpret_cast<const unsigned char*>(g.job[cur.job].bnr_x); }     // (a block's first tile: loads that nothing uses, from a valid address)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
-    X8 b[2][3];
+#ifndef MPN_C3_BD
+#define MPN_C3_BD 1      // weight fragments requested this many stages ahead (1: two register sets, 2: three)
+#endif
+    constexpr int BD = MPN_C3_BD;
+    X8 b[BD + 1][3];
     int cc = 0;                // running chunk counter: the chunk reads halo buffer cc & 1
     b_load(b[0], wsrc, 0);
+    if constexpr (BD == 2) b_load(b[1], wsrc, kStageBytes);
     a_load(cur, 0);
     if constexpr (AFFINE || BNR) tab_load(cur.job);
     __syncthreads();           // table visible
@@ -472,8 +480,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             for (int sl = 0; sl < 6; ++sl) {
                 const int a_off = (sl >> 1) * kRS + (sl & 1) * 64;
                 // the next stage's weight fragments (of this tile, or the first ones of the next tile) into the other register set
-                if (sl < 5) b_load(b[(sl + 1) & 1], ws, (chunk * 6 + sl + 1) * kStageBytes);
-                else b_load(b[0], last_chunk ? ws_next : ws, last_chunk ? 0 : (chunk * 6 + 6) * kStageBytes);
+                if (sl + BD < 6) b_load(b[(sl + BD) % (BD + 1)], ws, (chunk * 6 + sl + BD) * kStageBytes);
+                else b_load(b[(sl + BD) % (BD + 1)], last_chunk ? ws_next : ws, last_chunk ? (sl + BD - 6) * kStageBytes : (chunk * 6 + sl + BD) * kStageBytes);
                 if (sl == 0) a_load(st_tile, st_chunk);
                 X8 a[18];
 #pragma unroll
@@ -485,7 +493,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         const int r = h - ky;
-                        if (r >= 0 && r < 16) acc[r] = H::mfma(b[sl & 1][ky], a[h], acc[r]);       // D^T = W^T x A^T
+                        if (r >= 0 && r < 16) acc[r] = H::mfma(b[sl % (BD + 1)][ky], a[h], acc[r]);       // D^T = W^T x A^T
                     }
                     if (h + kRing < 18) a[h + kRing] = lds_ld<X8>(ab + a_off + (h + kRing) * (kHW * kRS));
                     if (sl >= 3) {
