@@ -169,15 +169,22 @@ def dry_run_cpu(args):
         red.finish()
     torch.distributed.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    # per-rank step times to rank 0 (the GPU path's `ms_per_step_per_rank`), then the max over ranks
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    torch.distributed.all_gather(per_rank, t)
     torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     want = world * (world + 1) / 2.0
-    ok = bool((grad == want).all())
+    okt = torch.tensor([1 if bool((grad == want).all()) else 0], dtype=torch.int32)
+    torch.distributed.all_reduce(okt, op=torch.distributed.ReduceOp.MIN)      # the sum is right on EVERY rank
+    ok = bool(okt.item())
     if rank == 0:
         print(json.dumps({"metric": "images/sec keypoint fwd+bwd+Adam @512x512 bs32/GPU", "value": None, "unit": "images/s",
                           "dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(1e3 * float(t) / max(1, args.steps), 3), "scaling": "weak",
                           "config": {"rccl_ranks": torch.distributed.get_world_size(), "backend": "gloo",
-                                     "gradient_elements": grad.numel(), "allreduce_sum_ok": ok}}))
+                                     "gradient_elements": grad.numel(), "allreduce_sum_ok": ok,
+                                     "exchange_ranges": [[split, grad.numel()], [deep, split], [0, deep]],
+                                     "ms_per_step_per_rank": [round(1e3 * float(x) / max(1, args.steps), 3) for x in per_rank]}}))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
     return 0 if ok else 1

@@ -176,6 +176,11 @@ def in_step_families(trainer, feats, labels, batch, size):
     # one rank enters hangs the job at the final barrier) - the reducer is detached for these steps. bench.py calls it at N = 1 only.
     graph, reducer = trainer.use_graph, trainer.reducer
     trainer.use_graph, trainer.reducer = False, None
+    # the three profiled steps are measurement, not training: variables, Adam slots, moving statistics and the step counter are
+    # put back afterwards (as Trainer.step does around its graph capture), so later legs see the model the timed region left
+    net = trainer.net
+    state = (net.theta, net.adam_m, net.adam_v, net.moving, net.global_step)
+    snap = [t.clone() for t in state]
     try:
         for _ in range(2):
             trainer.step(feats, labels)          # eager warm-up
@@ -187,6 +192,10 @@ def in_step_families(trainer, feats, labels, batch, size):
     finally:
         _lib.PROFILE = None
         trainer.use_graph, trainer.reducer = graph, reducer
+        for dst, src in zip(state, snap):
+            dst.copy_(src)
+        net.repack_weights()
+        net.mark_variables_changed()
     fam = {"depthwise": 0.0, "pointwise": 0.0}
     n = {"depthwise": 0, "pointwise": 0}
     total = 0.0

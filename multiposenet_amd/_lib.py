@@ -258,3 +258,20 @@ def dtype_code(torch_dtype):
         return {torch.float32: MPN_F32, torch.bfloat16: MPN_BF16, torch.float16: MPN_F16}[torch_dtype]
     except KeyError:
         raise ValueError(f"unsupported dtype {torch_dtype}")
+
+
+def current_device():
+    """The CUDA device of this process (one process per GPU: the rank's torch.cuda.set_device), for shims that receive host
+    data and have no network to take the device from - never a hard-coded "cuda:0", which is rank 0's card on every rank."""
+    import torch
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device_f32(x):
+    """numpy array or tensor -> contiguous f32 tensor on the process's device (a CUDA tensor stays on its own device)."""
+    import numpy as np
+    import torch
+    if isinstance(x, np.ndarray):
+        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+    dev = x.device if x.is_cuda else current_device()
+    return x.to(dev, torch.float32).contiguous()

@@ -2,6 +2,7 @@
 import numpy as np
 import torch
 
+from .. import _lib
 from ..prn import PoseResidualNet
 
 _nets = {}
@@ -13,14 +14,12 @@ def prn(x, is_training, values=None, dtype=torch.bfloat16, scope="PRN"):
     reference's dropout is commented out, prn.py:21). The network of a (shape, dtype, scope) is built once - the stand-in
     for tf.variable_scope('PRN') - and re-loaded whenever a different `values` mapping is passed (the cache holds a
     reference to the mapping it loaded, so identities cannot be recycled under it)."""
-    if isinstance(x, np.ndarray):
-        x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
-    x = x.to("cuda:0", torch.float32).contiguous()
-    key = (tuple(x.shape), dtype, scope)
+    x = _lib.to_device_f32(x)      # (the process's device - one process per GPU -, or the tensor's own)
+    key = (tuple(x.shape), dtype, scope, x.device.index)
     entry = _nets.get(key)
     if entry is None:
         b, h, w, c = x.shape
-        entry = _nets[key] = [PoseResidualNet(values=values, batch=b, h=h, w=w, c=c, dtype=dtype), values]
+        entry = _nets[key] = [PoseResidualNet(values=values, batch=b, h=h, w=w, c=c, dtype=dtype, device=x.device), values]
     elif values is not None and values is not entry[1]:
         entry[0].load_state_dict(values)
         entry[1] = values

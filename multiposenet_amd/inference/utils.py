@@ -41,10 +41,10 @@ def _box_hw(box):
 class KeypointDecoder:
     """Owns the (zero-initialised) decode workspace and output buffers for a batch size."""
 
-    def __init__(self, batch, device="cuda:0"):
+    def __init__(self, batch, device=None):
         import torch
         self.B = int(batch)
-        self.device = torch.device(device)
+        self.device = _lib.current_device() if device is None else torch.device(device)
         nbytes = _lib.lib().mpn_heatmap_decode_workspace_bytes(self.B)
         self.workspace = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         self.xyv = torch.empty((self.B, NUM_KEYPOINTS, 3), dtype=torch.int32, device=self.device)
@@ -86,7 +86,7 @@ def get_keypoints_batch(heatmaps, boxes, threshold, return_scores=False):
         np_dtype = heatmaps.dtype
         if np_dtype == np.float64:
             raise ValueError("float64 heatmaps are not supported (reference outputs are float32)")
-        hm = torch.from_numpy(np.ascontiguousarray(heatmaps)).to("cuda:0")
+        hm = torch.from_numpy(np.ascontiguousarray(heatmaps)).to(_lib.current_device())   # (one process per GPU: the rank's device)
     else:
         hm = heatmaps
         np_dtype = {torch.float32: np.float32, torch.float16: np.float16}.get(hm.dtype, np.float32)

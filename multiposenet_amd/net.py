@@ -193,11 +193,13 @@ class KeypointNet:
 
     def _init(self, values, depth_multiplier, dtype, seed):
         shapes, self._pads = internal_shapes(depth_multiplier)
-        ve = 8 if dtype == torch.bfloat16 else 4
+        # every batch-norm width a multiple of 16 (the stem's is padded to one inside the arena): the matrix-core kernels are
+        # exercised - end to end against the oracle - at such widths only (0.25, 0.5, 0.75, 1.0, ...); 0.375 would hand 24- and
+        # 48-channel pointwise layers to them
         for n, s in shapes.items():
-            if n.endswith("gamma") and (s[0] % ve != 0):
-                raise ValueError(f"depth_multiplier={depth_multiplier}: {n} has {s[0]} channels; {dtype} storage moves "
-                                 f"{ve}-channel vectors")
+            if n.endswith("gamma") and (s[0] % 16 != 0):
+                raise ValueError(f"depth_multiplier={depth_multiplier}: {n} has {s[0]} channels; every layer behind the stem "
+                                 f"must be a multiple of 16 channels wide (depth multipliers that are multiples of 0.25)")
         self._train_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if is_trainable(k)), self.device)
         self._stat_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if not is_trainable(k)), self.device)
         self.theta = self._train_arena.new()
@@ -415,7 +417,9 @@ class KeypointNet:
                               nbn(rows(b["dw"][i])) * 2 * cdw,
                               ops.conv_num_parts(N, *b["hw"][i + 1], 1) * 2 * cpw, nbn(rows(b["pw"][i])) * 2 * cpw,
                               ops.dwconv_bwd_data_bn_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw,
-                              ops.dwconv_wgrad_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw)   # (the fused backward's rows)
+                              ops.dwconv_wgrad_num_parts(N, hh, ww, cdw, blk["stride"], dt) * 2 * cdw,   # (the fused backward's rows)
+                              # (the fused thin pointwise backward's batch-norm rows: one pair per split-K part)
+                              ops.conv_wgrad_num_parts(N, *b["hw"][i + 1], cdw, cpw, 1, dt) * 2 * cdw)
         for l in lv:
             stat_floats = max(stat_floats, ops.conv_num_parts(N, *lv[l], 3) * 2 * DEPTH, nbn(N * lv[l][0] * lv[l][1]) * 2 * DEPTH)
         b["stat_part"] = torch.empty(stat_floats, dtype=torch.float32, device=dev)

@@ -8,12 +8,13 @@ import numpy as np
 import torch
 
 from .keypoints_model import EstimatorSpec, ModeKeys
+from . import _lib
 from .prn import PoseResidualNet
 
 _models = {}
 
 
-def _model(params, batch, shape):
+def _model(params, batch, shape, device=None):
     """One set of variables (+ optimizer state) per model configuration: tf.estimator keys its variables by `model_dir`
     (train_prn.py: RunConfig(model_dir=...)), so does this registry - never by object identity, which is recycled, and
     never by batch size: the reference's eval pipeline ends on a partial batch (`dataset.repeat(1).batch(b)`), which must
@@ -21,10 +22,11 @@ def _model(params, batch, shape):
     # storage type of the GEMM operands and activations (masters, accumulators and Adam stay f32); "fp16" is the type
     # BASELINE.json config 5 names
     dt = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16, "f16": torch.float16}[params.get("dtype", "bf16")]
-    key = (params.get("model_dir"), dt, int(params.get("seed", 0)), shape)
+    dev = _lib.current_device() if device is None else device
+    key = (params.get("model_dir"), dt, int(params.get("seed", 0)), shape, dev.index)
     if key not in _models:
         _models[key] = PoseResidualNet(values=params.get("values"), batch=batch, h=shape[0], w=shape[1], c=shape[2], dtype=dt,
-                                       seed=int(params.get("seed", 0)))
+                                       device=dev, seed=int(params.get("seed", 0)))
     return _models[key].for_batch(batch)
 
 
@@ -33,9 +35,7 @@ def reset_registry():
 
 
 def _dev(a):
-    if isinstance(a, np.ndarray):
-        a = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
-    return a.to("cuda:0", torch.float32).contiguous()
+    return _lib.to_device_f32(a)      # (the process's device - one process per GPU -, or the tensor's own)
 
 
 def model_fn(features, labels, mode, params):
@@ -43,7 +43,7 @@ def model_fn(features, labels, mode, params):
     x, y = _dev(features), _dev(labels)
     if x.dim() != 4 or x.shape != y.shape:
         raise ValueError(f"features and labels must be [b, h, w, c] of equal shape, got {tuple(x.shape)} / {tuple(y.shape)}")
-    net = _model(params, x.shape[0], tuple(x.shape[1:]))
+    net = _model(params, x.shape[0], tuple(x.shape[1:]), x.device)
     if mode == ModeKeys.TRAIN:
         loss = net.train_step(x, y, float(params["initial_learning_rate"]), int(params["num_steps"]))
         return EstimatorSpec(mode=mode, loss=loss, train_op=net.global_step, eval_metric_ops=None, losses={"logloss": loss})

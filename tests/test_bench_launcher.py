@@ -77,6 +77,29 @@ def test_two_rank_gloo_dry_run_through_the_launcher_prints_one_json_line():
     assert out["config"]["gradient_elements"] >= 5521490
 
 
+def test_eight_rank_gloo_dry_run_through_the_launcher():
+    """no 8-GPU node was available to any round of this build, so the launcher, the rendezvous, the three-range
+    gradient exchange (head end, deep backbone blocks, the rest: together the whole arena, once), the per-rank timing gather and
+    the max-over-ranks line run at the REAL rank count of BASELINE config 3 over gloo: every rank ends with the sum 1 + ... + 8."""
+    r = _run(["--gpus", "8", "--dry-run-cpu", "--steps", "3", "--warmup", "1"], timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["dry_run"] is True and out["n_gpus"] == 8 and cfg["rccl_ranks"] == 8 and cfg["allreduce_sum_ok"] is True
+    assert len(cfg["ms_per_step_per_rank"]) == 8 and out["ms_per_step"] >= max(cfg["ms_per_step_per_rank"]) - 1e-3
+    (a0, a1), (b0, b1), (c0, c1) = cfg["exchange_ranges"]
+    assert c0 == 0 and c1 == b0 and b1 == a0 and a1 == cfg["gradient_elements"]      # the ranges tile the arena in backward order
+
+
+def test_a_rank_dying_among_eight_ends_the_other_seven():
+    r = _run(["--gpus", "8", "--dry-run-cpu", "--steps", "4", "--warmup", "0"], env={"MPN_BENCH_FAIL_AT_STEP": "5:2"}, timeout=600)
+    assert r.returncode not in (0, None) and r.returncode > 0
+    assert "injected failure in step 2" in r.stderr and "rank exit codes" in r.stderr
+    assert r.stdout.strip() == ""
+
+
 def test_a_dying_rank_ends_the_others_and_the_launcher_returns_its_code():
     r = _run(["--gpus", "2", "--dry-run-cpu", "--steps", "2", "--warmup", "0"], env={"MPN_BENCH_FAIL_RANK": "1"}, timeout=120)
     assert r.returncode == 7
@@ -119,12 +142,27 @@ def test_rank0_only_legs_never_enter_the_gradient_exchange(monkeypatch):
             raise AssertionError("a collective on one rank")
         start = finish = all_reduce
 
+    class StubNet:
+        """the state the leg snapshots before its three profiled steps and puts back afterwards"""
+        def __init__(self):
+            self.theta, self.adam_m, self.adam_v = torch.ones(4), torch.zeros(4), torch.zeros(4)
+            self.moving, self.global_step = torch.ones(2), torch.zeros(1, dtype=torch.int64)
+            self.repacked = self.marked = 0
+
+        def repack_weights(self):
+            self.repacked += 1
+
+        def mark_variables_changed(self):
+            self.marked += 1
+
     class StubTrainer:
         def __init__(self):
-            self.use_graph, self.reducer, self.seen = True, Reducer(), []
+            self.use_graph, self.reducer, self.seen, self.net = True, Reducer(), [], StubNet()
 
         def step(self, feats, labels):
             self.seen.append((self.use_graph, self.reducer))
+            self.net.theta += 1.0            # (a step moves the variables and the step counter)
+            self.net.global_step += 1
             if self.reducer is not None:
                 self.reducer.all_reduce()
 
@@ -133,6 +171,8 @@ def test_rank0_only_legs_never_enter_the_gradient_exchange(monkeypatch):
     out = bench_legs.in_step_families(tr, None, None, 32, 512)
     assert tr.seen == [(False, None)] * 3 and tr.use_graph is True and isinstance(tr.reducer, Reducer)
     assert out["launches"] == 0
+    # the profiled steps are measurement, not training: the model is the one the timed region left
+    assert torch.equal(tr.net.theta, torch.ones(4)) and int(tr.net.global_step) == 0 and tr.net.repacked == 1 and tr.net.marked == 1
     src = inspect.getsource(bench.main)
     call = src.index("in_step_families(trainer")
     assert "if world == 1:" in src[call - 200:call]
