@@ -511,3 +511,43 @@ def test_depth_multiplier_train_step(cuda, dm, c0, c0_internal):
                     assert float(t.narrow(axis, n, t.shape[axis] - n).abs().max()) == 0.0, k
         assert bool(net._pads) == (c0 != c0_internal)
     np.testing.assert_allclose(out[torch.bfloat16][6], out[torch.float32][6], rtol=3e-2)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_backward_pass_teacher_forced_against_the_oracle(cuda, dtype):
+    """an ABSOLUTE bound on the benchmarked (bf16) build's step gradients. A plain comparison cannot carry one:
+    on trained variables and a held-out batch of 8 @ 256^2 the f64 oracle's OWN gradient moves by 0.93 in relative L2 when it
+    rounds where the build stores bf16 (3 of 127 tensors below 0.05: tools/bf16_grad_bound.py, profiles/r05_bf16_grad_bound.txt) -
+    forward rounding flips activation masks and shifts batch statistics, the backward pass amplifies it. So the perturbation is taken
+    out ("teacher forcing", tools/bf16_teacher_forced.py): the build runs its forward pass, then every tensor its backward pass
+    reads - 45 raw conv outputs, the FPN sums, the concat slices, the logits, mean / invstd / scale / shift of all 40 batch-norm
+    layers - is overwritten with the emulating oracle's values (exactly representable in bf16), and the build's loss gradient and
+    whole backward chain run from there, on variables the f32 build trained for 60 steps and a batch they have not seen.
+    What is left is the backward kernels' own arithmetic: every gradient tensor within 10 % (measured: 0.2-1.7 %, all tensors together
+    1.4 %) and cosine 0.99 of the oracle's - a systematic error of 20 % in any kernel of the chain fails. The only exception is
+    arithmetic, not tolerance: the gammas of batch-norms that feed a depthwise conv + batch-norm are nearly scale-invariant
+    directions (|dgamma| ~ 1e-2 of |dbeta|, a residue of cancelling sums): held to 5 % of that layer's |dbeta| instead.
+    The f32 build through the same machinery: 1e-4."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bf16_teacher_forced as tf
+    out = tf.run(steps=60, B=4, size=128, dtype=torch.bfloat16 if dtype == "bf16" else torch.float32, verbose=False)
+    rows = {r[0]: r for r in out["rows"]}
+    tol_rel, tol_cos = (0.10, 0.99) if dtype == "bf16" else (2e-3, 0.99999)
+    np.testing.assert_allclose(out["loss"], out["oracle_loss"], rtol=1e-5 if dtype == "bf16" else 1e-6)
+    bad, excepted = [], []
+    for k, (_, size, norm, rel, cos) in rows.items():
+        if rel <= tol_rel and cos >= tol_cos:
+            continue
+        if k.endswith("/gamma") and k[:-6] + "/beta" in rows:
+            nb = rows[k[:-6] + "/beta"][2]
+            if norm <= 0.1 * nb and rel * norm <= (0.05 if dtype == "bf16" else 1e-3) * nb:      # |error| against the layer's |dbeta|
+                excepted.append((k, round(rel, 3), norm / nb))
+                continue
+        bad.append((k, rel, cos))
+    print(f"\n[{dtype} backward, teacher-forced] all {len(rows)} gradient tensors together: rel-L2 {out['all_rel']:.5f}, cosine "
+          f"{out['all_cos']:.6f}; worst rel-L2 outside the exceptions {max(r[3] for k, r in rows.items() if k not in dict((e[0], 0) for e in excepted)):.4f}; "
+          f"{len(excepted)} nearly scale-invariant gammas held to their layer's |dbeta|: {excepted[:3]} ...")
+    assert not bad, bad
+    assert out["all_rel"] <= (0.03 if dtype == "bf16" else 5e-4) and len(excepted) <= 16
