@@ -524,16 +524,18 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         for (int j = 0; j < 5; ++j) commit_step(i, j, 0, 0);
     __syncthreads();
 
+    Tile nxt_c = tile_fast(g, w + (int)gridDim.x < total ? w + (int)gridDim.x : w);
+    const unsigned char* wsrc_next_c = reinterpret_cast<const unsigned char*>(g.job[nxt_c.job].wp) + nxt_c.ntile * wtile;
     for (;;) {
         CS_STAMP(0);
+        // (the NEXT tile's coordinates and weight pointer were computed under the previous tile's stages - their scalar loads and
+        //  divisions stood in front of every tile's first MFMA in all eight waves at once; the tile after it is computed under this one)
         const int wnext = w + (int)gridDim.x;
         const bool has_next = wnext < total;
-        const Tile nxt = tile_fast(g, has_next ? wnext : w);
-        const unsigned char* wsrc_next = reinterpret_cast<const unsigned char*>(g.job[nxt.job].wp) + nxt.ntile * wtile;
+        const Tile nxt = nxt_c;
+        const unsigned char* wsrc_next = wsrc_next_c;
 
-        f32x4_t acc[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        f32x4_t acc[16];     // (not zeroed: a tile's first MFMA into each tile takes a literal 0 as its C operand - 64 v_mov per tile less)
 
         // ONE chunk: six stages = (kx, k-step); per stage 48 MFMAs in 18 groups (halo row h feeds output rows h, h - 1, h - 2), each
         // followed by the read of row h + kRing and by whatever else the stage carries (sched_barrier pins every group: the order
@@ -541,8 +543,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         // stages 0..2 of a tile's FIRST chunk the previous tile's epilogue. (The two variants run one after the other, never as the
         // two sides of a branch: hipcc hoists what both sides share in front of the branch - 74 more live registers.)
         // (the weight pointers by value: captured by reference they stayed in scratch memory, one flat load + vmcnt(0) per stage)
-        auto chunk_body = [&](const int chunk, const unsigned char* const ws, const unsigned char* const ws_next, auto epi_tag) __attribute__((always_inline)) {
-            constexpr bool EPI = decltype(epi_tag)::value;
+        auto chunk_body = [&](const int chunk, const unsigned char* const ws, const unsigned char* const ws_next, auto epi_tag, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool EPI = decltype(epi_tag)::value, FIRST = decltype(first_tag)::value;     // FIRST: the tile's first chunk
             const lds_p ab = abase + halo_off(cc & 1);
             const bool last_chunk = chunk + 1 == nchunk;
             // the image to prepare under this chunk: the tile's next chunk, or the first chunk of the next tile (without a next tile
@@ -581,7 +583,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         const int r = h - ky;
-                        if (r >= 0 && r < 16) acc[r] = H::mfma(b[sl % (BD + 1)][ky], a[h], acc[r]);       // D^T = W^T x A^T
+                        if (r >= 0 && r < 16)       // D^T = W^T x A^T
+                            acc[r] = H::mfma(b[sl % (BD + 1)][ky], a[h], (FIRST && sl == 0 && ky == 0) ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : acc[r]);
                     }
                     if (h + kRing < 18) a[h + kRing] = lds_ld<X8>(ab + a_off + (h + kRing) * (kHW * kRS));
                     if (sl >= 3) {
@@ -590,6 +593,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                         if (h >= 9 && h <= 13) commit_step(2 * (sl - 3) + 1, h - 9, (cc + 1) & 1, st_chunk);
                     }
                     if (EPI && sl < 3) e2_step(sl, h);
+                    if (FIRST && sl == 1 && h == 2) {
+                        // the tile after the next (or, at the end of the walk, a tile this block already owns: never used)
+                        const int w2 = wnext + (int)gridDim.x;
+                        nxt_c = tile_fast(g, w2 < total ? w2 : w);
+                        wsrc_next_c = reinterpret_cast<const unsigned char*>(g.job[nxt_c.job].wp) + nxt_c.ntile * wtile;
+                    }
 #ifdef MPN_C3_PRIO    // (measured: the pair then runs stage by stage together, and the chunk takes the same time - off)
                     if (h == 0) { ++pcount; lds_st<int>(prog_mine, pcount); pseen = lds_ld<int>(prog_other); }
                     if (h == 8) {
@@ -617,8 +626,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             CS_STAMP(1 + (chunk < 7 ? chunk : 7));
             ++cc;
         };
-        if constexpr (PIPE) chunk_body(0, wsrc, wsrc_next, std::true_type{});
-        for (int chunk = PIPE ? 1 : 0; chunk < nchunk; ++chunk) chunk_body(chunk, wsrc, wsrc_next, std::false_type{});
+        if constexpr (PIPE) chunk_body(0, wsrc, wsrc_next, std::true_type{}, std::true_type{});
+        else chunk_body(0, wsrc, wsrc_next, std::false_type{}, std::true_type{});
+        for (int chunk = 1; chunk < nchunk; ++chunk) chunk_body(chunk, wsrc, wsrc_next, std::false_type{}, std::false_type{});
 
         // ================= tile `cur` into its image. Halo buffer (cc - 1) & 1 is free (the barrier above); the other one holds the
         // next tile's first chunk. The image [256 px][kRSO] lies over the free buffer and the spare region: output row r, pixel l15,
