@@ -19,7 +19,7 @@ def whole_step_mfma_fraction(batch, size, step_seconds):
 
 
 def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20, b=None):
-    """The dominant kernel of the step is the dense 3x3 implicit-GEMM conv (conv3x3_kernel of csrc/conv3x3.hip, 128->128 channels
+    """The dominant kernel of the step is the dense 3x3 implicit-GEMM conv (conv3x3_cs_kernel of csrc/conv3x3_cs.hip, 128->128 channels
     at stride 4: p2, phi_subnet_2/conv1, conv2 forward and their three data-gradients = 6 launches per step).
     Times that launch with HIP events on the launch stream, on the tensors of the live network - in the form the forward
     runs it (producer's batch-norm affine + ReLU on load, batch-norm partial sums of the output in the epilogue: 3 of the
@@ -52,14 +52,14 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20, b=Non
     traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
     here = os.path.dirname(os.path.abspath(__file__))
     src = None
-    for name in ("r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+    for name in ("r05_dominant_kernel_traffic.json", "r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
         tj = os.path.join(here, "profiles", name)
         if dtype == torch.bfloat16 and batch == 32 and size == 512 and os.path.exists(tj):
             import json
             traffic = json.load(open(tj))["hbm_bytes_per_launch"]
             src = "profiles/" + name + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/one_conv.py; not re-measured by this run)"
             break
-    return {"kernel": "conv3x3_kernel<bf16, affine> (3x3 128->128, persistent 8-wave blocks, 16x16-pixel tiles) @ [%d,%d,%d,128], affine + ReLU on load, batch-norm statistics epilogue" % (batch, h, w),
+    return {"kernel": "conv3x3_cs_kernel<bf16, affine, statistics> (3x3 128->128, persistent 8-wave blocks, 16x16-pixel tiles, waves split the output channels) @ [%d,%d,%d,128], affine + ReLU on load, batch-norm statistics epilogue" % (batch, h, w),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
             "traffic": traffic, "traffic_source": src, "launch_us": round(sec * 1e6, 2),
             "launch_us_without_statistics": round(sec_plain * 1e6, 2),

@@ -10,7 +10,12 @@ n_timed = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 def is_dom(r):
     # (rocprofv3 demangles the affine instance badly: "conv3x3_kernel<bool _Accum, bool, E>"; the other one stays mangled)
-    return 'conv3x3_kernel<' in r['Kernel_Name'] and int(r['Grid_Size_X']) == 256 * 512
+    # (round 5: conv3x3_cs_kernel<bf16, ACT = 1 affine + ReLU, MODE = 1 statistics> - mangled 'conv3x3_cs_kernelIDF16bLi1ELi1ELb0E')
+    nm = r['Kernel_Name']
+    # (rocprofv3 demangles "conv3x3_cs_kernel<__bf16, 1, 1, false>" as "conv3x3_cs_kernel<bool _Accum, int, E, 1, false>": the ACT
+    #  argument is lost, the MODE = 1 (statistics) and GA = false arguments survive)
+    cs = 'conv3x3_cs_kernel' in nm and ('E, 1, false>' in nm or 'Li1ELi1ELb0E' in nm)
+    return (cs or 'conv3x3_kernel<' in nm) and int(r['Grid_Size_X']) == 256 * 512
 
 
 best, cur = [], []
@@ -26,6 +31,6 @@ if len(cur) > len(best):
 timed = best[-n_timed:]
 d = [(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3 for r in timed]
 span = (int(timed[-1]['End_Timestamp']) - int(timed[0]['Start_Timestamp'])) / 1e3 / len(timed)
-print(f"dominant kernel (conv3x3_kernel<bf16, affine>), the {len(timed)} timed launches of bench.py's roofline leg "
+print(f"dominant kernel (3x3 128 -> 128 forward with affine + statistics), the {len(timed)} timed launches of bench.py's roofline leg "
       f"(run of {len(best)} consecutive dispatches on [32,128,128,128]): mean {sum(d) / len(d):.1f} us (min {min(d):.1f}, "
       f"max {max(d):.1f}); start-to-end span per launch {span:.1f} us")

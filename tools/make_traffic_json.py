@@ -10,12 +10,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTI
     agg = []
     for f in fs:
         for r in csv.DictReader(open(f)):
-            if "conv3x3_kernel" in r["Kernel_Name"] and r["Counter_Name"] == c:
+            if "conv3x3" in r["Kernel_Name"] and r["Counter_Name"] == c:
                 agg.append(float(r["Counter_Value"]))
     agg = agg[-4:]
     vals[c] = sum(agg) / len(agg)
     for f in glob.glob(f"gpurun_out/pmc_{pm}/{c}/**/*kernel_trace.csv", recursive=True):
-        rows = [r for r in csv.DictReader(open(f)) if "conv3x3_kernel" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(f)) if "conv3x3" in r["Kernel_Name"]]
         if c == "GRBM_GUI_ACTIVE":
             dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows][-4:]
 fetch, write = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
@@ -23,7 +23,7 @@ alg = 2 * 32 * 128 * 128 * 128 * 2
 us = sum(dur) / len(dur)
 cycles = vals["GRBM_GUI_ACTIVE"] / 8
 out = {
-    "kernel": "conv3x3_kernel<bf16, affine> (3x3 128->128, persistent 8-wave blocks) @ [32,128,128,128], affine + ReLU on load, batch-norm statistics epilogue",
+    "kernel": "3x3 128->128 forward (the persistent 8-wave kernel the library routes it to: conv3x3_cs_kernel from round 5) @ [32,128,128,128], affine + ReLU on load, batch-norm statistics epilogue",
     "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM)",
     "hbm_bytes_per_launch": int(fetch + write), "algorithmic_bytes_per_launch": alg,
