@@ -323,8 +323,11 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         // (Spreading the six loads over the chunk's first three stages, two per stage behind that stage's weight pieces,
                         //  with the commits two stages later, changes nothing: the counted waits are short - profiles/r04_c3_stage_stamps.txt)
                         if (last_chunk) a_load_part(0, kAVec, nxt, 0); else a_load_part(0, kAVec, cur, chunk + 1);
-                        // (last chunk: this tile's commits are all behind a barrier - the table may change for the next tile's job)
-                        if (last_chunk && has_next) tab_load(nxt.job);
+                        // (last chunk: this tile's commits are all behind a barrier - the table may change for the next tile's job.
+                        //  AFFINE only: the fused-reduction table is read by THIS tile's epilogue - it changes behind it, below. Round 4
+                        //  switched it here too, and a block that walked from one job of a group into the next masked its last tile of
+                        //  the first job with the second job's batch-norm: found in round 5: tests/test_ops_bwd_gpu.py::test_grouped_fused_reduction_when_a_block_walks_from_one_job_into_the_next)
+                        if constexpr (AFFINE) { if (last_chunk && has_next) tab_load(nxt.job); }
                     }
 #endif
                 };
@@ -619,6 +622,15 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         ++titer;
 #endif
         if (!has_next) break;
+        if constexpr (BNR) {
+            if (nxt.job != tab_job) {      // (block-uniform) the next job's batch-norm, once every wave has finished this tile's epilogue
+                if constexpr (!N64) {      // (N64: the barrier that ends the epilogue, above)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+                tab_load(nxt.job);
+            }
+        }
         cur = nxt;
         wsrc = wsrc_next;
         w = wnext;

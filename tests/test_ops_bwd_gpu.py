@@ -1001,3 +1001,61 @@ def test_conv_dgrad_with_the_apply_pass_on_load(cuda, K, C, act, fused_bnr, with
             d = (dys[j].float() - dy_want[j].float()).abs().max() / dy_want[j].float().abs().max()
             assert float(d) < 2 ** -7
             np.testing.assert_allclose(outs[j].float().cpu().numpy(), want_dx[j].float().cpu().numpy(), atol=0.05 * float(want_dx[j].float().abs().max()))
+
+
+@pytest.mark.parametrize("K,C", [(64, 64), (128, 64), (128, 128)], ids=["64->64", "128->64", "128->128"])
+def test_grouped_fused_reduction_when_a_block_walks_from_one_job_into_the_next(cuda, K, C):
+    """Round 5: with more tiles than blocks a persistent block finishes its last tile of job j and starts on
+    job j + 1. Round 4's kernel loaded job j + 1's batch-norm table while that last tile was still being multiplied and masked its
+    epilogue with the WRONG layer's scale / shift (the four pyramid levels of a subnet stage have four different batch-norms) - unseen by
+    the ragged-tile tests, whose groups are smaller than the grid. Here 336 tiles on 256 blocks, batch-norms of opposite signs per job:
+    the grouped launch equals each job launched alone, bit for bit (64-channel tiles: conv3x3.hip; 128: conv3x3_cs.hip)."""
+    from multiposenet_amd import ops
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(77 + K + C)
+    N = 4
+    sizes = [(128, 128), (64, 64), (32, 32)]
+    pc = ops.PackedConv(dev((rs.randn(3, 3, C, K) / np.sqrt(9 * C)).astype(np.float32)), dtype)
+    dys = [dev(rnd(rs.randn(N, h, w, K), dtype), dtype) for h, w in sizes]
+    xs = [dev(rnd(rs.randn(N, h, w, C) * 1.5, dtype), dtype) for h, w in sizes]
+    bns = []
+    for j, _ in enumerate(sizes):
+        bn = ops.BNState(dev(torch.tensor(0.5 + rs.rand(C), dtype=torch.float32)), dev(torch.tensor(rs.randn(C), dtype=torch.float32)),
+                         torch.zeros(C, device="cuda"), torch.ones(C, device="cuda"), 1)
+        bn.scale.copy_(bn.gamma * (1.0 if j % 2 == 0 else -1.0)); bn.shift.copy_(bn.beta)
+        bns.append(bn)
+    outs = [torch.empty(N, h, w, C, device="cuda", dtype=dtype) for h, w in sizes]
+    parts = [torch.zeros(ops.conv_num_parts(N, h, w, 3) * 2 * C, device="cuda") for h, w in sizes]
+    rows = ops.conv_bwd_data_bn_grouped(dys, [pc.bwd] * 3, C, bns, xs, outs, parts)
+    for j in range(3):
+        o1, p1 = [torch.empty_like(outs[j])], [torch.zeros_like(parts[j])]
+        r1 = ops.conv_bwd_data_bn_grouped([dys[j]], [pc.bwd], C, [bns[j]], [xs[j]], o1, p1)
+        assert torch.equal(o1[0], outs[j]), (j, int((o1[0] != outs[j]).sum()))
+        sg = parts[j][:rows[j] * 2 * C].view(rows[j], 2, C).double().sum(0).cpu().numpy()
+        s1 = p1[0][:r1[0] * 2 * C].view(r1[0], 2, C).double().sum(0).cpu().numpy()
+        np.testing.assert_allclose(sg, s1, rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(128, 128), (128, 64)], ids=["128->128", "128->64"])
+def test_grouped_forward_when_a_block_walks_from_one_job_into_the_next(cuda, Cin, Cout):
+    """The same walk for the forward launches: each job has its own producer affine (the table a block stages its halo with changes with
+    the job) and its own statistics slab row per block. 336 tiles on 256 blocks; outputs bit for bit those of the jobs launched alone, the
+    slabs' totals to f32 rounding of the blocks' sums."""
+    from multiposenet_amd import ops
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(5 + Cin + Cout)
+    N = 4
+    sizes = [(128, 128), (64, 64), (32, 32)]
+    xs = [dev(rnd(rs.randn(N, h, w, Cin), dtype), dtype) for h, w in sizes]
+    pcs = [ops.PackedConv(dev((rs.randn(3, 3, Cin, Cout) / np.sqrt(9 * Cin)).astype(np.float32)), dtype) for _ in sizes]
+    affs = [ops.Affine(dev(torch.tensor((0.5 + rs.rand(Cin)) * (1.0 if j % 2 == 0 else -1.0), dtype=torch.float32)),
+                       dev(torch.tensor(rs.randn(Cin) * 0.5, dtype=torch.float32)), 1) for j in range(3)]
+    outs = [torch.empty(N, h, w, Cout, device="cuda", dtype=dtype) for h, w in sizes]
+    parts = [torch.zeros(ops.conv_num_parts(N, h, w, 3), 2, Cout, device="cuda") for h, w in sizes]
+    ops.conv_fwd_grouped(xs, [pc.fwd for pc in pcs], Cout, 3, affs, outs, parts)
+    for j, (h, w) in enumerate(sizes):
+        p1 = torch.zeros_like(parts[j])
+        want = ops.conv_fwd(xs[j], pcs[j].fwd, Cout, 3, affs[j], stats_part=p1)
+        assert torch.equal(want, outs[j]), (j, int((want != outs[j]).sum()))
+        rows = ops.conv_stats_rows(N, h, w, Cin, Cout, 3, dtype)
+        np.testing.assert_allclose(parts[j][:rows].double().sum(0).cpu().numpy(), p1[:rows].double().sum(0).cpu().numpy(), rtol=1e-5, atol=1e-2)
