@@ -24,6 +24,7 @@
 // pair adds its two partial accumulators through LDS (each wave hands over the half of the rows it will not finish: 8 KB per
 // wave, one block barrier) and finishes 32 pixels x 64 channels each.
 #include "conv3x3.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -695,6 +696,10 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
         if (begin > cus) begin = cus - cus % n_tiles;
         MPN_REQUIRE(begin > 0, MPN_ERR_BAD_SHAPE, "conv3x3: %d channel tiles on %d compute units", n_tiles, cus);
     }
+#ifdef MPN_DIAG
+    // diagnostic builds only: fewer persistent blocks than compute units (what the clock does when part of the chip multiplies)
+    if (const char* e = getenv("MPN_DIAG_C3_BLOCKS")) { const int cap = atoi(e); if (cap > 0 && cap < begin) begin = cap; }
+#endif
     const bool bnr = jobs[0].bnr_x != nullptr;
     for (int j = 0; j < njobs; ++j) {
         MPN_REQUIRE((jobs[j].bnr_x != nullptr) == bnr, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the fused-reduction variant");

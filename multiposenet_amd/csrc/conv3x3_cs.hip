@@ -13,13 +13,15 @@
 //     h, h - 1, h - 2 at ky = 0, 1, 2 - 18 fragment reads per 48 MFMAs, streamed through a ring of six - and the weight image in
 //     global memory is the one conv3x3.hip streams by LDS-DMA (its 64-byte rows of one output channel: a wave's fragment (ky, its
 //     16 channels) is one contiguous KB of it), so mpn_conv_pack_weights is unchanged.
-//   * 48 KB of LDS are free: the tile leaves through ONE block-wide bf16 image [256 px][128 co] (the released halo buffer + a spare
-//     region between the two halo buffers), written from the accumulators (a lane holds 4 channels of one pixel), read back by
-//     transposing reads for the batch-norm statistics (ones x F, F^T x F on the matrix unit, as before) and as whole 256-byte pixel
-//     rows for the stores: every store instruction writes four complete pixels.
+//   * the tile leaves through ONE block-wide bf16 image [256 px][128 co] OF ITS OWN (nothing aliases: both halo images are unpadded
+//     128-byte pixel rows with XOR-swizzled 16-byte slots, so two of them, the image and the tables fit the CU's 160 KB), written
+//     from the accumulators by each wave as it finishes its last stage - no barrier in front, the chunk's barrier behind - read
+//     back by transposing reads for the batch-norm statistics (ones x F, F^T x F on the matrix unit: a wave sums ITS 16 channels
+//     over all 256 pixels in the accumulator of one MFMA chain) and as whole 256-byte pixel rows for the stores: every store
+//     instruction writes four complete pixels.
 // A stand-alone model of this stage (tools/stage2_ceiling.hip, profiles/r05_stage2_ceiling.txt) runs at 0.65 of the nominal MFMA
 // peak WITH the halo staging work, where the model of conv3x3.hip's stage reaches 0.66 without it.
-// LDS: [halo 0: 51 840][spare 17 792][halo 1: 51 840][statistics 8 192][scale / shift table 4 096] = 133 760 bytes.
+// LDS: [halo 0: 41 472][halo 1: 41 472][image 65 536][statistics 8 960][scale / shift table 4 096][apply-on-load table 2 048] = 163 648 bytes.
 #include "conv3x3.h"
 
 namespace {
@@ -35,13 +37,18 @@ template <typename V> __device__ __forceinline__ void lds_st(lds_p p, const V& v
 
 constexpr int kHW = 18;                      // halo width = height
 constexpr int kNPix = kHW * kHW;             // 324
-constexpr int kRS = 160;                     // LDS bytes per halo pixel: 128 bytes of K + 32 of padding (conflict-free ds_read_b128)
-constexpr int kABytes = kNPix * kRS;         // 51 840
-constexpr int kRSO = 272;                    // output image: bytes per pixel (256 + 16)
-constexpr int kImg = 256 * kRSO;             // 69 632
-constexpr int kSpare = kImg - kABytes;       // 17 792
-constexpr int kHaloArea = 2 * kABytes + kSpare;   // [halo 0][spare][halo 1]; the image of a tile = the released buffer + the spare
-constexpr int kRedBytes = (8 * 2 * 128 + 192) * (int)sizeof(float);   // [8 waves][2][128] + 192 dummy words (lanes off the Gram diagonal: 2048 + lane + 16 nt)
+// Halo image: 128 bytes per pixel (the chunk's 64 channels), NO padding; the eight 16-byte slots of pixel (hy, hx) are stored at slot ^ (hx & 7).
+// A fragment read (16 pixels of one halo row x 32 channels: lane (l15, lq) reads slot 4 ks + lq of pixel l15 + kx) then puts each of
+// ds_read_b128's 16-lane groups ({0-3, 12-15, 20-27}, ...: 8 pixels distinct mod 8 at lq, the other 8 at lq ^ 1) on 16 distinct slots
+// of the 256-byte bank row: conflict-free without the 32 bytes of padding per pixel the first version carried.
+constexpr int kRS = 128;
+constexpr int kABytes = kNPix * kRS;         // 41 472
+// Output image: 256 bytes per pixel, the sixteen 16-byte slots of pixel px stored at slot ^ (px & 15)
+constexpr int kRSO = 256;
+constexpr int kImg = 256 * kRSO;             // 65 536
+constexpr int kImgOff = 2 * kABytes;
+constexpr int kHaloArea = 2 * kABytes + kImg;     // [halo 0][halo 1][image]
+constexpr int kRedBytes = (8 * 2 * 128 + 192) * (int)sizeof(float);   // BNR: [8 waves][2][128]; statistics: [2 tiles][2][128]; + 192 dummy words (lanes off the Gram diagonal)
 constexpr int kMaxCin = 512;
 constexpr int kTabBytes = 2 * kMaxCin * (int)sizeof(float);
 #ifdef MPN_DIAG
@@ -49,19 +56,19 @@ constexpr int kDiagBytes = 8 * 32 * 8;       // per-wave stamps (below)
 #else
 constexpr int kDiagBytes = 0;
 #endif
-constexpr int kGaBytes = 4 * kMaxCin * (int)sizeof(float);   // apply on load: [4][kMaxCin] sc, sh, cb, cc of the batch-norm whose gradient is formed
+constexpr int kGaCin = 128;                  // apply on load: at most this many input channels (the subnet's / FPN's stages, final_bn)
+constexpr int kGaBytes = 4 * kGaCin * (int)sizeof(float);    // [4][kGaCin] sc, sh, cb, cc of the batch-norm whose gradient is formed
 constexpr int kProgBytes = 64;               // per wave: the number of stages it has started (priority feedback, below)
-constexpr int kLds = kHaloArea + kRedBytes + kTabBytes + kGaBytes + kProgBytes + kDiagBytes;
+constexpr int kLds = kHaloArea + kRedBytes + kTabBytes + kGaBytes + kProgBytes;     // (a diagnostic build keeps its stamps in the apply-on-load table)
+static_assert(kDiagBytes <= kGaBytes, "stamps");
 constexpr int kAVec = 6;                     // 16-byte pieces of a halo image per thread
 #ifndef MPN_C3_RING
 #define MPN_C3_RING 6
 #endif
 constexpr int kRingDefault = MPN_C3_RING;              // halo fragments in flight
 static_assert(kLds <= 160 * 1024, "LDS budget");
-static_assert(kSpare >= 0 && kHaloArea - kImg == kABytes, "the image over halo buffer 1 starts where halo buffer 0 ends");
 
-__device__ __forceinline__ int halo_off(int buf) { return buf ? kABytes + kSpare : 0; }
-__device__ __forceinline__ int image_off(int buf) { return buf ? kABytes : 0; }
+__device__ __forceinline__ int halo_off(int buf) { return buf ? kABytes : 0; }
 
 // diagnostic build (tools/stamp_c3cs.py; never in the shipped library): per WAVE, s_memtime of the block's THIRD tile at the loop top
 // (0), behind each chunk's barrier (1..8), behind the image's barrier (9); 10 = behind the barrier that ends the PREVIOUS tile's
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     const lds_f gat = (lds_f)(L + kHaloArea + kRedBytes + kTabBytes);     // GA: [4][kMaxCin] sc, sh, cb, cc of the job in `ga_job`
 
 #ifdef MPN_DIAG
-    LDS unsigned long long* wst = (LDS unsigned long long*)(L + kHaloArea + kRedBytes + kTabBytes + kGaBytes + kProgBytes);
+    LDS unsigned long long* wst = (LDS unsigned long long*)(L + kHaloArea + kRedBytes + kTabBytes);
     if (threadIdx.x < 256) wst[threadIdx.x] = 0;
     int titer = 0;
 #endif
@@ -152,7 +159,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     const long long wtile = 9ll * Cin * 128 * 2;
 
     // per-lane fragment bases; everything added later is a compile-time or wave-uniform offset
-    const lds_p abase = L + l15 * kRS + lq * 16;
+    // (byte offsets inside a halo buffer, one per kernel column kx: pixel c = l15 + kx of a halo row, slot (4 ks + lq) ^ (c & 7); the
+    //  k-step toggles bit 6: base ^ 64)
+    int abase_kx[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const int c = l15 + kx;
+        abase_kx[kx] = c * kRS + ((lq ^ (c & 3)) << 4) + (((c >> 2) & 1) << 6);
+    }
     // a wave's weight fragment (ky, channels 16 wave .. + 15) inside a stage of the packed image [ky 3][co 128][64 bytes]: rows of
     // 64 bytes = 32 input channels, their four 16-byte slots swizzled with swz(co) (the LDS image of conv3x3.hip)
     const unsigned lane_w = (unsigned)(wave * 1024 + l15 * 64 + ((lq ^ swz(l15)) << 4));
@@ -196,9 +210,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             const Job& p = g.job[job];
             for (int i = tid; i < Cin; i += kThreads) {
                 const float ss = p.ap_scale[i], hh = p.ap_shift[i], mm = p.ap_mean[i], ii = p.ap_invstd[i], aa = p.ap_k1[i], bb = p.ap_k2[i];
-                gat[i] = ss; gat[kMaxCin + i] = hh;
-                gat[2 * kMaxCin + i] = -ss * bb * ii;
-                gat[3 * kMaxCin + i] = -ss * (aa - mm * ii * bb);
+                gat[i] = ss; gat[kGaCin + i] = hh;
+                gat[2 * kGaCin + i] = -ss * bb * ii;
+                gat[3 * kGaCin + i] = -ss * (aa - mm * ii * bb);
             }
         }
         ga_job = job;
@@ -283,8 +297,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                 // (the coefficients of the two channels from the table at the use: four registers for two steps instead of 32 for a stage)
                 int toff = (chunk * 64 + slot * 8 + 2 * j) * 4;
                 asm volatile("" : "+v"(toff));
-                const f32x2_t sc2 = lds_ld<f32x2_t>((lds_p)gat + toff), sh2 = lds_ld<f32x2_t>((lds_p)gat + toff + kMaxCin * 4);
-                const f32x2_t cb2 = lds_ld<f32x2_t>((lds_p)gat + toff + 2 * kMaxCin * 4), cc2 = lds_ld<f32x2_t>((lds_p)gat + toff + 3 * kMaxCin * 4);
+                const f32x2_t sc2 = lds_ld<f32x2_t>((lds_p)gat + toff), sh2 = lds_ld<f32x2_t>((lds_p)gat + toff + kGaCin * 4);
+                const f32x2_t cb2 = lds_ld<f32x2_t>((lds_p)gat + toff + 2 * kGaCin * 4), cc2 = lds_ld<f32x2_t>((lds_p)gat + toff + 3 * kGaCin * 4);
                 const f32x2_t gg = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
                 const f32x2_t yy = {__uint_as_float(uy << 16), __uint_as_float(uy & 0xffff0000u)};
                 const f32x2_t pre = __builtin_elementwise_fma(yy, sc2, sh2);
@@ -317,7 +331,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             if (j == 0) av[i].raw.x = u; else if (j == 1) av[i].raw.y = u; else if (j == 2) av[i].raw.z = u; else av[i].raw.w = u;
         } else {
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-            lds_st<u32x4_t>(L + halo_off(buf) + q54 * kRS + slot * 16 + i * (54 * kRS), (u32x4_t){av[i].raw.x, av[i].raw.y, av[i].raw.z, av[i].raw.w});
+            // (pixels q54 + 54 i share the column qx: the swizzle is a constant of the thread)
+            lds_st<u32x4_t>(L + halo_off(buf) + q54 * kRS + ((slot ^ (qx & 7)) << 4) + i * (54 * kRS), (u32x4_t){av[i].raw.x, av[i].raw.y, av[i].raw.z, av[i].raw.w});
             if constexpr (GA) {
                 // the formed gradient of the tile's interior pixels (halo row / column 1..16) for the weight gradient: every pixel of the
                 // tensor is some tile's interior exactly once (the redundant copies of threads 432..511 write the same bytes)
@@ -331,13 +346,19 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     // Statistics: a block SUMS the rows of its tiles of one job (threads 0..255: one of the two sums, one channel; f32, in the order of
     // its walk) and writes them once, behind its last tile of that job: one slab row per block (mpn_conv_stats_rows).
     float* st_dst = nullptr;
+    int e_par = 0;             // which half of `red` the waiting tile's sums go to (0 / 256 words, alternating: a block reads the sums of
+                               // tile t behind a barrier while faster waves may already write those of tile t + 1)
     float st_acc = 0.f;
     bool st_pending = false, st_store = false;
     const int st_which = (tid >> 7) & 1, st_c = tid & 127;
     auto stats_flush = [&]() {
         if (st_pending) {
-            const lds_f r = red + st_which * 128 + st_c;    // red [8 waves][2][128], fixed order
-            st_acc += ((r[0] + r[256]) + (r[512] + r[768])) + ((r[1024] + r[1280]) + (r[1536] + r[1792]));
+            if constexpr (BNR) {
+                const lds_f r = red + st_which * 128 + st_c;    // red [8 waves][2][128], fixed order
+                st_acc += ((r[0] + r[256]) + (r[512] + r[768])) + ((r[1024] + r[1280]) + (r[1536] + r[1792]));
+            } else {
+                st_acc += red[e_par + st_which * 128 + st_c];   // red [2 tiles][2][128]: the tile's sums over its 256 pixels
+            }
             if (st_store) { *st_dst = st_acc; st_acc = 0.f; }
         }
         st_pending = false;
@@ -347,9 +368,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     // tile's first chunk does not read, and is released - one block barrier - before the commits of that chunk's stages 3..5 write
     // there): the state of the tile whose image is waiting
     // (a block's FIRST tile runs the same stages over an image that does not exist yet: prev_real = false masks its stores)
-    Tile prev = {};
     bool prev_real = false;
-    int prev_img = 0;
     // everything its stores need, as scalars fixed when the image was written (a job field read inside a stage is an s_load whose
     // wait - lgkmcnt(0) - also drains the fragment reads in flight: 250-300 cycles per store in the first version):
     // the tile's first output element, bytes per image row / per pixel, rows and columns of the tile inside the image
@@ -358,13 +377,19 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     const unsigned char* e_bx = nullptr;       // BNR: the same for the raw tensor of the fed batch-norm
     int e_bx_rowb = 0, e_bx_pxb = 0, e_bx_hmax = 0, e_bx_wmax = 0, e_ntile = 0;
     float e_blo = 0.f, e_bhi = 0.f;
-    // wave `wave` finishes pixels 32 wave .. + 31 (output rows 2 wave, 2 wave + 1), all 128 channels.
+    // Statistics: wave `wave` sums ITS 16 channels over all 256 pixels, 32 pixels per MFMA pair.
     // transposing reads (ds_read_b64_tr_b16): lane 4q+pp of a 16-lane group supplies the address of block row q, channels 4pp..4pp+3;
-    // lane group lq covers pixels {2 (lq >> 1) + 16 (lq & 1) + 4 q + {0, 1}}: 8 of the 32 (the k order of a sum is free)
-    const int t_off = (wave * 32 + (lq >> 1) * 2 + 4 * ((lq & 1) * 4 + (l15 >> 2))) * kRSO + (4 * (l15 & 3)) * 2;
-    const int piece = lane & 15, prow = lane >> 4;       // copy-out lanes: 16-byte piece of pixel rows prow + 4 k of the wave's 32
-    const int c_off = (wave * 32 + prow) * kRSO + piece * 16;
-    const int red_s = wave * 256 + l15, red_q = (lq == (l15 >> 2)) ? wave * 256 + 128 + l15 : 2048 + lane;   // (+ nt * 16; the dummy words: 2048..2223)
+    // lane group lq covers pixels 2 (4 lq + q) + {0, 1} of a 32-pixel group (the k order of a sum is free; the eight pixels of a
+    // 32-lane half differ in bits 1..3: with the image's swizzle their 8-byte pieces cover the 256-byte bank row once)
+    const int tP = 2 * (lq * 4 + (l15 >> 2));
+    const int t_lo = kImgOff + tP * kRSO + (((wave * 2 + ((l15 & 3) >> 1)) ^ (tP & 15)) << 4) + (l15 & 1) * 8;
+    const int t_hi = kImgOff + (tP + 1) * kRSO + (((wave * 2 + ((l15 & 3) >> 1)) ^ ((tP + 1) & 15)) << 4) + (l15 & 1) * 8;
+    // Copy-out: wave `wave` stores pixels 32 wave .. + 31 (output rows 2 wave, 2 wave + 1), all 128 channels: lane = 16-byte piece
+    // `piece` of pixels prow + 4 k, k = 0..7; its slot piece ^ (px & 15) = (piece ^ prow) ^ 4 (k & 3): bits 6, 7 of the byte offset
+    const int piece = lane & 15, prow = lane >> 4;
+    const int c_off = kImgOff + (wave * 32 + prow) * kRSO + ((piece ^ prow) << 4);
+    const int red_s = wave * 16 + l15, red_q = (lq == (l15 >> 2)) ? 128 + wave * 16 + l15 : 2048 + lane;   // (+ e_par; the dummy words: 2048..2111)
+    f32x4_t st_sa = {0.f, 0.f, 0.f, 0.f}, st_ga = {0.f, 0.f, 0.f, 0.f};
     X8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = 1.0f;
@@ -399,23 +424,24 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     // odd h; BNR: the raw tensor of the fed batch-norm at the first copy-out positions); sl = 1, 2: the copy-out of pixel rows
     // prow + 4 k, k = 4 (sl - 1) .. + 3 (LDS reads at h = 0..3, stores at h = 6, 8, 10, 12); BNR: the sums at the end of sl = 2
     auto e2_step = [&](const int sl, const int h) __attribute__((always_inline)) {
-        const lds_p im = L + prev_img;
         if constexpr (STATS) {
             if (sl == 0 && h < 16) {
-                const int nt = h >> 1;
+                const int pg = h >> 1;       // pixels 32 pg .. + 31
                 if ((h & 1) == 0) {
-                    tlo = tr_read_lds(im + t_off + nt * 32);
-                    thi = tr_read_lds(im + t_off + kRSO + nt * 32);
+                    tlo = tr_read_lds(L + t_lo + pg * (32 * kRSO));
+                    thi = tr_read_lds(L + t_hi + pg * (32 * kRSO));
                 } else {
                     const X8 f = __builtin_shufflevector(tlo, thi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    const f32x4_t sa = H::mfma(ones, f, (f32x4_t){0.f, 0.f, 0.f, 0.f});
-                    const f32x4_t ga = H::mfma(f, f, (f32x4_t){0.f, 0.f, 0.f, 0.f});
-                    // the Gram diagonal sits in element l15 & 3 of the lanes lq == l15 >> 2: picked by a 0 / 1 weight per element (exact:
-                    // the others add + 0; written as a select chain hipcc made three branches of it)
-                    const float q = __builtin_fmaf(ga[3], dsel[3], __builtin_fmaf(ga[2], dsel[2], __builtin_fmaf(ga[1], dsel[1], ga[0] * dsel[0])));
-                    red[red_s + nt * 16] = sa[0];        // (every row of ones x F is the column sum: the four lane groups write the same value)
-                    red[red_q + nt * 16] = q;            // (the Gram diagonal; the other lanes into the dummy words)
+                    st_sa = H::mfma(ones, f, pg == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : st_sa);
+                    st_ga = H::mfma(f, f, pg == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : st_ga);
                 }
+            }
+            if (sl == 0 && h == 17) {
+                // the Gram diagonal sits in element l15 & 3 of the lanes lq == l15 >> 2: picked by a 0 / 1 weight per element (exact:
+                // the others add + 0; written as a select chain hipcc made three branches of it)
+                const float q = __builtin_fmaf(st_ga[3], dsel[3], __builtin_fmaf(st_ga[2], dsel[2], __builtin_fmaf(st_ga[1], dsel[1], st_ga[0] * dsel[0])));
+                red[e_par + red_s] = st_sa[0];       // (every row of ones x F is the column sum: the four lane groups write the same value)
+                red[(lq == (l15 >> 2) ? e_par : 0) + red_q] = q;     // (the Gram diagonal; the other lanes into the dummy words)
             }
         }
         if constexpr (BNR) {
@@ -433,7 +459,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             if (h >= 1 && h <= 10 && (h - 1) % 3 == 0) {
                 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
                 const int kr = (h - 1) / 3;
-                const u32x4_t v = lds_ld<u32x4_t>(im + c_off + (4 * (half * 4 + kr)) * kRSO);
+                const u32x4_t v = lds_ld<u32x4_t>(L + (c_off ^ (kr * 64)) + (4 * (half * 4 + kr)) * kRSO);
                 co[kr & 1] = make_uint4(v[0], v[1], v[2], v[3]);
             }
             if constexpr (BNR) {
@@ -502,7 +528,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     };
 
     Tile cur = tile_of<false>(g, w);
-    prev = cur;
     if constexpr (BNR) { e_bx = reinterpret_cast<const unsigned char*>(g.job[cur.job].bnr_x); }     // (a block's first tile: loads that nothing uses, from a valid address)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
 #ifndef MPN_C3_BD
@@ -545,7 +570,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         // (the weight pointers by value: captured by reference they stayed in scratch memory, one flat load + vmcnt(0) per stage)
         auto chunk_body = [&](const int chunk, const unsigned char* const ws, const unsigned char* const ws_next, auto epi_tag, auto first_tag) __attribute__((always_inline)) {
             constexpr bool EPI = decltype(epi_tag)::value, FIRST = decltype(first_tag)::value;     // FIRST: the tile's first chunk
-            const lds_p ab = abase + halo_off(cc & 1);
+            const lds_p hb = L + halo_off(cc & 1);
             const bool last_chunk = chunk + 1 == nchunk;
             // the image to prepare under this chunk: the tile's next chunk, or the first chunk of the next tile (without a next tile
             // this tile's first chunk once more, never read: the staging stays unconditional)
@@ -568,14 +593,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             }
 #pragma unroll
             for (int sl = 0; sl < 6; ++sl) {
-                const int a_off = (sl >> 1) * kRS + (sl & 1) * 64;
+                const lds_p ab = hb + (abase_kx[sl >> 1] ^ ((sl & 1) * 64));
                 // the next stage's weight fragments (of this tile, or the first ones of the next tile) into the other register set
                 if (sl + BD < 6) b_load(b[(sl + BD) % (BD + 1)], ws, (chunk * 6 + sl + BD) * kStageBytes);
                 else b_load(b[(sl + BD) % (BD + 1)], last_chunk ? ws_next : ws, last_chunk ? (sl + BD - 6) * kStageBytes : (chunk * 6 + sl + BD) * kStageBytes);
                 if (sl == 0) a_load(st_tile, st_chunk);
                 X8 a[18];
 #pragma unroll
-                for (int h = 0; h < kRing; ++h) a[h] = lds_ld<X8>(ab + a_off + h * (kHW * kRS));
+                for (int h = 0; h < kRing; ++h) a[h] = lds_ld<X8>(ab + h * (kHW * kRS));
                 if (sl == 3) tab_read(st_chunk);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -586,7 +611,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                         if (r >= 0 && r < 16)       // D^T = W^T x A^T
                             acc[r] = H::mfma(b[sl % (BD + 1)][ky], a[h], (FIRST && sl == 0 && ky == 0) ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : acc[r]);
                     }
-                    if (h + kRing < 18) a[h + kRing] = lds_ld<X8>(ab + a_off + (h + kRing) * (kHW * kRS));
+                    if (h + kRing < 18) a[h + kRing] = lds_ld<X8>(ab + (h + kRing) * (kHW * kRS));
                     if (sl >= 3) {
                         // pieces 2 (sl - 3) at h = 1..5 and 2 (sl - 3) + 1 at h = 9..13
                         if (h >= 1 && h <= 5) commit_step(2 * (sl - 3), h - 1, (cc + 1) & 1, st_chunk);
@@ -611,69 +636,77 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 CS_STAMP(16 + (chunk < 1 ? chunk : 1) * 6 + sl);
-                if (EPI && sl == 2) {
-                    // every wave has read the waiting image and written its sums: the commits of stages 3..5 may write there
+                if (EPI && sl == 2 && last_chunk) {
+                    // (a one-chunk tile writes ITS image at the end of this chunk: every wave must have read the waiting one first)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     CS_STAMP(10);
                     e2_done(cur.job);
                 }
             }
-            // the chunk's barrier: every wave has read this halo image for the last time and committed its pieces of the next one
+            if (last_chunk) {
+                // ================= tile `cur` into its image, by every wave as it finishes - no barrier in front (the image is nobody's
+                // alias; the tile before it was read under this tile's FIRST chunk, a barrier ago), the chunk's barrier behind.
+                // Output row r, pixel l15, this wave's channels lq * 4 .. + 3; slot (2 wave + lq / 2) ^ l15 of the pixel's sixteen.
+                // Pixels outside the image must not count in the statistics: zeroed on edge tiles.
+                const Job& p = g.job[cur.job];
+                const bool full_tile = cur.oy0 + 16 <= p.H && cur.ox0 + 16 <= p.W;
+                const lds_p iw = L + kImgOff + l15 * kRSO + (((wave * 2 + (lq >> 1)) ^ l15) << 4) + (lq & 1) * 8;
+                if (full_tile) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(acc[r]));
+                } else {
+                    const bool okx = cur.ox0 + l15 < p.W;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = okx && cur.oy0 + r < p.H;
+                        lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(ok ? acc[r] : (f32x4_t){0.f, 0.f, 0.f, 0.f}));
+                    }
+                }
+                prev_real = true;
+                e_par ^= 256;
+                {
+                    const int wys = p.W * p.ys;
+                    e_y = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(p.y) + ((long long)cur.img * p.H + cur.oy0) * wys + (long long)cur.ox0 * p.ys + cur.ntile * 128);
+                    e_rowb = wys * 2; e_pxb = p.ys * 2; e_h = p.H - cur.oy0; e_w = p.W - cur.ox0; e_ntile = cur.ntile;
+                    if constexpr (BNR) {
+                        const int wbs = p.W * p.bnr_xs;
+                        e_bx = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.bnr_x) + ((long long)cur.img * p.H + cur.oy0) * wbs + (long long)cur.ox0 * p.bnr_xs + cur.ntile * 128);
+                        e_bx_rowb = wbs * 2; e_bx_pxb = p.bnr_xs * 2; e_bx_hmax = p.H - 1 - cur.oy0; e_bx_wmax = p.W - 1 - cur.ox0;
+                        e_blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
+                        e_bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
+                    }
+                }
+                if (STATS || BNR) {
+                    // the block's row of this job's slab: row = the position of the block's FIRST tile of the job among the job's first
+                    // gridDim.x tiles (mpn_conv_stats_rows; the grid is a multiple of n_tiles, so a block keeps its channel tile within a job)
+                    const int n_tiles = Cout >> 7, grid = (int)gridDim.x;
+                    int off = (w_first - g.begin[cur.job]) % grid;
+                    if (off < 0) off += grid;
+                    st_pending = tid < 256;
+                    st_store = !has_next || nxt.job != cur.job;
+                    st_dst = p.stats_part + ((long long)(off / n_tiles) * 2 + st_which) * Cout + cur.ntile * 128 + st_c;
+                }
+                CS_STAMP(9);
+            }
+            // the chunk's barrier: every wave has read this halo image for the last time and committed its pieces of the next one;
+            // behind a tile's last chunk its image is complete
             // (raw: only LDS traffic is ordered - the weight fragments in flight and the tile's output stores stay in flight)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             CS_STAMP(1 + (chunk < 7 ? chunk : 7));
             ++cc;
+            if (EPI && !last_chunk) {
+                // every wave has read the waiting image and written its sums
+                CS_STAMP(10);
+                e2_done(cur.job);
+            }
         };
         if constexpr (PIPE) chunk_body(0, wsrc, wsrc_next, std::true_type{}, std::true_type{});
         else chunk_body(0, wsrc, wsrc_next, std::false_type{}, std::true_type{});
         for (int chunk = 1; chunk < nchunk; ++chunk) chunk_body(chunk, wsrc, wsrc_next, std::false_type{}, std::false_type{});
 
-        // ================= tile `cur` into its image. Halo buffer (cc - 1) & 1 is free (the barrier above); the other one holds the
-        // next tile's first chunk. The image [256 px][kRSO] lies over the free buffer and the spare region: output row r, pixel l15,
-        // this wave's channels lq * 4 .. + 3. Pixels outside the image must not count in the statistics: zeroed on edge tiles.
         {
-            const Job& p = g.job[cur.job];
-            const bool full_tile = cur.oy0 + 16 <= p.H && cur.ox0 + 16 <= p.W;
-            const lds_p iw = L + image_off((cc - 1) & 1) + l15 * kRSO + wave * 32 + lq * 8;
-            if (full_tile) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(acc[r]));
-            } else {
-                const bool okx = cur.ox0 + l15 < p.W;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = okx && cur.oy0 + r < p.H;
-                    lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(ok ? acc[r] : (f32x4_t){0.f, 0.f, 0.f, 0.f}));
-                }
-            }
-            prev = cur; prev_real = true; prev_img = image_off((cc - 1) & 1);
-            {
-                const int wys = p.W * p.ys;
-                e_y = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(p.y) + ((long long)cur.img * p.H + cur.oy0) * wys + (long long)cur.ox0 * p.ys + cur.ntile * 128);
-                e_rowb = wys * 2; e_pxb = p.ys * 2; e_h = p.H - cur.oy0; e_w = p.W - cur.ox0; e_ntile = cur.ntile;
-                if constexpr (BNR) {
-                    const int wbs = p.W * p.bnr_xs;
-                    e_bx = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.bnr_x) + ((long long)cur.img * p.H + cur.oy0) * wbs + (long long)cur.ox0 * p.bnr_xs + cur.ntile * 128);
-                    e_bx_rowb = wbs * 2; e_bx_pxb = p.bnr_xs * 2; e_bx_hmax = p.H - 1 - cur.oy0; e_bx_wmax = p.W - 1 - cur.ox0;
-                    e_blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
-                    e_bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
-                }
-            }
-            if (STATS || BNR) {
-                // the block's row of this job's slab: row = the position of the block's FIRST tile of the job among the job's first
-                // gridDim.x tiles (mpn_conv_stats_rows; the grid is a multiple of n_tiles, so a block keeps its channel tile within a job)
-                const int n_tiles = Cout >> 7, grid = (int)gridDim.x;
-                int off = (w_first - g.begin[cur.job]) % grid;
-                if (off < 0) off += grid;
-                st_pending = tid < 256;
-                st_store = !has_next || nxt.job != cur.job;
-                st_dst = p.stats_part + ((long long)(off / n_tiles) * 2 + st_which) * Cout + cur.ntile * 128 + st_c;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            CS_STAMP(9);
             if constexpr (!PIPE) {
 #pragma unroll
                 for (int sl = 0; sl < 3; ++sl)
@@ -742,6 +775,7 @@ int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, hipS
         const Job& q = g.job[j];
         MPN_REQUIRE((q.ap_y != nullptr) == ga, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the apply-on-load variant");
         if (!ga) continue;
+        MPN_REQUIRE(q.Cin <= kGaCin, MPN_ERR_BAD_SHAPE, "conv3x3: apply on load: at most %d input channels", kGaCin);
         MPN_REQUIRE(!affine && dtype == MPN_BF16 && q.ap_dy && q.ap_scale && q.ap_shift && q.ap_mean && q.ap_invstd && q.ap_k1 && q.ap_k2 &&
                         mpn_aligned16(q.ap_y) && mpn_aligned16(q.ap_dy) && q.ap_ys >= q.Cin && q.ap_dys >= q.Cin && q.ap_ys % 8 == 0 && q.ap_dys % 8 == 0,
                     MPN_ERR_BAD_ARG, "conv3x3: apply on load needs a bf16 data gradient (no producer affine), the raw output, the formed gradient's buffer and the batch-norm's six vectors");

@@ -26,22 +26,30 @@ lib.mpn_diag_set_conv_stamps(None)
 d = dbg.cpu().numpy().reshape(256, 8, 32).astype(np.float64)
 d = d[d[:, 0, 0] > 0]
 nch = Cin // 64
-cols = [0, 10] + [1 + min(c, 7) for c in range(nch)] + [9]
-names = ["stages0-2+epi"] + ["chunk%d(rest)" % c for c in range(nch)] + ["image+barrier"]
+# stamps (conv3x3_cs.hip): 0 loop top; 16..21 ends of the first chunk's stages; 1 + c behind chunk c's barrier; 22..27 ends of the last
+# chunk's stages (nch > 1); 9 behind the image writes of the tile (in front of the last chunk's barrier)
+if nch == 1:
+    cols, names = [0, 21, 9, 1], ["stages+epi", "image", "barrier"]
+else:
+    cols = [0, 21, 1] + ([nch - 1] if nch > 2 else []) + [27, 9, nch]
+    names = ["chunk0 stages+epi", "barrier"] + (["middle chunks"] if nch > 2 else []) + ["last chunk", "image", "barrier"]
 ph = np.diff(d[:, :, cols], axis=2)          # [block][wave][phase]
 print("blocks with a third tile:", len(d), " block lifetime us: mean %.1f" % ((d[:, 0, 13] - d[:, 0, 12]).mean() / 100))
 print("phase cycles, mean over blocks, per wave (rows = waves 0..7):")
-print("   " + "  ".join("%14s" % n for n in names))
+print("   " + "  ".join("%18s" % n for n in names))
 for wv in range(8):
-    print("w%d " % wv + "  ".join("%14.0f" % v for v in ph[:, wv, :].mean(0)))
-print("tile total (wave 0): %.0f cycles; MFMA cycles per SIMD and tile: %d" % ((d[:, 0, 9] - d[:, 0, 0]).mean(), 2 * 16 * 16 * 9 * Cin // 32))
+    print("w%d " % wv + "  ".join("%18.0f" % v for v in ph[:, wv, :].mean(0)))
+print("tile total (wave 0): %.0f cycles; MFMA cycles per SIMD and tile: %d" % ((d[:, 0, nch] - d[:, 0, 0]).mean(), 2 * 16 * 16 * 9 * Cin // 32))
+tiles_per_block = N * ((H + 15) // 16) ** 2 * (Cout // 128) / len(d)
+print("blocks %d, tiles per block %.1f: clock estimate %.3f GHz (tile cycles x tiles per block / block lifetime)" % (
+    len(d), tiles_per_block, (d[:, 0, nch] - d[:, 0, 0]).mean() * tiles_per_block / ((d[:, 0, 13] - d[:, 0, 12]).mean() * 10)))
 
 st = [0] + [16 + i for i in range(6)]
 print("first chunk, per stage (loop top -> end of stage 0, ... stage 5), waves 0 and 4:")
 for wv in (0, 4):
     print("w%d " % wv + "  ".join("%8.0f" % v for v in np.diff(d[:, wv, st], axis=1).mean(0)))
 if nch > 1:
-    st = [1] + [22 + i for i in range(6)]
-    print("second chunk, per stage:")
+    st = [nch - 1] + [22 + i for i in range(6)]
+    print("last chunk, per stage:")
     for wv in (0, 4):
         print("w%d " % wv + "  ".join("%8.0f" % v for v in np.diff(d[:, wv, st], axis=1).mean(0)))
