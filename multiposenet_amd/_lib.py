@@ -209,7 +209,19 @@ class tagged:
         _TAG = self.prev
 
 
+# MPN_TRACE_CALLS=1 (debugging a device fault): every entry point is named on stderr BEFORE it launches and the device is
+# synchronised behind it, so the last name printed is the launch that faulted. Not for captured streams.
+TRACE_CALLS = os.environ.get("MPN_TRACE_CALLS", "0") == "1"
+
+
 def call(name, *args):
+    if TRACE_CALLS:
+        import sys
+        import torch
+        print(f"[mpn] {name}", file=sys.stderr, flush=True)
+        check(getattr(lib(), name)(*args))
+        torch.cuda.synchronize()
+        return
     if PROFILE is None:
         check(getattr(lib(), name)(*args))
         return

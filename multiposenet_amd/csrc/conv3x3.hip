@@ -24,7 +24,6 @@
 // pair adds its two partial accumulators through LDS (each wave hands over the half of the rows it will not finish: 8 KB per
 // wave, one block barrier) and finishes 32 pixels x 64 channels each.
 #include "conv3x3.h"
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -664,6 +663,11 @@ int launch_v(const Group& g, int blocks, bool affine, bool n64, bool bnr, hipStr
 
 }  // namespace
 
+#ifdef MPN_DIAG
+static int g_diag_block_cap = 0;
+extern "C" void mpn_diag_set_c3_blocks(int n) { g_diag_block_cap = n; }     // (tools/stamp_c3cs.py; never in the shipped library)
+#endif
+
 namespace mpn_c3 {
 
 int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
@@ -698,7 +702,7 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
     }
 #ifdef MPN_DIAG
     // diagnostic builds only: fewer persistent blocks than compute units (what the clock does when part of the chip multiplies)
-    if (const char* e = getenv("MPN_DIAG_C3_BLOCKS")) { const int cap = atoi(e); if (cap > 0 && cap < begin) begin = cap; }
+    if (g_diag_block_cap > 0 && g_diag_block_cap < begin) begin = g_diag_block_cap;
 #endif
     const bool bnr = jobs[0].bnr_x != nullptr;
     for (int j = 0; j < njobs; ++j) {

@@ -335,6 +335,11 @@ constexpr int kNmsThreads = 1024;
 struct NmsCand { float4 box; float score; int anchor; int pad0, pad1; };   // 32 bytes
 constexpr int kNmsLds = 4096;      // candidates kept in LDS (128 KB)
 
+__global__ void nms_reset_kernel(int* __restrict__ counts, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) counts[i] = 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void retina_candidates_kernel(const RetinaLevels lv, const float* __restrict__ cls_bias,
                                                                     const float* __restrict__ box_bias, const float* __restrict__ anchors,
@@ -382,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void retina_candidates_kernel(const Retin
         base = __shfl(base, leader, 64);
         if (live) {
             const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            cands[(long long)b * A + slot] = c;
+            if (slot < A) cands[(long long)b * A + slot] = c;      // (every anchor appends at most once: slot < A unless the counter was not reset)
         }
     }
 }
@@ -613,7 +618,10 @@ extern "C" int mpn_retina_nms(const void* const* logits, const void* const* boxe
     NmsCand* cands = reinterpret_cast<NmsCand*>(workspace);
     int* counts = reinterpret_cast<int*>(cands + (size_t)B * A);
     hipStream_t st = (hipStream_t)stream;
-    MPN_HIP(hipMemsetAsync(counts, 0, (size_t)B * sizeof(int), st));
+    // (a launch rather than hipMemsetAsync: inside a replayed hipGraph the memset node was seen to land AFTER the first appends of the
+    //  kernel behind it - a list that starts at the previous call's count runs past the workspace: a device fault, found in round 5)
+    nms_reset_kernel<<<(B + 63) / 64, 64, 0, st>>>(counts, B);
+    MPN_LAUNCH_CHECK();
     const dim3 grid((unsigned)((A + kThreads - 1) / kThreads), (unsigned)B);
     MPN_DISPATCH_DTYPE(dtype, (retina_candidates_kernel<T><<<grid, kThreads, 0, st>>>(lv, cls_bias, box_bias, anchors, A, score_threshold, cands, counts)));
     MPN_LAUNCH_CHECK();

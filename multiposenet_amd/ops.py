@@ -317,6 +317,17 @@ class BNState:
     def affine(self):
         return Affine(self.scale, self.shift, self.act)
 
+    def channel_slice(self, lo, hi):
+        """The layer of channels lo..hi-1 of a MERGED layer (two batch-norms whose variables lie side by side in the arenas and
+        whose inputs are channel slices of one tensor): every tensor of the result is a view of this state's."""
+        s = object.__new__(BNState)
+        s.C, s.act = hi - lo, self.act
+        for k in ("gamma", "beta", "moving_mean", "moving_var", "scale", "shift", "mean", "invstd", "k1", "k2"):
+            setattr(s, k, getattr(self, k)[lo:hi])
+        s.dgamma = self.dgamma[lo:hi] if self.dgamma is not None else None
+        s.dbeta = self.dbeta[lo:hi] if self.dbeta is not None else None
+        return s
+
 
 def bn_stats(x, part=None):
     M, C = x.numel() // x.shape[-1], x.shape[-1]

@@ -14,6 +14,7 @@ convolutions p6 / p7 are a gather (mpn_patchify3x3s2) + the 1x1 kernel. Image he
 """
 import ctypes
 import math
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -67,6 +68,21 @@ def head_variable_shapes(depth_multiplier=1.0):
 
 def _trainable(name):
     return not (name.endswith("moving_mean") or name.endswith("moving_variance"))
+
+
+_BN0 = tuple(f"{net}/batch_norm_0_for_level_" for net in ("box_net", "class_net"))
+
+
+def _arena_order(shapes):
+    """The arenas' order (an internal matter: checkpoints go by name): batch_norm_0 of the box tower and of the class tower lie side
+    by side, level by level and vector by vector - the two towers' first convolutions read the same tensor and run as ONE 128 -> 128
+    convolution (PersonDetectorNet.merge_tower0), whose batch-norm is then one 128-channel layer over adjacent variables."""
+    rest = OrderedDict((k, v) for k, v in shapes.items() if not k.startswith(_BN0))
+    for l in LEVELS:
+        for kind in ("gamma", "beta", "moving_mean", "moving_variance"):
+            for pre in _BN0:
+                rest[f"{pre}{l}/{kind}"] = shapes[f"{pre}{l}/{kind}"]
+    return rest
 
 
 def initial_head_values(seed=0, depth_multiplier=1.0):
@@ -142,7 +158,35 @@ class _Conv:
             self.pad[..., :self.w.shape[3]].copy_(self.w)
 
     def repack(self):
+        if getattr(self, "packed_unused", False):
+            return
         self.refresh_pad()
+        self.packed.repack()
+
+
+class _MergedConv:
+    """The first convolutions of the two towers as one: HWIO kernels side by side along the output channels (a staging tensor
+    refreshed with the variables), packed for the forward pass and for the data gradient. The weight gradients stay per tower."""
+
+    def __init__(self, convs, dtype):
+        self.convs = convs
+        self.src = torch.cat([c.w for c in convs], dim=3).contiguous()
+        self.ksize, self.cin, self.cout = self.src.shape[0], self.src.shape[2], self.src.shape[3]
+        self.packed = ops.PackedConv(self.src, dtype)
+        self.name = "+".join(c.name for c in convs)
+        self.dsrc = torch.zeros_like(self.src)      # the merged weight gradient; split_grad() hands the halves to the variables' gradients
+        self.pad = None
+        for c in convs:
+            c.packed_unused = True      # (nothing reads the separate packed operands: not refreshed)
+
+    def split_grad(self):
+        o = 0
+        for c in self.convs:
+            c.dw.copy_(self.dsrc[..., o:o + c.cout])
+            o += c.cout
+
+    def repack(self):
+        torch.cat([c.w for c in self.convs], dim=3, out=self.src)
         self.packed.repack()
 
 
@@ -167,18 +211,28 @@ class PersonDetectorNet:
         if backbone_values is not None:
             self.backbone.load_state_dict({k: v for k, v in backbone_values.items() if k.startswith("MobilenetV1/")}, strict=False)
         shapes = head_variable_shapes(self.dm)
-        self._train_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if _trainable(k)), self.device)
-        self._stat_arena = _Arena(OrderedDict((k, v) for k, v in shapes.items() if not _trainable(k)), self.device)
+        order = _arena_order(shapes)
+        self._train_arena = _Arena(OrderedDict((k, v) for k, v in order.items() if _trainable(k)), self.device)
+        self._stat_arena = _Arena(OrderedDict((k, v) for k, v in order.items() if not _trainable(k)), self.device)
         self.theta, self.grad = self._train_arena.new(), self._train_arena.new()
         self.adam_m, self.adam_v = self._train_arena.new(), self._train_arena.new()
         self.moving = self._stat_arena.new()
-        self.vars, self.grads = self._train_arena.views(self.theta), self._train_arena.views(self.grad)
-        self.stats = self._stat_arena.views(self.moving)
+
+        def named(arena, flat):      # (dictionaries in the reference's variable order, whatever the arena's)
+            v = arena.views(flat)
+            return OrderedDict((k, v[k]) for k in shapes if k in v)
+        self.vars, self.grads = named(self._train_arena, self.theta), named(self._train_arena, self.grad)
+        self.stats = named(self._stat_arena, self.moving)
         self.global_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.hyper = torch.zeros(4, dtype=torch.float32, device=self.device)
         self._convs = []
         self._wversion = 0
         self.fuse_conv_bn = True       # set before the first backward pass of a shape (the finalize tables are built once)
+        # The first convolutions of the box and class towers read the same tensor (box_predictor.py:101-103 under both scopes): ONE
+        # 128 -> 128 convolution on the 128-channel tile kernel instead of two 128 -> 64 ones, ONE 128 -> 128 data gradient whose
+        # contraction over the 128 merged channels IS the sum the two towers send into p{l}_batch_norm (and reduces for that layer).
+        # MPN_RETINA_MERGE=0: the two towers separately (A/B runs). Fixed before _build_layers.
+        self.merge_tower0 = os.environ.get("MPN_RETINA_MERGE", "1") != "0"
         # the head's inference affines (45 small launches) and the p6 operand cast are recomputed on EVERY inference pass
         # unless the owner opts in (inference/detector.py does and compares `var_version` before each graph replay): the clean
         # flag is host state, a replayed hipGraph of a train step cannot clear it
@@ -189,6 +243,7 @@ class PersonDetectorNet:
         self._l2 = None
         self._wd = None
         self._built = False
+        self.tower0m = None
         self.load_state_dict(head_values if head_values is not None else initial_head_values(seed, self.dm))
         self._build_layers()
         self._bufs = {}
@@ -244,24 +299,52 @@ class PersonDetectorNet:
         self.pre_p7_bn = self._bn("fpn/pre_p7_bn")
         self.p_bn = {l: self._bn(f"p{l}_batch_norm") for l in LEVELS}
         self.tower, self.tower_bn, self.out_conv, self.out_bias, self.out_dbias = {}, {}, {}, {}, {}
-        for net, out_name, cout in NETS:
+        self.bn0m = {l: self._bn_pair(l) for l in LEVELS} if self.merge_tower0 else None
+        for k, (net, out_name, cout) in enumerate(NETS):
             self.tower[net] = [self._conv(f"{net}/conv3x3_{i}/kernel") for i in range(4)]
             self.tower_bn[net] = [{l: self._bn(f"{net}/batch_norm_{i}_for_level_{l}") for l in LEVELS} for i in range(4)]
+            if self.merge_tower0:
+                for l in LEVELS:
+                    bn = self.bn0m[l].channel_slice(k * TOWER_DEPTH, (k + 1) * TOWER_DEPTH)
+                    bn.name = f"{net}/batch_norm_0_for_level_{l}"
+                    self.tower_bn[net][0][l] = bn
             self.out_conv[net] = self._conv(f"{net}/{out_name}/kernel", pad_cout=8 if cout % 8 else 0)
             self.out_bias[net] = self.vars[f"{net}/{out_name}/bias"]
             self.out_dbias[net] = self.grads[f"{net}/{out_name}/bias"]
         self.all_bn = [self.pre_p7_bn] + [self.p_bn[l] for l in LEVELS] + \
             [self.tower_bn[net][i][l] for net, _, _ in NETS for i in range(4) for l in LEVELS]
+        self.tower0m = _MergedConv([self.tower[net][0] for net, _, _ in NETS], self.dtype) if self.merge_tower0 else None
         self._built = True
+
+    def _bn_pair(self, l):
+        """batch_norm_0_for_level_l of the two towers as ONE 128-channel layer (box channels first): views over adjacent variables."""
+        names = [f"{pre}{l}" for pre in _BN0]
+
+        def pair(flat, arena, kind):
+            (o0, n0, _), (o1, n1, _) = arena.offsets[f"{names[0]}/{kind}"], arena.offsets[f"{names[1]}/{kind}"]
+            if o1 != o0 + n0:
+                raise RuntimeError("the towers' first batch-norms must lie side by side in the arena")
+            return flat[o0:o1 + n1]
+        bn = ops.BNState(pair(self.theta, self._train_arena, "gamma"), pair(self.theta, self._train_arena, "beta"),
+                         pair(self.moving, self._stat_arena, "moving_mean"), pair(self.moving, self._stat_arena, "moving_variance"), ACT_RELU)
+        bn.dgamma, bn.dbeta = pair(self.grad, self._train_arena, "gamma"), pair(self.grad, self._train_arena, "beta")
+        bn.name = f"box_net+class_net/batch_norm_0_for_level_{l}"
+        return bn
 
     def repack_weights(self):
         self._wversion += 1
         for c in self._convs:
             c.repack()
+        if self.tower0m is not None:
+            self.tower0m.repack()
 
     def _fused_out_bn(self, net):
         """The output convolution's data gradient also reduces for the tower's last batch-norm."""
         return self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(self.out_conv[net].cout, TOWER_DEPTH, 3, self.dtype)
+
+    def _fused_p_bn(self):
+        """The merged first-layer data gradient (128 -> 128) also reduces for p{l}_batch_norm."""
+        return self.merge_tower0 and self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(2 * TOWER_DEPTH, DEPTH, 3, self.dtype)
 
     def _fused_conv_bn(self):
         """The towers' 3x3 data gradients also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn_grouped)."""
@@ -289,6 +372,10 @@ class PersonDetectorNet:
         b["patches6"] = act(*lv[6], 9 * c5)
         b["patches7"] = act(*lv[7], 9 * DEPTH)
         b["t"] = {net: [{l: act(*lv[l], TOWER_DEPTH) for l in LEVELS} for _ in range(4)] for net, _, _ in NETS}
+        if self.merge_tower0:      # the towers' first raw outputs: channel slices of ONE tensor per level (box first)
+            b["t0m"] = {l: act(*lv[l], 2 * TOWER_DEPTH) for l in LEVELS}
+            for k, (net, _, _) in enumerate(NETS):
+                b["t"][net][0] = {l: b["t0m"][l][..., k * TOWER_DEPTH:(k + 1) * TOWER_DEPTH] for l in LEVELS}
         b["out"] = {"box_net": {l: act(*lv[l], 4 * APL) for l in LEVELS}, "class_net": {l: act(*lv[l], 8) for l in LEVELS}}
         nbn = _lib.lib().mpn_bn_stats_num_parts
         b["stat_lv"] = {l: torch.empty(max(ops.conv_num_parts(N, *lv[l], 3), ops.conv_num_parts(N, *lv[l], 1), nbn(N * lv[l][0] * lv[l][1])) * 2 * DEPTH,
@@ -308,7 +395,8 @@ class PersonDetectorNet:
         for net, _, _ in NETS:
             for i in range(4):
                 cin_i = DEPTH if i == 0 else TOWER_DEPTH
-                fin[(net, i)] = ops.BnFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], rows3(l, cin_i, TOWER_DEPTH), cnt[l]) for l in LEVELS], dev)
+                if not (i == 0 and self.merge_tower0):
+                    fin[(net, i)] = ops.BnFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], rows3(l, cin_i, TOWER_DEPTH), cnt[l]) for l in LEVELS], dev)
                 # batch_norm_0..2 are reduced inside the data gradient of the tower convolution above them (conv rows, raw x),
                 # batch_norm_3 inside the data gradient of the output convolution (the tiled kernel: 8 / 24 -> 64 channels)
                 if (i < 3 and self._fused_conv_bn()) or (i == 3 and self._fused_out_bn(net)):
@@ -316,7 +404,12 @@ class PersonDetectorNet:
                     fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], rows3(l, k_i, TOWER_DEPTH), cnt[l], True) for l in LEVELS], dev)
                 else:
                     fin[("d", net, i)] = ops.BnBwdFinalizeBatch([(self.tower_bn[net][i][l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
-        fin["dp"] = ops.BnBwdFinalizeBatch([(self.p_bn[l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
+        if self.merge_tower0:
+            fin[("m", 0)] = ops.BnFinalizeBatch([(self.bn0m[l], b["stat_lv"][l], rows3(l, DEPTH, 2 * TOWER_DEPTH), cnt[l]) for l in LEVELS], dev)
+        if self._fused_p_bn():     # p{l}_batch_norm is reduced inside the merged first-layer data gradient (conv rows, raw x)
+            fin["dp"] = ops.BnBwdFinalizeBatch([(self.p_bn[l], b["stat_lv"][l], rows3(l, 2 * TOWER_DEPTH, DEPTH), cnt[l], True) for l in LEVELS], dev)
+        else:
+            fin["dp"] = ops.BnBwdFinalizeBatch([(self.p_bn[l], b["stat_lv"][l], nbn(cnt[l]), cnt[l]) for l in LEVELS], dev)
         b["fin"] = fin
         b["levels_hw"] = ((ctypes.c_int * 5)(*[lv[l][0] for l in LEVELS]), (ctypes.c_int * 5)(*[lv[l][1] for l in LEVELS]))
         b["losses"] = torch.zeros(4, dtype=torch.float32, device=dev)
@@ -335,15 +428,20 @@ class PersonDetectorNet:
         dt, dev, lv = self.dtype, self.device, b["lv"]
         g = {"out": {net: {l: torch.empty_like(b["out"][net][l]) for l in LEVELS} for net, _, _ in NETS},
              "t": {net: [{l: torch.empty_like(b["t"][net][i][l]) for l in LEVELS} for i in range(4)] for net, _, _ in NETS},
-             "pn": {net: {l: torch.empty_like(b["p"][l]) for l in LEVELS} for net, _, _ in NETS},
+             "pn": {net: {l: torch.empty_like(b["p"][l]) for l in LEVELS} for net, _, _ in NETS[:1 if self.merge_tower0 else 2]},
              "x": {l: torch.empty_like(b["x"][l]) for l in (3, 4, 5)},
              "patches7": torch.empty_like(b["patches7"]),
              "pre7": torch.empty_like(b["p"][6])}
+        if self.merge_tower0:      # the gradients of the towers' first raw outputs: channel slices of one tensor per level
+            g["t0m"] = {l: torch.empty_like(b["t0m"][l]) for l in LEVELS}
+            for k, (net, _, _) in enumerate(NETS):
+                g["t"][net][0] = {l: g["t0m"][l][..., k * TOWER_DEPTH:(k + 1) * TOWER_DEPTH] for l in LEVELS}
         # weight-gradient slabs: a conv shared by the five levels owns five consecutive regions -> ONE reduction job
         sites = []   # (conv, [(key, nparts)], n)
-        for c in self._convs:
+        merged0 = [self.tower[net][0] for net, _, _ in NETS] if self.merge_tower0 else []
+        for c in [c for c in self._convs if c not in merged0] + ([self.tower0m] if self.merge_tower0 else []):
             n = c.src.numel()
-            if c in self.tower["box_net"] or c in self.tower["class_net"] or c in self.out_conv.values():
+            if c is self.tower0m or c in self.tower["box_net"] or c in self.tower["class_net"] or c in self.out_conv.values():
                 # (the five levels' weight gradients come from ONE grid: ops.conv_bwd_weight_grouped)
                 nps = ops.conv_wgrad_grouped_num_parts(N, [lv[l] for l in LEVELS], c.cin, c.cout, 3, dt)
                 parts = [((c.name, l), np_) for l, np_ in zip(LEVELS, nps)]
@@ -359,7 +457,7 @@ class PersonDetectorNet:
             for key, np_ in parts:
                 g["slab"][key] = slab[off:off + np_ * n]
                 off += np_ * n
-            out = c.dpad if c.pad is not None else c.dw
+            out = c.dsrc if c is self.tower0m else (c.dpad if c.pad is not None else c.dw)
             jobs.append((slab[first:off], sum(np_ for _, np_ in parts), n, out.view(-1)))
         g["reducer"] = ops.SlabReducer(jobs, dev)
         b["g"] = g
@@ -406,9 +504,17 @@ class PersonDetectorNet:
         ops.conv_fwd(b["patches7"], self.pconv[7].packed.fwd, DEPTH, 1, None, out=b["p"][7], stats_part=st(7))       # fpn.py:45
         if is_training:
             fin["p7"].run()
+        if self.merge_tower0:       # conv3x3_0 of both towers in one launch: box channels 0..63, class channels 64..127
+            ops.conv_fwd_grouped([b["p"][l] for l in LEVELS], [self.tower0m.packed.fwd] * 5, 2 * TOWER_DEPTH, 3,
+                                 [self.p_bn[l].affine for l in LEVELS], [b["t0m"][l] for l in LEVELS], [st(l) for l in LEVELS])
+            if is_training:
+                fin[("m", 0)].run()
         for net, _, cout in NETS:
             xs, affs = [b["p"][l] for l in LEVELS], [self.p_bn[l].affine for l in LEVELS]                            # retinanet.py:29-32
             for i in range(4):                                                                                        # box_predictor.py:101-103
+                if i == 0 and self.merge_tower0:
+                    xs, affs = [b["t"][net][0][l] for l in LEVELS], [self.tower_bn[net][0][l].affine for l in LEVELS]
+                    continue
                 c = self.tower[net][i]
                 outs = [b["t"][net][i][l] for l in LEVELS]
                 ops.conv_fwd_grouped(xs, [c.packed.fwd] * 5, TOWER_DEPTH, 3, affs, outs, [st(l) for l in LEVELS])
@@ -541,6 +647,8 @@ class PersonDetectorNet:
                 if not ((fused and i < 3) or (fused_out and i == 3)):      # (else: reduced by the data gradient above)
                     ops.bn_bwd_reduce_grouped(bns, dAs, xs, sps)
                 fin[("d", net, i)].run()
+                if i == 0 and self.merge_tower0:
+                    continue         # (the rest of the first layer: both towers at once, below)
                 ops.bn_bwd_apply_grouped(bns, dAs, xs)
                 c = self.tower[net][i]
                 if i > 0:
@@ -556,10 +664,22 @@ class PersonDetectorNet:
                     ops.conv_fwd_grouped(dAs, [c.packed.bwd] * 5, c.cin, 3, none5, dst, none5)
         # the two towers meet at act(bn(p_l)): sum, then through p{l}_batch_norm
         gp = [g["pn"]["box_net"][l] for l in LEVELS]
-        for l in LEVELS:
-            ops.add_inplace(g["pn"]["box_net"][l], g["pn"]["class_net"][l])
         pbns, bp = [self.p_bn[l] for l in LEVELS], [b["p"][l] for l in LEVELS]
-        ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
+        if self.merge_tower0:
+            gm, tm = [g["t0m"][l] for l in LEVELS], [b["t0m"][l] for l in LEVELS]
+            ops.bn_bwd_apply_grouped([self.bn0m[l] for l in LEVELS], gm, tm)           # both towers' batch_norm_0: one 128-channel pass
+            pa = [self.p_bn[l].affine for l in LEVELS]
+            ops.conv_bwd_weight_grouped(bp, gm, 3, pa, [slab[(self.tower0m.name, l)] for l in LEVELS])      # both towers' conv3x3_0
+            # ONE 128 -> 128 data gradient: the contraction over the merged channels is the sum of the two towers' gradients
+            if self._fused_p_bn():
+                ops.conv_bwd_data_bn_grouped(gm, [self.tower0m.packed.bwd] * 5, DEPTH, pbns, bp, gp, sps)
+            else:
+                ops.conv_fwd_grouped(gm, [self.tower0m.packed.bwd] * 5, DEPTH, 3, none5, gp, none5)
+                ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
+        else:
+            for l in LEVELS:
+                ops.add_inplace(g["pn"]["box_net"][l], g["pn"]["class_net"][l])
+            ops.bn_bwd_reduce_grouped(pbns, gp, bp, sps)
         fin["dp"].run()
         ops.bn_bwd_apply_grouped(pbns, gp, bp)
         gpl = {l: g["pn"]["box_net"][l] for l in LEVELS}              # gradient w.r.t. the raw p_l
@@ -582,6 +702,8 @@ class PersonDetectorNet:
             raw, aff = feats[f"c{l}"]
             ops.conv_bwd_weight(raw, g["x"][l], 1, aff, None, slab[(self.lateral[l].name, l)], reduce=False)
         g["reducer"].run()
+        if self.merge_tower0:
+            self.tower0m.split_grad()
         oc = self.out_conv["class_net"]
         oc.dw.copy_(oc.dpad[..., :oc.w.shape[3]])                     # drop the two padding columns
         if weight_decay > 0.0:

@@ -210,6 +210,74 @@ def test_detector_train_step_f32_vs_oracle(cuda):
     assert int(net.global_step.item()) == 1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_merged_first_tower_layer_equals_the_two_towers(cuda, monkeypatch, dtype):
+    """The box and class towers' first convolutions read the same tensor (box_predictor.py:101-103 under both scopes): the build runs
+    them as ONE 128 -> 128 convolution, one 128-channel batch-norm over adjacent variables, one weight gradient and ONE data gradient
+    whose contraction over the merged channels is the sum the two towers send into p{l}_batch_norm (PersonDetectorNet.merge_tower0).
+    Against the two towers run separately (MPN_RETINA_MERGE=0) on the same variables and batch: the same losses, predictions, moving
+    statistics and gradients - f32 to summation order; bf16 to storage rounding (the sum of the two towers' gradients is formed in
+    the accumulator instead of from two rounded tensors) - with and without the reductions fused into the data gradients."""
+    from multiposenet_amd.retinanet import PersonDetectorNet
+    B, H, W = 2, 128, 256
+    bb, hp, img, boxes, num = _setup(21, B, H, W)
+    gt = {"boxes": torch.tensor(boxes).cuda(), "num_boxes": torch.tensor(num).cuda()}
+
+    def run(merge, fuse):
+        monkeypatch.setenv("MPN_RETINA_MERGE", "1" if merge else "0")
+        net = PersonDetectorNet(backbone_values=bb, head_values=hp, dtype=dtype)
+        assert net.merge_tower0 == merge
+        net.fuse_conv_bn = fuse
+        bset = net.forward(torch.tensor(img).cuda(), True)
+        raw = {k: v.float().cpu().numpy() for k, v in net.raw_predictions(bset).items()}
+        net.create_targets(gt)
+        losses = net.compute_losses(HP).cpu().numpy().copy()
+        net.backward(HP["weight_decay"])
+        return raw, losses, {k: v.cpu().numpy().copy() for k, v in net.grads.items()}, {k: v.cpu().numpy().copy() for k, v in net.stats.items()}
+
+    ref = run(False, True)
+    f32 = dtype == torch.float32
+    for fuse in (True, False):
+        raw, losses, grads, stats = run(True, fuse)
+        for k in raw:
+            np.testing.assert_allclose(raw[k], ref[0][k], atol=(1e-5 if f32 else 3e-2) * float(np.abs(ref[0][k]).max()), err_msg=k)
+        np.testing.assert_allclose(losses, ref[1], rtol=1e-5 if f32 else 2e-2)
+        for k, v in stats.items():
+            np.testing.assert_allclose(v, ref[3][k], rtol=1e-4 if f32 else 2e-2, atol=1e-6 if f32 else 2e-3, err_msg=k)
+        bad = []
+        for k, g in grads.items():
+            want = ref[2][k]
+            err = float(np.linalg.norm((g - want).ravel()) / (np.linalg.norm(want.ravel()) + 1e-30))
+            if err > (2e-5 if f32 else 0.12):
+                bad.append((k, err))
+        assert not bad, (fuse, sorted(bad, key=lambda kv: -kv[1])[:8])
+
+
+def test_nms_replayed_from_a_hipgraph_with_every_anchor_a_candidate(cuda):
+    """Round 5, a device fault: the candidate lists' counters were cleared by hipMemsetAsync; inside a REPLAYED hipGraph that memset
+    node was seen to land after the first appends of the kernel behind it, so a list started at the previous call's count - with every
+    anchor above the score threshold (count = A) it ran past the workspace. The counters are cleared by a launch now (and an append
+    past the list is refused). Eager call, capture, three replays, every anchor a candidate: identical detections each time."""
+    from multiposenet_amd.retinanet import PersonDetectorNet
+    B, H, W = 2, 128, 256
+    bb, hp, img, _, _ = _setup(33, B, H, W)
+    hp["class_net/logits/kernel"] = (np.random.RandomState(3).randn(3, 3, 64, 6) * 0.4).astype(np.float32)
+    hp["class_net/logits/bias"] = np.full(6, -2.0, np.float32)
+    net = PersonDetectorNet(backbone_values=bb, head_values=hp, dtype=torch.float32)
+    b = net.forward(torch.tensor(img).cuda(), False)
+    want = {k: v.cpu().numpy().copy() for k, v in net.nms(b, 0.0, 0.6, 25).items()}
+    assert (want["num_boxes"] == 25).all()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = net.nms(b, 0.0, 0.6, 25)
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        for k, v in want.items():
+            np.testing.assert_array_equal(out[k].cpu().numpy(), v, err_msg=k)
+
+
 def test_detector_inference_and_bf16_build(cuda):
     """get_predictions (is_training=False) of the f32 build vs the oracle's NMS on the oracle's raw predictions; the bf16 build
     trains (finite losses, loss close to the f32 build's)."""

@@ -1,6 +1,7 @@
 """Per-wave phase stamps of the channel-split 3x3 kernel (diagnostic build: tools/build_variant.sh diag conv_mfma.hip,conv3x3.hip,conv3x3_cs.hip
 "-DMPN_DIAG", MPN_LIB=multiposenet_amd/libmpn_hip_diag.so): python tools/stamp_c3cs.py H Cin Cout [affine+stats 0/1]"""
 import ctypes
+import os
 import sys
 import numpy as np
 import torch
@@ -17,6 +18,8 @@ part = torch.empty(ops.conv_num_parts(N, H, H, 3) * 2 * Cout, device='cuda') if 
 dbg = torch.zeros(256 * 256, dtype=torch.int64, device='cuda')
 lib = _lib.lib()
 lib.mpn_diag_set_conv_stamps.argtypes = [ctypes.c_void_p]
+if os.environ.get("MPN_DIAG_C3_BLOCKS"):      # fewer persistent blocks than compute units: what the clock does when part of the chip multiplies
+    lib.mpn_diag_set_c3_blocks(int(os.environ["MPN_DIAG_C3_BLOCKS"]))
 for _ in range(3):
     ops.conv_fwd(x, pc.fwd, Cout, 3, aff, out=y, stats_part=part)
 lib.mpn_diag_set_conv_stamps(ctypes.c_void_p(dbg.data_ptr()))
