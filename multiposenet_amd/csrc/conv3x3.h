@@ -147,7 +147,7 @@ __device__ __forceinline__ Tile tile_of(const Group& g, int w) {
 }
 
 
-// the channel-split kernel (conv3x3_cs.hip): 128-channel tiles
-int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, hipStream_t st);   // (+ jobs with ap_y: input formed on load)
+// the channel-split kernel (conv3x3_cs.hip): 128-channel tiles, or (n64) 64-channel tiles
+int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, bool n64, hipStream_t st);   // (+ jobs with ap_y: input formed on load)
 
 }  // namespace mpn_c3

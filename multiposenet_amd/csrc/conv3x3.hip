@@ -714,8 +714,14 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
                     MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a data gradient (no producer affine), a partial slab and the layer's affine");
     }
 #ifndef MPN_C3_OLD
-    // 128-channel tiles: the channel-split kernel (conv3x3_cs.hip); -DMPN_C3_OLD builds keep this file's kernel for A/B runs
-    if (!n64) return launch_cs(g, begin, dtype, affine, bnr, st);
+    // the channel-split kernel (conv3x3_cs.hip); -DMPN_C3_OLD builds keep this file's kernel for A/B runs, -DMPN_C3_OLD64 for the
+    // 64-channel tiles only
+#ifdef MPN_C3_OLD64
+    if (!n64)
+#endif
+    // (64-channel tiles of MORE than one 64-channel chunk - final_conv3x3's forward, 512 -> 64 - stay on this file's kernel: 310 against
+    //  316 us; one-chunk tiles - the detector's 64 -> 64 towers - are 6-11 % faster on the channel-split one: profiles/r05_c3cs_n64.txt)
+    if (!n64 || jobs[0].Cin == 64) return launch_cs(g, begin, dtype, affine, bnr, n64, st);
 #endif
     if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, bnr, st);
     if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, bnr, st);

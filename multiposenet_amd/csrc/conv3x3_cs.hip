@@ -89,6 +89,7 @@ __device__ __forceinline__ int qdiv(int a, int b) {
     q -= (r < 0) ? 1 : 0;
     return q;
 }
+template <bool N64>
 __device__ __forceinline__ Tile tile_fast(const Group& g, int w) {
     Tile t;
     t.job = 0;
@@ -97,7 +98,7 @@ __device__ __forceinline__ Tile tile_fast(const Group& g, int w) {
         if (k < g.njobs && w >= g.begin[k]) t.job = k;
     const Job& p = g.job[t.job];
     int b = w - g.begin[t.job];
-    const int n_tiles = p.Cout >> 7, tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
+    const int n_tiles = N64 ? (p.Cout >> 6) : (p.Cout >> 7), tiles_x = (p.W + 15) >> 4, tiles_y = (p.H + 15) >> 4;
     int q = qdiv(b, n_tiles); t.ntile = b - q * n_tiles; b = q;
     q = qdiv(b, tiles_x); t.tx = b - q * tiles_x; b = q;
     q = qdiv(b, tiles_y); t.ty = b - q * tiles_y;
@@ -109,9 +110,19 @@ __device__ __forceinline__ Tile tile_fast(const Group& g, int w) {
 // ACT: 0 = no producer affine, 1 = affine + (ReLU or none, by in_act), 2 = affine + ReLU6
 // MODE: 0 = plain, 1 = batch-norm statistics of the output, 2 = data gradient that also reduces for the batch-norm it feeds (BNR)
 // GA: the input gradient is formed on load (Job::ap_y: apply-on-load of the batch-norm backward, no producer affine)
-template <typename T, int ACT, int MODE, bool GA = false>
+// N64: 64 output channels per tile (Cout an odd multiple of 64: final_conv3x3 512 -> 64, the detector's 64 -> 64 towers): the eight
+//   waves are FOUR channel groups of 16 x TWO pixel halves (output rows 8 ph .. 8 ph + 7): 24 MFMAs per wave and stage on 10 halo
+//   fragments and the same three weight fragments; the packed weight image is conv3x3.hip's 64-channel one
+//   ([chunk][kx 3][ky 3][k-step 2][co 64][64 bytes]), the output image 128 bytes per pixel.
+template <typename T, int ACT, int MODE, bool GA = false, bool N64 = false>
 __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) {
     constexpr bool AFFINE = ACT != 0, STATS = MODE == 1, BNR = MODE == 2;
+    constexpr int MT = N64 ? 8 : 16;            // output rows (m-tiles) of a wave
+    constexpr int HR = MT + 2;                  // halo rows (fragments) a stage reads
+    constexpr int CT = N64 ? 64 : 128;          // output channels of a tile
+    constexpr int kPx = CT * 2;                 // output image: bytes per pixel (= kRSO without N64)
+    constexpr int kSw = N64 ? 7 : 15;           // its slot swizzle: slot ^ (px & kSw)
+    static_assert(!GA || !N64, "apply on load: 128-channel tiles");
     static_assert(!GA || ACT == 0, "apply on load: the input is a gradient (no producer affine)");
     constexpr int kRing = kRingDefault;
     // the fused-reduction variant finishes a tile BEHIND its last chunk instead of under the next tile's first stages: its epilogue
@@ -143,6 +154,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = N64 ? (wave & 3) : wave, ph = N64 ? (wave >> 2) : 0;      // channel group of 16, pixel half
     // Priority feedback between the two waves of a SIMD (waves w and w ^ 4). Left alone the OLDER wave of a pair wins every
     // arbitration: it ran a chunk's six stages in 7.4 k cycles at almost the speed it has alone, its partner got the issue slots it
     // left (2.6 stages in that time) and then finished ALONE - 4 k cycles at 65 % of the matrix pipe - while the older wave waited
@@ -156,7 +168,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     const int l15 = lane & 15, lq = lane >> 4;
     const int Cin = g.job[0].Cin, Cout = g.job[0].Cout;    // (shared by the jobs of a group)
     const int nchunk = Cin >> 6;
-    const long long wtile = 9ll * Cin * 128 * 2;
+    const long long wtile = 9ll * Cin * CT * 2;
 
     // per-lane fragment bases; everything added later is a compile-time or wave-uniform offset
     // (byte offsets inside a halo buffer, one per kernel column kx: pixel c = l15 + kx of a halo row, slot (4 ks + lq) ^ (c & 7); the
@@ -169,7 +181,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     }
     // a wave's weight fragment (ky, channels 16 wave .. + 15) inside a stage of the packed image [ky 3][co 128][64 bytes]: rows of
     // 64 bytes = 32 input channels, their four 16-byte slots swizzled with swz(co) (the LDS image of conv3x3.hip)
-    const unsigned lane_w = (unsigned)(wave * 1024 + l15 * 64 + ((lq ^ swz(l15)) << 4));
+    const unsigned lane_w = (unsigned)(cg * 1024 + l15 * 64 + ((lq ^ swz(l15)) << 4));
     // buffer loads: the per-lane offset is a constant of the thread, the stage and tap offsets are scalar (no 64-bit vector address
     // arithmetic per load - plain pointer arithmetic cost two VALU per load and kept address pairs live across the loop, which
     // spilled). The descriptor is built AT the load from the readfirstlane'd halves of the tile's weight pointer: carried across
@@ -182,6 +194,14 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
             dst[ky] = __builtin_bit_cast(X8, (u32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rs, lane_w, soff + ky * 8192, 0));
+    };
+
+    // byte offset of stage `st` (0..5 of a chunk, continuing into the next chunk / tile) inside a tile's packed weights
+    // (128-channel tiles: [chunk][kx][k-step][ky 3][co 128][64 B], stages of 24 576 B; 64-channel tiles: [chunk][kx][ky 3][k-step 2][co 64][64 B]:
+    //  a stage pair of 24 576 B, the k-step 4 096 B inside it; the tap ky 8 192 B in both)
+    auto w_off = [&](int chunk, int st) __attribute__((always_inline)) -> int {
+        if constexpr (N64) return (chunk * 3 + (st >> 1)) * kStageBytes + (st & 1) * 4096;
+        else return (chunk * 6 + st) * kStageBytes;
     };
 
     // ---- halo staging (conv3x3.hip): thread -> 16-byte slot tid % 8 of halo pixels q + 54 i, q < 54, i = 0..5 (three halo rows per
@@ -357,7 +377,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                 const lds_f r = red + st_which * 128 + st_c;    // red [8 waves][2][128], fixed order
                 st_acc += ((r[0] + r[256]) + (r[512] + r[768])) + ((r[1024] + r[1280]) + (r[1536] + r[1792]));
             } else {
-                st_acc += red[e_par + st_which * 128 + st_c];   // red [2 tiles][2][128]: the tile's sums over its 256 pixels
+                if constexpr (N64) st_acc += red[e_par + st_which * 64 + st_c] + red[e_par + 128 + st_which * 64 + st_c];   // [2 tiles][2 halves][2][64]
+                else st_acc += red[e_par + st_which * 128 + st_c];   // red [2 tiles][2][128]: the tile's sums over its 256 pixels
             }
             if (st_store) { *st_dst = st_acc; st_acc = 0.f; }
         }
@@ -381,14 +402,20 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     // transposing reads (ds_read_b64_tr_b16): lane 4q+pp of a 16-lane group supplies the address of block row q, channels 4pp..4pp+3;
     // lane group lq covers pixels 2 (4 lq + q) + {0, 1} of a 32-pixel group (the k order of a sum is free; the eight pixels of a
     // 32-lane half differ in bits 1..3: with the image's swizzle their 8-byte pieces cover the 256-byte bank row once)
-    const int tP = 2 * (lq * 4 + (l15 >> 2));
-    const int t_lo = kImgOff + tP * kRSO + (((wave * 2 + ((l15 & 3) >> 1)) ^ (tP & 15)) << 4) + (l15 & 1) * 8;
-    const int t_hi = kImgOff + (tP + 1) * kRSO + (((wave * 2 + ((l15 & 3) >> 1)) ^ ((tP + 1) & 15)) << 4) + (l15 & 1) * 8;
-    // Copy-out: wave `wave` stores pixels 32 wave .. + 31 (output rows 2 wave, 2 wave + 1), all 128 channels: lane = 16-byte piece
+    // (64-channel tiles: 128-byte pixels; a wave sums its 16 channels over ITS 128 pixels - four groups of 32 -, lane group lq the
+    //  pixels 4 lq + q and + 16: four even and four odd pixels per 32-lane half, each on its own pair of slots)
+    const int tP = N64 ? lq * 4 + (l15 >> 2) : 2 * (lq * 4 + (l15 >> 2));
+    const int tQ = N64 ? tP + 16 : tP + 1;
+    const int t_lo = kImgOff + (ph * 128 + tP) * kPx + (((cg * 2 + ((l15 & 3) >> 1)) ^ (tP & kSw)) << 4) + (l15 & 1) * 8;
+    const int t_hi = kImgOff + (ph * 128 + tQ) * kPx + (((cg * 2 + ((l15 & 3) >> 1)) ^ (tQ & kSw)) << 4) + (l15 & 1) * 8;
+    // Copy-out: wave `wave` stores pixels 32 wave .. + 31 (output rows 2 wave, 2 wave + 1), all channels of the tile: lane = 16-byte piece
     // `piece` of pixels prow + 4 k, k = 0..7; its slot piece ^ (px & 15) = (piece ^ prow) ^ 4 (k & 3): bits 6, 7 of the byte offset
-    const int piece = lane & 15, prow = lane >> 4;
-    const int c_off = kImgOff + (wave * 32 + prow) * kRSO + ((piece ^ prow) << 4);
-    const int red_s = wave * 16 + l15, red_q = (lq == (l15 >> 2)) ? 128 + wave * 16 + l15 : 2048 + lane;   // (+ e_par; the dummy words: 2048..2111)
+    // (64-channel tiles: eight pieces per pixel, pixels prow + 8 k, k = 0..3: the slot piece ^ prow is the same for every k)
+    const int piece = N64 ? (lane & 7) : (lane & 15), prow = N64 ? (lane >> 3) : (lane >> 4);
+    const int c_off = kImgOff + (wave * 32 + prow) * kPx + ((piece ^ prow) << 4);
+    // (+ e_par; 128-channel tiles: [2][128]; 64-channel tiles: [2 pixel halves][2][64]; the dummy words: 2048..2111)
+    const int red_s = N64 ? ph * 128 + cg * 16 + l15 : wave * 16 + l15;
+    const int red_q = (lq == (l15 >> 2)) ? (N64 ? ph * 128 + 64 + cg * 16 + l15 : 128 + wave * 16 + l15) : 2048 + lane;
     f32x4_t st_sa = {0.f, 0.f, 0.f, 0.f}, st_ga = {0.f, 0.f, 0.f, 0.f};
     X8 ones;
 #pragma unroll
@@ -417,7 +444,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     f32x2_t bs[4], bq[4];
     auto bnr_ld = [&](const int k) __attribute__((always_inline)) -> uint4 {
         // (rows / columns past the image: clamped - their dy is 0)
-        const int oy = min(2 * wave + (k >> 2), e_bx_hmax), ox = min(prow + 4 * (k & 3), e_bx_wmax);
+        const int oy = min(2 * wave + (N64 ? (k >> 1) : (k >> 2)), e_bx_hmax), ox = min(prow + (N64 ? 8 * (k & 1) : 4 * (k & 3)), e_bx_wmax);
         return *reinterpret_cast<const uint4*>(e_bx + (unsigned)(oy * e_bx_rowb + ox * e_bx_pxb + piece * 16));
     };
     // step (sl, h) of the waiting epilogue: sl = 0: statistics (two transposing reads at even h, the two MFMAs + the sums' rows at
@@ -425,18 +452,19 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     // prow + 4 k, k = 4 (sl - 1) .. + 3 (LDS reads at h = 0..3, stores at h = 6, 8, 10, 12); BNR: the sums at the end of sl = 2
     auto e2_step = [&](const int sl, const int h) __attribute__((always_inline)) {
         if constexpr (STATS) {
-            if (sl == 0 && h < 16) {
-                const int pg = h >> 1;       // pixels 32 pg .. + 31
+            constexpr int NPG = N64 ? 4 : 8;      // groups of 32 pixels a wave sums
+            if (sl == 0 && h < 2 * NPG) {
+                const int pg = h >> 1;       // pixels 32 pg .. + 31 (of the wave's half)
                 if ((h & 1) == 0) {
-                    tlo = tr_read_lds(L + t_lo + pg * (32 * kRSO));
-                    thi = tr_read_lds(L + t_hi + pg * (32 * kRSO));
+                    tlo = tr_read_lds(L + t_lo + pg * (32 * kPx));
+                    thi = tr_read_lds(L + t_hi + pg * (32 * kPx));
                 } else {
                     const X8 f = __builtin_shufflevector(tlo, thi, 0, 1, 2, 3, 4, 5, 6, 7);
                     st_sa = H::mfma(ones, f, pg == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : st_sa);
                     st_ga = H::mfma(f, f, pg == 0 ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : st_ga);
                 }
             }
-            if (sl == 0 && h == 17) {
+            if (sl == 0 && h == 2 * NPG + 1) {
                 // the Gram diagonal sits in element l15 & 3 of the lanes lq == l15 >> 2: picked by a 0 / 1 weight per element (exact:
                 // the others add + 0; written as a select chain hipcc made three branches of it)
                 const float q = __builtin_fmaf(st_ga[3], dsel[3], __builtin_fmaf(st_ga[2], dsel[2], __builtin_fmaf(st_ga[1], dsel[1], st_ga[0] * dsel[0])));
@@ -451,7 +479,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             }
             if (sl == 0 && h >= 12 && h < 16) bx[h - 12] = bnr_ld(h - 12);
         }
-        if (sl == 1 || sl == 2) {
+        if (sl == 1 || (sl == 2 && !N64)) {
             // pixel rows prow + 4 k, k = 4 (sl - 1) + kk: the LDS read of row kk at h = 3 kk + 1, its store at h = 3 kk + 6 (two rows in
             // flight); BNR: the mask and the sums of its dwords 0, 1 at h = 3 kk + 4, of dwords 2, 3 at h = 3 kk + 5
             const int half = sl - 1;
@@ -459,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             if (h >= 1 && h <= 10 && (h - 1) % 3 == 0) {
                 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
                 const int kr = (h - 1) / 3;
-                const u32x4_t v = lds_ld<u32x4_t>(L + (c_off ^ (kr * 64)) + (4 * (half * 4 + kr)) * kRSO);
+                const u32x4_t v = N64 ? lds_ld<u32x4_t>(L + c_off + (8 * kr) * kPx) : lds_ld<u32x4_t>(L + (c_off ^ (kr * 64)) + (4 * (half * 4 + kr)) * kPx);
                 co[kr & 1] = make_uint4(v[0], v[1], v[2], v[3]);
             }
             if constexpr (BNR) {
@@ -469,7 +497,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                 // they spill; the opaque offset keeps hipcc from hoisting the reads back out).
                 if (h >= 4 && h <= 14 && (ph == 0 || ph == 1)) {
                     const int km = (h - 4) / 3;
-                    int toff = (e_ntile * 128 + piece * 8 + ph * 4) * 4;
+                    int toff = (e_ntile * CT + piece * 8 + ph * 4) * 4;
                     asm volatile("" : "+v"(toff));
                     const f32x4_t s4 = lds_ld<f32x4_t>((lds_p)tab + toff), h4 = lds_ld<f32x4_t>((lds_p)tab + toff + kMaxCin * 4);
                     const uint4 xv = bx[km];
@@ -490,7 +518,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                         bq[j] += gf * xf;
                     }
                     if (ph == 0) { co[km & 1].x = du[0]; co[km & 1].y = du[1]; } else { co[km & 1].z = du[0]; co[km & 1].w = du[1]; }
-                    if (ph == 1 && half == 0) bx[km] = bnr_ld(km + 4);
+                    if (!N64 && ph == 1 && half == 0) bx[km] = bnr_ld(km + 4);
                 }
             }
             if (h >= 6 && h <= 15 && (h - 6) % 3 == 0) {
@@ -499,7 +527,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                 // a block's first tile has no image yet (prev_real).
                 const int k = half * 4 + kk;
                 const uint4 o = co[kk & 1];
-                const int row = 2 * wave + (k >> 2), col = 4 * (k & 3);
+                const int row = 2 * wave + (N64 ? (k >> 1) : (k >> 2)), col = N64 ? 8 * (k & 1) : 4 * (k & 3);
                 unsigned char* yb = e_y + ((long long)row * e_rowb + col * e_pxb);       // (scalar)
                 const unsigned lane_off = (unsigned)(prow * e_pxb + piece * 16);
                 if (prev_real && row < e_h && col + prow < e_w) *reinterpret_cast<uint4*>(yb + lane_off) = o;
@@ -511,7 +539,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                 // spill), then all four lane groups hold the wave's sums of their channels and write the same values to the same words
                 const int j = h - 14;
 #pragma unroll
-                for (int o = 16; o < 64; o <<= 1) {
+                for (int o = N64 ? 8 : 16; o < 64; o <<= 1) {
                     bs[j][0] += __shfl_xor(bs[j][0], o, 64); bs[j][1] += __shfl_xor(bs[j][1], o, 64);
                     bq[j][0] += __shfl_xor(bq[j][0], o, 64); bq[j][1] += __shfl_xor(bq[j][1], o, 64);
                 }
@@ -527,7 +555,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         if constexpr (BNR) { if (next_job != tab_job) tab_load(next_job); }
     };
 
-    Tile cur = tile_of<false>(g, w);
+    Tile cur = tile_of<N64>(g, w);
     if constexpr (BNR) { e_bx = reinterpret_cast<const unsigned char*>(g.job[cur.job].bnr_x); }     // (a block's first tile: loads that nothing uses, from a valid address)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
 #ifndef MPN_C3_BD
@@ -537,7 +565,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     X8 b[BD + 1][3];
     int cc = 0;                // running chunk counter: the chunk reads halo buffer cc & 1
     b_load(b[0], wsrc, 0);
-    if constexpr (BD == 2) b_load(b[1], wsrc, kStageBytes);
+    if constexpr (BD == 2) b_load(b[1], wsrc, w_off(0, 1));
     a_load(cur, 0);
     if constexpr (AFFINE || BNR) tab_load(cur.job);
     if constexpr (GA) ga_load(cur.job);
@@ -549,7 +577,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         for (int j = 0; j < 5; ++j) commit_step(i, j, 0, 0);
     __syncthreads();
 
-    Tile nxt_c = tile_fast(g, w + (int)gridDim.x < total ? w + (int)gridDim.x : w);
+    Tile nxt_c = tile_fast<N64>(g, w + (int)gridDim.x < total ? w + (int)gridDim.x : w);
     const unsigned char* wsrc_next_c = reinterpret_cast<const unsigned char*>(g.job[nxt_c.job].wp) + nxt_c.ntile * wtile;
     for (;;) {
         CS_STAMP(0);
@@ -560,7 +588,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         const Tile nxt = nxt_c;
         const unsigned char* wsrc_next = wsrc_next_c;
 
-        f32x4_t acc[16];     // (not zeroed: a tile's first MFMA into each tile takes a literal 0 as its C operand - 64 v_mov per tile less)
+        f32x4_t acc[MT];     // (not zeroed: a tile's first MFMA into each tile takes a literal 0 as its C operand - 64 v_mov per tile less)
 
         // ONE chunk: six stages = (kx, k-step); per stage 48 MFMAs in 18 groups (halo row h feeds output rows h, h - 1, h - 2), each
         // followed by the read of row h + kRing and by whatever else the stage carries (sched_barrier pins every group: the order
@@ -570,7 +598,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         // (the weight pointers by value: captured by reference they stayed in scratch memory, one flat load + vmcnt(0) per stage)
         auto chunk_body = [&](const int chunk, const unsigned char* const ws, const unsigned char* const ws_next, auto epi_tag, auto first_tag) __attribute__((always_inline)) {
             constexpr bool EPI = decltype(epi_tag)::value, FIRST = decltype(first_tag)::value;     // FIRST: the tile's first chunk
-            const lds_p hb = L + halo_off(cc & 1);
+            const lds_p hb = L + halo_off(cc & 1) + ph * (8 * kHW * kRS);       // (this wave's first halo row)
             const bool last_chunk = chunk + 1 == nchunk;
             // the image to prepare under this chunk: the tile's next chunk, or the first chunk of the next tile (without a next tile
             // this tile's first chunk once more, never read: the staging stays unconditional)
@@ -595,33 +623,40 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             for (int sl = 0; sl < 6; ++sl) {
                 const lds_p ab = hb + (abase_kx[sl >> 1] ^ ((sl & 1) * 64));
                 // the next stage's weight fragments (of this tile, or the first ones of the next tile) into the other register set
-                if (sl + BD < 6) b_load(b[(sl + BD) % (BD + 1)], ws, (chunk * 6 + sl + BD) * kStageBytes);
-                else b_load(b[(sl + BD) % (BD + 1)], last_chunk ? ws_next : ws, last_chunk ? (sl + BD - 6) * kStageBytes : (chunk * 6 + sl + BD) * kStageBytes);
+                if (sl + BD < 6) b_load(b[(sl + BD) % (BD + 1)], ws, w_off(chunk, sl + BD));
+                else b_load(b[(sl + BD) % (BD + 1)], last_chunk ? ws_next : ws, last_chunk ? w_off(0, sl + BD - 6) : w_off(chunk, sl + BD));
                 if (sl == 0) a_load(st_tile, st_chunk);
-                X8 a[18];
+                X8 a[HR];
 #pragma unroll
                 for (int h = 0; h < kRing; ++h) a[h] = lds_ld<X8>(ab + h * (kHW * kRS));
                 if (sl == 3) tab_read(st_chunk);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int h = 0; h < 18; ++h) {
+                for (int h = 0; h < HR; ++h) {
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         const int r = h - ky;
-                        if (r >= 0 && r < 16)       // D^T = W^T x A^T
+                        if (r >= 0 && r < MT)       // D^T = W^T x A^T
                             acc[r] = H::mfma(b[sl % (BD + 1)][ky], a[h], (FIRST && sl == 0 && ky == 0) ? (f32x4_t){0.f, 0.f, 0.f, 0.f} : acc[r]);
                     }
-                    if (h + kRing < 18) a[h + kRing] = lds_ld<X8>(ab + (h + kRing) * (kHW * kRS));
+                    if (h + kRing < HR) a[h + kRing] = lds_ld<X8>(ab + (h + kRing) * (kHW * kRS));
                     if (sl >= 3) {
-                        // pieces 2 (sl - 3) at h = 1..5 and 2 (sl - 3) + 1 at h = 9..13
-                        if (h >= 1 && h <= 5) commit_step(2 * (sl - 3), h - 1, (cc + 1) & 1, st_chunk);
-                        if (h >= 9 && h <= 13) commit_step(2 * (sl - 3) + 1, h - 9, (cc + 1) & 1, st_chunk);
+                        // pieces 2 (sl - 3) at h = 1..5 and 2 (sl - 3) + 1 at h = 9..13 (64-channel tiles, ten groups: h = 0..4, 5..9)
+                        constexpr int c0 = N64 ? 0 : 1, c1 = N64 ? 5 : 9;
+                        if (h >= c0 && h < c0 + 5) commit_step(2 * (sl - 3), h - c0, (cc + 1) & 1, st_chunk);
+                        if (h >= c1 && h < c1 + 5) commit_step(2 * (sl - 3) + 1, h - c1, (cc + 1) & 1, st_chunk);
                     }
-                    if (EPI && sl < 3) e2_step(sl, h);
+                    if (EPI && sl < 3) {
+                        if constexpr (N64) {       // (the epilogue's 18 steps on ten groups: an odd step - MFMAs, stores - with the NEXT even one's reads)
+                            if (h >= 1) e2_step(sl, 2 * h - 1);
+                            if (h < 9) e2_step(sl, 2 * h);
+                        }
+                        else e2_step(sl, h);
+                    }
                     if (FIRST && sl == 1 && h == 2) {
                         // the tile after the next (or, at the end of the walk, a tile this block already owns: never used)
                         const int w2 = wnext + (int)gridDim.x;
-                        nxt_c = tile_fast(g, w2 < total ? w2 : w);
+                        nxt_c = tile_fast<N64>(g, w2 < total ? w2 : w);
                         wsrc_next_c = reinterpret_cast<const unsigned char*>(g.job[nxt_c.job].wp) + nxt_c.ntile * wtile;
                     }
 #ifdef MPN_C3_PRIO    // (measured: the pair then runs stage by stage together, and the chunk takes the same time - off)
@@ -651,27 +686,28 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                 // Pixels outside the image must not count in the statistics: zeroed on edge tiles.
                 const Job& p = g.job[cur.job];
                 const bool full_tile = cur.oy0 + 16 <= p.H && cur.ox0 + 16 <= p.W;
-                const lds_p iw = L + kImgOff + l15 * kRSO + (((wave * 2 + (lq >> 1)) ^ l15) << 4) + (lq & 1) * 8;
+                // (64-channel tiles: rows 8 ph + r, r < 8; 128-byte pixels, slot (2 cg + lq / 2) ^ (l15 & 7))
+                const lds_p iw = L + kImgOff + (ph * 128 + l15) * kPx + (((cg * 2 + (lq >> 1)) ^ (l15 & kSw)) << 4) + (lq & 1) * 8;
                 if (full_tile) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(acc[r]));
+                    for (int r = 0; r < MT; ++r) lds_st<u32x2_t>(iw + r * (16 * kPx), pack4(acc[r]));
                 } else {
                     const bool okx = cur.ox0 + l15 < p.W;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool ok = okx && cur.oy0 + r < p.H;
-                        lds_st<u32x2_t>(iw + r * (16 * kRSO), pack4(ok ? acc[r] : (f32x4_t){0.f, 0.f, 0.f, 0.f}));
+                    for (int r = 0; r < MT; ++r) {
+                        const bool ok = okx && cur.oy0 + ph * 8 + r < p.H;
+                        lds_st<u32x2_t>(iw + r * (16 * kPx), pack4(ok ? acc[r] : (f32x4_t){0.f, 0.f, 0.f, 0.f}));
                     }
                 }
                 prev_real = true;
                 e_par ^= 256;
                 {
                     const int wys = p.W * p.ys;
-                    e_y = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(p.y) + ((long long)cur.img * p.H + cur.oy0) * wys + (long long)cur.ox0 * p.ys + cur.ntile * 128);
+                    e_y = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(p.y) + ((long long)cur.img * p.H + cur.oy0) * wys + (long long)cur.ox0 * p.ys + cur.ntile * CT);
                     e_rowb = wys * 2; e_pxb = p.ys * 2; e_h = p.H - cur.oy0; e_w = p.W - cur.ox0; e_ntile = cur.ntile;
                     if constexpr (BNR) {
                         const int wbs = p.W * p.bnr_xs;
-                        e_bx = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.bnr_x) + ((long long)cur.img * p.H + cur.oy0) * wbs + (long long)cur.ox0 * p.bnr_xs + cur.ntile * 128);
+                        e_bx = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.bnr_x) + ((long long)cur.img * p.H + cur.oy0) * wbs + (long long)cur.ox0 * p.bnr_xs + cur.ntile * CT);
                         e_bx_rowb = wbs * 2; e_bx_pxb = p.bnr_xs * 2; e_bx_hmax = p.H - 1 - cur.oy0; e_bx_wmax = p.W - 1 - cur.ox0;
                         e_blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
                         e_bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
@@ -680,12 +716,12 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                 if (STATS || BNR) {
                     // the block's row of this job's slab: row = the position of the block's FIRST tile of the job among the job's first
                     // gridDim.x tiles (mpn_conv_stats_rows; the grid is a multiple of n_tiles, so a block keeps its channel tile within a job)
-                    const int n_tiles = Cout >> 7, grid = (int)gridDim.x;
+                    const int n_tiles = N64 ? (Cout >> 6) : (Cout >> 7), grid = (int)gridDim.x;
                     int off = (w_first - g.begin[cur.job]) % grid;
                     if (off < 0) off += grid;
-                    st_pending = tid < 256;
+                    st_pending = tid < 256 && (!N64 || st_c < 64);
                     st_store = !has_next || nxt.job != cur.job;
-                    st_dst = p.stats_part + ((long long)(off / n_tiles) * 2 + st_which) * Cout + cur.ntile * 128 + st_c;
+                    st_dst = p.stats_part + ((long long)(off / n_tiles) * 2 + st_which) * Cout + cur.ntile * CT + st_c;
                 }
                 CS_STAMP(9);
             }
@@ -744,33 +780,34 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
 #endif
 }
 
-template <typename T, int ACT, int MODE, bool GA = false>
+template <typename T, int ACT, int MODE, bool GA = false, bool N64 = false>
 int launch_t(const Group& g, int blocks, hipStream_t st) {
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_cs_kernel<T, ACT, MODE, GA>, kLds, &attr_mask));
-    conv3x3_cs_kernel<T, ACT, MODE, GA><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_cs_kernel<T, ACT, MODE, GA, N64>, kLds, &attr_mask));
+    conv3x3_cs_kernel<T, ACT, MODE, GA, N64><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
-template <typename T, int ACT>
+template <typename T, int ACT, bool N64>
 int launch_m(const Group& g, int blocks, bool stats, hipStream_t st) {
-    return stats ? launch_t<T, ACT, 1>(g, blocks, st) : launch_t<T, ACT, 0>(g, blocks, st);
+    return stats ? launch_t<T, ACT, 1, false, N64>(g, blocks, st) : launch_t<T, ACT, 0, false, N64>(g, blocks, st);
 }
-template <typename T>
+template <typename T, bool N64>
 int launch_v(const Group& g, int blocks, bool affine, bool bnr, hipStream_t st) {
-    if (bnr) return launch_t<T, 0, 2>(g, blocks, st);
+    if (bnr) return launch_t<T, 0, 2, false, N64>(g, blocks, st);
     const bool stats = g.job[0].stats_part != nullptr;
-    if (!affine) return launch_m<T, 0>(g, blocks, stats, st);
-    return g.job[0].in_act == MPN_ACT_RELU6 ? launch_m<T, 2>(g, blocks, stats, st) : launch_m<T, 1>(g, blocks, stats, st);
+    if (!affine) return launch_m<T, 0, N64>(g, blocks, stats, st);
+    return g.job[0].in_act == MPN_ACT_RELU6 ? launch_m<T, 2, N64>(g, blocks, stats, st) : launch_m<T, 1, N64>(g, blocks, stats, st);
 }
 
 }  // namespace
 
 namespace mpn_c3 {
 
-int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, hipStream_t st) {
+int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, bool n64, hipStream_t st) {
     MPN_REQUIRE(g.job[0].Cin <= kMaxCin && g.job[0].Cout <= kMaxCin, MPN_ERR_BAD_SHAPE, "conv3x3: at most %d channels", kMaxCin);
     const bool ga = g.job[0].ap_y != nullptr;
+    MPN_REQUIRE(!(ga && n64), MPN_ERR_BAD_SHAPE, "conv3x3: apply on load needs 128-channel tiles");
     for (int j = 0; j < g.njobs; ++j) {
         const Job& q = g.job[j];
         MPN_REQUIRE((q.ap_y != nullptr) == ga, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the apply-on-load variant");
@@ -791,8 +828,8 @@ int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, hipS
     for (int j = 1; j < g.njobs; ++j)
         MPN_REQUIRE((g.job[j].stats_part != nullptr) == (g.job[0].stats_part != nullptr), MPN_ERR_BAD_ARG,
                     "conv3x3: the jobs of a group share the statistics / no statistics variant");
-    if (dtype == MPN_BF16) return launch_v<bf16_t>(g, blocks, affine, bnr, st);
-    if (dtype == MPN_F16) return launch_v<half_t>(g, blocks, affine, bnr, st);
+    if (dtype == MPN_BF16) return n64 ? launch_v<bf16_t, true>(g, blocks, affine, bnr, st) : launch_v<bf16_t, false>(g, blocks, affine, bnr, st);
+    if (dtype == MPN_F16) return n64 ? launch_v<half_t, true>(g, blocks, affine, bnr, st) : launch_v<half_t, false>(g, blocks, affine, bnr, st);
     MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");
 }
 
