@@ -651,7 +651,7 @@ def retinanet_benchmark(batch=16, height=896, width=1408, iters=10):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     fl = 2.0 * batch * sum(px.values()) * 9 * 64 * 64
-    out["dominant_kernel"] = {"kernel": "conv3x3_kernel<bf16, affine, 64-channel tiles> (tower conv3x3 64->64, five levels in one grid)",
+    out["dominant_kernel"] = {"kernel": "conv3x3_cs_kernel<bf16, affine, statistics, 64-channel tiles> (tower conv3x3 64->64, five levels in one grid)",
                               "bound": "mfma", "launch_us": round(us, 1), "achieved": round(fl / us / 1e6, 1), "peak": PEAK_BF16_TFLOPS,
                               "unit": "TFLOP/s", "frac": round(fl / us / 1e6 / PEAK_BF16_TFLOPS, 4)}
     del net

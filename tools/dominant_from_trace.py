@@ -14,7 +14,8 @@ def is_dom(r):
     nm = r['Kernel_Name']
     # (rocprofv3 demangles "conv3x3_cs_kernel<__bf16, 1, 1, false>" as "conv3x3_cs_kernel<bool _Accum, int, E, 1, false>": the ACT
     #  argument is lost, the MODE = 1 (statistics) and GA = false arguments survive)
-    cs = 'conv3x3_cs_kernel' in nm and ('E, 1, false>' in nm or 'Li1ELi1ELb0E' in nm)
+    # (since the 64-channel-tile flag: "<bool _Accum, int, E, 1, false, false>" / 'Li1ELi1ELb0ELb0E')
+    cs = 'conv3x3_cs_kernel' in nm and ('E, 1, false, false>' in nm or 'Li1ELi1ELb0ELb0E' in nm or 'E, 1, false>' in nm or nm.endswith('Li1ELi1ELb0EEEvN6mpn_c35GroupE'))
     return (cs or 'conv3x3_kernel<' in nm) and int(r['Grid_Size_X']) == 256 * 512
 
 
