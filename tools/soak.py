@@ -1,5 +1,5 @@
-"""Long replay of the three train steps (keypoints bs32 @ 512, detector bs16 @ 896x1408, PRN 128 crops) from hipGraphs: finite
-losses and variables after thousands of steps, steady step time (python tools/soak.py [keypoint steps])."""
+"""Long replay of the keypoint train step (bs32 @ 512) from its hipGraph: finite losses and variables after thousands of steps, steady
+step time (python tools/soak.py [steps])."""
 import sys, time
 import numpy as np
 import torch
