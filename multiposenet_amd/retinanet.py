@@ -606,7 +606,8 @@ class PersonDetectorNet:
              float(params.get("gamma", 2.0)), float(params.get("alpha", 0.25)), lw, cw, ptr(b["loss_part"]), stream_ptr())
         ops.reduce_partials(b["loss_part"], b["loss_part"].numel() // 32, 32, b["loss_sums"])
         losses = b["losses"]
-        losses[2:3].zero_()           # (a memset: an element assignment from a Python scalar is a host copy, not capturable)
+        losses[2:3].zero_()           # (ATen's fill KERNEL - not a memset node, which can race inside a replayed graph: DESIGN 2 - and not an
+                                      #  element assignment from a Python scalar, which is a host copy and not capturable)
         wd = float(params.get("weight_decay", 0.0))
         if wd > 0.0:   # add_weight_decay (keypoints_model.py:129-138) sees EVERY kernel, the frozen backbone's included
             if self._l2 is None:
