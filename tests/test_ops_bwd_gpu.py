@@ -1009,7 +1009,8 @@ def test_grouped_fused_reduction_when_a_block_walks_from_one_job_into_the_next(c
     job j + 1. Round 4's kernel loaded job j + 1's batch-norm table while that last tile was still being multiplied and masked its
     epilogue with the WRONG layer's scale / shift (the four pyramid levels of a subnet stage have four different batch-norms) - unseen by
     the ragged-tile tests, whose groups are smaller than the grid. Here 336 tiles on 256 blocks, batch-norms of opposite signs per job:
-    the grouped launch equals each job launched alone, bit for bit (64-channel tiles: conv3x3.hip; 128: conv3x3_cs.hip)."""
+    the grouped launch equals each job launched alone, bit for bit (64-channel tiles deeper than one chunk: conv3x3.hip; 128-channel tiles
+    and one-chunk 64-channel tiles - the detector's towers: conv3x3_cs.hip)."""
     from multiposenet_amd import ops
     dtype = torch.bfloat16
     rs = np.random.RandomState(77 + K + C)
@@ -1036,7 +1037,7 @@ def test_grouped_fused_reduction_when_a_block_walks_from_one_job_into_the_next(c
         np.testing.assert_allclose(sg, s1, rtol=1e-5, atol=1e-3)
 
 
-@pytest.mark.parametrize("Cin,Cout", [(128, 128), (128, 64)], ids=["128->128", "128->64"])
+@pytest.mark.parametrize("Cin,Cout", [(128, 128), (128, 64), (64, 64)], ids=["128->128", "128->64", "64->64"])
 def test_grouped_forward_when_a_block_walks_from_one_job_into_the_next(cuda, Cin, Cout):
     """The same walk for the forward launches: each job has its own producer affine (the table a block stages its halo with changes with
     the job) and its own statistics slab row per block. 336 tiles on 256 blocks; outputs bit for bit those of the jobs launched alone, the
