@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MPN_VERSION 500   /* r5: see INTEGRATION.md "ABI revisions" */
+#define MPN_VERSION 600   /* r6: see INTEGRATION.md "ABI revisions" */
 
 enum { MPN_F32 = 0, MPN_BF16 = 1, MPN_F16 = 2 /* dense 1x1 / 3x3 convolutions (forward, weight gradient, pack), the PRN entry points and the decode input; the BN / depthwise / loss kernels of the keypoint step take F32 and BF16 only */ };
 
@@ -140,26 +140,6 @@ int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, const void* c
                                  const int* H, const int* W, int K, int C, const int* dy_stride, const int* dx_stride,
                                  int dtype, const void* const* bn_x, const int* bn_x_stride, const float* const* bn_scale,
                                  const float* const* bn_shift, int bn_act, float* const* part, mpn_stream_t stream);
-
-/* The same data gradients with the batch-norm backward APPLY pass of the layer ABOVE folded into their input staging ("apply on
- * load"; keypoint_subnet.py:75-78, fpn.py:39,52, layer_utils.py:9-16): g[j] [N,H,W,K] = the gradient w.r.t. the ACTIVATED output of
- * batch-norm layer A (what mpn_bn_bwd_apply turns into dy in place), y_raw[j] = A's raw output, ap_*[j] = A's affine, saved statistics and
- * the k1 / k2 of mpn_bn_bwd_finalize, ap_act its activation, ap_add_ch0[j] (array or NULL; entries may be NULL) the per-pixel addend on
- * channel 0. The kernel forms dy = scale * mask(g) + (cb * y + cc) - mpn_bn_bwd_apply's expression and rounding - while it stages its
- * input tiles, multiplies THAT (dx[j] [N,H,W,C] <- conv^T(dy)), and writes dy[j] [N,H,W,K] (every pixel once) for the weight gradient,
- * which must run afterwards: mpn_bn_bwd_apply's pass over the tensor (two reads and a write) disappears under a matrix-bound launch. dy[j]
- * may not alias g[j] (neighbouring tiles read g's halo). bn_x != NULL: the launch also reduces for the batch-norm that dx feeds, exactly as
- * mpn_conv_bwd_data_bn_grouped (bn_x / bn_scale / bn_shift / bn_act / part as there). bf16, 3x3, K % 64 == 0, K <= 512, C % 128 == 0,
- * C <= 512: mpn_conv_bwd_data_apply_supported(K, C, 3, dtype) != 0. */
-int mpn_conv_bwd_data_apply_supported(int K, int C, int ksize, int dtype);
-int mpn_conv_bwd_data_apply_grouped(int njobs, const void* const* g, const void* const* y_raw, void* const* dy,
-                                    const void* const* w_packed_t, void* const* dx, int N, const int* H, const int* W, int K, int C,
-                                    const int* g_stride, const int* y_stride, const int* dy_stride, const int* dx_stride, int dtype,
-                                    const float* const* ap_scale, const float* const* ap_shift, const float* const* ap_mean,
-                                    const float* const* ap_invstd, const float* const* ap_k1, const float* const* ap_k2, int ap_act,
-                                    const float* const* ap_add_ch0, const void* const* bn_x, const int* bn_x_stride,
-                                    const float* const* bn_scale, const float* const* bn_shift, int bn_act, float* const* part,
-                                    mpn_stream_t stream);
 
 /* Weight gradient of mpn_conv_fwd: dW[tap][ci][co] = sum_pixels act(bn(x))[pixel+tap][ci]*dy[pixel][co].
  * Split-K over pixel tiles: part [mpn_conv_wgrad_num_parts()][ksize*ksize][Cin][Cout] f32 (one HWIO slab
@@ -550,6 +530,11 @@ int mpn_prn_decode(const float* logits, int nb, int crop_h, int crop_w, int C, f
  *                         (finish with mpn_reduce_partials; the two losses still need the 1/normaliser).
  *   mpn_retina_nms        get_predictions: sigmoid, score >= threshold, decode + clip to [0,1], greedy NMS, zero padding:
  *                         out_boxes f32 [B,max_det,4], out_scores f32 [B,max_det], out_num int32 [B].
+ *                         The workspace holds one candidate list of A slots per image, a counter per image and ONE int32
+ *                         OVERFLOW word at byte mpn_retina_nms_overflow_offset(B, A): 0 after a good call, 1 when a list would
+ *                         have grown past its A slots (the appends past the list are refused, the selection never reads past
+ *                         it). A caller reads it WITH the outputs (the library never synchronises; from a captured graph it is
+ *                         the only report there is) and treats 1 as MPN_ERR_WORKSPACE.
  */
 int mpn_patchify3x3s2(const void* x, void* patches, int N, int H, int W, int C, int dtype, const float* in_scale,
                       const float* in_shift, int in_act, mpn_stream_t stream);
@@ -573,6 +558,7 @@ int mpn_retina_loss_finalize(const float* sums, const int* num_matched, float lo
                              float classification_loss_weight, float* losses, float* dbias_cls, float* dbias_box,
                              mpn_stream_t stream);
 size_t mpn_retina_nms_workspace_bytes(int B, int A);
+size_t mpn_retina_nms_overflow_offset(int B, int A);
 int mpn_retina_nms(const void* const* logits, const void* const* boxes, const int* h, const int* w, int dtype,
                    const float* cls_bias, const float* box_bias, const float* anchors, int B, float score_threshold,
                    float iou_threshold, int max_detections, float* out_boxes, float* out_scores, int* out_num,

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MPN_LIB: an alternative build of the same library (diagnostic A/B of compile-time variants, tools/build_variant.sh)
 LIB_PATH = os.environ.get("MPN_LIB") or os.path.join(_HERE, "libmpn_hip.so")
 
-MPN_VERSION = 500     # the ABI revision this binding was written against (include/mpn.h); lib() refuses another
+MPN_VERSION = 600     # the ABI revision this binding was written against (include/mpn.h); lib() refuses another
 MPN_F32, MPN_BF16, MPN_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
 
@@ -114,9 +114,6 @@ SIGNATURES = {
     "mpn_bn_bwd_finalize_raw": (_I, [_P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _P]),
     "mpn_conv_bwd_data_bn_grouped": (_I, [_I, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P, _P, _P, _I, _P, _P]),
     "mpn_bn_bwd_fin_desc_fill_raw": (_I, [_P, _P, _I, _I, _L, _P, _P, _P, _P, _P, _P, _I]),
-    "mpn_conv_bwd_data_apply_supported": (_I, [_I, _I, _I, _I]),
-    "mpn_conv_bwd_data_apply_grouped": (_I, [_I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P,
-                                             _P, _P, _P, _P, _I, _P, _P]),
     "mpn_prn_crop_slots": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P]),
     "mpn_prn_residual": (_I, [_P, _P, _I, _L, _P, _P]),
     "mpn_retina_loss_finalize": (_I, [_P, _P, _F, _F, _P, _P, _P, _P]),
@@ -129,6 +126,7 @@ SIGNATURES = {
     "mpn_retina_loss_num_parts": (_I, [_I, _I]),
     "mpn_retina_loss": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _P, _P]),
     "mpn_retina_nms_workspace_bytes": (_Z, [_I, _I]),
+    "mpn_retina_nms_overflow_offset": (_Z, [_I, _I]),
     "mpn_retina_nms": (_I, [_P, _P, _P, _P, _I, _P, _P, _P, _I, _F, _F, _I, _P, _P, _P, _P, _Z, _P]),
     "mpn_l2_loss_accumulate": (_I, [_L, _P, _F, _P, _P]),
     "mpn_l2_loss_batched_workspace_bytes": (_Z, [_I, _P]),

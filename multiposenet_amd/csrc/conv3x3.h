@@ -44,15 +44,6 @@ struct Job {
     const float* bnr_scale;
     const float* bnr_shift;
     int bnr_act, bnr_xs;
-    // Data-gradient launches whose INPUT is formed on load (mpn_conv_bwd_data_apply_grouped; the channel-split kernel only): x is g, the
-    // gradient w.r.t. the ACTIVATED output of batch-norm layer A (Cin channels), ap_y that layer's raw output. The kernel reads both,
-    // forms dy = scale * mask(g) + (cb * y + cc) - mpn_bn_bwd_apply's expression - while it commits its halo image, multiplies THAT, and
-    // writes the interior of every tile to ap_dy for the weight gradient: the apply pass over the tensor (2 reads + 1 write) is gone.
-    const void* ap_y;     // NULL: x is the gradient itself
-    void* ap_dy;
-    const float *ap_scale, *ap_shift, *ap_mean, *ap_invstd, *ap_k1, *ap_k2;
-    const float* ap_add0; // optional: + add0[pixel] on channel 0 (the auxiliary loss on p_l[..., 0], keypoints_model.py:59-66)
-    int ap_act, ap_ys, ap_dys;
 #ifdef MPN_DIAG
     unsigned long long* dbg;
 #endif
@@ -148,6 +139,6 @@ __device__ __forceinline__ Tile tile_of(const Group& g, int w) {
 
 
 // the channel-split kernel (conv3x3_cs.hip): 128-channel tiles, or (n64) 64-channel tiles
-int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, bool n64, hipStream_t st);   // (+ jobs with ap_y: input formed on load)
+int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, bool n64, hipStream_t st);
 
 }  // namespace mpn_c3

@@ -654,11 +654,11 @@ int launch_t(const Group& g, int blocks, hipStream_t st) {
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
+// (only the 64-channel tiles of several chunks still come here - launch() below: the 128-channel instantiations are gone)
 template <typename T>
-int launch_v(const Group& g, int blocks, bool affine, bool n64, bool bnr, hipStream_t st) {
-    if (bnr) return n64 ? launch_t<T, false, true, true>(g, blocks, st) : launch_t<T, false, false, true>(g, blocks, st);
-    if (n64) return affine ? launch_t<T, true, true>(g, blocks, st) : launch_t<T, false, true>(g, blocks, st);
-    return affine ? launch_t<T, true, false>(g, blocks, st) : launch_t<T, false, false>(g, blocks, st);
+int launch_v(const Group& g, int blocks, bool affine, bool bnr, hipStream_t st) {
+    if (bnr) return launch_t<T, false, true, true>(g, blocks, st);
+    return affine ? launch_t<T, true, true>(g, blocks, st) : launch_t<T, false, true>(g, blocks, st);
 }
 
 }  // namespace
@@ -713,18 +713,12 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
                              jobs[j].bnr_xs % 8 == 0 && jobs[j].Cout <= kMaxCin && mpn_aligned16(jobs[j].bnr_x)),
                     MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a data gradient (no producer affine), a partial slab and the layer's affine");
     }
-#ifndef MPN_C3_OLD
-    // the channel-split kernel (conv3x3_cs.hip); -DMPN_C3_OLD builds keep this file's kernel for A/B runs, -DMPN_C3_OLD64 for the
-    // 64-channel tiles only
-#ifdef MPN_C3_OLD64
-    if (!n64)
-#endif
+    // 128-channel tiles and one-chunk 64-channel tiles (the detector's 64 -> 64 towers) run on the channel-split kernel (conv3x3_cs.hip).
     // (64-channel tiles of MORE than one 64-channel chunk - final_conv3x3's forward, 512 -> 64 - stay on this file's kernel: 310 against
-    //  316 us; one-chunk tiles - the detector's 64 -> 64 towers - are 6-11 % faster on the channel-split one: profiles/r05_c3cs_n64.txt)
+    //  316 us; one-chunk tiles are 6-11 % faster on the channel-split one: profiles/r05_c3cs_n64.txt)
     if (!n64 || jobs[0].Cin == 64) return launch_cs(g, begin, dtype, affine, bnr, n64, st);
-#endif
-    if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, n64, bnr, st);
-    if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, n64, bnr, st);
+    if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, bnr, st);
+    if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, bnr, st);
     MPN_FAIL(MPN_ERR_BAD_DTYPE, "conv3x3: 16-bit storage only");
 }
 

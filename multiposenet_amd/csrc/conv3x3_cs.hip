@@ -21,7 +21,7 @@
 //     instruction writes four complete pixels.
 // A stand-alone model of this stage (tools/stage2_ceiling.hip, profiles/r05_stage2_ceiling.txt) runs at 0.65 of the nominal MFMA
 // peak WITH the halo staging work, where the model of conv3x3.hip's stage reaches 0.66 without it.
-// LDS: [halo 0: 41 472][halo 1: 41 472][image 65 536][statistics 8 960][scale / shift table 4 096][apply-on-load table 2 048] = 163 648 bytes.
+// LDS: [halo 0: 41 472][halo 1: 41 472][image 65 536][statistics 8 960][scale / shift table 4 096] = 161 536 bytes.
 #include "conv3x3.h"
 
 namespace {
@@ -56,16 +56,9 @@ constexpr int kDiagBytes = 8 * 32 * 8;       // per-wave stamps (below)
 #else
 constexpr int kDiagBytes = 0;
 #endif
-constexpr int kGaCin = 128;                  // apply on load: at most this many input channels (the subnet's / FPN's stages, final_bn)
-constexpr int kGaBytes = 4 * kGaCin * (int)sizeof(float);    // [4][kGaCin] sc, sh, cb, cc of the batch-norm whose gradient is formed
-constexpr int kProgBytes = 64;               // per wave: the number of stages it has started (priority feedback, below)
-constexpr int kLds = kHaloArea + kRedBytes + kTabBytes + kGaBytes + kProgBytes;     // (a diagnostic build keeps its stamps in the apply-on-load table)
-static_assert(kDiagBytes <= kGaBytes, "stamps");
+constexpr int kLds = kHaloArea + kRedBytes + kTabBytes + kDiagBytes;
 constexpr int kAVec = 6;                     // 16-byte pieces of a halo image per thread
-#ifndef MPN_C3_RING
-#define MPN_C3_RING 6
-#endif
-constexpr int kRingDefault = MPN_C3_RING;              // halo fragments in flight
+constexpr int kRing = 6;                     // halo fragments in flight (4 and 8 measured equal or slower: profiles/r05_c3cs_ab.txt)
 static_assert(kLds <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ int halo_off(int buf) { return buf ? kABytes : 0; }
@@ -109,12 +102,11 @@ __device__ __forceinline__ Tile tile_fast(const Group& g, int w) {
 
 // ACT: 0 = no producer affine, 1 = affine + (ReLU or none, by in_act), 2 = affine + ReLU6
 // MODE: 0 = plain, 1 = batch-norm statistics of the output, 2 = data gradient that also reduces for the batch-norm it feeds (BNR)
-// GA: the input gradient is formed on load (Job::ap_y: apply-on-load of the batch-norm backward, no producer affine)
 // N64: 64 output channels per tile (Cout an odd multiple of 64: final_conv3x3 512 -> 64, the detector's 64 -> 64 towers): the eight
 //   waves are FOUR channel groups of 16 x TWO pixel halves (output rows 8 ph .. 8 ph + 7): 24 MFMAs per wave and stage on 10 halo
 //   fragments and the same three weight fragments; the packed weight image is conv3x3.hip's 64-channel one
 //   ([chunk][kx 3][ky 3][k-step 2][co 64][64 bytes]), the output image 128 bytes per pixel.
-template <typename T, int ACT, int MODE, bool GA = false, bool N64 = false>
+template <typename T, int ACT, int MODE, bool N64 = false>
 __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) {
     constexpr bool AFFINE = ACT != 0, STATS = MODE == 1, BNR = MODE == 2;
     constexpr int MT = N64 ? 8 : 16;            // output rows (m-tiles) of a wave
@@ -122,9 +114,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     constexpr int CT = N64 ? 64 : 128;          // output channels of a tile
     constexpr int kPx = CT * 2;                 // output image: bytes per pixel (= kRSO without N64)
     constexpr int kSw = N64 ? 7 : 15;           // its slot swizzle: slot ^ (px & kSw)
-    static_assert(!GA || !N64, "apply on load: 128-channel tiles");
-    static_assert(!GA || ACT == 0, "apply on load: the input is a gradient (no producer affine)");
-    constexpr int kRing = kRingDefault;
     // the fused-reduction variant finishes a tile BEHIND its last chunk instead of under the next tile's first stages: its epilogue
     // (the raw tensor of the fed batch-norm, the masks, sixteen running sums) does not fit beside the accumulators - 43 spilled registers
     constexpr bool PIPE = !BNR;
@@ -135,10 +124,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     const lds_p L = (lds_p)smem;
     const lds_f red = (lds_f)(L + kHaloArea);                 // [8 waves][2][128] statistics of the tile that has just finished
     const lds_f tab = (lds_f)(L + kHaloArea + kRedBytes);     // [2][kMaxCin] scale, shift of the job in `tab_job`
-    const lds_f gat = (lds_f)(L + kHaloArea + kRedBytes + kTabBytes);     // GA: [4][kMaxCin] sc, sh, cb, cc of the job in `ga_job`
 
 #ifdef MPN_DIAG
-    LDS unsigned long long* wst = (LDS unsigned long long*)(L + kHaloArea + kRedBytes + kTabBytes);
+    LDS unsigned long long* wst = (LDS unsigned long long*)(L + kHaloArea + kRedBytes + kTabBytes);   // (kDiagBytes)
     if (threadIdx.x < 256) wst[threadIdx.x] = 0;
     int titer = 0;
 #endif
@@ -155,16 +143,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = N64 ? (wave & 3) : wave, ph = N64 ? (wave >> 2) : 0;      // channel group of 16, pixel half
-    // Priority feedback between the two waves of a SIMD (waves w and w ^ 4). Left alone the OLDER wave of a pair wins every
-    // arbitration: it ran a chunk's six stages in 7.4 k cycles at almost the speed it has alone, its partner got the issue slots it
-    // left (2.6 stages in that time) and then finished ALONE - 4 k cycles at 65 % of the matrix pipe - while the older wave waited
-    // at the chunk's barrier (tools/stamp_c3cs.py, profiles/r05_c3cs_stamps.txt). Each wave publishes the number of stages it has
-    // started and reads its partner's; the one that is behind raises its priority, so the pair stays within a stage of each other.
-#ifdef MPN_C3_PRIO
-    const lds_p prog_mine = L + kHaloArea + kRedBytes + kTabBytes + kGaBytes + wave * 4, prog_other = L + kHaloArea + kRedBytes + kTabBytes + kGaBytes + (wave ^ 4) * 4;
-    int pcount = 0, pseen = 0;
-    if (tid < 16) lds_st<int>(L + kHaloArea + kRedBytes + kTabBytes + kGaBytes + tid * 4, 0);
-#endif
     const int l15 = lane & 15, lq = lane >> 4;
     const int Cin = g.job[0].Cin, Cout = g.job[0].Cout;    // (shared by the jobs of a group)
     const int nchunk = Cin >> 6;
@@ -222,30 +200,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         }
         tab_job = job;
     };
-    // GA: the four per-channel coefficients of mpn_bn_bwd_apply (bn.hip, bn_bwd_apply_body - the same expressions):
-    //   dy = sc * g + (cb * y + cc),  g masked where lo < y * sc + sh < hi;  cb = -sc * k2 * invstd,  cc = -sc * (k1 - mean * invstd * k2)
-    int ga_job = -1;
-    auto ga_load = [&](int job) {
-        if constexpr (GA) {
-            const Job& p = g.job[job];
-            for (int i = tid; i < Cin; i += kThreads) {
-                const float ss = p.ap_scale[i], hh = p.ap_shift[i], mm = p.ap_mean[i], ii = p.ap_invstd[i], aa = p.ap_k1[i], bb = p.ap_k2[i];
-                gat[i] = ss; gat[kGaCin + i] = hh;
-                gat[2 * kGaCin + i] = -ss * bb * ii;
-                gat[3 * kGaCin + i] = -ss * (aa - mm * ii * bb);
-            }
-        }
-        ga_job = job;
-    };
     unsigned okmask = 0;        // of the image fetched last: piece i of this thread lies inside the image
     Vec16<T> av[kAVec];
-    Vec16<T> ay[GA ? kAVec : 1];    // GA: the raw output of the batch-norm layer at the same positions
-    // GA: where the formed gradient of piece i goes (the tile's INTERIOR pixels: every pixel of the tensor once over the grid), and
-    // the auxiliary loss gradient of its pixel
-    unsigned char* ga_dy = nullptr;
-    int ga_rowb = 0, ga_pxb = 0, ga_h = 0, ga_w = 0;
-    float ga_a0[GA ? kAVec : 1];    // (fetched with the image: a load inside a commit step would wait behind the weight fragments just requested)
-    float ga_lo = 0.f, ga_hi = 0.f;
     auto a_load = [&](const Tile& t, int chunk) __attribute__((always_inline)) {
         const Job& p = g.job[t.job];
         // the image base is scalar, row and column BYTE offsets are 24-bit multiplies added as an unsigned 32-bit offset
@@ -265,35 +221,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             okmask |= (ok ? 1u : 0u) << i;
             av[i].load(reinterpret_cast<const T*>(xb + (__umul24((unsigned)min(max(iy, 0), p.H - 1), (unsigned)wxb) + col)));
         }
-        if constexpr (GA) {
-            const int wyb = p.W * p.ap_ys * 2;
-            const unsigned char* yb = reinterpret_cast<const unsigned char*>(p.ap_y) + ((long long)t.img * p.H * (p.W * p.ap_ys) + chunk * 64) * 2;
-            const unsigned ycol = __umul24((unsigned)min(max(ix, 0), p.W - 1), (unsigned)(p.ap_ys * 2)) + slot * 16;
-#pragma unroll
-            for (int i = 0; i < kAVec; ++i) {
-                const int iy = t.oy0 + (3 * i - 1) + hy;
-                ay[i].load(reinterpret_cast<const T*>(yb + (__umul24((unsigned)min(max(iy, 0), p.H - 1), (unsigned)wyb) + ycol)));
-            }
-            // (scalars of the by-product store, fixed here: a job field read inside a stage is an s_load whose wait drains the fragment reads)
-            const int wdb = p.W * p.ap_dys;
-            ga_dy = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(p.ap_dy) + ((long long)t.img * p.H + t.oy0) * wdb + (long long)t.ox0 * p.ap_dys + chunk * 64);
-            ga_rowb = wdb * 2; ga_pxb = p.ap_dys * 2; ga_h = p.H - t.oy0; ga_w = p.W - t.ox0;
-            if (p.ap_add0 != nullptr && chunk == 0) {          // (block-uniform)
-                // (the halo ring needs its pixels' addends too - of the neighbouring tiles' pixels: image coordinates, clamped)
-                const float* a0 = p.ap_add0 + (long long)t.img * p.H * p.W;
-                const int rx = min(max(ix, 0), p.W - 1);
-#pragma unroll
-                for (int i = 0; i < kAVec; ++i) {
-                    const int ry = min(max(t.oy0 + (3 * i - 1) + hy, 0), p.H - 1);
-                    ga_a0[i] = slot == 0 ? a0[ry * p.W + rx] : 0.f;
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < kAVec; ++i) ga_a0[i] = 0.f;
-            }
-            ga_lo = p.ap_act != MPN_ACT_NONE ? 0.f : -INFINITY;
-            ga_hi = p.ap_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
-        }
     };
     // The commit of piece i of the fetched image into halo buffer `buf`, in five steps that a stage spreads over its MFMA groups:
     // j = 0..3: dword j (two channels: affine + activation + zero padding), j = 4: the 16-byte LDS store. The scale / shift of the
@@ -308,25 +235,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             sh[0] = (f32x2_t){h0[0], h0[1]}; sh[1] = (f32x2_t){h0[2], h0[3]}; sh[2] = (f32x2_t){h1[0], h1[1]}; sh[3] = (f32x2_t){h1[2], h1[3]};
         }
     };
-    auto commit_step = [&](const int i, const int j, int buf, int chunk = 0) __attribute__((always_inline)) {
+    auto commit_step = [&](const int i, const int j, int buf) __attribute__((always_inline)) {
         if (j < 4) {
             unsigned u = j == 0 ? av[i].raw.x : (j == 1 ? av[i].raw.y : (j == 2 ? av[i].raw.z : av[i].raw.w));
-            if constexpr (GA) {
-                static_assert(!GA || std::is_same<T, bf16_t>::value, "apply on load: bf16 storage (what mpn_bn_bwd_apply's callers run)");
-                const unsigned uy = j == 0 ? ay[i].raw.x : (j == 1 ? ay[i].raw.y : (j == 2 ? ay[i].raw.z : ay[i].raw.w));
-                // (the coefficients of the two channels from the table at the use: four registers for two steps instead of 32 for a stage)
-                int toff = (chunk * 64 + slot * 8 + 2 * j) * 4;
-                asm volatile("" : "+v"(toff));
-                const f32x2_t sc2 = lds_ld<f32x2_t>((lds_p)gat + toff), sh2 = lds_ld<f32x2_t>((lds_p)gat + toff + kGaCin * 4);
-                const f32x2_t cb2 = lds_ld<f32x2_t>((lds_p)gat + toff + 2 * kGaCin * 4), cc2 = lds_ld<f32x2_t>((lds_p)gat + toff + 3 * kGaCin * 4);
-                const f32x2_t gg = {__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
-                const f32x2_t yy = {__uint_as_float(uy << 16), __uint_as_float(uy & 0xffff0000u)};
-                const f32x2_t pre = __builtin_elementwise_fma(yy, sc2, sh2);
-                const f32x2_t gm = {(pre[0] > ga_lo && pre[0] < ga_hi) ? gg[0] : 0.f, (pre[1] > ga_lo && pre[1] < ga_hi) ? gg[1] : 0.f};
-                f32x2_t d = __builtin_elementwise_fma(sc2, gm, __builtin_elementwise_fma(cb2, yy, cc2));
-                if (j == 0) d[0] += ga_a0[i];   // the auxiliary loss gradient on channel 0 (slot 0 of the first chunk; 0 elsewhere), in f32 as the apply pass adds it
-                u = pack_bf16x2(d[0], d[1]);
-            }
             if constexpr (AFFINE) {
                 f32x2_t f;
                 if constexpr (std::is_same<T, bf16_t>::value) {
@@ -353,13 +264,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
             // (pixels q54 + 54 i share the column qx: the swizzle is a constant of the thread)
             lds_st<u32x4_t>(L + halo_off(buf) + q54 * kRS + ((slot ^ (qx & 7)) << 4) + i * (54 * kRS), (u32x4_t){av[i].raw.x, av[i].raw.y, av[i].raw.z, av[i].raw.w});
-            if constexpr (GA) {
-                // the formed gradient of the tile's interior pixels (halo row / column 1..16) for the weight gradient: every pixel of the
-                // tensor is some tile's interior exactly once (the redundant copies of threads 432..511 write the same bytes)
-                const int hyy = qy + 3 * i - 1, hxx = qx - 1;         // pixel inside the tile
-                if ((unsigned)hyy < 16u && (unsigned)hxx < 16u && hyy < ga_h && hxx < ga_w)
-                    *reinterpret_cast<uint4*>(ga_dy + (unsigned)(hyy * ga_rowb + hxx * ga_pxb + slot * 16)) = av[i].raw;
-            }
         }
     };
 
@@ -558,23 +462,19 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     Tile cur = tile_of<N64>(g, w);
     if constexpr (BNR) { e_bx = reinterpret_cast<const unsigned char*>(g.job[cur.job].bnr_x); }     // (a block's first tile: loads that nothing uses, from a valid address)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
-#ifndef MPN_C3_BD
-#define MPN_C3_BD 1      // weight fragments requested this many stages ahead (1: two register sets, 2: three)
-#endif
-    constexpr int BD = MPN_C3_BD;
+    constexpr int BD = 1;      // weight fragments requested this many stages ahead (two register sets; two stages ahead measured equal: profiles/r05_c3cs_ab.txt)
     X8 b[BD + 1][3];
     int cc = 0;                // running chunk counter: the chunk reads halo buffer cc & 1
     b_load(b[0], wsrc, 0);
     if constexpr (BD == 2) b_load(b[1], wsrc, w_off(0, 1));
     a_load(cur, 0);
     if constexpr (AFFINE || BNR) tab_load(cur.job);
-    if constexpr (GA) ga_load(cur.job);
     __syncthreads();           // table visible
     tab_read(0);
 #pragma unroll
     for (int i = 0; i < kAVec; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) commit_step(i, j, 0, 0);
+        for (int j = 0; j < 5; ++j) commit_step(i, j, 0);
     __syncthreads();
 
     Tile nxt_c = tile_fast<N64>(g, w + (int)gridDim.x < total ? w + (int)gridDim.x : w);
@@ -612,13 +512,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                     __builtin_amdgcn_s_barrier();
                 }
             }
-            if constexpr (GA) {
-                if (last_chunk && nxt.job != ga_job) {
-                    ga_load(nxt.job);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-            }
 #pragma unroll
             for (int sl = 0; sl < 6; ++sl) {
                 const lds_p ab = hb + (abase_kx[sl >> 1] ^ ((sl & 1) * 64));
@@ -643,8 +536,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                     if (sl >= 3) {
                         // pieces 2 (sl - 3) at h = 1..5 and 2 (sl - 3) + 1 at h = 9..13 (64-channel tiles, ten groups: h = 0..4, 5..9)
                         constexpr int c0 = N64 ? 0 : 1, c1 = N64 ? 5 : 9;
-                        if (h >= c0 && h < c0 + 5) commit_step(2 * (sl - 3), h - c0, (cc + 1) & 1, st_chunk);
-                        if (h >= c1 && h < c1 + 5) commit_step(2 * (sl - 3) + 1, h - c1, (cc + 1) & 1, st_chunk);
+                        if (h >= c0 && h < c0 + 5) commit_step(2 * (sl - 3), h - c0, (cc + 1) & 1);
+                        if (h >= c1 && h < c1 + 5) commit_step(2 * (sl - 3) + 1, h - c1, (cc + 1) & 1);
                     }
                     if (EPI && sl < 3) {
                         if constexpr (N64) {       // (the epilogue's 18 steps on ten groups: an odd step - MFMAs, stores - with the NEXT even one's reads)
@@ -659,15 +552,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                         nxt_c = tile_fast<N64>(g, w2 < total ? w2 : w);
                         wsrc_next_c = reinterpret_cast<const unsigned char*>(g.job[nxt_c.job].wp) + nxt_c.ntile * wtile;
                     }
-#ifdef MPN_C3_PRIO    // (measured: the pair then runs stage by stage together, and the chunk takes the same time - off)
-                    if (h == 0) { ++pcount; lds_st<int>(prog_mine, pcount); pseen = lds_ld<int>(prog_other); }
-                    if (h == 8) {
-                        const int ps = __builtin_amdgcn_readfirstlane(pseen);
-                        if (ps > pcount) __builtin_amdgcn_s_setprio(2);
-                        else if (ps < pcount) __builtin_amdgcn_s_setprio(0);
-                        else __builtin_amdgcn_s_setprio(1);
-                    }
-#endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 CS_STAMP(16 + (chunk < 1 ? chunk : 1) * 6 + sl);
@@ -780,21 +664,21 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
 #endif
 }
 
-template <typename T, int ACT, int MODE, bool GA = false, bool N64 = false>
+template <typename T, int ACT, int MODE, bool N64 = false>
 int launch_t(const Group& g, int blocks, hipStream_t st) {
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_cs_kernel<T, ACT, MODE, GA, N64>, kLds, &attr_mask));
-    conv3x3_cs_kernel<T, ACT, MODE, GA, N64><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_cs_kernel<T, ACT, MODE, N64>, kLds, &attr_mask));
+    conv3x3_cs_kernel<T, ACT, MODE, N64><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
 template <typename T, int ACT, bool N64>
 int launch_m(const Group& g, int blocks, bool stats, hipStream_t st) {
-    return stats ? launch_t<T, ACT, 1, false, N64>(g, blocks, st) : launch_t<T, ACT, 0, false, N64>(g, blocks, st);
+    return stats ? launch_t<T, ACT, 1, N64>(g, blocks, st) : launch_t<T, ACT, 0, N64>(g, blocks, st);
 }
 template <typename T, bool N64>
 int launch_v(const Group& g, int blocks, bool affine, bool bnr, hipStream_t st) {
-    if (bnr) return launch_t<T, 0, 2, false, N64>(g, blocks, st);
+    if (bnr) return launch_t<T, 0, 2, N64>(g, blocks, st);
     const bool stats = g.job[0].stats_part != nullptr;
     if (!affine) return launch_m<T, 0, N64>(g, blocks, stats, st);
     return g.job[0].in_act == MPN_ACT_RELU6 ? launch_m<T, 2, N64>(g, blocks, stats, st) : launch_m<T, 1, N64>(g, blocks, stats, st);
@@ -805,26 +689,10 @@ int launch_v(const Group& g, int blocks, bool affine, bool bnr, hipStream_t st) 
 namespace mpn_c3 {
 
 int launch_cs(const Group& g, int blocks, int dtype, bool affine, bool bnr, bool n64, hipStream_t st) {
-    MPN_REQUIRE(g.job[0].Cin <= kMaxCin && g.job[0].Cout <= kMaxCin, MPN_ERR_BAD_SHAPE, "conv3x3: at most %d channels", kMaxCin);
-    const bool ga = g.job[0].ap_y != nullptr;
-    MPN_REQUIRE(!(ga && n64), MPN_ERR_BAD_SHAPE, "conv3x3: apply on load needs 128-channel tiles");
-    for (int j = 0; j < g.njobs; ++j) {
-        const Job& q = g.job[j];
-        MPN_REQUIRE((q.ap_y != nullptr) == ga, MPN_ERR_BAD_ARG, "conv3x3: the jobs of a group share the apply-on-load variant");
-        if (!ga) continue;
-        MPN_REQUIRE(q.Cin <= kGaCin, MPN_ERR_BAD_SHAPE, "conv3x3: apply on load: at most %d input channels", kGaCin);
-        MPN_REQUIRE(!affine && dtype == MPN_BF16 && q.ap_dy && q.ap_scale && q.ap_shift && q.ap_mean && q.ap_invstd && q.ap_k1 && q.ap_k2 &&
-                        mpn_aligned16(q.ap_y) && mpn_aligned16(q.ap_dy) && q.ap_ys >= q.Cin && q.ap_dys >= q.Cin && q.ap_ys % 8 == 0 && q.ap_dys % 8 == 0,
-                    MPN_ERR_BAD_ARG, "conv3x3: apply on load needs a bf16 data gradient (no producer affine), the raw output, the formed gradient's buffer and the batch-norm's six vectors");
-        MPN_REQUIRE((long long)q.W * q.ap_ys < (1ll << 23) && (long long)q.N * q.H * q.W * q.ap_ys < (1ll << 31) &&
-                        (long long)q.N * q.H * q.W * q.ap_dys < (1ll << 31) && (long long)16 * q.W * q.ap_dys * 2 + 32768 < (1ll << 31),
-                    MPN_ERR_BAD_SHAPE, "conv3x3: apply on load: tensors must span fewer than 2^31 elements");
-    }
-    if (ga) {
-        if (bnr) return launch_t<bf16_t, 0, 2, true>(g, blocks, st);
-        MPN_REQUIRE(g.job[0].stats_part == nullptr, MPN_ERR_BAD_ARG, "conv3x3: apply on load rides on a data gradient (no output statistics)");
-        return launch_t<bf16_t, 0, 0, true>(g, blocks, st);
-    }
+    // (the table holds the producer's affine per INPUT channel, or - fused reduction - the fed batch-norm's per OUTPUT channel; nothing else
+    //  is sized by the channel counts)
+    MPN_REQUIRE(g.job[0].Cin <= kMaxCin, MPN_ERR_BAD_SHAPE, "conv3x3: at most %d input channels", kMaxCin);
+    MPN_REQUIRE(!bnr || g.job[0].Cout <= kMaxCin, MPN_ERR_BAD_SHAPE, "conv3x3: the fused reduction takes at most %d output channels", kMaxCin);
     for (int j = 1; j < g.njobs; ++j)
         MPN_REQUIRE((g.job[j].stats_part != nullptr) == (g.job[0].stats_part != nullptr), MPN_ERR_BAD_ARG,
                     "conv3x3: the jobs of a group share the statistics / no statistics variant");

@@ -909,8 +909,6 @@ static void c3_fill_job(mpn_c3::Job& j, const void* x, const void* w_packed, voi
     j.N = N; j.H = H; j.W = W; j.Cin = Cin; j.Cout = Cout;
     j.xs = x_stride > 0 ? x_stride : Cin; j.ys = y_stride > 0 ? y_stride : Cout;
     j.bnr_x = nullptr; j.bnr_scale = nullptr; j.bnr_shift = nullptr; j.bnr_act = MPN_ACT_NONE; j.bnr_xs = 0;
-    j.ap_y = nullptr; j.ap_dy = nullptr; j.ap_scale = j.ap_shift = j.ap_mean = j.ap_invstd = j.ap_k1 = j.ap_k2 = j.ap_add0 = nullptr;
-    j.ap_act = MPN_ACT_NONE; j.ap_ys = j.ap_dys = 0;
 #ifdef MPN_DIAG
     j.dbg = (unsigned long long*)g_conv_dbg;
 #endif
@@ -1101,57 +1099,6 @@ extern "C" int mpn_conv_bwd_data_bn_grouped(int njobs, const void* const* dy, co
         c3_fill_job(jobs[j], dy[j], w_packed_t[j], dx[j], N, H[j], W[j], K, C, xs, ys, nullptr, nullptr, MPN_ACT_NONE, part[j]);
         jobs[j].bnr_x = bn_x[j]; jobs[j].bnr_scale = bn_scale[j]; jobs[j].bnr_shift = bn_shift[j]; jobs[j].bnr_act = bn_act;
         jobs[j].bnr_xs = bs > 0 ? bs : C;
-    }
-    return mpn_c3::launch(jobs, njobs, dtype, (hipStream_t)stream);
-}
-
-/* 1 when mpn_conv_bwd_data_apply_grouped takes the geometry: bf16, 3x3, the channel-split kernel's shapes (K % 64 == 0, K <= 512 channels of
- * the gradient, C % 128 == 0, C <= 512 channels of the data gradient) */
-extern "C" int mpn_conv_bwd_data_apply_supported(int K, int C, int ksize, int dtype) {
-    return (ksize == 3 && dtype == MPN_BF16 && mpn_c3::eligible(K, C, 9, 2) && C <= 512) ? 1 : 0;
-}
-
-/* Data gradients of up to five independent 3x3 convolutions whose INPUT is formed on load: g[j] = the gradient w.r.t. the ACTIVATED output
- * of a batch-norm layer (what mpn_bn_bwd_apply would turn into dy in place), y_raw[j] = that layer's raw output, ap_* its affine, saved
- * statistics and the k1 / k2 of its backward finalize. dx[j] <- conv^T(dy), dy[j] <- the formed gradient (every pixel once: the weight
- * gradient reads it afterwards); g and y_raw are not written. With bn_x != NULL the launch also reduces for the batch-norm dx feeds, as
- * mpn_conv_bwd_data_bn_grouped does. */
-extern "C" int mpn_conv_bwd_data_apply_grouped(int njobs, const void* const* g, const void* const* y_raw, void* const* dy,
-                                               const void* const* w_packed_t, void* const* dx, int N, const int* H, const int* W, int K, int C,
-                                               const int* g_stride, const int* y_stride, const int* dy_stride, const int* dx_stride, int dtype,
-                                               const float* const* ap_scale, const float* const* ap_shift, const float* const* ap_mean,
-                                               const float* const* ap_invstd, const float* const* ap_k1, const float* const* ap_k2, int ap_act,
-                                               const float* const* ap_add_ch0, const void* const* bn_x, const int* bn_x_stride,
-                                               const float* const* bn_scale, const float* const* bn_shift, int bn_act, float* const* part,
-                                               mpn_stream_t stream) {
-    MPN_REQUIRE(njobs > 0 && njobs <= mpn_c3::kMaxJobs && g && y_raw && dy && w_packed_t && dx && H && W && ap_scale && ap_shift && ap_mean &&
-                    ap_invstd && ap_k1 && ap_k2, MPN_ERR_BAD_ARG, "conv_bwd_data_apply: bad arguments");
-    MPN_REQUIRE(mpn_conv_bwd_data_apply_supported(K, C, 3, dtype), MPN_ERR_BAD_SHAPE, "conv_bwd_data_apply: geometry not covered (K %d, C %d)", K, C);
-    MPN_REQUIRE(N > 0, MPN_ERR_BAD_SHAPE, "conv_bwd_data_apply: bad shape");
-    const bool bnr = bn_x != nullptr;
-    MPN_REQUIRE(!bnr || (bn_scale && bn_shift && part), MPN_ERR_BAD_ARG, "conv_bwd_data_apply: the fused reduction needs the fed batch-norm's affine and a slab");
-    mpn_c3::Job jobs[mpn_c3::kMaxJobs];
-    for (int j = 0; j < njobs; ++j) {
-        MPN_REQUIRE(g[j] && y_raw[j] && dy[j] && w_packed_t[j] && dx[j] && H[j] > 0 && W[j] > 0 && ap_scale[j] && ap_shift[j] && ap_mean[j] &&
-                        ap_invstd[j] && ap_k1[j] && ap_k2[j], MPN_ERR_BAD_ARG, "conv_bwd_data_apply: null pointer / bad size");
-        MPN_REQUIRE(mpn_aligned16(g[j]) && mpn_aligned16(y_raw[j]) && mpn_aligned16(dy[j]) && mpn_aligned16(w_packed_t[j]) && mpn_aligned16(dx[j]),
-                    MPN_ERR_BAD_ALIGN, "conv_bwd_data_apply: pointers must be 16-byte aligned");
-        MPN_REQUIRE(dy[j] != g[j] && dy[j] != y_raw[j] && dx[j] != g[j] && dx[j] != dy[j], MPN_ERR_BAD_ARG,
-                    "conv_bwd_data_apply: the formed gradient cannot overwrite g in place (neighbouring tiles read g's halo)");
-        const int gs = g_stride ? g_stride[j] : 0, ys = y_stride ? y_stride[j] : 0, ds = dy_stride ? dy_stride[j] : 0, xs = dx_stride ? dx_stride[j] : 0;
-        const int bs = (bnr && bn_x_stride) ? bn_x_stride[j] : 0;
-        MPN_REQUIRE((gs == 0 || (gs >= K && gs % 8 == 0)) && (ys == 0 || (ys >= K && ys % 8 == 0)) && (ds == 0 || (ds >= K && ds % 8 == 0)) &&
-                        (xs == 0 || (xs >= C && xs % 8 == 0)) && (bs == 0 || (bs >= C && bs % 8 == 0)), MPN_ERR_BAD_SHAPE,
-                    "conv_bwd_data_apply: bad pixel strides %d, %d, %d, %d, %d", gs, ys, ds, xs, bs);
-        c3_fill_job(jobs[j], g[j], w_packed_t[j], dx[j], N, H[j], W[j], K, C, gs, xs, nullptr, nullptr, MPN_ACT_NONE, bnr ? part[j] : nullptr);
-        jobs[j].ap_y = y_raw[j]; jobs[j].ap_dy = dy[j]; jobs[j].ap_ys = ys > 0 ? ys : K; jobs[j].ap_dys = ds > 0 ? ds : K;
-        jobs[j].ap_scale = ap_scale[j]; jobs[j].ap_shift = ap_shift[j]; jobs[j].ap_mean = ap_mean[j]; jobs[j].ap_invstd = ap_invstd[j];
-        jobs[j].ap_k1 = ap_k1[j]; jobs[j].ap_k2 = ap_k2[j]; jobs[j].ap_act = ap_act; jobs[j].ap_add0 = ap_add_ch0 ? ap_add_ch0[j] : nullptr;
-        if (bnr) {
-            MPN_REQUIRE(bn_x[j] && bn_scale[j] && bn_shift[j] && part[j] && mpn_aligned16(bn_x[j]), MPN_ERR_BAD_ARG, "conv_bwd_data_apply: bad fused-reduction arguments");
-            jobs[j].bnr_x = bn_x[j]; jobs[j].bnr_scale = bn_scale[j]; jobs[j].bnr_shift = bn_shift[j]; jobs[j].bnr_act = bn_act;
-            jobs[j].bnr_xs = bs > 0 ? bs : C;
-        }
     }
     return mpn_c3::launch(jobs, njobs, dtype, (hipStream_t)stream);
 }

@@ -93,29 +93,7 @@ __device__ __forceinline__ void glds16(const void* src, void* dst) {
 
 // ================= epilogue shared by the kernels below: bf16 image of the tile in LDS (over the dead staging buffers:
 // the caller has passed a barrier after the last fragment read), statistics on the matrix unit, 16-byte row stores
-// the accumulators of the 32x32x16 variant into the same image: tile (mt, nt) of 32 pixels x 32 channels, register group jj holds the
-// four consecutive channels 8 jj + 4 (lane >> 5) .. + 3 of pixel lane & 31
-template <int BM>
-__device__ __forceinline__ void pw_write_image32(const PwParams& p, unsigned char* smem, const f32x16_t (&acc)[BM / 64][2], const long long m0) {
-    constexpr int RSO = BN * 2 + 8;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 2, wn = wave & 3, r32 = lane & 31, g = lane >> 5;
-#pragma unroll
-    for (int mt = 0; mt < BM / 64; ++mt) {
-        const int row = wm * (BM / 2) + mt * 32 + r32;
-        const bool ok = (m0 + row) < p.M;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                f32x4_t v = {acc[mt][nt][4 * jj], acc[mt][nt][4 * jj + 1], acc[mt][nt][4 * jj + 2], acc[mt][nt][4 * jj + 3]};
-                if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                store4_bf16(smem + row * RSO + (wn * 64 + nt * 32 + jj * 8 + g * 4) * 2, v);
-            }
-    }
-}
-
-template <int BM, bool BNR, bool IMAGE_WRITTEN = false>
+template <int BM, bool BNR>
 __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* smem, f32x4_t (&acc)[BM / 32][4], const int mtile,
                                             const int n0, const long long m0) {
     constexpr int MT = BM / 32, NT = 4;
@@ -127,7 +105,6 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* sm
     unsigned char* O = smem;
     float* red = reinterpret_cast<float*>(smem + BM * RSO);   // BM == 128 only: [2 wm][2][BN]
 
-    if constexpr (!IMAGE_WRITTEN) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int row = wm * (BM / 2) + mt * 16 + l15;
@@ -138,7 +115,6 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* sm
             if (!ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // rows past the end must not count in the statistics
             store4_bf16(O + row * RSO + (wn * 64 + nt * 16 + lq * 4) * 2, v);
         }
-    }
     }
     PW_STAMP(3);
     if (!BNR && p.stats_part != nullptr) {
@@ -291,11 +267,8 @@ __device__ __forceinline__ void pw_epilogue(const PwParams& p, unsigned char* sm
 }
 
 // BM: pixels per block (256 or 128); AFFINE: A rows through registers with batch-norm affine + activation, else LDS-DMA
-// M32: the same tiles, LDS images and staging on v_mfma_f32_32x32x16_bf16 (round 5): half the MFMA instructions per FLOP on a k-step
-// whose vector issue port is what bounds it (64 MFMAs hold the port 512 cycles per wave beside 140 other vector
-// instructions). On the MFMA-dense 3x3 kernels the chip answered this shape with a lower clock; these layers run the
-// matrix pipes at a quarter of their peak, far from the power limit.
-template <int BM, bool AFFINE, bool BNR = false, bool M32 = false>
+// (a v_mfma_f32_32x32x16_bf16 variant of the same tiles was 3-8 % slower on every layer: profiles/r05_pointwise_m32.txt; removed in round 6)
+template <int BM, bool AFFINE, bool BNR = false>
 __global__ __launch_bounds__(kThreads, 2) void pw_gemm_kernel(const PwParams p) {
     static_assert(!BNR || !AFFINE, "the fused batch-norm backward reduction rides on a data gradient (no producer affine)");
     constexpr int MT = BM / 32;                  // 16-pixel m-tiles per wave (waves: 2 along M x 4 along N)
@@ -409,28 +382,11 @@ __global__ __launch_bounds__(kThreads, 2) void pw_gemm_kernel(const PwParams p) 
     const int a_lane = (wm * (BM / 2) + l15) * KB;
     const int b_lane = (wn * 64 + l15) * KB;
 
-    f32x4_t acc[M32 ? 1 : MT][NT];
-    constexpr int MT32 = BM / 64;                // M32: 32-pixel m-tiles per wave (x 2 n-tiles of 32 channels)
-    f32x16_t acc32[M32 ? MT32 : 1][2];
-    if constexpr (!M32) {
+    f32x4_t acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    } else {
-#pragma unroll
-    for (int i = 0; i < MT32; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc32[i][j][e] = 0.f;
-    }
-    // M32 fragments: lane (row lane & 31, k group lane >> 5) reads 16 bytes = 8 k of its row; the k-step's four 16-deep MFMA steps
-    // kk sit at logical 16-byte slots 2 kk + (lane >> 5), swizzled with ((row >> 1) & 7) like every slot of the images (tile rows
-    // start at multiples of 32: the swizzle is a constant of the lane) - the ds_read_b128 lane groups stay conflict-free
-    const int r32 = lane & 31;
-    const int f32off = (((lane >> 5) ^ ((r32 >> 1) & 7)) << 4);
-    const int a_lane32 = (wm * (BM / 2) + r32) * KB, b_lane32 = (wn * 64 + r32) * KB;
 
     // ---- prologue: stage k-step 0
     PW_STAMP(0);
@@ -502,59 +458,6 @@ __global__ __launch_bounds__(kThreads, 2) void pw_gemm_kernel(const PwParams p) 
         }
     };
 
-    bf16x8_t a32P[M32 ? MT32 : 1], a32Q[M32 ? MT32 : 1], b32P[2], b32Q[2];
-    auto read32 = [&](bf16x8_t (&a)[M32 ? MT32 : 1], bf16x8_t (&b)[2], const unsigned char* Ab, const unsigned char* Bb, const int kk) {
-        const int fo = f32off ^ (kk << 5);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) b[nt] = *reinterpret_cast<const bf16x8_t*>(Bb + nt * 32 * KB + fo);
-#pragma unroll
-        for (int mt = 0; mt < MT32; ++mt) a[mt] = *reinterpret_cast<const bf16x8_t*>(Ab + mt * 32 * KB + fo);
-    };
-    auto mma32 = [&](const bf16x8_t (&a)[M32 ? MT32 : 1], const bf16x8_t (&b)[2]) {
-#pragma unroll
-        for (int mt = 0; mt < MT32; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                acc32[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[nt], a[mt], acc32[mt][nt], 0, 0, 0);   // D^T = W^T x A^T
-    };
-    // M32 k-step: four 16-deep steps kk; [staging work of the NEXT k-step | fragment reads of step kk + 1 | MT32 x 2 MFMAs of step kk]
-    auto kstep32 = [&](int ks, auto more_tag) {
-        constexpr bool more = decltype(more_tag)::value;
-        const int buf = ks & 1;
-        __syncthreads();
-        const unsigned char* Ab = As + buf * A_BYTES + a_lane32;
-        const unsigned char* Bb = Bs + buf * B_BYTES + b_lane32;
-        read32(a32P, b32P, Ab, Bb, 0);
-        if constexpr (more) stage(ks + 1, buf ^ 1, 0);
-        read32(a32Q, b32Q, Ab, Bb, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma32(a32P, b32P);
-        if constexpr (more) stage(ks + 1, buf ^ 1, 1);
-        read32(a32P, b32P, Ab, Bb, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        mma32(a32Q, b32Q);
-        read32(a32Q, b32Q, Ab, Bb, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (more) stage(ks + 1, buf ^ 1, 2);
-        mma32(a32P, b32P);
-        if constexpr (AFFINE && more) {   // the commit's VALU instructions into the issue gaps between the MFMAs
-#pragma unroll
-            for (int i = 0; i < MT32 * 2; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, 2 * AV, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (more) stage(ks + 1, buf ^ 1, 3);
-        mma32(a32Q, b32Q);
-        if constexpr (AFFINE && more) {
-#pragma unroll
-            for (int i = 0; i < MT32 * 2; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x2, 2 * AV, 0);
-            }
-        }
-    };
     auto kstep = [&](int ks, auto more_tag) {
         constexpr bool more = decltype(more_tag)::value;
         const int buf = ks & 1;
@@ -601,39 +504,24 @@ __global__ __launch_bounds__(kThreads, 2) void pw_gemm_kernel(const PwParams p) 
     };
     // the last k-step has nothing to stage: peeled, so that the staging code of the others is branch-free (one basic block
     // with the MFMAs: the scheduler can interleave them)
-    if constexpr (M32) {
-        for (int ks = 0; ks + 1 < ksteps; ++ks) kstep32(ks, std::true_type{});
-        kstep32(ksteps - 1, std::false_type{});
-    } else {
-        for (int ks = 0; ks + 1 < ksteps; ++ks) kstep(ks, std::true_type{});
-        kstep(ksteps - 1, std::false_type{});
-    }
+    for (int ks = 0; ks + 1 < ksteps; ++ks) kstep(ks, std::true_type{});
+    kstep(ksteps - 1, std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PW_STAMP(2);
     __syncthreads();   // every wave is done with the staging buffers: the output image may overwrite them
 
-    if constexpr (M32) {
-        pw_write_image32<BM>(p, smem, acc32, m0);
-        f32x4_t none[BM / 32][4];
-        pw_epilogue<BM, BNR, true>(p, smem, none, mtile, n0, m0);
-    } else {
-        pw_epilogue<BM, BNR>(p, smem, acc, mtile, n0, m0);
-    }
+    pw_epilogue<BM, BNR>(p, smem, acc, mtile, n0, m0);
 }
 
-#ifndef MPN_PW_M32
-#define MPN_PW_M32 0     // 1: the 32x32x16 variant (A/B builds: tools/build_variant.sh m32 pointwise.hip -DMPN_PW_M32=1)
-#endif
 template <int BM, bool AFFINE, bool BNR = false>
 int launch_pw(const PwParams& p, hipStream_t st) {
-    constexpr bool M32 = MPN_PW_M32 != 0;
     const int smem = 2 * BM * KB + 2 * BN * KB + (AFFINE ? 2 * p.K * (int)sizeof(float) : 0);
     const int need = BM * (BN * 2 + 8) + (BM == 128 ? 4 * BN * (int)sizeof(float) : 0);   // the epilogue's image (+ red)
     const int bytes = smem > need ? smem : need;
     MPN_REQUIRE(bytes <= 160 * 1024, MPN_ERR_BAD_SHAPE, "pointwise: K = %d needs %d bytes of LDS", p.K, bytes);
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)pw_gemm_kernel<BM, AFFINE, BNR, M32>, 160 * 1024, &attr_mask));
-    pw_gemm_kernel<BM, AFFINE, BNR, M32><<<dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(kThreads), bytes, st>>>(p);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)pw_gemm_kernel<BM, AFFINE, BNR>, 160 * 1024, &attr_mask));
+    pw_gemm_kernel<BM, AFFINE, BNR><<<dim3((unsigned)(p.m_tiles * p.n_tiles)), dim3(kThreads), bytes, st>>>(p);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }

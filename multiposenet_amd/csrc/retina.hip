@@ -335,9 +335,11 @@ constexpr int kNmsThreads = 1024;
 struct NmsCand { float4 box; float score; int anchor; int pad0, pad1; };   // 32 bytes
 constexpr int kNmsLds = 4096;      // candidates kept in LDS (128 KB)
 
+// (counts[B] is the call's OVERFLOW word: set when a list would grow past its A slots - possible only if a counter was not 0 when
+//  the appends began; the host reads it with the outputs: mpn_retina_nms_overflow_offset)
 __global__ void nms_reset_kernel(int* __restrict__ counts, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < B) counts[i] = 0;
+    if (i <= B) counts[i] = 0;
 }
 
 template <typename T>
@@ -387,7 +389,9 @@ __global__ __launch_bounds__(kThreads) void retina_candidates_kernel(const Retin
         base = __shfl(base, leader, 64);
         if (live) {
             const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (slot < A) cands[(long long)b * A + slot] = c;      // (every anchor appends at most once: slot < A unless the counter was not reset)
+            // (every anchor appends at most once: slot < A unless the counter did not start at 0 - refused AND reported, never dropped silently)
+            if (slot < A) cands[(long long)b * A + slot] = c;
+            else counts[gridDim.y] = 1;
         }
     }
 }
@@ -401,7 +405,9 @@ __global__ __launch_bounds__(kNmsThreads) void retina_nms_kernel(const NmsCand* 
     __shared__ unsigned long long best_key;
     __shared__ float4 best_box;
     const int b = blockIdx.x;
-    const int C = counts[b];
+    const int C_raw = counts[b];
+    const int C = C_raw < A ? C_raw : A;          // (never past the image's list, whatever the counter holds)
+    if (C_raw > A && threadIdx.x == 0) const_cast<int*>(counts)[gridDim.x] = 1;
     const bool in_lds = C <= kNmsLds;
     const NmsCand* gl = cands + (long long)b * A;
     float4* lbox = reinterpret_cast<float4*>(nms_smem);                          // [kNmsLds]
@@ -600,8 +606,9 @@ extern "C" int mpn_retina_loss_finalize(const float* sums, const int* num_matche
     return MPN_OK;
 }
 
-// the candidate lists (32 bytes per anchor: every anchor may pass the score test) + one counter per image
-extern "C" size_t mpn_retina_nms_workspace_bytes(int B, int A) { return (size_t)B * A * sizeof(NmsCand) + (((size_t)B * sizeof(int) + 15) & ~(size_t)15); }
+// the candidate lists (32 bytes per anchor: every anchor may pass the score test) + one counter per image + the overflow word
+extern "C" size_t mpn_retina_nms_workspace_bytes(int B, int A) { return (size_t)B * A * sizeof(NmsCand) + ((((size_t)B + 1) * sizeof(int) + 15) & ~(size_t)15); }
+extern "C" size_t mpn_retina_nms_overflow_offset(int B, int A) { return (size_t)B * A * sizeof(NmsCand) + (size_t)B * sizeof(int); }
 
 extern "C" int mpn_retina_nms(const void* const* logits, const void* const* boxes, const int* h, const int* w, int dtype,
                               const float* cls_bias, const float* box_bias, const float* anchors, int B, float score_threshold,
@@ -618,9 +625,9 @@ extern "C" int mpn_retina_nms(const void* const* logits, const void* const* boxe
     NmsCand* cands = reinterpret_cast<NmsCand*>(workspace);
     int* counts = reinterpret_cast<int*>(cands + (size_t)B * A);
     hipStream_t st = (hipStream_t)stream;
-    // (a launch rather than hipMemsetAsync: inside a replayed hipGraph the memset node was seen to land AFTER the first appends of the
-    //  kernel behind it - a list that starts at the previous call's count runs past the workspace: a device fault, found in round 5)
-    nms_reset_kernel<<<(B + 63) / 64, 64, 0, st>>>(counts, B);
+    // (a launch rather than hipMemsetAsync - round 5's device fault: the second store of an append in retina_candidates_kernel, replayed
+    //  from a hipGraph; what was observed and what is inferred about the memset node: DESIGN section 2)
+    nms_reset_kernel<<<(B + 1 + 63) / 64, 64, 0, st>>>(counts, B);
     MPN_LAUNCH_CHECK();
     const dim3 grid((unsigned)((A + kThreads - 1) / kThreads), (unsigned)B);
     MPN_DISPATCH_DTYPE(dtype, (retina_candidates_kernel<T><<<grid, kThreads, 0, st>>>(lv, cls_bias, box_bias, anchors, A, score_threshold, cands, counts)));

@@ -105,7 +105,7 @@ class Detector:
                 ks, kp = self.assigner(heat.contiguous(), dboxes, torch.tensor([n], device=net.device), compact=True)
                 kscore, kpos = ks.cpu().numpy(), kp.cpu().numpy()
         elif 'pred' in dev:
-            pred = dev['pred']
+            pred = self.retinanet.check_nms(dev['pred'])
             n = int(pred['num_boxes'][0].item())
             gb, gs = pred['boxes'][0, :n].cpu().numpy(), pred['scores'][0, :n].cpu().numpy()
             if n and 'kscore' in dev:       # the padded slots (>= n) hold the results of zero crops: drop them

@@ -325,11 +325,8 @@ class KeypointNet:
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
         self.fuse_conv_bn = True
-        # ... and can form their own INPUT on load (mpn_conv_bwd_data_apply_grouped, round 5): the apply pass of bn2 / bn1 /
-        # p{l}_batch_norm / final_bn (2 reads + 1 write over the tensor each, 0.28 ms of the step) disappears - MEASURED SLOWER and off:
-        # the data gradients are bound by vector issue, and forming dy costs them what the pass saved (alone: 80.8 + 235.5 us against
-        # 313.9 us in one launch; the step 7.55 against 7.43 ms, profiles/r05_apply_on_load.txt). Parity-tested, kept for the record.
-        self.fuse_apply_dgrad = False
+        # (forming their own INPUT on load - the batch-norm apply pass inside the data gradient, round 5 - was measured slower in the step,
+        #  7.55 against 7.43 ms, profiles/r05_apply_on_load.txt, and is gone since round 6: DESIGN's table of negatives)
         self._l2 = None           # the regularisation term's batched launch (add_weight_decay_loss)
         self._wd = None           # ... and its gradient's (add_weight_decay_gradients)
         self.cache_inference_affine = False   # see prepare_inference
@@ -451,11 +448,6 @@ class KeypointNet:
             g[k] = {l: torch.empty_like(b[k][l]) for l in b["lv"]}
         g["y2"] = {l: torch.empty_like(b["y2"][l]) for l in b["lv"] if l != 2}
         g["y2"][2] = g["concat"][..., :DEPTH]          # ... and so does its gradient
-        # apply on load (fuse_apply_dgrad): the batch-norm backward's apply pass happens inside the 3x3 data gradient, which leaves the
-        # formed gradient here for the weight gradient (one set per stage: a weight gradient on the side stream may still read the last)
-        if self._apply_on_load():
-            g["dy"] = {k: {l: torch.empty_like(b["y1"][l]) for l in b["lv"]} for k in ("bn2", "bn1", "p")}
-            g["dy"]["final"] = torch.empty_like(b["final"])
         g["c"] = {}   # gradient w.r.t. the activated c_l (from the lateral convs)
         for i, name in FEATURE_BLOCKS.items():
             g["c"][name] = torch.empty_like(b["pw"][i - 1])
@@ -641,11 +633,6 @@ class KeypointNet:
         out.update({"d" + k: ops.BnBwdFinalizeBatch(v, self.device) for k, v in bwd.items()})
         return out
 
-    def _apply_on_load(self):
-        """The apply pass of the subnet's / FPN's batch-norm backward inside the 3x3 data gradients (mpn_conv_bwd_data_apply_grouped)."""
-        return self.fuse_apply_dgrad and self._fused_conv_bn() and ops.conv_bwd_data_apply_supported(DEPTH, DEPTH, self.dtype) and \
-            ops.conv_bwd_data_apply_supported(64, 4 * DEPTH, self.dtype)
-
     def _fused_conv_bn(self):
         """The 3x3 data gradients of the subnet also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn_grouped)."""
         return self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(DEPTH, DEPTH, 3, self.dtype)
@@ -723,24 +710,18 @@ class KeypointNet:
                 g["reducer"][ph].run()   # (after phase 2: every gradient is in the arena)
 
     def _backward_head(self, b, g, feats, sp, slab, W):
-        aol = self._apply_on_load()
         # ---- head + final conv
         if self._fused_conv_bn() and ops.heatmap_head_bwd_bn_supported(b["final"].shape[3], self.dtype):
             # the head's backward kernel also reduces for final_bn (its input's batch-norm): one launch and one pass less
             rows = ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
                                         slab[id(self._head_grad)], reduce=False, bn_part=sp)
-            ops.bn_backward(self.final_bn, g["final"], b["final"], sp, reduced_parts=rows, raw=True, apply=not aol)
+            ops.bn_backward(self.final_bn, g["final"], b["final"], sp, reduced_parts=rows, raw=True)
         else:
             ops.heatmap_head_bwd(b["final"], g["dlogits"], self.heat_w, self.final_bn.affine, g["final"], self._head_grad,
                                  slab[id(self._head_grad)], reduce=False)
-            ops.bn_backward(self.final_bn, g["final"], b["final"], sp, apply=not aol)
-        if aol:     # final_conv3x3's data gradient forms final_bn's dy on load and leaves it for the weight gradient
-            dyf = g["dy"]["final"]
-            ops.conv_bwd_data_apply_grouped([g["final"]], [b["final"]], [self.final_bn], [dyf], [self.final_conv.packed.bwd], 4 * DEPTH, [g["concat"]])
-            W(lambda: ops.conv_bwd_weight(b["concat"], dyf, 3, self.concat_affine, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
-        else:
-            W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, self.concat_affine, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
-            ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
+            ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
+        W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, self.concat_affine, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
+        ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm, stage by stage over the four levels (see subnet_forward): reductions into
         # per-level scratch, ONE finalize launch per stage, then the applies and the convolutions' gradients
         if b["fin"] is None:
@@ -757,39 +738,20 @@ class KeypointNet:
         fin["dbn2"].run()
         none4 = [None] * 4
         fused = self._fused_conv_bn()
-        if aol:
-            # conv2's data gradient forms bn2's dy on load (no apply pass), reduces for bn1, and leaves dy for the weight gradient
-            dy2 = [g["dy"]["bn2"][l] for l in LV]
-            ops.conv_bwd_data_apply_grouped(gy2, by2, bn2s, dy2, [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, gy1,
-                                            bns=bn1s, xs_bn=by1, parts=sps)
-            W(lambda: ops.conv_bwd_weight_grouped(by1, dy2, 3, [self.phi[l]["bn1"].affine for l in LV],
-                                                  [slab[id(self.phi[l]["conv2"].dw)] for l in LV]))
-        else:
-            ops.bn_bwd_apply_grouped(bn2s, gy2, by2)
-            W(lambda: ops.conv_bwd_weight_grouped(by1, gy2, 3, [self.phi[l]["bn1"].affine for l in LV],
-                                                  [slab[id(self.phi[l]["conv2"].dw)] for l in LV]))
-        if aol:
-            pass
-        elif fused:   # conv2's data gradient also reduces for bn1 (and writes the gradient masked by bn1's ReLU)
+        ops.bn_bwd_apply_grouped(bn2s, gy2, by2)
+        W(lambda: ops.conv_bwd_weight_grouped(by1, gy2, 3, [self.phi[l]["bn1"].affine for l in LV],
+                                              [slab[id(self.phi[l]["conv2"].dw)] for l in LV]))
+        if fused:   # conv2's data gradient also reduces for bn1 (and writes the gradient masked by bn1's ReLU)
             ops.conv_bwd_data_bn_grouped(gy2, [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, bn1s, by1, gy1, sps)
         else:
             ops.conv_fwd_grouped([g["y2"][l] for l in LV], [self.phi[l]["conv2"].packed.bwd for l in LV], DEPTH, 3, none4,
                                  [g["y1"][l] for l in LV], none4)
             ops.bn_bwd_reduce_grouped(bn1s, gy1, by1, sps)
         fin["dbn1"].run()
-        if aol:
-            dy1 = [g["dy"]["bn1"][l] for l in LV]
-            ops.conv_bwd_data_apply_grouped(gy1, by1, bn1s, dy1, [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, gp,
-                                            bns=pbns, xs_bn=bp, parts=sps)
-            W(lambda: ops.conv_bwd_weight_grouped(bp, dy1, 3, [self.p_bn[l].affine for l in LV],
-                                                  [slab[id(self.phi[l]["conv1"].dw)] for l in LV]))
-        else:
-            ops.bn_bwd_apply_grouped(bn1s, gy1, by1)
-            W(lambda: ops.conv_bwd_weight_grouped(bp, gy1, 3, [self.p_bn[l].affine for l in LV],
-                                                  [slab[id(self.phi[l]["conv1"].dw)] for l in LV]))
-        if aol:
-            pass
-        elif fused:
+        ops.bn_bwd_apply_grouped(bn1s, gy1, by1)
+        W(lambda: ops.conv_bwd_weight_grouped(bp, gy1, 3, [self.p_bn[l].affine for l in LV],
+                                              [slab[id(self.phi[l]["conv1"].dw)] for l in LV]))
+        if fused:
             ops.conv_bwd_data_bn_grouped(gy1, [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, pbns, bp, gp, sps)
         else:
             ops.conv_fwd_grouped([g["y1"][l] for l in LV], [self.phi[l]["conv1"].packed.bwd for l in LV], DEPTH, 3, none4,
@@ -799,15 +761,9 @@ class KeypointNet:
         # ---- FPN (top-down path reversed)
         # the four 3x3 convolutions (fpn.py:39,52) are independent: ONE grid for their weight gradients, one for their data
         # gradients; the nearest-upsample gradients then chain the levels
-        if aol:     # (the auxiliary loss's gradient on channel 0 rides on the formed gradient, as in the apply pass)
-            dyp = [g["dy"]["p"][l] for l in LV]
-            ops.conv_bwd_data_apply_grouped(gp, bp, pbns, dyp, [self.pconv[l].packed.bwd for l in LV], DEPTH, [g["x"][l] for l in LV],
-                                            add_ch0=[g["daux"][l] for l in LV])
-            W(lambda: ops.conv_bwd_weight_grouped([b["x"][l] for l in LV], dyp, 3, none4, [slab[id(self.pconv[l].dw)] for l in LV]))
-        else:
-            ops.bn_bwd_apply_grouped(pbns, gp, bp, [g["daux"][l] for l in LV])
-            W(lambda: ops.conv_bwd_weight_grouped([b["x"][l] for l in LV], gp, 3, none4, [slab[id(self.pconv[l].dw)] for l in LV]))
-            ops.conv_fwd_grouped(gp, [self.pconv[l].packed.bwd for l in LV], DEPTH, 3, none4, [g["x"][l] for l in LV], none4)
+        ops.bn_bwd_apply_grouped(pbns, gp, bp, [g["daux"][l] for l in LV])
+        W(lambda: ops.conv_bwd_weight_grouped([b["x"][l] for l in LV], gp, 3, none4, [slab[id(self.pconv[l].dw)] for l in LV]))
+        ops.conv_fwd_grouped(gp, [self.pconv[l].packed.bwd for l in LV], DEPTH, 3, none4, [g["x"][l] for l in LV], none4)
         for l in (2, 3, 4, 5):
             if l > 2:
                 ops.sumpool2x2(g["x"][l - 1], g["x"][l], accumulate=True)        # grad of nearest 2x upsample

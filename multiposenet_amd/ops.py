@@ -163,37 +163,6 @@ def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
     return [conv_stats_rows(N, t.shape[1], t.shape[2], k, c, 3, t.dtype) for t in dys]
 
 
-def conv_bwd_data_apply_supported(k, c, dtype):
-    """True when conv_bwd_data_apply_grouped takes 3x3 data gradients from k to c channels (bf16, k % 64 == 0, c % 128 == 0, both <= 512)."""
-    return _lib.lib().mpn_conv_bwd_data_apply_supported(int(k), int(c), 3, _lib.dtype_code(dtype)) == 1
-
-
-def conv_bwd_data_apply_grouped(gs, ys_raw, apply_bns, dys, packeds_t, c, outs, add_ch0=None, bns=None, xs_bn=None, parts=None):
-    """Data gradients of several independent 3x3 convolutions in one grid with the batch-norm backward APPLY pass of the layer above
-    folded in: gs[j] = gradient w.r.t. the activated output of batch-norm `apply_bns[j]` (after its backward finalize: k1 / k2),
-    ys_raw[j] = that layer's raw output. outs[j] <- conv^T(dy), dys[j] <- the formed gradient dy (for the weight gradient, which must
-    run afterwards). With bns / xs_bn / parts the launch also reduces for the batch-norms the outputs feed (as
-    conv_bwd_data_bn_grouped); returns the rows each slab then holds."""
-    import ctypes
-    n = len(gs)
-    N, _, _, k = gs[0].shape
-    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
-    null = PA(*[None] * n)
-    ab = apply_bns
-    add = PA(*[ptr(t) if t is not None else None for t in add_ch0]) if add_ch0 is not None else None
-    fused = bns is not None
-    call("mpn_conv_bwd_data_apply_grouped", n, PA(*[ptr(t) for t in gs]), PA(*[ptr(t) for t in ys_raw]), PA(*[ptr(t) for t in dys]),
-         PA(*[ptr(p) for p in packeds_t]), PA(*[ptr(o) for o in outs]), N, IA(*[t.shape[1] for t in gs]), IA(*[t.shape[2] for t in gs]), k, int(c),
-         IA(*[_slice_stride(t, k) for t in gs]), IA(*[_slice_stride(t, k) for t in ys_raw]), IA(*[_slice_stride(t, k) for t in dys]),
-         IA(*[_slice_stride(o, c) for o in outs]), _lib.dtype_code(gs[0].dtype),
-         PA(*[ptr(b.scale) for b in ab]), PA(*[ptr(b.shift) for b in ab]), PA(*[ptr(b.mean) for b in ab]), PA(*[ptr(b.invstd) for b in ab]),
-         PA(*[ptr(b.k1) for b in ab]), PA(*[ptr(b.k2) for b in ab]), int(ab[0].act), add,
-         PA(*[ptr(x) for x in xs_bn]) if fused else None, IA(*[_slice_stride(x, c) for x in xs_bn]) if fused else None,
-         PA(*[ptr(b.scale) for b in bns]) if fused else None, PA(*[ptr(b.shift) for b in bns]) if fused else None,
-         int(bns[0].act) if fused else 0, PA(*[ptr(t) for t in parts]) if fused else None, stream_ptr())
-    return [conv_stats_rows(N, t.shape[1], t.shape[2], k, c, 3, t.dtype) for t in gs] if fused else None
-
-
 def conv1x1_bwd_fused_supported(cin, cout, dtype):
     """True when conv1x1_bwd_fused takes this pointwise layer (bf16 storage, Cin <= 128, Cout <= 128)."""
     return _lib.lib().mpn_conv1x1_bwd_fused_supported(int(cin), int(cout), _lib.dtype_code(dtype)) == 1

@@ -735,7 +735,9 @@ class PersonDetectorNet:
         return self.nms(self.forward(images, False), score_threshold, iou_threshold, max_detections)
 
     def nms(self, b, score_threshold=0.05, iou_threshold=0.5, max_detections=25):
-        """get_predictions on the raw outputs of the last forward over buffer set `b`."""
+        """get_predictions on the raw outputs of the last forward over buffer set `b`. Besides the reference's three keys the dict
+        holds 'overflow': the call's int32[1] overflow word (a view into the workspace, 0 after a good call); whoever reads the
+        outputs on the host passes the dict through `check_nms` first."""
         N, A = b["shape"][0], b["A"]
         need = _lib.lib().mpn_retina_nms_workspace_bytes(N, A)
         ws = b.get("nms_ws")
@@ -749,4 +751,13 @@ class PersonDetectorNet:
         call("mpn_retina_nms", lg, bx, hs, ws_, _lib.dtype_code(self.dtype), ptr(self.out_bias["class_net"]), ptr(self.out_bias["box_net"]),
              ptr(b["anchors"]), N, float(score_threshold), float(iou_threshold), int(max_detections), ptr(boxes), ptr(scores), ptr(num),
              ptr(ws), ws.numel(), stream_ptr())
-        return {"boxes": boxes, "scores": scores, "num_boxes": num}
+        off = _lib.lib().mpn_retina_nms_overflow_offset(N, A)
+        return {"boxes": boxes, "scores": scores, "num_boxes": num, "overflow": ws[off:off + 4].view(torch.int32)}
+
+    @staticmethod
+    def check_nms(pred):
+        """Raises if the NMS call behind `pred` ran out of list slots (MPN_ERR_WORKSPACE: a candidate counter that did not start
+        at zero). Synchronises on the overflow word; a graph replay has no other way to report it."""
+        if int(pred["overflow"].item()) != 0:
+            raise RuntimeError("mpn_retina_nms: a candidate list overflowed its workspace (MPN_ERR_WORKSPACE); the detections are incomplete")
+        return pred

@@ -48,7 +48,7 @@ def test_version_and_error_string():
     import re
     hdr = open(os.path.join(ROOT, "include", "mpn.h")).read()
     declared = int(re.search(r"#define\s+MPN_VERSION\s+(\d+)", hdr).group(1))
-    assert l.mpn_version() == declared == _lib.MPN_VERSION == 500
+    assert l.mpn_version() == declared == _lib.MPN_VERSION == 600
     assert isinstance(_lib.last_error(), str)
 
 

@@ -45,6 +45,8 @@ CONV_CASES = [
     (6, 112, 112, 128, 128, 3, 1, True, False),  # 294 tiles on 256 persistent blocks: some blocks walk two tiles
     (3, 100, 52, 64, 256, 3, 2, True, False),    # one 64-channel chunk per tile, two n-tiles, ragged tiles (100 = 6 x 16 + 4)
     (2, 40, 24, 256, 128, 3, 0, False, False),   # four chunks, no affine / statistics (the data-gradient configuration)
+    (1, 20, 36, 64, 640, 3, 1, True, False),     # more than 512 OUTPUT channels (five n-tiles): only the fused reduction's table is sized by Cout
+    (1, 16, 16, 64, 1024, 3, 0, False, False),   # ... plain
     # its 64-channel-tile variant (Cout % 128 == 64: the two waves of a row group split K and add their sums through LDS)
     (5, 128, 128, 512, 64, 3, 1, True, False),   # final_conv3x3 at its full map: 320 tiles on 256 blocks, 8 chunks, affine + statistics
     (2, 50, 38, 64, 64, 3, 1, True, False),      # the detector's tower shape, one chunk, ragged tiles

@@ -256,8 +256,9 @@ def test_merged_first_tower_layer_equals_the_two_towers(cuda, monkeypatch, dtype
 def test_nms_replayed_from_a_hipgraph_with_every_anchor_a_candidate(cuda):
     """Round 5, a device fault: the candidate lists' counters were cleared by hipMemsetAsync; inside a REPLAYED hipGraph that memset
     node was seen to land after the first appends of the kernel behind it, so a list started at the previous call's count - with every
-    anchor above the score threshold (count = A) it ran past the workspace. The counters are cleared by a launch now (and an append
-    past the list is refused). Eager call, capture, three replays, every anchor a candidate: identical detections each time."""
+    anchor above the score threshold (count = A) it ran past the workspace. The counters are cleared by a launch now, an append
+    past the list is refused AND reported in the workspace's overflow word, the selection never reads past a list. Eager call, capture,
+    three replays, every anchor a candidate: identical detections each time, the overflow word clear."""
     from multiposenet_amd.retinanet import PersonDetectorNet
     B, H, W = 2, 128, 256
     bb, hp, img, _, _ = _setup(33, B, H, W)
@@ -271,9 +272,11 @@ def test_nms_replayed_from_a_hipgraph_with_every_anchor_a_candidate(cuda):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         out = net.nms(b, 0.0, 0.6, 25)
+    assert int(want["overflow"][0]) == 0
     for _ in range(3):
         graph.replay()
         torch.cuda.synchronize()
+        net.check_nms(out)                                  # the call's overflow word (mpn_retina_nms_overflow_offset): clear
         for k, v in want.items():
             np.testing.assert_array_equal(out[k].cpu().numpy(), v, err_msg=k)
 

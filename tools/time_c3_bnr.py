@@ -36,16 +36,3 @@ a = t(lambda: ops.conv_fwd_grouped(dys, [pc.bwd] * 4, C, 3, none4, outs, none4))
 b = t(lambda: ops.bn_bwd_reduce_grouped(bns, outs, xs, parts))
 c = t(lambda: ops.conv_bwd_data_bn_grouped(dys, [pc.bwd] * 4, C, bns, xs, outs, parts))
 print(f"grouped 4-level 3x3 data gradient {a:.1f} us + separate reduction {b:.1f} us = {a + b:.1f} us; fused {c:.1f} us", flush=True)
-# apply on load (round 5): the separate apply pass + the fused data gradient against ONE launch that forms dy while it stages its input
-abns = []
-for _ in sizes:
-    bn = ops.BNState(torch.rand(C, device='cuda') + 0.5, torch.randn(C, device='cuda') * 0.1, torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), 1)
-    bn.scale.copy_(bn.gamma); bn.shift.copy_(bn.beta); bn.invstd.fill_(1.0); bn.k1.normal_(0, 0.05); bn.k2.normal_(0, 0.05)
-    abns.append(bn)
-ys = [torch.randn(N, h, w, C, device='cuda').to(dt) for h, w in sizes]
-dyo = [torch.empty_like(x) for x in xs]
-gsc = [d.clone() for d in dys]
-d = t(lambda: ops.bn_bwd_apply_grouped(abns, gsc, ys))
-e = t(lambda: ops.conv_bwd_data_apply_grouped(dys, ys, abns, dyo, [pc.bwd] * 4, C, outs, bns=bns, xs_bn=xs, parts=parts))
-f = t(lambda: ops.conv_bwd_data_apply_grouped(dys, ys, abns, dyo, [pc.bwd] * 4, C, outs))
-print(f"separate apply pass {d:.1f} us + fused data gradient {c:.1f} us = {c + d:.1f} us; apply on load + reduction {e:.1f} us; apply on load, plain {f:.1f} us (plain data gradient {a:.1f} us)", flush=True)
