@@ -28,7 +28,9 @@ class RetinaNet:
 
     def get_predictions(self, score_threshold=0.05, iou_threshold=0.5, max_detections=25):
         """{'boxes': [b, N, 4], 'scores': [b, N], 'num_boxes': [b]} with N = max_detections (retinanet.py:60-84)."""
-        return self._net.nms(self._b, score_threshold, iou_threshold, max_detections)
+        pred = self._net.check_nms(self._net.nms(self._b, score_threshold, iou_threshold, max_detections))
+        pred.pop("overflow")                                            # (checked here: the reference's three keys)
+        return pred
 
     def loss(self, groundtruth, params):
         """{'localization_loss', 'classification_loss'}: scalar device tensors (retinanet.py:86-144)."""

@@ -360,6 +360,10 @@ class KeypointNet:
 
     def repack_weights(self):
         """Refresh the packed (bf16/f32, MFMA tile order) copies after the f32 masters changed: one launch."""
+        if ops.LAUNCH_JOBS_ALONE:      # (test switch: one packing launch per image instead of the batched table)
+            for c in self.convs:
+                c.packed.repack()
+            return
         ops.call("mpn_conv_pack_weights_batched", ops.ptr(self._pack_table), self._pack_jobs, self._pack_blocks,
                  ops._lib.dtype_code(self.dtype), ops.stream_ptr())
 

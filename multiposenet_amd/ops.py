@@ -15,6 +15,12 @@ from ._lib import ACT_NONE, ACT_RELU, ACT_RELU6, call, ptr, stream_ptr
 BN_MOMENTUM = 0.95   # detector/utils/layer_utils.py:5, detector/backbones/mobilenet_v1.py:7
 BN_EPSILON = 1e-3    # layer_utils.py:6, mobilenet_v1.py:8
 
+# Test switch (tests/test_fullsize_gpu.py): True launches every job of every grouped / batched entry point ALONE - the same entry point
+# with one job per call - so that a step with shared grids can be compared with one where no block ever walks from one job into the
+# next. Read when a launch is made (grouped calls) or a device table is built (the batched finalizes / reductions): set it before the
+# net's first step of a shape. Not a product path: nothing in the package sets it.
+LAUNCH_JOBS_ALONE = False
+
 # Producer-side batch-norm record that consumers apply on load.
 Affine = namedtuple("Affine", ["scale", "shift", "act"])
 
@@ -119,6 +125,10 @@ def conv_fwd_grouped(xs, packeds, cout, ksize, affines, outs, stats_parts):
     affines / stats_parts entries may be None. All inputs [N,H_j,W_j,Cin] of one dtype, same activation code."""
     import ctypes
     n = len(xs)
+    if LAUNCH_JOBS_ALONE and n > 1:
+        for j in range(n):
+            conv_fwd_grouped([xs[j]], [packeds[j]], cout, ksize, [affines[j]], [outs[j]], [stats_parts[j]])
+        return outs
     N, _, _, cin = xs[0].shape
     PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
     sc, sh, act = [], [], ACT_NONE
@@ -153,6 +163,8 @@ def conv_bwd_data_bn_grouped(dys, packeds_t, c, bns, xs_bn, outs, parts):
     BnBwdFinalizeBatch job marked raw). Returns the rows each slab holds (conv_stats_rows)."""
     import ctypes
     n = len(dys)
+    if LAUNCH_JOBS_ALONE and n > 1:
+        return [conv_bwd_data_bn_grouped([dys[j]], [packeds_t[j]], c, [bns[j]], [xs_bn[j]], [outs[j]], [parts[j]])[0] for j in range(n)]
     N, _, _, k = dys[0].shape
     PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
     call("mpn_conv_bwd_data_bn_grouped", n, PA(*[ptr(t) for t in dys]), PA(*[ptr(p) for p in packeds_t]), PA(*[ptr(o) for o in outs]), N,
@@ -225,6 +237,7 @@ class SlabReducer:
 
     def __init__(self, jobs, device):
         import ctypes
+        self._alone = [SlabReducer([j], device) for j in jobs] if LAUNCH_JOBS_ALONE and len(jobs) > 1 else None
         lib = _lib.lib()
         nb = lib.mpn_reduce_desc_bytes()
         host = (ctypes.c_ubyte * (nb * len(jobs)))()
@@ -239,6 +252,10 @@ class SlabReducer:
         self._keep = jobs   # the tensors the table points at
 
     def run(self):
+        if self._alone is not None:
+            for r in self._alone:
+                r.run()
+            return
         call("mpn_reduce_partials_batched", ptr(self.table), self.njobs, self.blocks, stream_ptr())
 
 
@@ -246,6 +263,8 @@ def conv_wgrad_grouped_num_parts(N, hws, cin, cout, ksize, dtype):
     """Slab counts of conv_bwd_weight_grouped for jobs of sizes hws = [(H, W), ...]."""
     import ctypes
     n = len(hws)
+    if LAUNCH_JOBS_ALONE and n > 1:
+        return [conv_wgrad_grouped_num_parts(N, [hw], cin, cout, ksize, dtype)[0] for hw in hws]
     IA = ctypes.c_int * n
     out = IA()
     call("mpn_conv_wgrad_grouped_num_parts", n, N, IA(*[h for h, _ in hws]), IA(*[w for _, w in hws]), cin, cout, ksize,
@@ -258,6 +277,10 @@ def conv_bwd_weight_grouped(xs, dys, ksize, affines, parts):
     stage); the slabs stay in `parts` (sized by conv_wgrad_grouped_num_parts) for the batched reduction."""
     import ctypes
     n = len(xs)
+    if LAUNCH_JOBS_ALONE and n > 1:
+        for j in range(n):
+            conv_bwd_weight_grouped([xs[j]], [dys[j]], ksize, [affines[j]], [parts[j]])
+        return
     PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
     N, cin, cout = xs[0].shape[0], xs[0].shape[3], dys[0].shape[3]
     sc, sh, act = zip(*[_aff(a) for a in affines])
@@ -319,6 +342,7 @@ class BnFinalizeBatch:
 
     def __init__(self, jobs, device):
         import ctypes
+        self._alone = [BnFinalizeBatch([j], device) for j in jobs] if LAUNCH_JOBS_ALONE and len(jobs) > 1 else None
         lib = _lib.lib()
         nb = lib.mpn_bn_fin_desc_bytes()
         host = (ctypes.c_ubyte * (nb * len(jobs)))()
@@ -334,6 +358,10 @@ class BnFinalizeBatch:
         self.njobs, self.blocks, self._keep = len(jobs), begin, jobs
 
     def run(self):
+        if self._alone is not None:
+            for r in self._alone:
+                r.run()
+            return
         call("mpn_bn_finalize_batched", ptr(self.table), self.njobs, self.blocks, BN_MOMENTUM, BN_EPSILON, stream_ptr())
 
 
@@ -342,6 +370,7 @@ class BnBwdFinalizeBatch:
 
     def __init__(self, jobs, device):
         import ctypes
+        self._alone = [BnBwdFinalizeBatch([j], device) for j in jobs] if LAUNCH_JOBS_ALONE and len(jobs) > 1 else None
         lib = _lib.lib()
         nb = lib.mpn_bn_bwd_fin_desc_bytes()
         host = (ctypes.c_ubyte * (nb * len(jobs)))()
@@ -362,6 +391,10 @@ class BnBwdFinalizeBatch:
         self.njobs, self.blocks, self._keep = len(jobs), begin, jobs
 
     def run(self):
+        if self._alone is not None:
+            for r in self._alone:
+                r.run()
+            return
         call("mpn_bn_bwd_finalize_batched", ptr(self.table), self.njobs, self.blocks, stream_ptr())
 
 
@@ -393,6 +426,10 @@ def _bn_group_args(bns, dAs, xs):
 
 def bn_bwd_reduce_grouped(bns, dAs, xs, parts):
     """bn_bwd_reduce of several independent layers (same channel count, dtype, activation) in one grid."""
+    if LAUNCH_JOBS_ALONE and len(bns) > 1:
+        for j in range(len(bns)):
+            bn_bwd_reduce_grouped([bns[j]], [dAs[j]], [xs[j]], [parts[j]])
+        return
     n, PA, pd, px, Ms, C, dc, (sd, sx) = _bn_group_args(bns, dAs, xs)
     call("mpn_bn_bwd_reduce_grouped", n, pd, px, Ms, C, dc, PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]),
          PA(*[ptr(b.mean) for b in bns]), PA(*[ptr(b.invstd) for b in bns]), int(bns[0].act), PA(*[ptr(p) for p in parts]),
@@ -401,6 +438,10 @@ def bn_bwd_reduce_grouped(bns, dAs, xs, parts):
 
 def bn_bwd_apply_grouped(bns, dAs, xs, add_ch0s=None):
     """bn_bwd_apply of several independent layers in one grid (after their finalizes)."""
+    if LAUNCH_JOBS_ALONE and len(bns) > 1:
+        for j in range(len(bns)):
+            bn_bwd_apply_grouped([bns[j]], [dAs[j]], [xs[j]], None if add_ch0s is None else [add_ch0s[j]])
+        return
     n, PA, pd, px, Ms, C, dc, (sd, sx) = _bn_group_args(bns, dAs, xs)
     add = add_ch0s if add_ch0s is not None else [None] * n
     call("mpn_bn_bwd_apply_grouped", n, pd, px, Ms, C, dc, PA(*[ptr(b.scale) for b in bns]), PA(*[ptr(b.shift) for b in bns]),
@@ -784,6 +825,11 @@ class AxpyBatch:
         self.counts = (ctypes.c_longlong * n)(*[t.numel() for t in xs])
 
     def run(self, a):
+        if LAUNCH_JOBS_ALONE:
+            for x, y in zip(*self._keep):
+                call("mpn_axpy_batched", 1, (ctypes.c_void_p * 1)(x.data_ptr()), (ctypes.c_void_p * 1)(y.data_ptr()),
+                     (ctypes.c_longlong * 1)(x.numel()), float(a), stream_ptr())
+            return
         call("mpn_axpy_batched", self.n, self.xp, self.yp, self.counts, float(a), stream_ptr())
 
 

@@ -214,32 +214,41 @@ def get_training_targets(anchors, groundtruth_boxes):
 
 # ----------------------------------------------------------------------------- network (fpn.py, box_predictor.py)
 def fpn_retina(features, p, is_training, updates=None, taps=None):
-    """fpn.py:36-55 with min_level=3, add_coarse_features=True, scope 'fpn'. features: NCHW c3, c4, c5 (activated)."""
-    x = onet.conv2d_same(features["c5"], p["fpn/lateral5/kernel"])
-    out = {"p5": onet.conv2d_same(x, p["fpn/p5/kernel"])}
-    p6 = onet.conv2d_same(features["c5"], p["fpn/p6/kernel"], stride=2)
-    pre_p7 = F.relu(onet.batch_norm(p6, p, "fpn/pre_p7_bn", is_training, updates))
-    out["p6"], out["p7"] = p6, onet.conv2d_same(pre_p7, p["fpn/p7/kernel"], stride=2)
+    """fpn.py:36-55 with min_level=3, add_coarse_features=True, scope 'fpn'. features: NCHW c3, c4, c5 (activated).
+    (onet._raw / _act / _w16: no-ops unless onet.storage_emulation(dtype) is active - then this restatement rounds where the 16-bit
+    build stores, as oracle/network.py does for the keypoint net: raw convolution outputs and the FPN sums are stored tensors, normalised
+    activations exist only as gradients, the matrix cores multiply 16-bit copies of the kernels.)"""
+    R, A, W16 = onet._raw, onet._act, onet._w16
+    x = R(onet.conv2d_same(features["c5"], W16(p["fpn/lateral5/kernel"])))
+    out = {"p5": R(onet.conv2d_same(x, W16(p["fpn/p5/kernel"])))}
+    p6 = R(onet.conv2d_same(features["c5"], W16(p["fpn/p6/kernel"]), stride=2))
+    pre_p7 = A(F.relu(onet.batch_norm(p6, p, "fpn/pre_p7_bn", is_training, updates)))
+    out["p6"], out["p7"] = p6, R(onet.conv2d_same(pre_p7, W16(p["fpn/p7/kernel"]), stride=2))
     if taps is not None:
         taps["x5"] = x
     for i in (4, 3):
-        lateral = onet.conv2d_same(features[f"c{i}"], p[f"fpn/lateral{i}/kernel"])
-        x = onet.nearest_neighbor_upsample(x) + lateral
+        lateral = onet.conv2d_same(features[f"c{i}"], W16(p[f"fpn/lateral{i}/kernel"]))
+        x = R(onet.nearest_neighbor_upsample(x) + lateral)        # (one store: the lateral's epilogue adds the upsampled sum)
         if taps is not None:
             taps[f"x{i}"] = x
-        out[f"p{i}"] = onet.conv2d_same(x, p[f"fpn/p{i}/kernel"])
+        out[f"p{i}"] = R(onet.conv2d_same(x, W16(p[f"fpn/p{i}/kernel"])))
     return out
 
 
 def tower(x, p, net, out_name, level, is_training, updates=None, taps=None):
     """box_net / class_net (box_predictor.py:93-142): 4 x (shared conv3x3 + per-level batch-norm + ReLU), then a 3x3 'same'
     convolution with bias. x NCHW; returns NHWC [b,h,w,cout]."""
+    R, A, W16 = onet._raw, onet._act, onet._w16
     for i in range(4):
-        x = onet.conv2d_same(x, p[f"{net}/conv3x3_{i}/kernel"])
+        x = R(onet.conv2d_same(x, W16(p[f"{net}/conv3x3_{i}/kernel"])))
         if taps is not None:
             taps[f"{net}/conv{i}/l{level}"] = x
-        x = F.relu(onet.batch_norm(x, p, f"{net}/batch_norm_{i}_for_level_{level}", is_training, updates))
-    y = onet.conv2d_same(x, p[f"{net}/{out_name}/kernel"], bias=p[f"{net}/{out_name}/bias"])   # padding='same', stride 1 == pad 1
+        x = A(F.relu(onet.batch_norm(x, p, f"{net}/batch_norm_{i}_for_level_{level}", is_training, updates)))
+    # padding='same', stride 1 == pad 1; the build stores the convolution WITHOUT its bias (the loss / NMS kernels add it in f32)
+    y = R(onet.conv2d_same(x, W16(p[f"{net}/{out_name}/kernel"])))
+    if taps is not None:
+        taps[f"{net}/out/l{level}"] = y
+    y = y + p[f"{net}/{out_name}/bias"].view(1, -1, 1, 1)
     return y.permute(0, 2, 3, 1)
 
 
@@ -250,7 +259,7 @@ def head_forward(backbone_features, p, is_training, updates=None, taps=None):
     if taps is not None:
         for n, v in enriched.items():
             taps[n] = v
-    normalized = {n: F.relu(onet.batch_norm(x, p, f"{n}_batch_norm", is_training, updates)) for n, x in enriched.items()}
+    normalized = {n: onet._act(F.relu(onet.batch_norm(x, p, f"{n}_batch_norm", is_training, updates))) for n, x in enriched.items()}
     boxes, logits = [], []
     for l in LEVELS:
         boxes.append(tower(normalized[f"p{l}"], p, "box_net", "encoded_boxes", l, is_training, updates, taps))
