@@ -25,7 +25,7 @@
 // the transform, the LDS commit, weights from L2, one barrier per chunk, and per tile the output transform, the tile's image in LDS and
 // its copy-out in 256-byte pixel rows - on random data, and prints ALGORITHMIC TFLOP/s (the direct convolution's 2 x 256 x 128 x 1152
 // per tile). Numbers are not checked (it is a model: the operands are random, the index arithmetic is the real one).
-// Gate (VERDICT): >= 1 550 algorithmic TFLOP/s, or stop. For scale: tools/stage2_ceiling.hip's model of the SHIPPED stage reaches 1 620
+// Gate (VERDICT): >= 1 550 algorithmic TFLOP/s, or stop. MEASURED 1 423-1 496 (profiles/r06_stage3_ceiling.txt): not met, no kernel built. For scale: tools/stage2_ceiling.hip's model of the SHIPPED stage reaches 1 620
 // without epilogue and tile walk, the shipped kernel 1 200.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/stage3_ceiling.hip -o tools/build/stage3_ceiling && tools/build/stage3_ceiling
 #include <hip/hip_runtime.h>
@@ -55,6 +55,8 @@ constexpr int kW = 128, kH = 128, kC = 128;   // the tensor: [32][128][128][128]
 constexpr int kTilesX = kW / 32, kTilesY = kH / 8;
 
 enum { BARE = 0, WEIGHTS = 1, CHUNK = 2, FULL = 3 };   // + weight loads, + chunk barrier, + input transform / epilogue
+// parts of FULL, for the attribution: XF = loads + input transform + commit; EPI = 0 none, 1 = output transform + LDS image + row stores,
+// 2 = output transform + 8-byte stores straight from the accumulators (no image, no barrier: 32-byte segments per pixel)
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     typedef __bf16 b2_t __attribute__((ext_vector_type(2)));
@@ -63,7 +65,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, b2_t));
 }
 
-template <int MODE, bool AFF>
+template <int MODE, bool AFF, bool XF = true, int EPI = 1>
 __global__ void __launch_bounds__(512, 1) wino_loop(const unsigned char* __restrict__ w, const unsigned char* __restrict__ in,
                                                      unsigned char* __restrict__ out, int tiles_total, long long* __restrict__ stamps) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(512, 1) wino_loop(const unsigned char* __restr
         for (int ky = 0; ky < 3; ++ky) b[1][ky] = b[0][ky];
     }
     int tile = blockIdx.x;
-    if (MODE >= FULL) in_load(tile, 0);
+    if (MODE >= FULL && XF) in_load(tile, 0);
     const long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     int cc = 0;            // running chunk counter: the chunk reads transformed image cc & 1
 #pragma unroll 1
@@ -163,7 +165,7 @@ __global__ void __launch_bounds__(512, 1) wino_loop(const unsigned char* __restr
                             acc[j][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j & 1][ky], a[h], (FIRST && ky == 0) ? (acc_t){0.f, 0.f, 0.f, 0.f} : acc[j][r], 0, 0, 0);
                     }
                     if (h + kRing < 10) a[h + kRing] = *(const LDS x8*)(vb + ((h + kRing) * 4 + j) * kPlane);
-                    if (MODE >= FULL) {
+                    if (MODE >= FULL && XF) {
                         // dword j of the own unit in sub-steps at h = 1..6, the extra dword's at h = 8 of stage 0
                         if (h >= 1 && h <= 6) {
                             const unsigned u[4] = {j == 0 ? px[0].x : j == 1 ? px[0].y : j == 2 ? px[0].z : px[0].w,
@@ -206,7 +208,18 @@ __global__ void __launch_bounds__(512, 1) wino_loop(const unsigned char* __restr
         chunk(0, std::true_type{});
 #pragma unroll 1
         for (int ks = 1; ks < 4; ++ks) chunk(ks, std::false_type{});
-        if (MODE >= FULL) {
+        if (MODE >= FULL && EPI == 2) {
+            const int img_i = tile / (kTilesX * kTilesY), rem = tile - img_i * (kTilesX * kTilesY);
+            const int ty = rem / kTilesX, tx = rem - ty * kTilesX;
+            unsigned char* ob = out + (((size_t)img_i * kH + ty * 8) * kW + tx * 32 + 2 * l15) * (kC * 2) + (wave * 16 + lq * 4) * 2;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const acc_t o0 = acc[0][r] + acc[1][r] + acc[2][r], o1 = acc[1][r] - acc[2][r] - acc[3][r];
+                *reinterpret_cast<u32x2_t*>(ob + (size_t)r * kW * (kC * 2)) = (u32x2_t){pack_bf16x2(o0[0], o0[1]), pack_bf16x2(o0[2], o0[3])};
+                *reinterpret_cast<u32x2_t*>(ob + (size_t)r * kW * (kC * 2) + kC * 2) = (u32x2_t){pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3])};
+            }
+        }
+        if (MODE >= FULL && EPI == 1) {
             // ---- the tile's epilogue (the kernel would run it under the next tile's first stages): output transform, bf16 image in LDS
             // (pixel (row r, column 2 l15 + e), this wave's channels 4 lq .. + 3: 8 bytes), copy-out in whole 256-byte pixel rows
             const lds_p img = L + 2 * kVBuf;
@@ -237,7 +250,7 @@ __global__ void __launch_bounds__(512, 1) wino_loop(const unsigned char* __restr
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
-    if (MODE < FULL) {
+    if (MODE < FULL || EPI == 0) {
         acc_t s = (acc_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -252,15 +265,15 @@ __global__ void __launch_bounds__(512, 1) wino_loop(const unsigned char* __restr
     }
 }
 
-template <int MODE, bool AFF>
+template <int MODE, bool AFF, bool XF = true, int EPI = 1>
 static void run(const char* name, const unsigned char* w, const unsigned char* in, unsigned char* out, long long* stamps, int cus, int tiles) {
-    CK(hipFuncSetAttribute((const void*)wino_loop<MODE, AFF>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    CK(hipFuncSetAttribute((const void*)wino_loop<MODE, AFF, XF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0.f;
     for (float total = 0.f; total < 1500.f;) {        // warm: the clock settles under load
         CK(hipEventRecord(e0));
-        for (int i = 0; i < 8; ++i) wino_loop<MODE, AFF><<<cus, 512, kLds>>>(w, in, out, tiles, stamps);
+        for (int i = 0; i < 8; ++i) wino_loop<MODE, AFF, XF, EPI><<<cus, 512, kLds>>>(w, in, out, tiles, stamps);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -269,7 +282,7 @@ static void run(const char* name, const unsigned char* w, const unsigned char* i
     std::vector<float> t;
     for (int r = 0; r < 9; ++r) {
         CK(hipEventRecord(e0));
-        for (int i = 0; i < 8; ++i) wino_loop<MODE, AFF><<<cus, 512, kLds>>>(w, in, out, tiles, stamps);
+        for (int i = 0; i < 8; ++i) wino_loop<MODE, AFF, XF, EPI><<<cus, 512, kLds>>>(w, in, out, tiles, stamps);
         CK(hipEventRecord(e1));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
@@ -295,7 +308,7 @@ static void run(const char* name, const unsigned char* w, const unsigned char* i
     fflush(stdout);
 }
 
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
@@ -315,11 +328,22 @@ int main() {
     CK(hipMalloc(&w, kWeights));
     CK(hipMemcpy(in, h.data(), n_in * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(w, h.data(), kWeights, hipMemcpyHostToDevice));
+    if (argc > 1 && !strcmp(argv[1], "loop")) {     // the full model back to back for ~8 s: board power is sampled beside it (rocm-smi)
+        CK(hipFuncSetAttribute((const void*)wino_loop<FULL, false, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+        for (int i = 0; i < 70000; ++i) wino_loop<FULL, false, true, 1><<<cus, 512, kLds>>>(w, in, out, tiles, stamps);
+        CK(hipDeviceSynchronize());
+        printf("loop done\n");
+        return 0;
+    }
     run<BARE, false>("bare (MFMAs + fragment reads)", w, in, out, stamps, cus, tiles);
     run<WEIGHTS, false>("+ weights from L2", w, in, out, stamps, cus, tiles);
     run<CHUNK, false>("+ chunk barrier", w, in, out, stamps, cus, tiles);
     run<FULL, false>("full: + input transform, commit, epilogue", w, in, out, stamps, cus, tiles);
     run<FULL, true>("full + affine / ReLU on load", w, in, out, stamps, cus, tiles);
     run<FULL, false>("full (again)", w, in, out, stamps, cus, tiles);
+    run<FULL, false, true, 0>("input transform only (no epilogue)", w, in, out, stamps, cus, tiles);
+    run<FULL, false, false, 1>("epilogue only (no input transform)", w, in, out, stamps, cus, tiles);
+    run<FULL, false, false, 2>("epilogue only, 8-byte stores from the accumulators", w, in, out, stamps, cus, tiles);
+    run<FULL, false, true, 2>("full, 8-byte stores from the accumulators", w, in, out, stamps, cus, tiles);
     return 0;
 }
