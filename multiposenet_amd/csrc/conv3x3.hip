@@ -714,8 +714,10 @@ int launch(const Job* jobs, int njobs, int dtype, hipStream_t st) {
                     MPN_ERR_BAD_ARG, "conv3x3: the fused batch-norm reduction needs a data gradient (no producer affine), a partial slab and the layer's affine");
     }
     // 128-channel tiles and one-chunk 64-channel tiles (the detector's 64 -> 64 towers) run on the channel-split kernel (conv3x3_cs.hip).
-    // (64-channel tiles of MORE than one 64-channel chunk - final_conv3x3's forward, 512 -> 64 - stay on this file's kernel: 310 against
-    //  316 us; one-chunk tiles are 6-11 % faster on the channel-split one: profiles/r05_c3cs_n64.txt)
+    // (64-channel tiles of MORE than one 64-channel chunk - final_conv3x3's forward, 512 -> 64 - stay on this file's kernel: measured
+    //  again in round 6 with the weights two stages ahead, 255.8 / 285.6 us (plain / affine + statistics) here against 264.8 / 287.7 there:
+    //  a 64-channel tile pulls its weight fragments from L2 at twice the 128-channel tile's rate per MFMA, this kernel shares them through
+    //  LDS; one-chunk tiles are 6-11 % faster on the channel-split one: profiles/r05_c3cs_n64.txt, r06_c3_n64_ab.txt)
     if (!n64 || jobs[0].Cin == 64) return launch_cs(g, begin, dtype, affine, bnr, n64, st);
     if (dtype == MPN_BF16) return launch_v<bf16_t>(g, begin, affine, bnr, st);
     if (dtype == MPN_F16) return launch_v<half_t>(g, begin, affine, bnr, st);

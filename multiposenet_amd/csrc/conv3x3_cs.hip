@@ -462,7 +462,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     Tile cur = tile_of<N64>(g, w);
     if constexpr (BNR) { e_bx = reinterpret_cast<const unsigned char*>(g.job[cur.job].bnr_x); }     // (a block's first tile: loads that nothing uses, from a valid address)
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
-    constexpr int BD = 1;      // weight fragments requested this many stages ahead (two register sets; two stages ahead measured equal: profiles/r05_c3cs_ab.txt)
+    // weight fragments requested this many stages ahead (BD + 1 register sets): on 128-channel tiles two stages ahead measured equal
+    // (profiles/r05_c3cs_ab.txt); a 64-channel tile's stage is half as long (24 MFMAs per wave): two ahead, 1.5-2.5 % faster on the
+    // detector's 64 -> 64 towers (profiles/r06_c3_n64_ab.txt)
+    constexpr int BD = N64 ? 2 : 1;
     X8 b[BD + 1][3];
     int cc = 0;                // running chunk counter: the chunk reads halo buffer cc & 1
     b_load(b[0], wsrc, 0);
