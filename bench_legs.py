@@ -52,7 +52,7 @@ def dominant_kernel_roofline(net, batch, size, dtype, iters=50, warmup=20, b=Non
     traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE)
     here = os.path.dirname(os.path.abspath(__file__))
     src = None
-    for name in ("r05_dominant_kernel_traffic.json", "r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
+    for name in ("r06_dominant_kernel_traffic.json", "r05_dominant_kernel_traffic.json", "r04_dominant_kernel_traffic.json", "r03_dominant_kernel_traffic.json", "r02_dominant_kernel_traffic.json", "r01_dominant_kernel_traffic.json"):
         tj = os.path.join(here, "profiles", name)
         if dtype == torch.bfloat16 and batch == 32 and size == 512 and os.path.exists(tj):
             import json
