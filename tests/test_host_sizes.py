@@ -29,6 +29,11 @@ def test_config4_detector_workspaces_at_157542_anchors():
     assert n16 >= 16 * ANCHORS * 4 and n16 < (1 << 36)
     # the formulas are monotone in the batch and do not wrap a 32-bit product: 512 images x 157 542 anchors x 4 bytes > 2^28
     assert lib.mpn_retina_nms_workspace_bytes(512, ANCHORS) >= 32 * n16 - 4096
+    # the overflow word (ABI 600): inside the workspace, behind the candidate lists and the per-image counters, 4-byte aligned - at any batch
+    lib.mpn_retina_nms_overflow_offset.restype = ctypes.c_size_t
+    for b in (1, 2, 16, 17, 512):
+        off, size = lib.mpn_retina_nms_overflow_offset(b, ANCHORS), lib.mpn_retina_nms_workspace_bytes(b, ANCHORS)
+        assert off == b * ANCHORS * 32 + b * 4 and off % 4 == 0 and off + 4 <= size and size % 16 == 0
     assert lib.mpn_retina_match_workspace_bytes(4096, 1000) >= 4096 * 1000 * 8
     parts = lib.mpn_retina_loss_num_parts(16, ANCHORS)
     assert 0 < parts <= 16 * ANCHORS
