@@ -932,6 +932,45 @@ def test_dwconv_bwd_fused_stride2_equals_the_separate_launches(cuda, dtype, N, H
     assert r0 == 0 and torch.equal(dA_n, dA_b) and torch.equal(wp_n, wp_a)
 
 
+def test_data_gradient_split_over_channel_tiles_of_one_packed_image(cuda):
+    """Round 6: final_conv3x3's data gradient (64 -> 512 channels of the concat gradient, keypoint_subnet.py:37-38) runs as TWO launches over
+    the channel tiles of ONE packed image - tile 0 into the concat's first slice with the reduction for phi_subnet_2/bn2 fused
+    (mpn_conv_bwd_data_bn: raw x = the same slice of the forward tensor, pixel stride 512), tiles 1..3 plain into the other slices. The
+    packed data-gradient image is [channel tile of 128][...] with a tile's weights one contiguous block, so the two launches take
+    offsets into it. Against the single 64 -> 512 launch: slices 1..3 bit for bit; slice 0 = the same values masked by bn2's ReLU, bit
+    for bit; the slab's sums = sum g and sum g * x of that slice."""
+    from multiposenet_amd import ops
+    dtype = torch.bfloat16
+    rs = np.random.RandomState(91)
+    N, H, W, K, C = 2, 37, 21, 64, 512
+    w = (rs.randn(3, 3, C, K) / np.sqrt(9 * C)).astype(np.float32)        # the forward convolution 512 -> 64
+    pc = ops.PackedConv(dev(w), dtype)
+    dy = dev(rnd(rs.randn(N, H, W, K), dtype), dtype)
+    want = ops.conv_fwd(dy, pc.bwd, C, 3)                                  # one launch, four channel tiles
+    xcat = dev(rnd(rs.randn(N, H, W, C) * 1.5 + 0.3, dtype), dtype)       # the forward concat tensor: slice 0 = the raw y2 of level 2
+    x0 = xcat[..., :128]
+    bn = ops.BNState(dev(torch.tensor(0.5 + rs.rand(128), dtype=torch.float32)), dev(torch.tensor(rs.randn(128) * 0.3, dtype=torch.float32)),
+                     torch.zeros(128, device="cuda"), torch.ones(128, device="cuda"), 1)
+    xf = x0.float().reshape(-1, 128)
+    mean, var = xf.mean(0), xf.var(0, unbiased=False)
+    bn.mean.copy_(mean); bn.invstd.copy_(1.0 / torch.sqrt(var + 1e-3))
+    bn.scale.copy_(bn.gamma * bn.invstd); bn.shift.copy_(bn.beta - mean * bn.scale)
+    got = torch.full((N, H, W, C), float("nan"), device="cuda", dtype=dtype)
+    part = torch.full((ops.conv_num_parts(N, H, W, 3) * 2 * 128,), float("nan"), device="cuda")
+    tile_bytes = pc.bwd.numel() // 4
+    assert pc.bwd.numel() % 4 == 0 and tile_bytes % 16 == 0
+    rows = ops.conv_bwd_data_bn(dy, pc.bwd[:tile_bytes], 128, 3, bn, x0, got[..., :128], part)
+    ops.conv_fwd(dy, pc.bwd[tile_bytes:], 384, 3, None, out=got[..., 128:])
+    assert torch.equal(got[..., 128:], want[..., 128:])
+    pre = (x0.double() * bn.scale.double() + bn.shift.double()).float()
+    g0 = torch.where(pre > 0, want[..., :128], torch.zeros_like(want[..., :128]))
+    assert int((got[..., :128] != g0).sum()) <= 2
+    s = part[:rows * 2 * 128].view(rows, 2, 128).double().sum(0).cpu()
+    gd, xd = got[..., :128].double().reshape(-1, 128).cpu(), x0.double().reshape(-1, 128).cpu()
+    np.testing.assert_allclose(s[0].numpy(), gd.sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(s[1].numpy(), (gd * xd).sum(0).numpy(), rtol=1e-4, atol=2e-3)
+
+
 def _batch_for_more_tiles_than_blocks():
     """Batch size at which the three maps 128^2 + 64^2 + 32^2 (84 tiles of 16 x 16 pixels per image and channel tile) give at least 1.3 x
     as many tiles as the device has compute units (= persistent blocks): 4 on an MI355X (336 tiles on 256 blocks), more on a larger part -
