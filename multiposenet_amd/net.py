@@ -325,10 +325,6 @@ class KeypointNet:
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
         self.fuse_conv_bn = True
-        # ... and final_conv3x3's data gradient for the concat's first 128 channels (= phi_subnet_2's raw y2) reduces for that level's bn2: the
-        # data gradient runs as two launches over channel tiles of the same packed image (tile 0 with the fused reduction, tiles 1..3 plain)
-        # and the grouped reduction behind it keeps levels 3..5 only (round 6)
-        self.fuse_final_dgrad_bn = True
         # (forming their own INPUT on load - the batch-norm apply pass inside the data gradient, round 5 - was measured slower in the step,
         #  7.55 against 7.43 ms, profiles/r05_apply_on_load.txt, and is gone since round 6: DESIGN's table of negatives)
         self._l2 = None           # the regularisation term's batched launch (add_weight_decay_loss)
@@ -635,17 +631,11 @@ class KeypointNet:
                 # p / bn1: reduced inside the data gradient that produces their gradient (conv rows, sum g * x with the raw x)
                 if k != "bn2" and self._fused_conv_bn():
                     bwd[k].append((bn, b["stat_lv"][l], rows3, cnt, True))
-                elif k == "bn2" and l == 2 and self._fused_final_dgrad():      # reduced by final_conv3x3's data gradient (64 -> its 128-channel tile 0)
-                    bwd[k].append((bn, b["stat_lv"][l], ops.conv_stats_rows(N, h, w, 64, DEPTH, 3, self.dtype), cnt, True))
                 else:
                     bwd[k].append((bn, b["stat_lv"][l], nbn(cnt), cnt))
         out = {k: ops.BnFinalizeBatch(v, self.device) for k, v in fwd.items()}
         out.update({"d" + k: ops.BnBwdFinalizeBatch(v, self.device) for k, v in bwd.items()})
         return out
-
-    def _fused_final_dgrad(self):
-        """final_conv3x3's data gradient reduces for phi_subnet_2/bn2 on its first channel tile (see _backward_head)."""
-        return self.fuse_final_dgrad_bn and self._fused_conv_bn() and ops.conv_bwd_data_bn_supported(64, DEPTH, 3, self.dtype)
 
     def _fused_conv_bn(self):
         """The 3x3 data gradients of the subnet also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn_grouped)."""
@@ -735,17 +725,7 @@ class KeypointNet:
                                  slab[id(self._head_grad)], reduce=False)
             ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
         W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, self.concat_affine, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
-        ffd = self._fused_final_dgrad()
-        if ffd:
-            # final_conv3x3's data gradient: channel tile 0 (-> g["y2"][2], the concat's first slice) with the reduction for phi_subnet_2/bn2
-            # (raw x = b["y2"][2], the same slice of the forward tensor), channel tiles 1..3 (-> the slices the bilinear gradients read) plain:
-            # the packed image is [channel tile][...], a tile's weights one contiguous block
-            tile_bytes = self.final_conv.packed.bwd.numel() // 4
-            ops.conv_bwd_data_bn(g["final"], self.final_conv.packed.bwd[:tile_bytes], DEPTH, 3, self.phi[2]["bn2"], b["y2"][2], g["y2"][2],
-                                 b["stat_lv"][2])
-            ops.conv_fwd(g["final"], self.final_conv.packed.bwd[tile_bytes:], 3 * DEPTH, 3, None, out=g["concat"][..., DEPTH:])
-        else:
-            ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
+        ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm, stage by stage over the four levels (see subnet_forward): reductions into
         # per-level scratch, ONE finalize launch per stage, then the applies and the convolutions' gradients
         if b["fin"] is None:
@@ -758,10 +738,7 @@ class KeypointNet:
         by2, by1, bp = [b["y2"][l] for l in LV], [b["y1"][l] for l in LV], [b["p"][l] for l in LV]
         for l in (3, 4, 5):   # (level 2's gradient IS the first slice of g["concat"])
             ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
-        if ffd:     # (level 2 was reduced by the data gradient above)
-            ops.bn_bwd_reduce_grouped(bn2s[1:], gy2[1:], by2[1:], sps[1:])
-        else:
-            ops.bn_bwd_reduce_grouped(bn2s, gy2, by2, sps)
+        ops.bn_bwd_reduce_grouped(bn2s, gy2, by2, sps)
         fin["dbn2"].run()
         none4 = [None] * 4
         fused = self._fused_conv_bn()

@@ -933,11 +933,12 @@ def test_dwconv_bwd_fused_stride2_equals_the_separate_launches(cuda, dtype, N, H
 
 
 def test_data_gradient_split_over_channel_tiles_of_one_packed_image(cuda):
-    """Round 6: final_conv3x3's data gradient (64 -> 512 channels of the concat gradient, keypoint_subnet.py:37-38) runs as TWO launches over
-    the channel tiles of ONE packed image - tile 0 into the concat's first slice with the reduction for phi_subnet_2/bn2 fused
+    """Round 6: final_conv3x3's data gradient (64 -> 512 channels of the concat gradient, keypoint_subnet.py:37-38) as TWO launches over the
+    channel tiles of ONE packed image - tile 0 into the concat's first slice with the reduction for phi_subnet_2/bn2 fused
     (mpn_conv_bwd_data_bn: raw x = the same slice of the forward tensor, pixel stride 512), tiles 1..3 plain into the other slices. The
     packed data-gradient image is [channel tile of 128][...] with a tile's weights one contiguous block, so the two launches take
-    offsets into it. Against the single 64 -> 512 launch: slices 1..3 bit for bit; slice 0 = the same values masked by bn2's ReLU, bit
+    offsets into it. (Measured in the step and NOT adopted - 7.52 against 7.50 ms, profiles/r06_final_dgrad_split.txt: the one-chunk tiles
+    of the fused-reduction variant cost what the level's share of the grouped reduction saved; the entry points' contract stays tested.) Against the single 64 -> 512 launch: slices 1..3 bit for bit; slice 0 = the same values masked by bn2's ReLU, bit
     for bit; the slab's sums = sum g and sum g * x of that slice."""
     from multiposenet_amd import ops
     dtype = torch.bfloat16
