@@ -439,7 +439,7 @@ def test_detector_backward_pass_teacher_forced_against_the_oracle(cuda, dtype):
     assert len(out["rows"]) == 112                                     # every trainable head variable
     # (a tower level without a matched anchor has no box gradient at all: the oracle's is exactly zero and so must the build's be)
     bad = [(k, rel, cos) for k, _, norm, rel, cos in out["rows"] if not ((norm == 0.0 and rel == 0.0) or (rel <= tol_rel and cos >= tol_cos))]
-    assert sum(1 for r in out["rows"] if r[2] > 0.0) >= 100
+    assert sum(1 for r in out["rows"] if r[2] > 0.0) >= 80              # (88 with this batch: three levels without a matched anchor)
     worst = sorted(out["rows"], key=lambda r: -r[3])[:4]
     print(f"\n[{dtype} detector backward, teacher-forced] all {len(out['rows'])} gradient tensors together: rel-L2 {out['all_rel']:.5f}, "
           f"cosine {out['all_cos']:.6f}; worst: {[(r[0], round(r[3], 4)) for r in worst]}")
