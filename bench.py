@@ -203,8 +203,6 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-fuse-stem-stats", action="store_true", help="A/B: batch-norm statistics of the stem output as a separate pass")
     ap.add_argument("--no-fuse-conv-bn", action="store_true", help="A/B: batch-norm reductions behind the 3x3 data gradients as separate passes")
-    ap.add_argument("--interleaved-concat-grad", action="store_true",
-                    help="A/B: the concat tensor's gradient as ONE interleaved 512-channel tensor (rounds 1-5) instead of four dense per-level ones")
     ap.add_argument("--dry-run-cpu", action="store_true", help="rehearse launcher + exchange on CPU over gloo (tests)")
     ap.add_argument("--rehearse-shared-device", action="store_true",
                     help="REHEARSAL, not a measurement: the N ranks of the real GPU path (graphs, exchange, every rank-0 leg) all on "
@@ -240,8 +238,6 @@ def main():
     net = KeypointNet(dtype=dt, device=dev, seed=0)          # identical replicas on every rank
     if args.no_fuse_conv_bn:
         net.fuse_conv_bn = False
-    if args.interleaved_concat_grad:
-        net.dense_concat_grad = False
     if args.no_fuse_stem_stats:
         net.fuse_stem_stats = False
     params = {"initial_learning_rate": 3e-4, "num_steps": 200000, "weight_decay": 0.0, "depth_multiplier": 1.0}

@@ -325,11 +325,6 @@ class KeypointNet:
         # ... and so do the subnet's 3x3 data gradients (mpn_conv_bwd_data_bn_grouped: bn1 under conv2's, p{l}_batch_norm under
         # conv1's); set before the first backward pass of a shape (the finalize tables are built once)
         self.fuse_conv_bn = True
-        # the GRADIENT of the 512-channel concat tensor as four dense 128-channel tensors, one per pyramid level (round 6): final_conv3x3's
-        # data gradient runs as four jobs of one grouped launch over the channel tiles of its packed image (a tile's weights are one
-        # contiguous block), each writing a dense tensor - the bilinear gradients and level 2's batch-norm / convolution gradients then
-        # read whole pixel rows instead of 256 bytes of every 1 KB pixel of an interleaved tensor (set before the first backward pass)
-        self.dense_concat_grad = True
         # (forming their own INPUT on load - the batch-norm apply pass inside the data gradient, round 5 - was measured slower in the step,
         #  7.55 against 7.43 ms, profiles/r05_apply_on_load.txt, and is gone since round 6: DESIGN's table of negatives)
         self._l2 = None           # the regularisation term's batched launch (add_weight_decay_loss)
@@ -452,15 +447,11 @@ class KeypointNet:
         g["dlogits"] = torch.empty_like(b["logits"])
         g["daux"] = {l: torch.empty((N, *b["lv"][l]), dtype=torch.float32, device=dev) for l in b["lv"]}
         g["final"] = torch.empty_like(b["final"])
-        dense = self._dense_concat_grad()
-        if dense:
-            g["cat"] = [torch.empty((N, *b["lv"][2], DEPTH), dtype=dt, device=dev) for _ in range(4)]
-        else:
-            g["concat"] = torch.empty_like(b["concat"])
+        g["concat"] = torch.empty_like(b["concat"])
         for k in ("y1", "p", "x"):
             g[k] = {l: torch.empty_like(b[k][l]) for l in b["lv"]}
         g["y2"] = {l: torch.empty_like(b["y2"][l]) for l in b["lv"] if l != 2}
-        g["y2"][2] = g["cat"][0] if dense else g["concat"][..., :DEPTH]          # ... and so does its gradient (or it is the first dense one)
+        g["y2"][2] = g["concat"][..., :DEPTH]          # ... and so does its gradient
         g["c"] = {}   # gradient w.r.t. the activated c_l (from the lateral convs)
         for i, name in FEATURE_BLOCKS.items():
             g["c"][name] = torch.empty_like(b["pw"][i - 1])
@@ -646,10 +637,6 @@ class KeypointNet:
         out.update({"d" + k: ops.BnBwdFinalizeBatch(v, self.device) for k, v in bwd.items()})
         return out
 
-    def _dense_concat_grad(self):
-        """The concat tensor's gradient as four dense per-level tensors (16-bit builds: the packed data-gradient image is tiled by 128 channels)."""
-        return self.dense_concat_grad and self.dtype != torch.float32 and ops.conv_bwd_data_bn_supported(64, DEPTH, 3, self.dtype)
-
     def _fused_conv_bn(self):
         """The 3x3 data gradients of the subnet also reduce for the batch-norm they feed (mpn_conv_bwd_data_bn_grouped)."""
         return self.fuse_conv_bn and ops.conv_bwd_data_bn_supported(DEPTH, DEPTH, 3, self.dtype)
@@ -738,12 +725,7 @@ class KeypointNet:
                                  slab[id(self._head_grad)], reduce=False)
             ops.bn_backward(self.final_bn, g["final"], b["final"], sp)
         W(lambda: ops.conv_bwd_weight(b["concat"], g["final"], 3, self.concat_affine, self.final_conv.dw, slab[id(self.final_conv.dw)], reduce=False))
-        if "cat" in g:      # four jobs = the four 128-channel tiles of the packed data-gradient image, each into a dense tensor
-            tb = self.final_conv.packed.bwd.numel() // 4
-            ops.conv_fwd_grouped([g["final"]] * 4, [self.final_conv.packed.bwd[j * tb:(j + 1) * tb] for j in range(4)], DEPTH, 3, [None] * 4,
-                                 g["cat"], [None] * 4)
-        else:
-            ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
+        ops.conv_fwd(g["final"], self.final_conv.packed.bwd, 4 * DEPTH, 3, None, out=g["concat"])
         # ---- phi subnets + p{l}_batch_norm, stage by stage over the four levels (see subnet_forward): reductions into
         # per-level scratch, ONE finalize launch per stage, then the applies and the convolutions' gradients
         if b["fin"] is None:
@@ -755,10 +737,7 @@ class KeypointNet:
         gy2, gy1, gp = [g["y2"][l] for l in LV], [g["y1"][l] for l in LV], [g["p"][l] for l in LV]
         by2, by1, bp = [b["y2"][l] for l in LV], [b["y1"][l] for l in LV], [b["p"][l] for l in LV]
         for l in (3, 4, 5):   # (level 2's gradient IS the first slice of g["concat"])
-            if "cat" in g:
-                ops.bilinear_up_bwd(g["cat"][l - 2], 2 ** (l - 2), 0, DEPTH, out=g["y2"][l])
-            else:
-                ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
+            ops.bilinear_up_bwd(g["concat"], 2 ** (l - 2), (l - 2) * DEPTH, DEPTH, out=g["y2"][l])
         ops.bn_bwd_reduce_grouped(bn2s, gy2, by2, sps)
         fin["dbn2"].run()
         none4 = [None] * 4
