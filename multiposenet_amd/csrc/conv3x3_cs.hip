@@ -116,6 +116,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
     constexpr int kSw = N64 ? 7 : 15;           // its slot swizzle: slot ^ (px & kSw)
     // the fused-reduction variant finishes a tile BEHIND its last chunk instead of under the next tile's first stages: its epilogue
     // (the raw tensor of the fed batch-norm, the masks, sixteen running sums) does not fit beside the accumulators - 43 spilled registers
+    // (round 6: on 64-channel tiles the overlapped form fits - 212 registers, no spill - and is SLOWER in the detector's step, 5.61-5.63 against
+    //  5.55-5.60 ms, profiles/r06_bnr64_pipe.txt: a one-chunk tile has six stages to hide it under; on 128-channel tiles it spills 36-48 registers
+    //  whatever the fragment ring's depth)
     constexpr bool PIPE = !BNR;
     static_assert(!BNR || ACT == 0, "the fused batch-norm backward reduction rides on a data gradient (no producer affine)");
     using H = H16<T>;
