@@ -100,20 +100,17 @@ def test_two_rank_rccl_step_equals_single_rank_step(cuda, tmp_path):
         np.testing.assert_array_equal(g["grad"], 2.0 * want["grad"], err_msg=f"rank {r}: grad")
 
 
-def test_two_ranks_on_one_device_over_gloo_equal_single_rank_step(cuda, tmp_path):
-    """World size 2 on ONE device (both ranks LOCAL_RANK 0, backend gloo): what a 1-GPU box can check of the data-parallel step
-    with a real second rank - identical batches on both ranks, so the all-reduced sum is exactly twice each rank's gradient and
-    the averaged step reproduces the single-rank step bit for bit (variables, Adam slots, per-replica moving statistics)."""
-    want = _run_steps("cuda:0", distributed=False)
+def _ranks_on_one_device_over_gloo(world, prefix):
+    """`world` ranks on ONE device (every rank LOCAL_RANK 0, backend gloo): what a 1-GPU box can run of the data-parallel step with real
+    peers; returns what each rank saved (tests/test_dp_gpu.py run as a rank: losses, gradient arena, variables, Adam slots, moving statistics)."""
     port = _free_port()
     procs = []
-    prefix = str(tmp_path / "dpg")
-    for r in range(2):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2",
+    for r in range(world):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(world),
                    MPN_TEST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), prefix], env=env, cwd=ROOT))
     import time
-    deadline = time.monotonic() + 300
+    deadline = time.monotonic() + 400
     try:
         while any(p.poll() is None for p in procs):
             if any(p.poll() not in (None, 0) for p in procs) or time.monotonic() > deadline:
@@ -129,13 +126,39 @@ def test_two_ranks_on_one_device_over_gloo_equal_single_rank_step(cuda, tmp_path
             except subprocess.TimeoutExpired:
                 p.kill()
                 p.wait()
-    assert [p.returncode for p in procs] == [0, 0]
-    for r in range(2):
-        g = dict(np.load(f"{prefix}.rank{r}.npz"))
+    assert [p.returncode for p in procs] == [0] * world
+    return [dict(np.load(f"{prefix}.rank{r}.npz")) for r in range(world)]
+
+
+def test_two_ranks_on_one_device_over_gloo_equal_single_rank_step(cuda, tmp_path):
+    """World size 2 on ONE device (both ranks LOCAL_RANK 0, backend gloo): what a 1-GPU box can check of the data-parallel step
+    with a real second rank - identical batches on both ranks, so the all-reduced sum is exactly twice each rank's gradient and
+    the averaged step reproduces the single-rank step bit for bit (variables, Adam slots, per-replica moving statistics)."""
+    want = _run_steps("cuda:0", distributed=False)
+    for r, g in enumerate(_ranks_on_one_device_over_gloo(2, str(tmp_path / "dpg"))):
         assert int(g["world"]) == 2
         for k in ("losses", "theta", "m", "v", "moving"):
             np.testing.assert_array_equal(g[k], want[k], err_msg=f"rank {r}: {k}")
         np.testing.assert_array_equal(g["grad"], 2.0 * want["grad"], err_msg=f"rank {r}: grad")
+
+
+def test_four_ranks_on_one_device_over_gloo_follow_the_single_rank_step(cuda, tmp_path):
+    """Round 6 (no multi-GPU node in any round): the same with FOUR ranks on the one device - four graphs around three exchanges per step,
+    the 1 / world average in the Adam kernel - the most a 1-GPU box's process guard allows next to the test runner. A sum of four equal
+    f32 values is exact only when the collective adds them pairwise, so the sum is held to 4 x one rank's gradient within one f32
+    rounding of a three-fold sum and the variables / Adam slots / moving statistics to that rounding carried through two steps; every
+    rank must hold the SAME bits (the all-reduce leaves identical arenas everywhere)."""
+    want = _run_steps("cuda:0", distributed=False)
+    got = _ranks_on_one_device_over_gloo(4, str(tmp_path / "dp4"))
+    for r, g in enumerate(got):
+        assert int(g["world"]) == 4
+        np.testing.assert_allclose(g["grad"], 4.0 * want["grad"], rtol=3e-7, atol=0, err_msg=f"rank {r}: grad")
+        np.testing.assert_allclose(g["losses"], want["losses"], rtol=1e-6, err_msg=f"rank {r}: losses")
+        np.testing.assert_array_equal(g["moving"], want["moving"], err_msg=f"rank {r}: moving statistics are per replica")
+        for k in ("theta", "m", "v"):
+            np.testing.assert_allclose(g[k], want[k], rtol=2e-5, atol=2e-7, err_msg=f"rank {r}: {k}")
+        for k in ("grad", "theta", "m", "v"):
+            np.testing.assert_array_equal(g[k], got[0][k], err_msg=f"rank {r} differs from rank 0: {k}")
 
 
 def test_one_rank_rccl_rehearsal_equals_plain_step(cuda, tmp_path):
