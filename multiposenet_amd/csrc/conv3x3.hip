@@ -1,28 +1,23 @@
-// 3x3 convolution (forward and data gradient), 16-bit storage, on v_mfma_f32_16x16x32_{bf16,f16}: ONE 8-wave block per CU
-// owns a 16 x 16 pixel tile x 128 output channels.
-//
-// Why a second 3x3 kernel: the tiled kernel of conv_mfma.hip (4 waves, 128 pixels x 128 channels, two blocks per CU) streams
-// all 9 x Cin x 128 weights through LDS once per 128 pixels - 36 bytes per CU and clock of L2 -> LDS traffic at full MFMA
-// rate, which is what a CU can ingest - and reads one LDS fragment per two MFMAs, which is what the LDS can deliver. Here
-//   * the weight stream is shared by 256 pixels (20 bytes per clock),
-//   * a stage holds the three taps of one kernel COLUMN (ky = 0..2 at fixed kx): output row r at tap ky reads the same
-//     halo row r + ky as output row r + 1 at tap ky - 1, so a wave loads the 6 halo rows of its 4 output rows ONCE per
-//     stage and uses each fragment for up to three taps: 18 fragment reads per 48 MFMAs instead of 24,
-//   * the 18 x 18 halo image of the next 64-channel chunk is fetched into registers and committed (producer's batch-norm
-//     affine + activation + zero padding) into the other half of a double-buffered LDS image while the current chunk is
-//     multiplied: the only exposed staging is that of a tile's first chunk.
-// LDS: 2 x 51 840 (halo images, 160-byte rows: conflict-free ds_read_b128) + 2 x 24 576 (weight stages, LDS-DMA) = 152 832 B.
-// Epilogue as in the tiled kernel: the tile leaves through a bf16 LDS image (whole 256-byte pixel rows to HBM), the
-// batch-norm partial sums come from the matrix unit (ones x F and F^T x F over transposed reads of that image) and are
-// summed over a block's tiles of a layer: one row of the partial slab per block (mpn_conv_stats_rows).
-//
-// N64 variant (64 output channels per tile: final_conv3x3 512 -> 64, keypoint_subnet.py:38, and the detector's tower convolutions,
-// box_predictor.py:101-103): the same 16 x 16 pixel tile, the same stage bytes and the same 48 MFMAs per wave and stage - the two
-// waves of a row group split the K dimension instead of the channels: a stage holds the three taps of a kernel column for ALL 64
-// input channels of the chunk ([ky][k-step 2][co 64][64 bytes] = the [ky][row 128][64 bytes] image of the 128-channel variant
-// with row = k-step * 64 + co), wave (wm, wk) multiplies k-step wk. 3 stages per chunk instead of 6. At the end of a tile the
-// pair adds its two partial accumulators through LDS (each wave hands over the half of the rows it will not finish: 8 KB per
-// wave, one block barrier) and finishes 32 pixels x 64 channels each.
+// 3x3 convolution (forward and data gradient), 16-bit storage, on v_mfma_f32_16x16x32_{bf16,f16}: ONE 8-wave block per CU owns a
+// 16 x 16 pixel tile x 64 output channels - the kernel of the 64-CHANNEL TILES THAT ARE DEEPER THAN ONE 64-CHANNEL CHUNK (Cout an odd
+// multiple of 64, Cin > 64: final_conv3x3's forward 512 -> 64, keypoint_subnet.py:38). Rounds 2-4 ran every 3x3 shape here; since
+// round 5 the 128-channel tiles and the one-chunk 64-channel tiles (the detector's 64 -> 64 towers, box_predictor.py:101-103) run on
+// the channel-split kernel of conv3x3_cs.hip, and round 6 removed this file's 128-channel form (its history: docs/DESIGN_history_r1-r5.md
+// 4f-4i). What is left is the variant that still wins its shape (profiles/r06_c3_n64_ab.txt): it shares a stage's weights through LDS
+// among the eight waves, where the channel-split kernel's 64-channel tile pulls them from L2 at twice its 128-channel tile's rate.
+//   * a weight stage holds the three taps of one kernel COLUMN (ky = 0..2 at fixed kx) for ALL 64 input channels of the chunk
+//     ([ky 3][k-step 2][co 64][64 bytes] = 24 576 bytes by LDS-DMA, two buffers): output row r at tap ky reads the same halo row r + ky
+//     as output row r + 1 at tap ky - 1, so a wave loads the 6 halo rows of its 4 output rows ONCE per stage and uses each fragment for
+//     up to three taps: 18 fragment reads per 48 MFMAs; 3 stages per chunk;
+//   * waves = 4 row groups (4 output rows each) x 2 K halves: wave (wm, wk) multiplies k-step wk of every stage; at the end of a tile the
+//     pair adds its two partial accumulators through LDS (each wave hands over the half of the rows it will not finish: 8 KB per wave,
+//     one block barrier) and finishes 32 pixels x 64 channels each;
+//   * the 18 x 18 halo image of the next 64-channel chunk is fetched into registers and committed (producer's batch-norm affine +
+//     activation + zero padding) into the other half of a double-buffered LDS image while the current chunk is multiplied.
+// LDS: 2 x 51 840 (halo images, 160-byte rows: conflict-free ds_read_b128) + 2 x 24 576 (weight stages) = 152 832 B.
+// Epilogue: wave-local through a bf16 LDS image (whole 128-byte pixel rows to HBM), the batch-norm partial sums from the matrix unit
+// (ones x F and F^T x F over transposed reads of that image), summed over a block's tiles of a layer: one row of the partial slab
+// per block (mpn_conv_stats_rows).
 #include "conv3x3.h"
 #include <type_traits>
 
@@ -85,11 +80,11 @@ __device__ __forceinline__ void lds_store16_raw(unsigned char* p, const uint4& v
 // 64 pixels x 64 channels, stores them straight from the registers (8 bytes per lane: the four 16-channel pieces of a
 // pixel's 128 bytes come from four consecutive stores of one wave and merge in the L2) and - when statistics are asked for -
 // takes them from a wave-private LDS image of 32 pixels at a time in the halo buffer that has just been released.
-template <typename T, bool AFFINE, bool N64, bool BNR = false>
+template <typename T, bool AFFINE, bool BNR = false>
 __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     static_assert(!BNR || !AFFINE, "the fused batch-norm backward reduction rides on a data gradient (no producer affine)");
-    constexpr int NS = N64 ? 3 : 6;     // weight stages per 64-channel chunk
-    constexpr int BN = N64 ? 64 : 128;  // output channels per tile
+    constexpr int NS = 3;     // weight stages per 64-channel chunk (one per kernel column, both k-steps inside)
+    constexpr int BN = 64;    // output channels per tile
     using H = H16<T>;
     using X8 = typename H::x8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -116,8 +111,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;       // 4 waves along the tile's rows (4 rows each) x 2 along the channels (64 each;
-                                                   // N64: along the two k-steps of a chunk)
+    const int wm = wave >> 1, wn = wave & 1;       // 4 waves along the tile's rows (4 rows each) x 2 along the two k-steps of a stage
     const int l15 = lane & 15, lq = lane >> 4;
     const int Cin = g.job[0].Cin, Cout = g.job[0].Cout;    // (shared by the jobs of a group)
     const int nchunk = Cin >> 6;
@@ -238,39 +232,33 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
     const int st_which = (tid >> 7) & 1, st_c = tid & 127;
     auto stats_flush = [&]() {
         if (st_pending) {
-            if constexpr (N64) {   // red [8 waves][2][64], fixed order: the four waves of the upper half, then of the lower half
-                const float* r = red + st_which * 64 + st_c;
-                st_acc += ((r[0] + r[128]) + (r[256] + r[384])) + ((r[512] + r[640]) + (r[768] + r[896]));
-            } else {               // red [4 wm][2][128]
-                const float* r = red + st_which * 128 + st_c;
-                st_acc += (r[0] + r[256]) + (r[512] + r[768]);
-            }
+            // red [8 waves][2][64], fixed order: the four waves of the upper half, then of the lower half
+            const float* r = red + st_which * 64 + st_c;
+            st_acc += ((r[0] + r[128]) + (r[256] + r[384])) + ((r[512] + r[640]) + (r[768] + r[896]));
             if (st_store) { *st_dst = st_acc; st_acc = 0.f; }
         }
         st_pending = false;
     };
 
     // BNR: the raw tensor of the fed batch-norm at this wave's 64 pixels x 64 channels, in the copy-out layout of the epilogue
-    // (lane = 16-byte piece lane % 8 of image rows lane / 8 + 8 k; two passes of 32 pixels): eight 16-byte loads per lane,
-    // requested under the tile's LAST weight stage and consumed by the epilogue
-    // (the first pass's four loads under the last stage - all eight there spill -, the second pass's at the top of the epilogue)
-    // (N64: a wave finishes ONE pass - rows 2 wn, 2 wn + 1 of its row group, all 64 channels - into bx[0..3])
-    uint4 bx[BNR ? (N64 ? 4 : 8) : 1];
+    // (lane = 16-byte piece lane % 8 of image rows lane / 8 + 8 k; a wave finishes rows 2 wn, 2 wn + 1 of its row group, all 64 channels):
+    // four 16-byte loads per lane, requested under the tile's LAST weight stage and consumed by the epilogue
+    uint4 bx[BNR ? 4 : 1];
     auto bnr_load = [&](const Tile& t, int hp) {
         if constexpr (BNR) {
             const Job& p = g.job[t.job];
             const int wbs = p.W * p.bnr_xs;          // (scalar image base + 24-bit offsets: see a_load)
-            const T* xb = reinterpret_cast<const T*>(p.bnr_x) + (long long)t.img * p.H * wbs + t.ntile * BN + (N64 ? 0 : wn * 64) + (lane & 7) * 8;
+            const T* xb = reinterpret_cast<const T*>(p.bnr_x) + (long long)t.img * p.H * wbs + t.ntile * BN + (lane & 7) * 8;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int row = (lane >> 3) + 8 * k;
                 const int oy = min(t.oy0 + 4 * wm + hp * 2 + (row >> 4), p.H - 1), ox = min(t.ox0 + (row & 15), p.W - 1);
-                bx[(N64 ? 0 : hp * 4) + k] = *reinterpret_cast<const uint4*>(xb + (int)(__umul24((unsigned)oy, (unsigned)wbs) + __umul24((unsigned)ox, (unsigned)p.bnr_xs)));
+                bx[k] = *reinterpret_cast<const uint4*>(xb + (int)(__umul24((unsigned)oy, (unsigned)wbs) + __umul24((unsigned)ox, (unsigned)p.bnr_xs)));
             }
         }
     };
 
-    Tile cur = tile_of<N64>(g, w);
+    Tile cur = tile_of<true>(g, w);
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(g.job[cur.job].wp) + cur.ntile * wtile;
     int cc = 0, ss = 0;        // running chunk / stage counters: halo buffer cc & 1, weight buffer ss & 1
     b_issue(wsrc, 0, 0);
@@ -288,7 +276,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
         C3_STAMP(0);
         const int wnext = w + (int)gridDim.x;
         const bool has_next = wnext < total;
-        const Tile nxt = tile_of<N64>(g, has_next ? wnext : w);
+        const Tile nxt = tile_of<true>(g, has_next ? wnext : w);
         const unsigned char* wsrc_next = reinterpret_cast<const unsigned char*>(g.job[nxt.job].wp) + nxt.ntile * wtile;
 
         f32x4_t acc[4][4];
@@ -303,9 +291,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             const bool stage_more = !last_chunk || has_next;       // a halo image to prepare under this chunk
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl, ++ss) {
-                // stage sl = (kx, k-step): taps (ky, kx) for ky = 0..2, input channels chunk * 64 + ks * 32 .. + 31
-                // (N64: stage sl = kx holds both k-steps, this wave multiplies k-step wn)
-                const int a_off = N64 ? sl * kRS + wn * 64 : (sl >> 1) * kRS + (sl & 1) * 64;
+                // stage sl = kx: taps (ky, kx) for ky = 0..2, both k-steps of the chunk; this wave multiplies k-step wn (input channels
+                // chunk * 64 + wn * 32 .. + 31)
+                const int a_off = sl * kRS + wn * 64;
                 const unsigned char* bb = bbase + (ss & 1) * kStageBytes;
                 // The stage's requests (next weight stage, in a chunk's first stage the next halo image): BEHIND the stage's first fragment
                 // reads - in front of them every wave of the block spent its first ~200 cycles behind the barrier issuing LDS-DMA pieces
@@ -315,7 +303,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                     // the next weight stage (of this tile, or the first one of the next tile) into the buffer that stage ss - 1 read
                     if (sl < NS - 1 || !last_chunk) b_issue(wsrc, chunk * NS + sl + 1, (ss + 1) & 1);
                     else if (has_next) b_issue(wsrc_next, 0, (ss + 1) & 1);
-                    if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, N64 ? wn : 0); }
+                    if constexpr (BNR) { if (last_chunk && sl == NS - 1) bnr_load(cur, wn); }
 #if !(MPN_KO & 2)
                     if (sl == 0) {
                         // UNCONDITIONAL (without a following image the same chunk is fetched again and dropped): behind a condition
@@ -355,7 +343,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 __builtin_amdgcn_sched_barrier(0);
                 // the halo image prepared under this chunk: its loads have had two stages to land, and the buffer was last read
                 // in the previous chunk (the wave-private epilogue images in it: before the barrier of this chunk's first stage)
-                // (N64: sl == 2 is the chunk's last stage - the commit still completes in front of its barrier)
+                // (sl == 2 is the chunk's last stage - the commit still completes in front of its barrier)
 #if !(MPN_KO & 2)
                 if (sl == 2 && stage_more) a_commit_part(0, kAVec, (cc + 1) & 1, last_chunk ? 0 : chunk + 1);
 #endif
@@ -402,7 +390,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             const int n0 = cur.ntile * BN;
             constexpr int RSW = 64 * 2 + 8;                                   // wave-private image: 32 pixels x (128 + 8) bytes
             unsigned char* Ow = As + ((cc - 1) & 1) * kABytes + wave * (32 * RSW);
-            if constexpr (N64) {
+            {
                 // the pair (wm, 0), (wm, 1) holds two partial sums of the same 64 pixels x 64 channels. Each wave hands over the
                 // two image rows it will NOT finish (wave wn keeps rows 2 wn, 2 wn + 1) as f32: 8 KB per wave, slots 0..5 in the
                 // released halo buffer, 6 and 7 in the released weight buffer ((ss + 1) & 1: the last stage read ss - 1... the
@@ -453,8 +441,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             f32x2_t bsc[4], bsh[4], bs[4], bq[4];
             float blo = -INFINITY, bhi = INFINITY;
             if constexpr (BNR) {
-                if constexpr (!N64) bnr_load(cur, 1);
-                const float* ts = tab + cur.ntile * BN + (N64 ? 0 : wn * 64) + (lane & 7) * 8;
+                const float* ts = tab + cur.ntile * BN + (lane & 7) * 8;
                 const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(ts), s1 = *reinterpret_cast<const f32x4_t*>(ts + 4);
                 const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin), h1 = *reinterpret_cast<const f32x4_t*>(ts + kMaxCin + 4);
                 bsc[0] = (f32x2_t){s0[0], s0[1]}; bsc[1] = (f32x2_t){s0[2], s0[3]}; bsc[2] = (f32x2_t){s1[0], s1[1]}; bsc[3] = (f32x2_t){s1[2], s1[3]};
@@ -473,23 +460,23 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
             // copy-out lanes: lane j moves 16-byte piece j % 8 of image rows j / 8 + 8 k (8 lanes = the wave's 128 bytes of a pixel)
             const int cpiece = lane & 7, crow = lane >> 3;
             const int wys = p.W * p.ys;
-            T* __restrict__ yimg = y + (long long)cur.img * p.H * wys + n0 + (N64 ? 0 : wn * 64);   // (wave-uniform)
+            T* __restrict__ yimg = y + (long long)cur.img * p.H * wys + n0;   // (wave-uniform)
             // Full tiles (block-uniform) skip the zeroing of pixels outside the image (64 selects per wave) and the store predicates:
             // a branch around the whole pass - inside it hipcc if-converts the test back into the selects.
             const bool full_tile = cur.oy0 + 16 <= p.H && cur.ox0 + 16 <= p.W;
             // a lane's store offset inside its wave's 32 pixels is a constant (row = crow + 8 k -> image row k / 2, column crow + 8 (k & 1));
             // the rest of the address is scalar: the stores take a scalar base + this 32-bit byte offset, no vector address arithmetic
             const unsigned lane_off = (unsigned)(crow * p.ys + cpiece * 8) * 2u;
-            auto ep_pass = [&](auto edge, const int hpi) __attribute__((always_inline)) {
+            auto ep_pass = [&](auto edge) __attribute__((always_inline)) {
                 constexpr bool EDGE = decltype(edge)::value;
-                const int hp = N64 ? wn : hpi;                                // (N64: the rows this wave finishes; their sums sit in acc[0..1])
+                const int hp = wn;                                            // (the rows this wave finishes; their sums sit in acc[0..1])
 #pragma unroll
                 for (int ml = 0; ml < 2; ++ml) {
                     const int mt = hp * 2 + ml;
                     const bool ok = !EDGE || ((cur.oy0 + 4 * wm + mt) < p.H && (cur.ox0 + l15) < p.W);
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) {
-                        f32x4_t v = N64 ? acc[ml][nt] : acc[hpi * 2 + ml][nt];
+                        f32x4_t v = acc[ml][nt];
                         if (EDGE && !ok) v = (f32x4_t){0.f, 0.f, 0.f, 0.f};   // pixels outside the image must not count in the statistics
                         store4(reinterpret_cast<T*>(Ow + (ml * 16 + l15) * RSW + (nt * 16 + lq * 4) * 2), v);
                     }
@@ -507,7 +494,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         ga[nt] = H::mfma(f, f, ga[nt]);
                     }
                 }
-                // whole 128-byte pieces of pixel rows to HBM (the other 64-channel wave writes the other half of the 256 bytes):
+                // whole 128-byte pixel rows (the tile's 64 channels) to HBM:
                 // all eight LDS reads first (unconditional), then the stores - one LDS round trip per 32 pixels
                 uint2 ca[4], cb[4];
 #pragma unroll
@@ -524,7 +511,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         // g = dy where the fed batch-norm's activation passes (lo < x * scale + shift < hi, the test of
                         // bn_bwd_reduce / bn_bwd_apply, fused multiply-add), else 0; sums of g and g * x (pixels outside the image
                         // hold dy = 0). 16-bit storage: element pairs per dword.
-                        const uint4 xv = bx[hpi * 4 + k];
+                        const uint4 xv = bx[k];
                         const unsigned xu[4] = {xv.x, xv.y, xv.z, xv.w};
                         unsigned du[4] = {o.x, o.y, o.z, o.w};
 #pragma unroll
@@ -548,10 +535,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                         *reinterpret_cast<uint4*>(ybase + lane_off) = o;
                 }
             };
-#pragma unroll
-            for (int hpi = 0; hpi < (N64 ? 1 : 2); ++hpi) {
-                if (full_tile) ep_pass(std::false_type{}, hpi); else ep_pass(std::true_type{}, hpi);
-            }
+            if (full_tile) ep_pass(std::false_type{}); else ep_pass(std::true_type{});
             if constexpr (BNR) {
                 // the lanes of one 16-byte piece (lane bits 3..5 = the 8 row lanes): fixed butterfly, then lanes 0..7 hold the wave's
                 // sums of their 8 channels
@@ -565,15 +549,9 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 if (lane < 8) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if constexpr (N64) {      // red [8 waves][2][64]
-                            const int cl = lane * 8 + 2 * j;
-                            red[(wave * 2 + 0) * 64 + cl] = bs[j][0]; red[(wave * 2 + 0) * 64 + cl + 1] = bs[j][1];
-                            red[(wave * 2 + 1) * 64 + cl] = bq[j][0]; red[(wave * 2 + 1) * 64 + cl + 1] = bq[j][1];
-                        } else {
-                            const int cl = wn * 64 + lane * 8 + 2 * j;
-                            red[(wm * 2 + 0) * 128 + cl] = bs[j][0]; red[(wm * 2 + 0) * 128 + cl + 1] = bs[j][1];
-                            red[(wm * 2 + 1) * 128 + cl] = bq[j][0]; red[(wm * 2 + 1) * 128 + cl + 1] = bq[j][1];
-                        }
+                        const int cl = lane * 8 + 2 * j;      // red [8 waves][2][64]
+                        red[(wave * 2 + 0) * 64 + cl] = bs[j][0]; red[(wave * 2 + 0) * 64 + cl + 1] = bs[j][1];
+                        red[(wave * 2 + 1) * 64 + cl] = bq[j][0]; red[(wave * 2 + 1) * 64 + cl + 1] = bq[j][1];
                     }
                 }
             }
@@ -583,36 +561,28 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
                 for (int nt = 0; nt < 4 && !BNR; ++nt) {
                     const float q = r == 0 ? ga[nt][0] : (r == 1 ? ga[nt][1] : (r == 2 ? ga[nt][2] : ga[nt][3]));
                     if (lq == (l15 >> 2)) {
-                        if constexpr (N64) {
-                            const int cl = nt * 16 + l15;
-                            red[(wave * 2 + 0) * 64 + cl] = sa[nt][0];
-                            red[(wave * 2 + 1) * 64 + cl] = q;
-                        } else {
-                            const int cl = wn * 64 + nt * 16 + l15;
-                            red[(wm * 2 + 0) * 128 + cl] = sa[nt][0];
-                            red[(wm * 2 + 1) * 128 + cl] = q;
-                        }
+                        const int cl = nt * 16 + l15;
+                        red[(wave * 2 + 0) * 64 + cl] = sa[nt][0];
+                        red[(wave * 2 + 1) * 64 + cl] = q;
                     }
                 }
                 // the block's row of this job's slab (pixels outside the image count as zeros): row = the position of the block's
                 // FIRST tile of the job among the job's first gridDim.x tiles, i.e. rows 0 .. min(grid, tiles) / n_tiles - 1
                 // (mpn_conv_stats_rows; the grid is a multiple of n_tiles, so a block keeps its channel tile within a job)
                 {
-                    const int n_tiles = N64 ? (Cout >> 6) : (Cout >> 7), grid = (int)gridDim.x;
+                    const int n_tiles = Cout >> 6, grid = (int)gridDim.x;
                     int off = (w_first - g.begin[cur.job]) % grid;
                     if (off < 0) off += grid;
-                    st_pending = tid < 256 && (!N64 || st_c < 64);
+                    st_pending = tid < 256 && st_c < 64;
                     st_store = !has_next || nxt.job != cur.job;
                     st_dst = p.stats_part + ((long long)(off / n_tiles) * 2 + st_which) * Cout + n0 + st_c;
                 }
             }
-            // N64: the next tile's first weight stage is requested into the weight buffer that held slots 6 and 7
+            // the next tile's first weight stage is requested into the weight buffer that held slots 6 and 7
             // (a raw barrier: the tile's output stores stay in flight)
-            if constexpr (N64) {
-                if (has_next) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
+            if (has_next) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
         }
 #endif
@@ -623,13 +593,8 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 #endif
         if (!has_next) break;
         if constexpr (BNR) {
-            if (nxt.job != tab_job) {      // (block-uniform) the next job's batch-norm, once every wave has finished this tile's epilogue
-                if constexpr (!N64) {      // (N64: the barrier that ends the epilogue, above)
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-                tab_load(nxt.job);
-            }
+            // (block-uniform) the next job's batch-norm, once every wave has finished this tile's epilogue (the barrier that ends it, above)
+            if (nxt.job != tab_job) tab_load(nxt.job);
         }
         cur = nxt;
         wsrc = wsrc_next;
@@ -646,19 +611,18 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_kernel(const Group g) {
 #endif
 }
 
-template <typename T, bool AFFINE, bool N64, bool BNR = false>
+template <typename T, bool AFFINE, bool BNR = false>
 int launch_t(const Group& g, int blocks, hipStream_t st) {
     static mpn_attr_mask_t attr_mask{0};
-    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE, N64, BNR>, kLds, &attr_mask));
-    conv3x3_kernel<T, AFFINE, N64, BNR><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
+    MPN_HIP(mpn_ensure_dynamic_lds((const void*)conv3x3_kernel<T, AFFINE, BNR>, kLds, &attr_mask));
+    conv3x3_kernel<T, AFFINE, BNR><<<dim3((unsigned)blocks), dim3(kThreads), kLds, st>>>(g);
     MPN_LAUNCH_CHECK();
     return MPN_OK;
 }
-// (only the 64-channel tiles of several chunks still come here - launch() below: the 128-channel instantiations are gone)
 template <typename T>
 int launch_v(const Group& g, int blocks, bool affine, bool bnr, hipStream_t st) {
-    if (bnr) return launch_t<T, false, true, true>(g, blocks, st);
-    return affine ? launch_t<T, true, true>(g, blocks, st) : launch_t<T, false, true>(g, blocks, st);
+    if (bnr) return launch_t<T, false, true>(g, blocks, st);
+    return affine ? launch_t<T, true>(g, blocks, st) : launch_t<T, false>(g, blocks, st);
 }
 
 }  // namespace
