@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { bs[j] = (f32x2_t){0.f, 0.f}; bq[j] = (f32x2_t){0.f, 0.f}; }
             }
-            if (sl == 0 && h >= 12 && h < 16) bx[h - 12] = bnr_ld(h - 12);
+            // (the raw tensor's first four pieces were requested under the tile's last stage: chunk_body)
         }
         if (sl == 1 || (sl == 2 && !N64)) {
             // pixel rows prow + 4 k, k = 4 (sl - 1) + kk: the LDS read of row kk at h = 3 kk + 1, its store at h = 3 kk + 6 (two rows in
@@ -510,6 +510,17 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
             // this tile's first chunk once more, never read: the staging stays unconditional)
             const Tile& st_tile = last_chunk ? nxt : cur;
             const int st_chunk = last_chunk ? 0 : chunk + 1;
+            if constexpr (BNR) {
+                // the fused reduction's epilogue runs BEHIND the tile (not under the next one): where it reads the fed batch-norm's raw tensor
+                // is known now, and its first four pieces are requested under the tile's last stage instead of in front of their use
+                // (round 6: ~2 k cycles of exposed load latency per tile)
+                if (last_chunk) {
+                    const Job& p = g.job[cur.job];
+                    const int wbs = p.W * p.bnr_xs;
+                    e_bx = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.bnr_x) + ((long long)cur.img * p.H + cur.oy0) * wbs + (long long)cur.ox0 * p.bnr_xs + cur.ntile * CT);
+                    e_bx_rowb = wbs * 2; e_bx_pxb = p.bnr_xs * 2; e_bx_hmax = p.H - 1 - cur.oy0; e_bx_wmax = p.W - 1 - cur.ox0;
+                }
+            }
             if constexpr (AFFINE) {
                 // another job's table (a few times per launch): no wave commits between a chunk's barrier and its stage 3
                 if (last_chunk && nxt.job != tab_job) {
@@ -545,6 +556,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                         if (h >= c0 && h < c0 + 5) commit_step(2 * (sl - 3), h - c0, (cc + 1) & 1);
                         if (h >= c1 && h < c1 + 5) commit_step(2 * (sl - 3) + 1, h - c1, (cc + 1) & 1);
                     }
+                    if constexpr (BNR) { if (last_chunk && sl == 5 && h >= 2 && h < 6) bx[h - 2] = bnr_ld(h - 2); }
                     if (EPI && sl < 3) {
                         if constexpr (N64) {       // (the epilogue's 18 steps on ten groups: an odd step - MFMAs, stores - with the NEXT even one's reads)
                             if (h >= 1) e2_step(sl, 2 * h - 1);
@@ -595,10 +607,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                     const int wys = p.W * p.ys;
                     e_y = reinterpret_cast<unsigned char*>(reinterpret_cast<T*>(p.y) + ((long long)cur.img * p.H + cur.oy0) * wys + (long long)cur.ox0 * p.ys + cur.ntile * CT);
                     e_rowb = wys * 2; e_pxb = p.ys * 2; e_h = p.H - cur.oy0; e_w = p.W - cur.ox0; e_ntile = cur.ntile;
-                    if constexpr (BNR) {
-                        const int wbs = p.W * p.bnr_xs;
-                        e_bx = reinterpret_cast<const unsigned char*>(reinterpret_cast<const T*>(p.bnr_x) + ((long long)cur.img * p.H + cur.oy0) * wbs + (long long)cur.ox0 * p.bnr_xs + cur.ntile * CT);
-                        e_bx_rowb = wbs * 2; e_bx_pxb = p.bnr_xs * 2; e_bx_hmax = p.H - 1 - cur.oy0; e_bx_wmax = p.W - 1 - cur.ox0;
+                    if constexpr (BNR) {      // (e_bx and its strides: at the top of the chunk)
                         e_blo = p.bnr_act != MPN_ACT_NONE ? 0.f : -INFINITY;
                         e_bhi = p.bnr_act == MPN_ACT_RELU6 ? 6.f : INFINITY;
                     }
