@@ -347,7 +347,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
         }
     };
     typename H::x4 tlo, thi;
-    uint4 co[2], bx[BNR ? 4 : 1];
+    uint4 co[2], bx[BNR ? (N64 ? 4 : 8) : 1];      // (128-channel tiles: all eight pieces of a lane in flight from the tile's last stage on)
     f32x2_t bs[4], bq[4];
     auto bnr_ld = [&](const int k) __attribute__((always_inline)) -> uint4 {
         // (rows / columns past the image: clamped - their dy is 0)
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                     int toff = (e_ntile * CT + piece * 8 + ph * 4) * 4;
                     asm volatile("" : "+v"(toff));
                     const f32x4_t s4 = lds_ld<f32x4_t>((lds_p)tab + toff), h4 = lds_ld<f32x4_t>((lds_p)tab + toff + kMaxCin * 4);
-                    const uint4 xv = bx[km];
+                    const uint4 xv = bx[(N64 ? 0 : half * 4) + km];
                     unsigned du[2] = {ph == 0 ? co[km & 1].x : co[km & 1].z, ph == 0 ? co[km & 1].y : co[km & 1].w};
                     const unsigned xu[2] = {ph == 0 ? xv.x : xv.z, ph == 0 ? xv.y : xv.w};
 #pragma unroll
@@ -425,7 +425,6 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                         bq[j] += gf * xf;
                     }
                     if (ph == 0) { co[km & 1].x = du[0]; co[km & 1].y = du[1]; } else { co[km & 1].z = du[0]; co[km & 1].w = du[1]; }
-                    if (!N64 && ph == 1 && half == 0) bx[km] = bnr_ld(km + 4);
                 }
             }
             if (h >= 6 && h <= 15 && (h - 6) % 3 == 0) {
@@ -556,7 +555,10 @@ __global__ __launch_bounds__(kThreads, 1) void conv3x3_cs_kernel(const Group g) 
                         if (h >= c0 && h < c0 + 5) commit_step(2 * (sl - 3), h - c0, (cc + 1) & 1);
                         if (h >= c1 && h < c1 + 5) commit_step(2 * (sl - 3) + 1, h - c1, (cc + 1) & 1);
                     }
-                    if constexpr (BNR) { if (last_chunk && sl == 5 && h >= 2 && h < 6) bx[h - 2] = bnr_ld(h - 2); }
+                    if constexpr (BNR) {
+                        if (last_chunk && sl == 5 && h >= 2 && h < 6) bx[h - 2] = bnr_ld(h - 2);
+                        if (!N64 && last_chunk && sl == 5 && h >= 10 && h < 14) bx[h - 6] = bnr_ld(h - 6);
+                    }
                     if (EPI && sl < 3) {
                         if constexpr (N64) {       // (the epilogue's 18 steps on ten groups: an odd step - MFMAs, stores - with the NEXT even one's reads)
                             if (h >= 1) e2_step(sl, 2 * h - 1);
