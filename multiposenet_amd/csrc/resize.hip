@@ -155,6 +155,154 @@ __global__ __launch_bounds__(kThreads) void bilinear_up_bwd_kernel(const T* __re
     ov.store(dx + (((long long)n * h + iy) * w + ix) * C + c0);
 }
 
+// The same sums with every element of dY loaded ONCE by ONE thread (the gather above loads it (2U-1)^2 / U^2 = 2.3-3.5 times
+// and walks 2U-1 dependent rows per thread: 37-48 us per level of the subnet where the bytes take 27). The tent is separable:
+// a thread owns up to IT (output column, 16-byte channel vector) items of one channel group and walks DOWN the output rows of
+// a strip of R input rows. Output row oy = p*U + k feeds input row p with 1 - k/U and input row min(p + 1, h - 1) with k/U,
+// so two running sums per item (the input row being finished, the next one) take every row exactly once; at each finished
+// input row the column sums go to LDS and w * cvn threads combine 2U-1 of them with the x tent. A strip re-reads only the
+// U-1 rows above its first input row. Sums are f32 in a fixed order (rows, then columns): deterministic.
+template <typename T, int U>
+__global__ __launch_bounds__(kThreads) void bilinear_up_bwd_walk_kernel(const T* __restrict__ dy, T* __restrict__ dx, int h,
+                                                                        int w, int C, int y_coff, int y_ctot, int R,
+                                                                        int cvb, int ncg, int nstrips) {
+    constexpr int VE = Vec16<T>::N;
+    constexpr int IT = 4;                                            // items per thread (the launcher keeps OW * cvb <= IT * kThreads)
+    constexpr int G = 2;                                             // rows in flight per thread (8 vectors: 32 KB per block; 4 rows: equal or slower)
+    constexpr int NT = 2 * U - 1;
+    constexpr float inv = 1.0f / (float)U;
+    extern __shared__ __attribute__((aligned(16))) float colsum[];   // [OW * cvn][VE]
+    // XCD-aware block -> work map (dwconv.hip): the blocks of one XCD take neighbouring strips, which share U-1 rows
+    int wid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wid >> 3);
+    }
+    const int cg = wid % ncg;
+    const int strip = (wid / ncg) % nstrips;
+    const int n = wid / (ncg * nstrips);
+    const int cvec = C / VE;
+    const int cv0 = cg * cvb, cvn = min(cvb, cvec - cv0);
+    const int OW = w * U, OH = h * U;
+    const int items = OW * cvn;
+    const int iy0 = strip * R, iy1 = min(h, iy0 + R);
+    const int tid = threadIdx.x;
+
+    int off[IT];                                                     // element offset of the item inside an output row
+    bool valid[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const int i = tid + j * kThreads;
+        valid[j] = i < items;
+        const int ii = valid[j] ? i : 0;
+        const int col = ii / cvn, cv = ii - col * cvn;
+        off[j] = col * y_ctot + y_coff + (cv0 + cv) * VE;
+    }
+    const T* base = dy + (long long)n * OH * OW * y_ctot;
+    float cur[IT][VE], nxt[IT][VE];
+#pragma unroll
+    for (int j = 0; j < IT; ++j)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) nxt[j][e] = 0.f;
+
+    // The walk as ONE flat sequence of groups of <= G rows that never straddle an input row: the loads of group g + 1 are
+    // issued right after the sums of group g, BEFORE the LDS exchange that ends an input row, so they fly under it.
+    Vec16<T> v[G][IT];
+    auto issue = [&](int p, int k0, int k1) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (k0 + g < k1) {
+                const T* row = base + (long long)(p * U + k0 + g) * OW * y_ctot;
+#pragma unroll
+                for (int j = 0; j < IT; ++j) v[g][j].load(row + off[j]);
+            }
+        }
+    };
+    // rows k0 .. k1-1 of the U output rows under input row p: cur += wc * row (rows of the strip only), nxt += wn * row
+    auto sums = [&](int k0, int k1, bool into_cur, bool last_row) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int k = k0 + g;
+            if (k < k1) {
+                const float fy = (float)k * inv;
+                const float wc = !into_cur ? 0.f : (last_row ? (1.f - fy) + fy : 1.f - fy);
+                const float wn = last_row ? 0.f : fy;
+#pragma unroll
+                for (int j = 0; j < IT; ++j) {
+                    float f[VE];
+                    v[g][j].unpack(f);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        cur[j][e] += wc * f[e];
+                        nxt[j][e] += wn * f[e];
+                    }
+                }
+            }
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < IT; ++j)
+#pragma unroll
+        for (int e = 0; e < VE; ++e) cur[j][e] = 0.f;
+
+    int p = iy0 > 0 ? iy0 - 1 : iy0, k = iy0 > 0 ? 1 : 0;           // the U-1 rows above the strip feed its first input row
+    issue(p, k, min(k + G, U));
+#pragma unroll 1
+    for (;;) {
+        const int k1 = min(k + G, U);
+        const int np = k1 == U ? p + 1 : p, nk = k1 == U ? 0 : k1;
+        const bool more = np < iy1;
+        sums(k, k1, p >= iy0, p == h - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(np, nk, min(nk + G, U));
+        if (k1 == U) {
+            if (p >= iy0) {
+                const int iy = p;
+#pragma unroll
+                for (int j = 0; j < IT; ++j) {
+                    if (valid[j]) {
+                        float* s = colsum + (size_t)(tid + j * kThreads) * VE;
+#pragma unroll
+                        for (int e = 0; e < VE; e += 4)
+                            *reinterpret_cast<float4*>(s + e) = make_float4(cur[j][e], cur[j][e + 1], cur[j][e + 2], cur[j][e + 3]);
+                    }
+                }
+                __syncthreads();
+                for (int o = tid; o < w * cvn; o += kThreads) {
+                    const int ix = o / cvn, cv = o - ix * cvn;
+                    const bool last_x = ix == w - 1;
+                    float acc[VE];
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+#pragma unroll 3
+                    for (int tk = 0; tk < NT; ++tk) {
+                        const int dxo = tk - (U - 1);
+                        const bool ok = dxo >= 0 || ix > 0;
+                        const float fx = (float)(dxo >= 0 ? dxo : U + dxo) * inv;
+                        const float wx = !ok ? 0.f : (dxo < 0 ? fx : (last_x ? (1.f - fx) + fx : 1.f - fx));
+                        const float* s = colsum + (size_t)((ix * U + (ok ? dxo : 0)) * cvn + cv) * VE;
+#pragma unroll
+                        for (int e = 0; e < VE; e += 4) {
+                            const float4 q = *reinterpret_cast<const float4*>(s + e);
+                            acc[e] += wx * q.x; acc[e + 1] += wx * q.y; acc[e + 2] += wx * q.z; acc[e + 3] += wx * q.w;
+                        }
+                    }
+                    Vec16<T> ov;
+                    ov.pack(acc);
+                    ov.store(dx + (((long long)n * h + iy) * w + ix) * C + (cv0 + cv) * VE);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int j = 0; j < IT; ++j)
+#pragma unroll
+                for (int e = 0; e < VE; ++e) { cur[j][e] = nxt[j][e]; nxt[j][e] = 0.f; }
+        }
+        if (!more) break;
+        p = np; k = nk;
+    }
+}
+
 // upsample 1 forward: act(x * scale + shift) written into the concat slice (the general kernel loads all four taps of
 // every output although fx = fy = 0), 4 vectors in flight per thread
 template <typename T>
@@ -345,6 +493,30 @@ extern "C" int mpn_bilinear_up_bwd(const void* dy, void* dx, int N, int h, int w
         return MPN_OK;
     }
     MPN_REQUIRE(upsample == 2 || upsample == 4 || upsample == 8, MPN_ERR_BAD_SHAPE, "bilinear bwd: upsample must be 1, 2, 4 or 8");
+    const int OW = w * upsample, cvec = C / ve;
+    if (upsample >= 4 && OW <= 4 * kThreads) {
+        // the walk: channel groups of cvb vectors so that one output row of a group is at most 4 items per thread; strips of
+        // R input rows so that the launch has >= 512 blocks (each strip re-reads upsample - 1 rows; 256 / 1024 blocks are
+        // slower). On the subnet's levels, [32,128,128,128 of 512] cold: 32.6-33.5 us (x4), 33.6-34.2 (x8) against the
+        // gather's 40.6-40.9; x2 stays on the gather (36.6 us there, 41-44 here: an LDS exchange every two rows).
+        int cvb = 4 * kThreads / OW;
+        if (cvb > cvec) cvb = cvec;
+        const int ncg = mpn_div_up(cvec, cvb);
+        int nstrips = mpn_div_up(512, (long long)N * ncg);
+        if (nstrips > h) nstrips = h;
+        const int R = mpn_div_up(h, nstrips);
+        nstrips = mpn_div_up(h, R);
+        const long long blocks = (long long)N * ncg * nstrips;
+        MPN_REQUIRE(blocks < (1ll << 31), MPN_ERR_BAD_SHAPE, "bilinear bwd: too many blocks");
+        const size_t lds = (size_t)OW * cvb * ve * sizeof(float);
+        MPN_DISPATCH_DTYPE(dtype, {
+            if (upsample == 2) bilinear_up_bwd_walk_kernel<T, 2><<<(unsigned)blocks, kThreads, lds, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total, R, cvb, ncg, nstrips);
+            else if (upsample == 4) bilinear_up_bwd_walk_kernel<T, 4><<<(unsigned)blocks, kThreads, lds, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total, R, cvb, ncg, nstrips);
+            else bilinear_up_bwd_walk_kernel<T, 8><<<(unsigned)blocks, kThreads, lds, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total, R, cvb, ncg, nstrips);
+        });
+        MPN_LAUNCH_CHECK();
+        return MPN_OK;
+    }
     MPN_DISPATCH_DTYPE(dtype, {
         if (upsample == 2) bilinear_up_bwd_kernel<T, 2><<<grid, kThreads, 0, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total);
         else if (upsample == 4) bilinear_up_bwd_kernel<T, 4><<<grid, kThreads, 0, st>>>((const T*)dy, (T*)dx, h, w, C, y_channel_offset, y_channels_total);

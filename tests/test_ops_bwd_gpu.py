@@ -142,7 +142,8 @@ def test_bn_backward(cuda, dtype, M, C, act, ch0):
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
 @pytest.mark.parametrize("u", [1, 2, 4, 8])
-@pytest.mark.parametrize("N,h,w,C", [(2, 6, 10, 128), (1, 3, 37, 64), (1, 4, 5, 24)], ids=["128ch", "wide-64ch", "24ch"])
+@pytest.mark.parametrize("N,h,w,C", [(2, 6, 10, 128), (1, 3, 37, 64), (1, 4, 5, 24), (1, 2, 260, 8)],
+                         ids=["128ch", "wide-64ch", "24ch", "rows-wider-than-a-walk"])
 def test_bilinear_backward(cuda, dtype, u, N, h, w, C):
     """The transposed legacy resize on a channel slice of the 512-channel concat gradient (one partial block per row, several
     blocks per row, a channel count that is not a power of two) against autograd through the oracle's forward."""
@@ -153,6 +154,24 @@ def test_bilinear_backward(cuda, dtype, u, N, h, w, C):
     dyfull = rnd(rs.randn(N, h * u, w * u, 512), dtype)
     out.backward(nchw(dyfull[..., 128:128 + C]))
     got = ops.bilinear_up_bwd(dev(dyfull, dtype), u, 128, C)
+    assert_close(got, nhwc(a.grad), dtype, 4 * u * u)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=IDS)
+@pytest.mark.parametrize("u", [4, 8])
+@pytest.mark.parametrize("N,h", [(40, 19), (150, 16)], ids=["strips-of-2-rows-last-of-1", "strips-of-4-rows"])
+def test_bilinear_backward_walks_strips_of_several_input_rows(cuda, dtype, u, N, h):
+    """Enough images that the walking kernel (upsample 4 and 8) takes strips of R > 1 input rows - the subnet's real geometry
+    has R = 2 and 4 - so the sum carried from one input row of a strip into the next, the U - 1 rows above a strip and a last
+    strip that is shorter than the others are all on the path; against autograd through the oracle's forward."""
+    ops = _ops()
+    w, C, ctot, coff = 4, 8, 16, 8
+    rs = np.random.RandomState(u + h)
+    a = torch.zeros(N, C, h, w, requires_grad=True)
+    out = onet.resize_bilinear_legacy(a, h * u, w * u)
+    dyfull = rnd(rs.randn(N, h * u, w * u, ctot), dtype)
+    out.backward(nchw(dyfull[..., coff:coff + C]))
+    got = ops.bilinear_up_bwd(dev(dyfull, dtype), u, coff, C)
     assert_close(got, nhwc(a.grad), dtype, 4 * u * u)
 
 
